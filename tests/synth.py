@@ -1,0 +1,96 @@
+"""Seeded synthetic read piles / reference windows (SURVEY.md section 8d shapes).  Shared by tests and bench.py."""
+import numpy as np
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def rand_seq(rng, n):
+    return ACGT[rng.integers(0, 4, size=n)]
+
+
+def mutate(rng, seq, sub_rate, n_rate=0.0):
+    seq = seq.copy()
+    if sub_rate > 0:
+        m = rng.random(len(seq)) < sub_rate
+        # substitute with a DIFFERENT base
+        idx = np.nonzero(m)[0]
+        for i in idx:
+            c = seq[i]
+            while True:
+                d = ACGT[rng.integers(0, 4)]
+                if d != c:
+                    break
+            seq[i] = d
+    if n_rate > 0:
+        seq[rng.random(len(seq)) < n_rate] = ord("N")
+    return seq
+
+
+def small_indel_locus(seed, n_reads=80, read_len=150, ref_len=1800, sub_rate=0.003, n_rate=0.0, tandem=False):
+    """Config-2 shape: ref = random ACGT; alt = ref with a deletion U{10..60} or an insertion (50/50) at the middle;
+    reads sampled from alt so that each overlaps the breakpoint by >= 10 bp."""
+    rng = np.random.default_rng(seed)
+    ref = rand_seq(rng, ref_len)
+    if tandem:
+        unit = rand_seq(rng, int(rng.integers(2, 12)))
+        reps = int(rng.integers(6, 20))
+        blk = np.tile(unit, reps)
+        p = ref_len // 2 - len(blk) // 2
+        ref[p:p + len(blk)] = blk
+    bp = ref_len // 2
+    size = int(rng.integers(10, 61))
+    if rng.random() < 0.5:
+        alt = np.concatenate([ref[:bp], ref[bp + size:]])
+    else:
+        alt = np.concatenate([ref[:bp], rand_seq(rng, size), ref[bp:]])
+    reads = []
+    lo = max(0, bp - read_len + 10)
+    hi = min(len(alt) - read_len, bp - 10)
+    for _ in range(n_reads):
+        s = int(rng.integers(lo, hi + 1))
+        reads.append(mutate(rng, alt[s:s + read_len], sub_rate, n_rate).tobytes())
+    return reads, ref.tobytes()
+
+
+def breakend_locus(seed, n_reads=200, read_len=250, ref_len=900, sub_rate=0.005, n_rate=0.01, tandem_frac=0.1):
+    """Config-5 shape: fused haplotype ref1[0..450+d1) + ins(U{0..20}) + ref2[450+d2..900); reads span the junction."""
+    rng = np.random.default_rng(seed)
+    ref1 = rand_seq(rng, ref_len)
+    ref2 = rand_seq(rng, ref_len)
+    if rng.random() < tandem_frac:
+        unit = rand_seq(rng, int(rng.integers(2, 10)))
+        blk = np.tile(unit, int(rng.integers(8, 25)))
+        p = ref_len // 2 - len(blk) - 5
+        ref1[p:p + len(blk)] = blk
+    d1, d2 = int(rng.integers(-20, 21)), int(rng.integers(-20, 21))
+    ins = rand_seq(rng, int(rng.integers(0, 21)))
+    hap = np.concatenate([ref1[:ref_len // 2 + d1], ins, ref2[ref_len // 2 + d2:]])
+    j = ref_len // 2 + d1
+    reads = []
+    lo = max(0, j - read_len + 20)
+    hi = min(len(hap) - read_len, j - 20)
+    for _ in range(n_reads):
+        s = int(rng.integers(lo, hi + 1))
+        reads.append(mutate(rng, hap[s:s + read_len], sub_rate, n_rate).tobytes())
+    return reads, ref1.tobytes(), ref2.tobytes()
+
+
+def repeat_rich_pile(seed, n_reads=12, read_len=40, alphabet=b"ACGT"):
+    """Small adversarial piles with many cycles in the k-mer graph (exercise repeat detection + k iteration)."""
+    rng = np.random.default_rng(seed)
+    al = np.frombuffer(alphabet, dtype=np.uint8)
+    n_units = int(rng.integers(1, 4))
+    parts = []
+    for _ in range(n_units):
+        unit = al[rng.integers(0, len(al), size=int(rng.integers(1, 9)))]
+        parts.append(np.tile(unit, int(rng.integers(2, 10))))
+        parts.append(al[rng.integers(0, len(al), size=int(rng.integers(3, 25)))])
+    hap = np.concatenate(parts)
+    if len(hap) < read_len + 5:
+        hap = np.concatenate([hap, al[rng.integers(0, len(al), size=read_len + 5 - len(hap))]])
+    reads = []
+    for _ in range(n_reads):
+        L = int(rng.integers(max(8, read_len // 2), read_len + 1))
+        s = int(rng.integers(0, len(hap) - L + 1))
+        reads.append(mutate(rng, hap[s:s + L], 0.02, 0.01).tobytes())
+    return reads
