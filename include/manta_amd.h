@@ -1,0 +1,97 @@
+/*
+ * manta_amd.h -- C ABI of the MI355X-native assemble+align hot path of Manta's GenerateSVCandidates.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Each
+ * entry point names the reference interface it replaces (paths relative to /root/reference/src/c++/lib).
+ * The C++ adapters in manta_amd/host/ re-create the reference's own signatures
+ * (runIterativeAssembler, GlobalAligner<int>::align, ...) on top of these functions; INTEGRATION.md shows the
+ * edits a Manta maintainer makes to call them.
+ *
+ * Conventions
+ *   - every function returns MANTA_OK (0) or a negative MANTA_E_* code; manta_last_error() gives the message
+ *     (the reference reports errors as C++ exceptions, common/Exceptions.hpp:54-85; the C++ adapter re-throws).
+ *   - sequences are raw bytes exactly as the reference's std::string holds them (1 byte per base).
+ *   - all batch calls are synchronous; a context is bound to one GPU and is NOT re-entrant (the reference's
+ *     aligner/refiner objects are not either: alignment/GlobalJumpAligner.hpp:117-124) -- use one context per
+ *     host worker thread (GenerateSVCandidates.cpp:232-250).
+ *   - there is no CPU fallback: if no gfx950 device / HIP runtime is usable, manta_ctx_create fails.
+ */
+#ifndef MANTA_AMD_H
+#define MANTA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MANTA_OK 0
+#define MANTA_E_INVALID_ARG (-1)  /* null pointer, bad enum, inconsistent sizes */
+#define MANTA_E_NO_DEVICE (-2)    /* HIP runtime / device unavailable */
+#define MANTA_E_HIP (-3)          /* a HIP call failed; see manta_last_error */
+#define MANTA_E_EMPTY_SEQ (-4)    /* empty query/reference (GlobalJumpAlignerImpl.hpp:50-58) */
+#define MANTA_E_UNSUPPORTED (-5)  /* input outside the supported envelope (see DESIGN.md limits) */
+#define MANTA_E_CAPACITY (-6)     /* caller-provided output arena too small */
+#define MANTA_E_DEVICE_FAULT (-7) /* kernel reported an internal overflow for some locus/task */
+
+typedef struct manta_ctx manta_ctx_t;
+
+/* device_id < 0 selects the current HIP device */
+int         manta_ctx_create(int device_id, manta_ctx_t** ctx);
+void        manta_ctx_destroy(manta_ctx_t* ctx);
+const char* manta_last_error(const manta_ctx_t* ctx); /* ctx may be NULL: error of the last failed create */
+/* "gfx950 / <CUs> CUs / <bytes> HBM" style description, for logs */
+const char* manta_ctx_device_name(const manta_ctx_t* ctx);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Aligners.  Replaces
+ *   GlobalAligner<int>::align            alignment/GlobalAligner.hpp:36-46   (kind MANTA_ALIGNER_GLOBAL)
+ *   GlobalLargeIndelAligner<int>::align  alignment/GlobalLargeIndelAligner.hpp:39-54 (MANTA_ALIGNER_LARGE_INDEL)
+ *   GlobalJumpAligner<int>::align        alignment/GlobalJumpAligner.hpp:36-53       (MANTA_ALIGNER_JUMP)
+ * called at SVCandidateAssemblyRefiner.cpp:933, 1668, 1706, 2032.
+ * ---------------------------------------------------------------------------------------------------- */
+enum { MANTA_ALIGNER_GLOBAL = 0, MANTA_ALIGNER_LARGE_INDEL = 1, MANTA_ALIGNER_JUMP = 2 };
+
+/* alignment/AlignmentScores.hpp:23-57 */
+typedef struct {
+  int32_t match, mismatch, open, extend, off_edge;
+  int32_t is_allow_edge_insertion; /* must be 0 for MANTA_ALIGNER_JUMP (GlobalJumpAligner.hpp:41-42) */
+} manta_align_scores_t;
+
+/* one query/reference(s) problem; offsets index the caller's sequence arena */
+typedef struct {
+  uint64_t query_off;
+  uint64_t ref1_off;
+  uint64_t ref2_off; /* MANTA_ALIGNER_JUMP only */
+  uint32_t query_len;
+  uint32_t ref1_len;
+  uint32_t ref2_len;
+  uint32_t reserved;
+} manta_align_task_t;
+
+/* CIGAR segments are BAM-packed: (length << 4) | op, op = 0 M,1 I,2 D,3 N,4 S,5 H,6 P,7 '=',8 'X'
+ * (ALIGNPATH::align_t, blt_util/align_path.hpp:35-62).  Paths are always in '='/'X' form, as the reference's
+ * aligners emit them (SingleRefAlignerSharedImpl.hpp:160-166). */
+typedef struct {
+  int32_t  status;    /* MANTA_OK or MANTA_E_* for this task */
+  int32_t  score;     /* AlignmentResult::score / JumpAlignmentResult::score */
+  int32_t  is_jumped; /* AlignmentResult::isJumped (single-reference aligners) */
+  int32_t  begin_pos1; /* align.beginPos / align1.beginPos */
+  int32_t  begin_pos2; /* align2.beginPos (jump) */
+  uint32_t jump_insert_size; /* JumpAlignmentResult::jumpInsertSize */
+  uint32_t jump_range;       /* JumpAlignmentResult::jumpRange */
+  uint32_t cigar1_len, cigar2_len; /* number of segments */
+  uint64_t cigar1_off, cigar2_off; /* into the caller's cigar arena */
+} manta_align_result_t;
+
+/* extra_score = largeIndelScore (LARGE_INDEL) or jumpScore (JUMP); ignored for GLOBAL.
+ * cigar arena: 2*query_len+8 segments per task always suffice. */
+int manta_align_batch(
+    manta_ctx_t* ctx, int kind, const manta_align_scores_t* scores, int32_t extra_score, uint32_t n_tasks,
+    const manta_align_task_t* tasks, const uint8_t* seq_arena, uint64_t seq_arena_bytes,
+    manta_align_result_t* results, uint32_t* cigar_arena, uint64_t cigar_arena_cap, uint64_t* cigar_arena_used);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MANTA_AMD_H */

@@ -1,0 +1,85 @@
+// Host-side runtime shim: the product build talks to the HIP runtime; the test-only emulator build
+// (-DMANTA_WAVE_EMU, tests/emu/) maps "device" memory to host memory and runs kernels on the lock-step
+// wave emulator.  Nothing in the product library selects between them at run time.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#ifdef MANTA_WAVE_EMU
+#include <cstdlib>
+#include <cstring>
+#include "wave.hpp"
+namespace rt {
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+inline void  init(int) {}
+inline std::string deviceName() { return "wave-emulator (test infrastructure)"; }
+inline int   cuCount() { return 2; }
+inline size_t freeBytes() { return size_t(1) << 30; }
+inline void* dmalloc(size_t n) { void* p = std::malloc(n ? n : 1); if (!p) throw Error("emu malloc failed"); std::memset(p, 0xab, n); return p; }
+inline void  dfree(void* p) { std::free(p); }
+inline void  h2d(void* d, const void* h, size_t n) { if (n) std::memcpy(d, h, n); }
+inline void  d2h(void* h, const void* d, size_t n) { if (n) std::memcpy(h, d, n); }
+inline void  dzero(void* d, size_t n) { if (n) std::memset(d, 0, n); }
+inline void  dfill(void* d, int byte, size_t n) { if (n) std::memset(d, byte, n); }
+inline void  sync() {}
+template <typename K, typename P>
+inline void launch(K kernel, int grid, size_t ldsBytes, const P& params) { wv_emu::launch(grid, ldsBytes, [&]() { kernel(params); }); }
+}  // namespace rt
+#else
+#include <hip/hip_runtime.h>
+namespace rt {
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+inline void check(hipError_t e, const char* what)
+{
+  if (e != hipSuccess) throw Error(std::string(what) + ": " + hipGetErrorString(e));
+}
+inline void init(int dev)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw Error("no HIP device available (this library has no CPU path)");
+  if (dev >= 0) check(hipSetDevice(dev), "hipSetDevice");
+}
+inline std::string deviceName()
+{
+  int dev = 0;
+  check(hipGetDevice(&dev), "hipGetDevice");
+  hipDeviceProp_t p;
+  check(hipGetDeviceProperties(&p, dev), "hipGetDeviceProperties");
+  return std::string(p.gcnArchName) + " / " + std::to_string(p.multiProcessorCount) + " CUs / " + std::to_string(p.totalGlobalMem) + " B";
+}
+inline int cuCount()
+{
+  int dev = 0;
+  check(hipGetDevice(&dev), "hipGetDevice");
+  hipDeviceProp_t p;
+  check(hipGetDeviceProperties(&p, dev), "hipGetDeviceProperties");
+  return p.multiProcessorCount;
+}
+inline size_t freeBytes()
+{
+  size_t f = 0, t = 0;
+  check(hipMemGetInfo(&f, &t), "hipMemGetInfo");
+  return f;
+}
+inline void* dmalloc(size_t n)
+{
+  void* p = nullptr;
+  check(hipMalloc(&p, n ? n : 1), "hipMalloc");
+  return p;
+}
+inline void dfree(void* p) { (void)hipFree(p); }
+inline void h2d(void* d, const void* h, size_t n) { if (n) check(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D"); }
+inline void d2h(void* h, const void* d, size_t n) { if (n) check(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
+inline void dzero(void* d, size_t n) { if (n) check(hipMemsetAsync(d, 0, n, 0), "hipMemset"); }
+inline void dfill(void* d, int byte, size_t n) { if (n) check(hipMemsetAsync(d, byte, n, 0), "hipMemset"); }
+inline void sync() { check(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
+template <typename K, typename P>
+inline void launch(K kernel, int grid, size_t ldsBytes, const P& params)
+{
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), ldsBytes, 0, params);
+  check(hipGetLastError(), "kernel launch");
+}
+}  // namespace rt
+#endif

@@ -1,0 +1,67 @@
+// Wave-level primitives for the gfx950 kernels (one workgroup == one 64-lane wavefront everywhere in this
+// library).  Kernels use ONLY these wrappers for lane ids, cross-lane traffic, LDS and atomics, so that the
+// identical kernel source can also be run by the lock-step wave emulator in tests/emu/ (test infrastructure:
+// it exists so the CPU-only test tier can execute the real kernel bodies; the product library is never built
+// that way and has no CPU path).
+#pragma once
+#include <cstdint>
+
+#ifdef MANTA_WAVE_EMU
+#include "wave_emu.hpp"  // tests/emu/
+#else
+
+#include <hip/hip_runtime.h>
+
+#define WV_DEV __device__ __forceinline__
+#define WV_KERNEL __global__ __launch_bounds__(64)
+
+extern __shared__ __attribute__((aligned(16))) char wv_dyn_lds[];
+
+namespace wv {
+
+WV_DEV int lane() { return int(threadIdx.x); }
+WV_DEV int block() { return int(blockIdx.x); }
+WV_DEV int nblocks() { return int(gridDim.x); }
+WV_DEV char* lds() { return wv_dyn_lds; }
+
+/// lane l receives lane (l-1)'s value; lane 0 receives `fill`   (v_mov_b32_dpp wave_shr:1)
+WV_DEV int shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+WV_DEV unsigned shr1(unsigned v, unsigned fill) { return unsigned(shr1(int(v), int(fill))); }
+
+/// arbitrary gather (ds_bpermute_b32)
+WV_DEV int shfl(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
+WV_DEV unsigned shfl(unsigned v, int src) { return unsigned(shfl(int(v), src)); }
+WV_DEV uint64_t shfl(uint64_t v, int src)
+{
+  const unsigned lo = shfl(unsigned(v), src), hi = shfl(unsigned(v >> 32), src);
+  return (uint64_t(hi) << 32) | lo;
+}
+
+/// wave-uniform source lane (v_readlane_b32)
+WV_DEV int readlane(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+WV_DEV unsigned readlane(unsigned v, int src) { return unsigned(__builtin_amdgcn_readlane(int(v), src)); }
+WV_DEV uint64_t readlane(uint64_t v, int src)
+{
+  return (uint64_t(readlane(unsigned(v >> 32), src)) << 32) | readlane(unsigned(v), src);
+}
+WV_DEV int first(int v) { return __builtin_amdgcn_readfirstlane(v); }
+WV_DEV unsigned first(unsigned v) { return unsigned(__builtin_amdgcn_readfirstlane(int(v))); }
+
+WV_DEV uint64_t ballot(bool p) { return __ballot(p); }
+WV_DEV bool any(bool p) { return __ballot(p) != 0; }
+
+/// makes this wave's earlier LDS/global writes visible to its other lanes (block == wave)
+WV_DEV void sync() { __syncthreads(); }
+
+WV_DEV unsigned atomic_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }
+WV_DEV unsigned atomic_cas(unsigned* p, unsigned cmp, unsigned v) { return atomicCAS(p, cmp, v); }
+WV_DEV unsigned atomic_or(unsigned* p, unsigned v) { return atomicOr(p, v); }
+WV_DEV unsigned atomic_sub(unsigned* p, unsigned v) { return atomicSub(p, v); }
+WV_DEV unsigned long long atomic_or(unsigned long long* p, unsigned long long v) { return atomicOr(p, v); }
+
+WV_DEV int popc(unsigned v) { return __popc(v); }
+WV_DEV int popc(uint64_t v) { return __popcll(v); }
+WV_DEV int ctz(uint64_t v) { return __builtin_ctzll(v); }  // v != 0
+
+}  // namespace wv
+#endif

@@ -1,0 +1,189 @@
+// TEST INFRASTRUCTURE: lock-step 64-lane wavefront emulator.
+//
+// Lets the CPU-only test tier execute the REAL kernel bodies of manta_amd/csrc (compiled with -DMANTA_WAVE_EMU
+// into tests/emu/libmanta_amd_emu.so).  Each lane is a cooperative fiber (ucontext) on one OS thread; every
+// cross-lane primitive is a rendezvous: all live lanes run up to it, exchange through a ping-pong buffer, and
+// continue.  Between rendezvous points exactly one lane runs, so "atomics" are plain read-modify-writes.
+// This is NOT a product code path: manta_amd/ never builds, loads or falls back to it.
+#pragma once
+#include <ucontext.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define WV_DEV inline
+#define WV_KERNEL
+
+namespace wv_emu {
+
+struct Wave {
+  static const int      N = 64;
+  ucontext_t            sched;
+  ucontext_t            lanes[N];
+  std::vector<char>     stacks;
+  bool                  done[N];
+  int                   cur = 0;
+  uint64_t              xbuf[2][N];
+  unsigned              opSeq[N];    // number of rendezvous each lane has executed (convergence check)
+  const char*           opTag[N];
+  std::vector<char>     ldsMem;
+  int                   block = 0, nblocks = 1;
+  std::function<void()> body;
+};
+
+inline Wave*& W()
+{
+  static thread_local Wave* w = nullptr;
+  return w;
+}
+
+inline void trampoline()
+{
+  Wave* w = W();
+  w->body();
+  w->done[w->cur] = true;
+  swapcontext(&w->lanes[w->cur], &w->sched);
+}
+
+inline void yieldLane(const char* tag)
+{
+  Wave* w          = W();
+  w->opSeq[w->cur] += 1;
+  w->opTag[w->cur] = tag;
+  swapcontext(&w->lanes[w->cur], &w->sched);
+}
+
+/// run `grid` workgroups (one wave each) sequentially
+inline void launch(int grid, size_t ldsBytes, const std::function<void()>& body)
+{
+  static const size_t STACK = 256 * 1024;
+  Wave                w;
+  w.stacks.resize(STACK * Wave::N);
+  w.ldsMem.assign(ldsBytes + 64, 0);
+  w.body    = body;
+  w.nblocks = grid;
+  Wave* saved = W();
+  W()         = &w;
+  for (int b = 0; b < grid; ++b) {
+    w.block = b;
+    std::fill(w.ldsMem.begin(), w.ldsMem.end(), char(0xcd));  // LDS is NOT zero-initialised on hardware
+    for (int l = 0; l < Wave::N; ++l) {
+      w.done[l]  = false;
+      w.opSeq[l] = 0;
+      w.opTag[l] = "start";
+      getcontext(&w.lanes[l]);
+      w.lanes[l].uc_stack.ss_sp   = w.stacks.data() + STACK * l;
+      w.lanes[l].uc_stack.ss_size = STACK;
+      w.lanes[l].uc_link          = &w.sched;
+      makecontext(&w.lanes[l], (void (*)())trampoline, 0);
+    }
+    while (true) {
+      bool anyLive = false;
+      for (int l = 0; l < Wave::N; ++l) {
+        if (w.done[l]) continue;
+        anyLive = true;
+        w.cur   = l;
+        swapcontext(&w.sched, &w.lanes[l]);
+      }
+      if (!anyLive) break;
+      // convergence check: all live lanes must sit at the same rendezvous
+      unsigned    seq = 0;
+      const char* tag = nullptr;
+      for (int l = 0; l < Wave::N; ++l) {
+        if (w.done[l]) continue;
+        if (!tag) {
+          seq = w.opSeq[l];
+          tag = w.opTag[l];
+        } else if (w.opSeq[l] != seq || w.opTag[l] != tag) {
+          std::fprintf(stderr, "wave_emu: divergent rendezvous: lane %d at '%s'#%u vs '%s'#%u (block %d)\n", l, w.opTag[l],
+                       w.opSeq[l], tag, seq, b);
+          std::abort();
+        }
+      }
+    }
+  }
+  W() = saved;
+}
+
+template <typename T>
+inline T exchange(T v, int src, const char* tag)
+{
+  Wave*     w = W();
+  const int p = w->opSeq[w->cur] & 1;
+  uint64_t  raw = 0;
+  std::memcpy(&raw, &v, sizeof(T));
+  w->xbuf[p][w->cur] = raw;
+  yieldLane(tag);
+  T r;
+  std::memcpy(&r, &w->xbuf[p][src & 63], sizeof(T));
+  return r;
+}
+
+}  // namespace wv_emu
+
+namespace wv {
+
+inline int lane() { return wv_emu::W()->cur; }
+inline int block() { return wv_emu::W()->block; }
+inline int nblocks() { return wv_emu::W()->nblocks; }
+inline char* lds()
+{
+  char* p = wv_emu::W()->ldsMem.data();
+  return p + ((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15);
+}
+
+inline int shr1(int v, int fill)
+{
+  const int l = lane();
+  const int r = wv_emu::exchange(v, l - 1, "shr1");
+  return (l == 0) ? fill : r;
+}
+inline unsigned shr1(unsigned v, unsigned fill) { return unsigned(shr1(int(v), int(fill))); }
+
+inline int shfl(int v, int src) { return wv_emu::exchange(v, src, "shfl"); }
+inline unsigned shfl(unsigned v, int src) { return wv_emu::exchange(v, src, "shfl"); }
+inline uint64_t shfl(uint64_t v, int src) { return wv_emu::exchange(v, src, "shfl64"); }
+
+inline int readlane(int v, int src) { return wv_emu::exchange(v, src, "readlane"); }
+inline unsigned readlane(unsigned v, int src) { return wv_emu::exchange(v, src, "readlane"); }
+inline uint64_t readlane(uint64_t v, int src) { return wv_emu::exchange(v, src, "readlane64"); }
+
+inline uint64_t ballot(bool p)
+{
+  wv_emu::Wave* w   = wv_emu::W();
+  const int     par = w->opSeq[w->cur] & 1;
+  w->xbuf[par][w->cur] = p ? 1 : 0;
+  wv_emu::yieldLane("ballot");
+  uint64_t m = 0;
+  for (int l = 0; l < 64; ++l)
+    if (!w->done[l] && w->xbuf[par][l]) m |= (uint64_t(1) << l);
+  return m;
+}
+inline bool any(bool p) { return ballot(p) != 0; }
+
+inline int first(int v)
+{
+  wv_emu::Wave* w = wv_emu::W();
+  int           f = 0;
+  while (w->done[f]) ++f;
+  return wv_emu::exchange(v, f, "first");
+}
+inline unsigned first(unsigned v) { return unsigned(first(int(v))); }
+
+inline void sync() { wv_emu::yieldLane("sync"); }
+
+inline unsigned atomic_add(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+inline unsigned atomic_sub(unsigned* p, unsigned v) { const unsigned o = *p; *p = o - v; return o; }
+inline unsigned atomic_cas(unsigned* p, unsigned cmp, unsigned v) { const unsigned o = *p; if (o == cmp) *p = v; return o; }
+inline unsigned atomic_or(unsigned* p, unsigned v) { const unsigned o = *p; *p = o | v; return o; }
+inline unsigned long long atomic_or(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o | v; return o; }
+
+inline int popc(unsigned v) { return __builtin_popcount(v); }
+inline int popc(uint64_t v) { return __builtin_popcountll(v); }
+inline int ctz(uint64_t v) { return __builtin_ctzll(v); }
+
+}  // namespace wv

@@ -1,0 +1,70 @@
+"""HIP aligner kernels vs the oracle: on the wave emulator (CPU tier, small) and on the GPU (-m gpu, large)."""
+import random
+
+import pytest
+
+from manta_amd._capi import align_text
+from test_oracle_vs_ref import SCORE_SETS, _rand_align_case
+
+
+def _run(lib, oracle, seed, n_batches, per_batch, maxlen):
+    rng = random.Random(seed)
+    n = 0
+    for _ in range(n_batches):
+        kind = rng.choice([0, 1, 2])
+        sc = list(rng.choice(SCORE_SETS))
+        if kind == 2:
+            sc[5] = 0
+        extra = rng.choice([-100, -3, -20, -50])
+        probs = [_rand_align_case(rng, kind, maxlen) for _ in range(per_batch)]
+        res = lib.align_batch(kind, sc, extra, probs)
+        for p, r in zip(probs, res):
+            assert r["status"] == 0
+            assert align_text(kind, r) == oracle.align(kind, sc, extra, *p), (kind, sc, extra, p)
+            n += 1
+    return n
+
+
+def test_emulated_align_small(emu, oracle):
+    _run(emu, oracle, 3, 40, 4, 100)
+
+
+def test_emulated_align_multi_column(emu, oracle):
+    _run(emu, oracle, 5, 8, 3, 420)  # queries up to ~400 bp -> several columns per lane
+
+
+def test_empty_inputs_report_status(emu):
+    res = emu.align_batch(0, [2, -4, -5, -1, -4, 0], 0, [("", "ACGT"), ("ACGT", ""), ("AC", "ACGT")], strict=False)
+    assert [r["status"] for r in res] == [-4, -4, 0]
+    res = emu.align_batch(2, [2, -4, -5, -1, -1, 0], -3, [("AC", "ACGT", "")], strict=False)
+    assert res[0]["status"] == -4
+
+
+@pytest.mark.gpu
+def test_gpu_align_random(gpu, oracle):
+    assert _run(gpu, oracle, 17, 60, 64, 160) == 60 * 64
+
+
+@pytest.mark.gpu
+def test_gpu_align_long(gpu, oracle):
+    _run(gpu, oracle, 19, 12, 16, 1200)  # exercises every columns-per-lane bucket up to E=24
+
+
+@pytest.mark.gpu
+def test_gpu_align_config2_shape(gpu, oracle):
+    """contig ~270 bp vs ~1.5 kb window, production small-SV scores (SVRefinerOptions.hpp:40,44)"""
+    import numpy as np
+    from synth import rand_seq, mutate
+    rng = np.random.default_rng(5)
+    probs = []
+    for i in range(64):
+        ref = rand_seq(rng, 1500)
+        bp = 750
+        size = int(rng.integers(10, 61))
+        alt = np.concatenate([ref[:bp], ref[bp + size:]]) if i % 2 else np.concatenate([ref[:bp], rand_seq(rng, size), ref[bp:]])
+        s = bp - 130
+        probs.append((mutate(rng, alt[s:s + 270], 0.003).tobytes(), ref.tobytes()))
+    sc = [2, -8, -24, -1, -1, 0]
+    res = gpu.align_batch(1, sc, -100, probs)
+    for p, r in zip(probs, res):
+        assert align_text(1, r) == oracle.align(1, sc, -100, *p)
