@@ -91,6 +91,58 @@ int manta_align_batch(
     const manta_align_task_t* tasks, const uint8_t* seq_arena, uint64_t seq_arena_bytes,
     manta_align_result_t* results, uint32_t* cigar_arena, uint64_t cigar_arena_cap, uint64_t* cigar_arena_used);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Assembler.  Replaces
+ *   void runIterativeAssembler(const IterativeAssemblerOptions&, AssemblyReadInput& reads,
+ *                              AssemblyReadOutput& readInfo, Assembly& contigs)
+ *                                                   assembly/IterativeAssembler.hpp:43-47
+ * called at manta/SVCandidateAssembler.cpp:674,697, for a whole batch of candidate loci at once.
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* options/IterativeAssemblerOptions.hpp:26-59.  The alphabet is the reference's default "ACGT"; minQval and
+ * maxError are not read by the assembler itself (they act upstream, in read gathering). */
+typedef struct {
+  uint32_t min_word_length, max_word_length, word_step_size, min_contig_length;
+  uint32_t min_coverage, min_conservative_coverage, min_unused_reads, min_support_reads, max_assembly_count;
+} manta_asm_options_t;
+
+/* assembly/AssembledContig.hpp:38-54 */
+typedef struct {
+  uint64_t seq_off;     /* contig.seq in the caller's sequence arena */
+  uint64_t support_off; /* contig.supportReads as a bitset of n_words qwords in the caller's bitset arena */
+  uint64_t reject_off;  /* contig.rejectReads, same form */
+  uint32_t seq_len;
+  uint32_t seed_read_count; /* always 0: never written by the reference (AssembledContig.hpp:45) */
+  int32_t  conservative_begin, conservative_end; /* contig.conservativeRange */
+} manta_asm_contig_t;
+
+typedef struct {
+  int32_t  status;       /* MANTA_OK or MANTA_E_* for this locus */
+  uint32_t n_contigs;    /* contigs.size() */
+  uint32_t first_contig; /* index of this locus' first record in the contigs array */
+  uint32_t n_words;      /* qwords per read bitset: ceil((reads + 2*max_assembly_count)/64).  Bit r == read r;
+                            r >= n_reads are pseudo reads (contigs fed back as reads, IterativeAssembler.cpp:897-910) */
+  uint32_t n_pseudo;     /* pseudo reads the reference leaves appended to `reads` on return (:902) */
+  uint32_t final_word_length;
+  uint32_t n_iterations;
+  uint32_t cyclic_iterations; /* word lengths whose k-mer graph was cyclic (exact repeat search taken) */
+  uint64_t pseudo_seq_off;    /* n_pseudo sequences back to back in the sequence arena */
+  uint64_t pseudo_len_off;    /* their lengths, one qword each, in the bitset arena */
+} manta_asm_locus_result_t;
+
+/* Input layout (what SVCandidateAssembler hands to runIterativeAssembler, flattened):
+ *   bases              all reads of all loci, 1 byte per base {A,C,G,T,N}
+ *   read_off[R+1]      byte offsets of the reads
+ *   locus_read_begin[n_loci+1]  read-index range of every locus
+ * Output: one manta_asm_locus_result_t per locus, at most max_assembly_count contig records per locus.
+ * readInfo (AssemblyReadInfo.hpp:31-46) is implied: read r isUsed <=> some contig's support holds r, its contigIds
+ * are those contigs in order (IterativeAssembler.cpp:826-834); the C++ adapter materialises it. */
+int manta_assemble_batch(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, uint32_t n_loci, const uint8_t* bases, const uint64_t* read_off,
+    const uint32_t* locus_read_begin, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, uint64_t contigs_cap,
+    uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
+    uint64_t* bits_arena_used);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,36 @@ class AlignResult(ctypes.Structure):
                 ("cigar1_off", ctypes.c_uint64), ("cigar2_off", ctypes.c_uint64)]
 
 
+class AsmOptions(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in ("min_word_length", "max_word_length", "word_step_size", "min_contig_length",
+                                               "min_coverage", "min_conservative_coverage", "min_unused_reads",
+                                               "min_support_reads", "max_assembly_count")]
+
+
+class AsmContig(ctypes.Structure):
+    _fields_ = [("seq_off", ctypes.c_uint64), ("support_off", ctypes.c_uint64), ("reject_off", ctypes.c_uint64),
+                ("seq_len", ctypes.c_uint32), ("seed_read_count", ctypes.c_uint32), ("conservative_begin", ctypes.c_int32),
+                ("conservative_end", ctypes.c_int32)]
+
+
+class AsmLocusResult(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int32), ("n_contigs", ctypes.c_uint32), ("first_contig", ctypes.c_uint32),
+                ("n_words", ctypes.c_uint32), ("n_pseudo", ctypes.c_uint32), ("final_word_length", ctypes.c_uint32),
+                ("n_iterations", ctypes.c_uint32), ("cyclic_iterations", ctypes.c_uint32), ("pseudo_seq_off", ctypes.c_uint64),
+                ("pseudo_len_off", ctypes.c_uint64)]
+
+
+def _bits_members(words):
+    out = []
+    for wi, w in enumerate(words):
+        w = int(w)
+        while w:
+            b = (w & -w).bit_length() - 1
+            out.append(wi * 64 + b)
+            w &= w - 1
+    return out
+
+
 def cigar_string(packed):
     return "".join("%d%s" % (int(v) >> 4, CIGAR_OPS[int(v) & 15]) for v in packed)
 
@@ -121,6 +151,78 @@ class Lib:
                             cigar1=cigar_string(cig[r.cigar1_off:r.cigar1_off + r.cigar1_len]),
                             cigar2=cigar_string(cig[r.cigar2_off:r.cigar2_off + r.cigar2_len])))
         return out
+
+
+def pack_loci(loci_reads):
+    """list (per locus) of lists of read byte strings -> (bases uint8, read_off uint64, locus_read_begin uint32)"""
+    flat = [_b(r) for reads in loci_reads for r in reads]
+    lens = np.fromiter((len(r) for r in flat), dtype=np.uint64, count=len(flat))
+    read_off = np.zeros(len(flat) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=read_off[1:])
+    bases = np.frombuffer(b"".join(flat) + b"\0", dtype=np.uint8)
+    begin = np.zeros(len(loci_reads) + 1, dtype=np.uint32)
+    np.cumsum([len(r) for r in loci_reads], out=begin[1:])
+    return bases, read_off, begin
+
+
+def _assemble_batch(self, opts, loci_reads, strict=True):
+    """opts: 9 values in manta_asm_options_t order.  Returns one dict per locus."""
+    bases, read_off, begin = pack_loci(loci_reads)
+    n_loci = len(loci_reads)
+    o = AsmOptions(*opts)
+    res = (AsmLocusResult * max(1, n_loci))()
+    ccap = n_loci * o.max_assembly_count + 1
+    contigs = (AsmContig * ccap)()
+    seq_cap = int(read_off[-1]) * 2 + 65536 * max(1, n_loci)
+    seq = np.zeros(seq_cap, dtype=np.uint8)
+    bits_cap = n_loci * (o.max_assembly_count * 2 * 16 + 64) + 64
+    bits = np.zeros(bits_cap, dtype=np.uint64)
+    su, bu = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    rc = self.lib.manta_assemble_batch(self.ctx, ctypes.byref(o), n_loci, bases.ctypes.data_as(ctypes.c_void_p),
+                                       read_off.ctypes.data_as(ctypes.c_void_p), begin.ctypes.data_as(ctypes.c_void_p), res,
+                                       contigs, ctypes.c_uint64(ccap), seq.ctypes.data_as(ctypes.c_void_p),
+                                       ctypes.c_uint64(seq_cap), ctypes.byref(su), bits.ctypes.data_as(ctypes.c_void_p),
+                                       ctypes.c_uint64(bits_cap), ctypes.byref(bu))
+    self._check(rc, allow=() if strict else (-5, -6, -7))
+    out = []
+    for l in range(n_loci):
+        r = res[l]
+        d = dict(status=r.status, n_reads=len(loci_reads[l]), n_words=r.n_words, final_word_length=r.final_word_length,
+                 n_iterations=r.n_iterations, cyclic_iterations=r.cyclic_iterations, contigs=[], pseudo=[])
+        if r.status == 0:
+            for c in range(r.n_contigs):
+                cc = contigs[r.first_contig + c]
+                d["contigs"].append(dict(seq=seq[cc.seq_off:cc.seq_off + cc.seq_len].tobytes().decode("latin-1"),
+                                         seed=cc.seed_read_count, cons=(cc.conservative_begin, cc.conservative_end),
+                                         support=_bits_members(bits[cc.support_off:cc.support_off + r.n_words]),
+                                         reject=_bits_members(bits[cc.reject_off:cc.reject_off + r.n_words])))
+            off = int(r.pseudo_seq_off)
+            for p in range(r.n_pseudo):
+                ln = int(bits[r.pseudo_len_off + p])
+                d["pseudo"].append(seq[off:off + ln].tobytes().decode("latin-1"))
+                off += ln
+        out.append(d)
+    return out
+
+
+Lib.assemble_batch = _assemble_batch
+
+
+def assembly_text(d):
+    """canonical text of oracle/ref_driver.cpp for one locus result dict (readInfo re-derived as the C++ adapter does)"""
+    lines = ["contigs %d" % len(d["contigs"])]
+    for i, c in enumerate(d["contigs"]):
+        lines.append("contig %d seq=%s seed=%d cons=%d,%d support=%s reject=%s" % (
+            i, c["seq"], c["seed"], c["cons"][0], c["cons"][1], ",".join(map(str, c["support"])), ",".join(map(str, c["reject"]))))
+    n_total = d["n_reads"] + len(d["pseudo"])
+    lines.append("reads %d normal %d" % (n_total, d["n_reads"]))
+    for r in range(n_total):
+        ids = [i for i, c in enumerate(d["contigs"]) if r in c["support"]]
+        lines.append("read %d used=%d filtered=0 pseudo=%d ids=%s" % (r, 1 if ids else 0, 1 if r >= d["n_reads"] else 0,
+                                                                       ",".join(map(str, ids))))
+    for i, p in enumerate(d["pseudo"]):
+        lines.append("pseudo %d seq=%s" % (d["n_reads"] + i, p))
+    return "\n".join(lines) + "\n"
 
 
 def align_text(kind, r):

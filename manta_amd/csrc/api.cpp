@@ -5,11 +5,14 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "align_kernels.hpp"
+#include "assemble_kernels.hpp"
+#include <unordered_map>
 #include "rt.hpp"
 
 using namespace manta_dev;
@@ -54,6 +57,9 @@ struct manta_ctx {
   int         cuCount = 0;
   // align scratch
   DevBuf dSeq, dTasks, dResults, dCigar, dTaskIds, dCounter, dPtrWs;
+  // assembler scratch
+  DevBuf aBases, aReadOff, aLocusBegin, aLoci, aContigs, aSeqArena, aBitsArena, aCounters, aWs, aGrowth;
+  std::vector<uint32_t> growthSize, growthBuckets;  // libstdc++ bucket growth schedule (see repeat_exact.hpp)
 };
 
 namespace {
@@ -111,6 +117,72 @@ void launchAlignKind(int kind, int eIdx, int grid, const AlignParams& P)
     launchAlignE<2>(eIdx, grid, P);
 }
 
+/// bucket_count() transitions of the libstdc++ this library is linked against, recorded from a live
+/// std::unordered_map (the reference's repeat search iterates such maps: assembly/IterativeAssembler.cpp:630-641)
+void recordGrowthSchedule(std::vector<uint32_t>& sizes, std::vector<uint32_t>& buckets, const uint32_t upTo)
+{
+  std::unordered_map<int, int> m;
+  size_t                       last = m.bucket_count();
+  for (uint32_t i = 0; i < upTo; ++i) {
+    m[int(i)] = 0;
+    if (m.bucket_count() != last) {
+      sizes.push_back(i);
+      buckets.push_back(uint32_t(m.bucket_count()));
+      last = m.bucket_count();
+    }
+  }
+}
+
+/// host twin of manta_dev::libstdcxxStringHash, used once per context to verify that the murmur restatement the
+/// kernels use matches the std::hash<std::string> of the libstdc++ this process runs against
+bool stringHashMatchesLibstdcxx()
+{
+  auto mix = [](uint64_t v) { return v ^ (v >> 47); };
+  const char* probes[] = {"A", "ACGTACG", "ACGTACGT", "ACGTTGCAAGCTTGACCATGGTACCAGTCAGT", "TTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTGACGATCGATCGTAGCTAGCTAGCTAGCTAGCTAGTCG"};
+  for (const char* p : probes) {
+    const std::string s(p);
+    const uint64_t    mul  = (uint64_t(0xc6a4a793UL) << 32) + uint64_t(0x5bd1e995UL);
+    uint64_t          hash = uint64_t(0xc70f6907UL) ^ (uint64_t(s.size()) * mul);
+    const size_t      al   = s.size() & ~size_t(7);
+    for (size_t i = 0; i < al; i += 8) {
+      uint64_t d = 0;
+      for (int b = 0; b < 8; ++b) d |= uint64_t(uint8_t(s[i + b])) << (8 * b);
+      d = mix(d * mul) * mul;
+      hash ^= d;
+      hash *= mul;
+    }
+    if (s.size() & 7) {
+      uint64_t d = 0;
+      for (size_t b = 0; b < (s.size() & 7); ++b) d |= uint64_t(uint8_t(s[al + b])) << (8 * b);
+      hash ^= d;
+      hash *= mul;
+    }
+    hash = mix(hash) * mul;
+    hash = mix(hash);
+    if (hash != uint64_t(std::hash<std::string>()(s))) return false;
+  }
+  return true;
+}
+
+uint32_t nextPow2(uint64_t v)
+{
+  uint64_t p = 1;
+  while (p < v) p <<= 1;
+  return uint32_t(p);
+}
+
+int asmStatusToAbi(int st)
+{
+  switch (st) {
+  case ASM_OK: return MANTA_OK;
+  case ASM_E_ALPHABET:
+  case ASM_E_WORD_TOO_LONG:
+  case ASM_E_TOO_MANY_READS: return MANTA_E_UNSUPPORTED;
+  case ASM_E_OUT_CAPACITY: return MANTA_E_CAPACITY;
+  default: return MANTA_E_DEVICE_FAULT;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -124,6 +196,10 @@ int manta_ctx_create(int device_id, manta_ctx_t** out)
   *out = nullptr;
   try {
     rt::init(device_id);
+    if (!stringHashMatchesLibstdcxx()) {
+      g_createError = "this libstdc++'s std::hash<std::string> is not the Murmur variant the exact repeat search restates";
+      return MANTA_E_UNSUPPORTED;
+    }
     manta_ctx_t* ctx = new manta_ctx();
     ctx->deviceName  = rt::deviceName();
     ctx->cuCount     = rt::cuCount();
@@ -280,6 +356,190 @@ int manta_align_batch(
     }
     if (cigar_arena_used) *cigar_arena_used = used;
     if (worst != MANTA_OK) return fail(ctx, worst, "manta_align_batch: one or more tasks failed; see per-task status");
+    return MANTA_OK;
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
+}
+
+
+int manta_assemble_batch(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, uint32_t n_loci, const uint8_t* bases, const uint64_t* read_off,
+    const uint32_t* locus_read_begin, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, uint64_t contigs_cap,
+    uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
+    uint64_t* bits_arena_used)
+{
+  if (!ctx) return MANTA_E_INVALID_ARG;
+  if (!opt || (n_loci && (!bases || !read_off || !locus_read_begin || !loci || !contigs || !seq_arena || !bits_arena)))
+    return fail(ctx, MANTA_E_INVALID_ARG, "manta_assemble_batch: null argument");
+  if (seq_arena_used) *seq_arena_used = 0;
+  if (bits_arena_used) *bits_arena_used = 0;
+  if (n_loci == 0) return MANTA_OK;
+  if (opt->min_word_length == 0 || opt->word_step_size == 0 || opt->min_coverage == 0 || opt->max_assembly_count == 0)
+    return fail(ctx, MANTA_E_INVALID_ARG, "manta_assemble_batch: word length, step, minCoverage and maxAssemblyCount must be >= 1");
+  if (opt->max_word_length > 16u * ASM_MAX_KW)
+    return fail(ctx, MANTA_E_UNSUPPORTED, "manta_assemble_batch: word lengths above 128 are not supported");
+  if (2 * opt->max_assembly_count > ASM_MAX_CAND)
+    return fail(ctx, MANTA_E_UNSUPPORTED, "manta_assemble_batch: maxAssemblyCount above 32 is not supported");
+
+  try {
+    const uint32_t nReadsTotal = locus_read_begin[n_loci];
+    const uint64_t nBases      = read_off[nReadsTotal];
+    // ---- workspace sizing from the batch shape ----
+    uint64_t maxLocusBases = 0, maxLocusWords = 0, bitsBound = 0;
+    uint32_t maxLocusReads = 0, maxReadLen = 0;
+    for (uint32_t l = 0; l < n_loci; ++l) {
+      const uint32_t rb = locus_read_begin[l], re = locus_read_begin[l + 1];
+      if (re < rb || re > nReadsTotal) return fail(ctx, MANTA_E_INVALID_ARG, "manta_assemble_batch: locus_read_begin not monotone");
+      uint64_t b = 0, w = 0;
+      for (uint32_t r = rb; r < re; ++r) {
+        if (read_off[r + 1] < read_off[r]) return fail(ctx, MANTA_E_INVALID_ARG, "manta_assemble_batch: read_off not monotone");
+        const uint64_t len = read_off[r + 1] - read_off[r];
+        b += len;
+        w += (len + 15) / 16 + 1;
+        maxReadLen = std::max<uint32_t>(maxReadLen, uint32_t(len));
+      }
+      maxLocusBases = std::max(maxLocusBases, b);
+      maxLocusWords = std::max(maxLocusWords, w);
+      maxLocusReads = std::max(maxLocusReads, re - rb);
+      const uint64_t W = ((re - rb) + 2 * opt->max_assembly_count + 63) / 64;
+      bitsBound += uint64_t(opt->max_assembly_count) * 2 * W + 2 * opt->max_assembly_count;
+    }
+    const uint32_t nCandMax     = 2 * opt->max_assembly_count;
+    const uint32_t wMax         = uint32_t((maxLocusReads + nCandMax + 63) / 64);
+    if (wMax > ASM_MAX_W) return fail(ctx, MANTA_E_UNSUPPORTED, "manta_assemble_batch: more than ~1000 reads in one locus");
+    const uint32_t maxContigLen = uint32_t(std::min<uint64_t>(maxLocusBases, 32768) + opt->max_word_length + 16);
+    const uint64_t pseudoLen    = std::min<uint64_t>(maxContigLen, 3ull * maxReadLen + opt->max_word_length);
+    const uint64_t pseudoBases  = uint64_t(nCandMax) * pseudoLen;
+    const uint32_t capWords     = uint32_t(maxLocusWords + pseudoBases / 16 + 2 * nCandMax + 8);
+    const uint32_t capReads     = maxLocusReads + nCandMax + 1;
+    const uint32_t capNodes     = uint32_t(maxLocusBases + pseudoBases + 64);
+    const uint32_t capSlots     = nextPow2(2ull * capNodes);
+    const AsmWsLayout L = asmWorkspaceLayout(capSlots, capNodes, capWords, capReads, maxContigLen, wMax, opt->max_assembly_count);
+    const uint64_t stride = (L.total + 255) & ~uint64_t(255);
+
+    const size_t wsBudget = std::min<size_t>(rt::freeBytes() / 2, size_t(64) << 30);
+    int          grid     = int(std::min<uint64_t>(n_loci, uint64_t(std::max(1, ctx->cuCount * 8))));
+    grid                  = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(grid), wsBudget / stride)));
+
+    // device-side output arenas
+    const uint64_t devSeqCap  = uint64_t(n_loci) * std::min<uint64_t>(3ull * opt->max_assembly_count * pseudoLen, 65536) + 4096;
+    const uint64_t devBitsCap = bitsBound + 64;
+
+    if (ctx->growthSize.empty()) recordGrowthSchedule(ctx->growthSize, ctx->growthBuckets, 4u << 20);
+
+    uint8_t*        dBases  = ctx->aBases.as<uint8_t>(nBases + 16);
+    uint64_t*       dOff    = ctx->aReadOff.as<uint64_t>(nReadsTotal + 1);
+    uint32_t*       dBegin  = ctx->aLocusBegin.as<uint32_t>(n_loci + 1);
+    AsmLocusOut*    dLoci   = ctx->aLoci.as<AsmLocusOut>(n_loci);
+    AsmContigOut*   dCont   = ctx->aContigs.as<AsmContigOut>(uint64_t(n_loci) * opt->max_assembly_count);
+    uint8_t*        dSeq    = ctx->aSeqArena.as<uint8_t>(devSeqCap);
+    uint64_t*       dBits   = ctx->aBitsArena.as<uint64_t>(devBitsCap);
+    uint64_t*       dCnt    = ctx->aCounters.as<uint64_t>(4);
+    uint8_t*        dWs     = ctx->aWs.as<uint8_t>(stride * grid);
+    uint32_t*       dGrowth = ctx->aGrowth.as<uint32_t>(2 * ctx->growthSize.size() + 2);
+    rt::h2d(dBases, bases, nBases);
+    rt::h2d(dOff, read_off, sizeof(uint64_t) * (nReadsTotal + 1));
+    rt::h2d(dBegin, locus_read_begin, sizeof(uint32_t) * (n_loci + 1));
+    rt::h2d(dGrowth, ctx->growthSize.data(), sizeof(uint32_t) * ctx->growthSize.size());
+    rt::h2d(dGrowth + ctx->growthSize.size(), ctx->growthBuckets.data(), sizeof(uint32_t) * ctx->growthBuckets.size());
+    rt::dzero(dCnt, sizeof(uint64_t) * 4);
+    rt::dfill(dLoci, 0xff, sizeof(AsmLocusOut) * n_loci);
+
+    AsmParams P;
+    P.bases            = dBases;
+    P.read_off         = dOff;
+    P.locus_read_begin = dBegin;
+    P.n_loci           = n_loci;
+    P.opt = AsmOptsDev{opt->min_word_length, opt->max_word_length, opt->word_step_size, opt->min_coverage,
+                       opt->min_conservative_coverage, opt->min_unused_reads, opt->min_support_reads, opt->max_assembly_count};
+    P.counter        = reinterpret_cast<uint32_t*>(dCnt);
+    P.ws             = dWs;
+    P.ws_stride      = stride;
+    P.cap_slots      = capSlots;
+    P.cap_nodes      = capNodes;
+    P.cap_words      = capWords;
+    P.cap_reads      = capReads;
+    P.max_contig_len = maxContigLen;
+    P.w_max          = wMax;
+    P.loci           = dLoci;
+    P.contigs        = dCont;
+    P.seq_arena      = dSeq;
+    P.seq_cap        = devSeqCap;
+    P.seq_used       = reinterpret_cast<unsigned long long*>(dCnt + 1);
+    P.bits_arena     = dBits;
+    P.bits_cap       = devBitsCap;
+    P.bits_used      = reinterpret_cast<unsigned long long*>(dCnt + 2);
+    P.growth_size    = dGrowth;
+    P.growth_buckets = dGrowth + ctx->growthSize.size();
+    P.n_growth       = uint32_t(ctx->growthSize.size());
+    rt::launch(assemble_kernel, grid, 0, P);
+    rt::sync();
+
+    // ---- fetch ----
+    std::vector<AsmLocusOut>  hLoci(n_loci);
+    std::vector<AsmContigOut> hCont(uint64_t(n_loci) * opt->max_assembly_count);
+    uint64_t                  hCnt[4];
+    rt::d2h(hCnt, dCnt, sizeof(hCnt));
+    rt::d2h(hLoci.data(), dLoci, sizeof(AsmLocusOut) * n_loci);
+    rt::d2h(hCont.data(), dCont, sizeof(AsmContigOut) * hCont.size());
+    const uint64_t seqUsedDev = std::min<uint64_t>(hCnt[1], devSeqCap), bitsUsedDev = std::min<uint64_t>(hCnt[2], devBitsCap);
+    std::vector<uint8_t>  hSeq(seqUsedDev + 1);
+    std::vector<uint64_t> hBits(bitsUsedDev + 1);
+    rt::d2h(hSeq.data(), dSeq, seqUsedDev);
+    rt::d2h(hBits.data(), dBits, sizeof(uint64_t) * bitsUsedDev);
+
+    uint64_t seqUsed = 0, bitsUsed = 0, nContigs = 0;
+    int      worst = MANTA_OK;
+    for (uint32_t l = 0; l < n_loci; ++l) {
+      const AsmLocusOut&        h(hLoci[l]);
+      manta_asm_locus_result_t& o(loci[l]);
+      std::memset(&o, 0, sizeof(o));
+      o.status       = asmStatusToAbi(h.status);
+      o.first_contig = uint32_t(nContigs);
+      if (o.status != MANTA_OK) {
+        worst = o.status;
+        if (std::getenv("MANTA_AMD_DEBUG")) std::fprintf(stderr, "manta_amd: locus %u device status %d (k=%u iter=%u)\n", l, h.status, h.final_word_length, h.n_iterations);
+        continue;
+      }
+      o.n_contigs         = h.n_contigs;
+      o.n_words           = h.n_words;
+      o.n_pseudo          = h.n_pseudo;
+      o.final_word_length = h.final_word_length;
+      o.n_iterations      = h.n_iterations;
+      o.cyclic_iterations = h.cyclic_iterations;
+      if (nContigs + h.n_contigs > contigs_cap) return fail(ctx, MANTA_E_CAPACITY, "manta_assemble_batch: contig array too small");
+      for (uint32_t c = 0; c < h.n_contigs; ++c) {
+        const AsmContigOut& hc(hCont[uint64_t(l) * opt->max_assembly_count + c]);
+        manta_asm_contig_t& oc(contigs[nContigs++]);
+        if (seqUsed + hc.seq_len > seq_arena_cap || bitsUsed + 2ull * h.n_words > bits_arena_cap)
+          return fail(ctx, MANTA_E_CAPACITY, "manta_assemble_batch: output arena too small");
+        std::memcpy(seq_arena + seqUsed, hSeq.data() + hc.seq_off, hc.seq_len);
+        std::memcpy(bits_arena + bitsUsed, hBits.data() + hc.bits_off, sizeof(uint64_t) * 2 * h.n_words);
+        oc.seq_off            = seqUsed;
+        oc.seq_len            = hc.seq_len;
+        oc.support_off        = bitsUsed;
+        oc.reject_off         = bitsUsed + h.n_words;
+        oc.seed_read_count    = 0;
+        oc.conservative_begin = hc.cons_begin;
+        oc.conservative_end   = hc.cons_end;
+        seqUsed += hc.seq_len;
+        bitsUsed += 2ull * h.n_words;
+      }
+      uint64_t pBytes = 0;
+      for (uint32_t p = 0; p < h.n_pseudo; ++p) pBytes += hBits[h.pseudo_len_off + p];
+      if (seqUsed + pBytes > seq_arena_cap || bitsUsed + h.n_pseudo > bits_arena_cap)
+        return fail(ctx, MANTA_E_CAPACITY, "manta_assemble_batch: output arena too small");
+      std::memcpy(seq_arena + seqUsed, hSeq.data() + h.pseudo_off, pBytes);
+      std::memcpy(bits_arena + bitsUsed, hBits.data() + h.pseudo_len_off, sizeof(uint64_t) * h.n_pseudo);
+      o.pseudo_seq_off = seqUsed;
+      o.pseudo_len_off = bitsUsed;
+      seqUsed += pBytes;
+      bitsUsed += h.n_pseudo;
+    }
+    if (seq_arena_used) *seq_arena_used = seqUsed;
+    if (bits_arena_used) *bits_arena_used = bitsUsed;
+    if (worst != MANTA_OK) return fail(ctx, worst, "manta_assemble_batch: one or more loci failed; see per-locus status");
     return MANTA_OK;
   } catch (const std::exception& e) {
     return fail(ctx, MANTA_E_HIP, e.what());

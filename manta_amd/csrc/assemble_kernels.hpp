@@ -1,0 +1,1095 @@
+// HIP kernel (gfx950) for Manta's iterative de Bruijn contig assembler
+//   runIterativeAssembler            assembly/IterativeAssembler.cpp:844-931
+//     buildContigs                   :644-720   (getKmerCounts :506-550, getRepeatKmers :627-642, walk :149-501)
+//     selectContigs                  :722-842
+// (paths relative to /root/reference/src/c++/lib).
+//
+// Mapping to the hardware: ONE 64-lane wavefront per candidate locus, pulled from an atomic work queue.
+// The reference's three string-keyed hash maps and its std::set<unsigned> algebra become
+//   * a 2-bit packed read pile (16 bases / dword, MSB first so dword order == lexicographic order) + N bitmap,
+//   * an open-addressing table of distinct k-mers keyed by "packed base index of the first occurrence"
+//     (lanes insert all k-mer instances of a read in parallel, one atomicCAS each),
+//   * dense node arrays: read-support BITSETS (W = ceil((reads+pseudo)/64) qwords, lane w owns word w),
+//     counts, and precomputed successor / predecessor links (8 table lookups per node, lanes over nodes), so
+//     that the serial greedy walk touches no keys at all: every extension step is 2 link loads + <=7 bitset
+//     loads + a handful of and/or/popcount lane ops.
+// Everything between the packed input and the selected contigs stays on the device.
+//
+// Repeat k-mers: homopolymer words are found from self links.  Whether the k-mer graph has any other cycle is
+// decided by a wave-parallel in-degree peel (Kahn); if it has none (the normal case for k >= 25) the
+// reference's DFS cannot mark anything else.  For cyclic graphs the reference's result depends on libstdc++'s
+// unordered_map iteration order (SURVEY.md hard part 1); that order is re-derived on the device
+// (repeat_exact.hpp) and the same DFS is replayed by one lane.
+#pragma once
+#include "wave.hpp"
+
+namespace manta_dev {
+
+enum {
+  ASM_OK               = 0,
+  ASM_E_ALPHABET       = 1,  // read contains a byte outside {A,C,G,T,N}
+  ASM_E_TABLE_FULL     = 2,  // more k-mer instances / nodes than the workspace was sized for
+  ASM_E_CONTIG_TOO_LONG = 3,
+  ASM_E_OUT_CAPACITY   = 4,  // output arenas exhausted
+  ASM_E_WORD_TOO_LONG  = 5,  // word length > 128
+  ASM_E_TOO_MANY_READS = 6,
+  ASM_E_INTERNAL       = 7
+};
+
+static const unsigned ASM_NONE     = 0xffffffffu;
+static const int      ASM_MAX_KW   = 8;    // k <= 128
+static const unsigned ASM_MAX_W    = 16;   // <= 1024 reads incl. pseudo reads
+static const unsigned ASM_MAX_CAND = 64;   // 2*maxAssemblyCount must not exceed this
+
+struct AsmOptsDev {
+  uint32_t minWordLength, maxWordLength, wordStepSize, minCoverage, minConservativeCoverage, minUnusedReads,
+      minSupportReads, maxAssemblyCount;
+};
+
+struct AsmContigOut {
+  uint64_t seq_off;   ///< into seq_arena
+  uint64_t bits_off;  ///< into bits_arena: W words support, then W words reject
+  uint32_t seq_len;
+  int32_t  cons_begin, cons_end;
+  uint32_t reserved;
+};
+
+struct AsmLocusOut {
+  int32_t  status;
+  uint32_t n_contigs;
+  uint32_t n_words;        ///< W: qwords per bitset
+  uint32_t n_pseudo;       ///< pseudo reads left appended to `reads` on return
+  uint64_t pseudo_off;     ///< into seq_arena: n_pseudo sequences back to back
+  uint64_t pseudo_len_off; ///< into bits_arena: n_pseudo lengths (one qword each)
+  uint32_t final_word_length;
+  uint32_t n_iterations;
+  uint32_t cyclic_iterations;  ///< iterations that needed the exact (order-emulating) repeat search
+  uint32_t reserved;
+};
+
+struct AsmParams {
+  const uint8_t*      bases;
+  const uint64_t*     read_off;          ///< n_reads_total + 1
+  const uint32_t*     locus_read_begin;  ///< n_loci + 1
+  uint32_t            n_loci;
+  AsmOptsDev          opt;
+  uint32_t*           counter;
+  uint8_t*            ws;
+  uint64_t            ws_stride;
+  // workspace capacities (identical for every workgroup)
+  uint32_t cap_slots;       ///< power of two
+  uint32_t cap_nodes;
+  uint32_t cap_words;       ///< packed code dwords (16 bases each) incl. pseudo reads and padding
+  uint32_t cap_reads;       ///< normal + pseudo
+  uint32_t max_contig_len;
+  uint32_t w_max;           ///< bitset qwords the workspace is sized for
+  // outputs
+  AsmLocusOut*        loci;
+  AsmContigOut*       contigs;  ///< n_loci * opt.maxAssemblyCount
+  uint8_t*            seq_arena;
+  uint64_t            seq_cap;
+  unsigned long long* seq_used;
+  uint64_t*           bits_arena;
+  uint64_t            bits_cap;
+  unsigned long long* bits_used;
+  // libstdc++ bucket growth schedule for the exact repeat search (host records it from the live library)
+  const uint32_t* growth_size;     ///< map.size() right before the insertion that rehashes
+  const uint32_t* growth_buckets;  ///< bucket count after it
+  uint32_t        n_growth;
+};
+
+// --------------------------------------------------------------------------------------------------
+// per-workgroup workspace carve (host and device agree through asmWorkspaceLayout)
+// --------------------------------------------------------------------------------------------------
+struct AsmWsLayout {
+  uint64_t codes, nmask, rd_cw, rd_mw, rd_len, slots, slot_id, inst_slot, node_key, node_cnt, node_flag, node_aux, node_sup,
+      succ, pred, frontier, cand_seq, cand_bits, cand_meta, walk_left, walk_right, pseudo_seq, pseudo_len, exact, total;
+};
+
+WV_HD uint64_t asmAlign16(uint64_t v)
+{
+  return (v + 15) & ~uint64_t(15);
+}
+
+WV_HD uint64_t asmPut(uint64_t& cursor, const uint64_t bytes)
+{
+  const uint64_t at = cursor;
+  cursor            = asmAlign16(cursor + bytes);
+  return at;
+}
+
+WV_HD AsmWsLayout asmWorkspaceLayout(
+    const uint32_t cap_slots, const uint32_t cap_nodes, const uint32_t cap_words, const uint32_t cap_reads,
+    const uint32_t max_contig_len, const uint32_t w_max, const uint32_t maxAssemblyCount)
+{
+  AsmWsLayout    L;
+  uint64_t       o     = 0;
+  const uint64_t nCand = 2ull * maxAssemblyCount;
+  L.codes      = asmPut(o, 4ull * (cap_words + 2));
+  L.nmask      = asmPut(o, 4ull * (cap_words / 2 + cap_reads + 8));
+  L.rd_cw      = asmPut(o, 4ull * (cap_reads + 1));
+  L.rd_mw      = asmPut(o, 4ull * (cap_reads + 1));
+  L.rd_len     = asmPut(o, 4ull * (cap_reads + 1));
+  L.slots      = asmPut(o, 4ull * cap_slots);
+  L.slot_id    = asmPut(o, 4ull * cap_slots);
+  L.inst_slot  = asmPut(o, 4ull * 16 * (cap_words + 2));
+  L.node_key   = asmPut(o, 4ull * cap_nodes);
+  L.node_cnt   = asmPut(o, 4ull * cap_nodes);
+  L.node_flag  = asmPut(o, 4ull * cap_nodes);
+  L.node_aux   = asmPut(o, 4ull * cap_nodes);
+  L.node_sup   = asmPut(o, 8ull * cap_nodes * w_max);
+  L.succ       = asmPut(o, 16ull * cap_nodes);
+  L.pred       = asmPut(o, 16ull * cap_nodes);
+  L.frontier   = asmPut(o, 8ull * cap_nodes + 256);
+  L.cand_seq   = asmPut(o, nCand * max_contig_len);
+  L.cand_bits  = asmPut(o, nCand * 2 * 8ull * w_max);
+  L.cand_meta  = asmPut(o, nCand * 16);
+  L.walk_left  = asmPut(o, max_contig_len);
+  L.walk_right = asmPut(o, max_contig_len);
+  L.pseudo_seq = asmPut(o, nCand * max_contig_len);
+  L.pseudo_len = asmPut(o, nCand * 4);
+  L.exact      = asmPut(o, 4ull * (14ull * cap_nodes + 256));
+  L.total      = asmAlign16(o);
+  return L;
+}
+
+// node_flag bits
+static const unsigned NF_UNUSED = 1u;   // still eligible as a seed ("unusedWords", :678-682)
+static const unsigned NF_REPEAT = 2u;   // member of repeatWords
+// bits 8.. : serial of the last contig that used the word ("wordsInContig", :182)
+
+WV_DEV unsigned baseCode(const uint8_t c)
+{
+  return (c == 'A') ? 0u : (c == 'C') ? 1u : (c == 'G') ? 2u : (c == 'T') ? 3u : (c == 'N') ? 4u : 5u;
+}
+
+WV_DEV uint32_t hashMix(uint32_t h, const uint32_t v)
+{
+  h ^= v;
+  h *= 0x9E3779B1u;
+  h ^= h >> 15;
+  return h;
+}
+
+template <int KW>
+struct Key {
+  uint32_t w[KW];
+};
+
+struct Assembler {
+  const AsmParams& P;
+  uint8_t*         ws;
+  AsmWsLayout      L;
+  // workspace views
+  uint32_t *codes, *nmask, *rd_cw, *rd_mw, *rd_len, *slots, *slot_id, *inst_slot, *node_key, *node_cnt, *node_flag, *node_aux;
+  uint64_t* node_sup;
+  uint32_t *succ, *pred, *frontier;
+  uint8_t * cand_seq, *walk_left, *walk_right, *pseudo_seq;
+  uint64_t* cand_bits;
+  int32_t*  cand_meta;  // per candidate: len, consBegin, consEnd, pad
+  uint32_t* pseudo_len;
+  uint32_t* exact_ws;
+  // per-locus state (wave-uniform)
+  unsigned nNormal, nReads, W, k, nNodes, nCodeWordsNormal, nMaskWordsNormal, nCand;
+  unsigned codeWordsUsed, maskWordsUsed;
+  int      status;
+  unsigned cyclicIters;
+
+  WV_DEV Assembler(const AsmParams& p, uint8_t* wsBase) : P(p), ws(wsBase)
+  {
+    L = asmWorkspaceLayout(p.cap_slots, p.cap_nodes, p.cap_words, p.cap_reads, p.max_contig_len, p.w_max, p.opt.maxAssemblyCount);
+    codes      = reinterpret_cast<uint32_t*>(ws + L.codes);
+    nmask      = reinterpret_cast<uint32_t*>(ws + L.nmask);
+    rd_cw      = reinterpret_cast<uint32_t*>(ws + L.rd_cw);
+    rd_mw      = reinterpret_cast<uint32_t*>(ws + L.rd_mw);
+    rd_len     = reinterpret_cast<uint32_t*>(ws + L.rd_len);
+    slots      = reinterpret_cast<uint32_t*>(ws + L.slots);
+    slot_id    = reinterpret_cast<uint32_t*>(ws + L.slot_id);
+    inst_slot  = reinterpret_cast<uint32_t*>(ws + L.inst_slot);
+    node_key   = reinterpret_cast<uint32_t*>(ws + L.node_key);
+    node_cnt   = reinterpret_cast<uint32_t*>(ws + L.node_cnt);
+    node_flag  = reinterpret_cast<uint32_t*>(ws + L.node_flag);
+    node_aux   = reinterpret_cast<uint32_t*>(ws + L.node_aux);
+    node_sup   = reinterpret_cast<uint64_t*>(ws + L.node_sup);
+    succ       = reinterpret_cast<uint32_t*>(ws + L.succ);
+    pred       = reinterpret_cast<uint32_t*>(ws + L.pred);
+    frontier   = reinterpret_cast<uint32_t*>(ws + L.frontier);
+    cand_seq   = ws + L.cand_seq;
+    cand_bits  = reinterpret_cast<uint64_t*>(ws + L.cand_bits);
+    cand_meta  = reinterpret_cast<int32_t*>(ws + L.cand_meta);
+    walk_left  = ws + L.walk_left;
+    walk_right = ws + L.walk_right;
+    pseudo_seq = ws + L.pseudo_seq;
+    pseudo_len = reinterpret_cast<uint32_t*>(ws + L.pseudo_len);
+    exact_ws   = reinterpret_cast<uint32_t*>(ws + L.exact);
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // wave helpers (all lanes must call)
+  // ------------------------------------------------------------------------------------------------
+  WV_DEV static unsigned waveSum(unsigned v)
+  {
+    for (int off = 1; off < 64; off <<= 1) v += wv::shfl(v, wv::lane() ^ off);
+    return v;
+  }
+  WV_DEV static unsigned waveMax(unsigned v)
+  {
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = wv::shfl(v, wv::lane() ^ off);
+      v                = (o > v) ? o : v;
+    }
+    return v;
+  }
+  WV_DEV static uint64_t waveSum64(uint64_t v)
+  {
+    for (int off = 1; off < 64; off <<= 1) v += wv::shfl(v, wv::lane() ^ off);
+    return v;
+  }
+  WV_DEV static bool waveAny64(const uint64_t v) { return wv::any(v != 0); }
+
+  // ------------------------------------------------------------------------------------------------
+  // packed reads
+  // ------------------------------------------------------------------------------------------------
+  /// 16 bases starting at packed base index pb, MSB first
+  WV_DEV uint32_t codes16(const unsigned pb) const
+  {
+    const unsigned wi = pb >> 4, sh = (pb & 15) * 2;
+    const uint32_t a = codes[wi];
+    if (sh == 0) return a;
+    return (a << sh) | (codes[wi + 1] >> (32 - sh));
+  }
+
+  template <int KW>
+  WV_DEV Key<KW> keyAt(const unsigned pb) const
+  {
+    Key<KW>        key;
+    const unsigned kw = (k + 15) >> 4;
+    for (int i = 0; i < KW; ++i) {
+      uint32_t v = 0;
+      if (unsigned(i) < kw) {
+        v                   = codes16(pb + 16u * unsigned(i));
+        const unsigned have = k - 16u * unsigned(i);  // bases that belong to the word in this dword
+        if (have < 16) v &= ~((1u << (32 - 2 * have)) - 1u);
+      }
+      key.w[i] = v;
+    }
+    return key;
+  }
+
+  template <int KW>
+  WV_DEV static uint32_t keyHash(const Key<KW>& key)
+  {
+    uint32_t h = 0x811C9DC5u;
+    for (int i = 0; i < KW; ++i) h = hashMix(h, key.w[i]);
+    h ^= h >> 13;
+    return h;
+  }
+  template <int KW>
+  WV_DEV static bool keyEq(const Key<KW>& a, const Key<KW>& b)
+  {
+    bool eq = true;
+    for (int i = 0; i < KW; ++i) eq = eq && (a.w[i] == b.w[i]);
+    return eq;
+  }
+  /// lexicographic a < b (dword order == base order because bases are packed MSB first)
+  template <int KW>
+  WV_DEV static bool keyLess(const Key<KW>& a, const Key<KW>& b)
+  {
+    for (int i = 0; i < KW; ++i) {
+      if (a.w[i] != b.w[i]) return a.w[i] < b.w[i];
+    }
+    return false;
+  }
+  template <int KW>
+  WV_DEV void keySetBase(Key<KW>& key, const unsigned i, const unsigned c) const
+  {
+    const unsigned sh = 30 - 2 * (i & 15);
+    for (int w = 0; w < KW; ++w)
+      if (unsigned(w) == (i >> 4)) key.w[w] = (key.w[w] & ~(3u << sh)) | (c << sh);
+  }
+  /// word[1..k-1] + c
+  template <int KW>
+  WV_DEV Key<KW> keyShiftAppend(const Key<KW>& key, const unsigned c) const
+  {
+    Key<KW> r;
+    for (int w = 0; w < KW; ++w) r.w[w] = (key.w[w] << 2) | ((w + 1 < KW) ? (key.w[w + 1] >> 30) : 0u);
+    keySetBase(r, k - 1, c);
+    return r;
+  }
+  /// c + word[0..k-2]
+  template <int KW>
+  WV_DEV Key<KW> keyShiftPrepend(const Key<KW>& key, const unsigned c) const
+  {
+    Key<KW> r;
+    for (int w = 0; w < KW; ++w) r.w[w] = (key.w[w] >> 2) | ((w > 0) ? (key.w[w - 1] << 30) : 0u);
+    // drop the base that moved to position k
+    const unsigned kw = (k + 15) >> 4;
+    for (int w = 0; w < KW; ++w) {
+      if (unsigned(w) >= kw) {
+        r.w[w] = 0;
+      } else if (unsigned(w) == kw - 1) {
+        const unsigned have = k - 16u * unsigned(w);
+        if (have < 16) r.w[w] &= ~((1u << (32 - 2 * have)) - 1u);
+      }
+    }
+    keySetBase(r, 0, c);
+    return r;
+  }
+
+  /// does [j, j+k) of read r contain an 'N' ?
+  WV_DEV bool windowHasN(const unsigned maskWordBase, const unsigned j) const
+  {
+    unsigned pos = j, left = k;
+    while (left > 0) {
+      const unsigned wi = pos >> 5, bit = pos & 31;
+      const unsigned take = (32 - bit < left) ? (32 - bit) : left;
+      uint32_t       m    = nmask[maskWordBase + wi] >> bit;
+      if (take < 32) m &= (1u << take) - 1u;
+      if (m) return true;
+      pos += take;
+      left -= take;
+    }
+    return false;
+  }
+
+  /// node id of the k-mer `key`, or ASM_NONE
+  template <int KW>
+  WV_DEV unsigned lookup(const Key<KW>& key) const
+  {
+    const unsigned mask = P.cap_slots - 1;
+    unsigned       s    = keyHash(key) & mask;
+    for (unsigned probe = 0; probe < P.cap_slots; ++probe) {
+      const uint32_t cur = slots[s];
+      if (cur == ASM_NONE) return ASM_NONE;
+      if (keyEq(keyAt<KW>(cur), key)) return slot_id[s];
+      s = (s + 1) & mask;
+    }
+    return ASM_NONE;
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // stage 0: pack this locus' reads (bytes -> 2 bit + N bitmap).  Coalesced: lane i converts 16 bases.
+  // ------------------------------------------------------------------------------------------------
+  WV_DEV void packNormalReads(const unsigned locus)
+  {
+    const unsigned rBegin = P.locus_read_begin[locus], rEnd = P.locus_read_begin[locus + 1];
+    nNormal               = rEnd - rBegin;
+    status                = ASM_OK;
+    if (nNormal + 2 * P.opt.maxAssemblyCount > P.cap_reads || nNormal + 2 * P.opt.maxAssemblyCount > 64 * P.w_max) {
+      status = ASM_E_TOO_MANY_READS;
+      return;
+    }
+    // word offsets: serial prefix by lane 0 would be slow for 1000 reads -> chunked scan
+    unsigned cw = 0, mw = 0;
+    for (unsigned base = 0; base < nNormal; base += 64) {
+      const unsigned r   = base + unsigned(wv::lane());
+      unsigned       len = 0;
+      if (r < nNormal) len = unsigned(P.read_off[rBegin + r + 1] - P.read_off[rBegin + r]);
+      const unsigned myC = (r < nNormal) ? (len + 15) / 16 + 1 : 0u;  // +1 padding dword so codes16() may read one past
+      const unsigned myM = (r < nNormal) ? (len + 31) / 32 + 1 : 0u;
+      // inclusive scan over lanes
+      unsigned sc = myC, sm = myM;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned oc = wv::shfl(sc, wv::lane() - off), om = wv::shfl(sm, wv::lane() - off);
+        if (wv::lane() >= off) {
+          sc += oc;
+          sm += om;
+        }
+      }
+      if (r < nNormal) {
+        rd_cw[r]               = cw + sc - myC;
+        rd_len[r]              = len;
+        rd_mw[r]               = mw + sm - myM;
+      }
+      cw += wv::readlane(sc, 63);
+      mw += wv::readlane(sm, 63);
+    }
+    if (cw + 2 > P.cap_words || mw + 2 > maskWordCap()) {
+      status = ASM_E_TABLE_FULL;
+      return;
+    }
+    nCodeWordsNormal = cw;
+    nMaskWordsNormal = mw;
+    wv::sync();
+    bool badAlphabet = false;
+    for (unsigned r = 0; r < nNormal; ++r) {
+      const uint8_t* src = P.bases + P.read_off[rBegin + r];
+      const unsigned len = rd_len[r], cwo = rd_cw[r], mwo = rd_mw[r];
+      const unsigned nCw = (len + 15) / 16 + 1;
+      for (unsigned wi = unsigned(wv::lane()); wi < nCw; wi += 64) {
+        uint32_t code = 0, nbits = 0;
+        for (unsigned b = 0; b < 16; ++b) {
+          const unsigned i = wi * 16 + b;
+          unsigned       c = 0;
+          if (i < len) {
+            c = baseCode(src[i]);
+            if (c == 5) badAlphabet = true;
+            if (c >= 4) {
+              nbits |= (1u << b);
+              c = 0;
+            }
+          }
+          code |= c << (30 - 2 * b);
+        }
+        codes[cwo + wi] = code;
+        // two code dwords share one mask dword
+        uint32_t* mp = &nmask[mwo + (wi >> 1)];
+        if (wi & 1)
+          wv::atomic_or(mp, nbits << 16);
+        else
+          wv::atomic_or(mp, nbits);
+      }
+    }
+    if (wv::any(badAlphabet)) status = ASM_E_ALPHABET;
+  }
+
+  WV_DEV unsigned maskWordCap() const { return P.cap_words / 2 + P.cap_reads + 2; }
+
+  // ------------------------------------------------------------------------------------------------
+  // k-mer graph for the current word length
+  // ------------------------------------------------------------------------------------------------
+  template <int KW>
+  WV_DEV void buildGraph()
+  {
+    const unsigned lane = unsigned(wv::lane());
+    for (unsigned s = lane; s < P.cap_slots; s += 64) slots[s] = ASM_NONE;
+    wv::sync();
+
+    // pass 1: distinct k-mers (assembly/IterativeAssembler.cpp:516-534); per-read de-dup is implicit (sets)
+    bool full = false;
+    const unsigned mask = P.cap_slots - 1;
+    for (unsigned r = 0; r < nReads; ++r) {
+      const unsigned len = rd_len[r];
+      if (len < k) continue;  // :522
+      const unsigned cwo = rd_cw[r], mwo = rd_mw[r];
+      for (unsigned j = lane; j + k <= len; j += 64) {
+        const unsigned pb = cwo * 16 + j;
+        unsigned       slot = ASM_NONE;
+        if (!windowHasN(mwo, j)) {  // :531
+          const Key<KW> key = keyAt<KW>(pb);
+          unsigned      s   = keyHash(key) & mask;
+          for (unsigned probe = 0; probe < P.cap_slots; ++probe) {
+            uint32_t cur = slots[s];
+            if (cur == ASM_NONE) {
+              cur = wv::atomic_cas(&slots[s], ASM_NONE, pb);
+              if (cur == ASM_NONE) {
+                slot = s;
+                break;
+              }
+            }
+            if (keyEq(keyAt<KW>(cur), key)) {
+              slot = s;
+              break;
+            }
+            s = (s + 1) & mask;
+          }
+          if (slot == ASM_NONE) full = true;
+        }
+        inst_slot[pb] = slot;
+      }
+    }
+    wv::sync();
+    wv::fence_acquire();  // slots[] was filled by L2 atomics: drop any stale L1 lines before plain re-reads
+    if (wv::any(full)) {
+      status = ASM_E_TABLE_FULL;
+      return;
+    }
+
+    // pass 2: dense node ids
+    unsigned n = 0;
+    for (unsigned base = 0; base < P.cap_slots; base += 64) {
+      const unsigned s   = base + lane;
+      const uint32_t pb  = slots[s];
+      const bool     occ = (pb != ASM_NONE);
+      const uint64_t m   = wv::ballot(occ);
+      const unsigned id  = n + unsigned(wv::popc(m & ((uint64_t(1) << lane) - 1)));
+      if (occ && id < P.cap_nodes) {
+        slot_id[s]   = id;
+        node_key[id] = pb;
+      }
+      n += unsigned(wv::popc(m));
+    }
+    nNodes = n;
+    if (nNodes > P.cap_nodes) {
+      status = ASM_E_TABLE_FULL;
+      return;
+    }
+    for (unsigned i = lane; i < nNodes * W; i += 64) node_sup[i] = 0;
+    wv::sync();
+
+    // pass 3: supporting reads (:544-548)
+    for (unsigned r = 0; r < nReads; ++r) {
+      const unsigned len = rd_len[r];
+      if (len < k) continue;
+      const unsigned cwo = rd_cw[r];
+      const uint64_t bit = uint64_t(1) << (r & 63);
+      for (unsigned j = lane; j + k <= len; j += 64) {
+        const unsigned s = inst_slot[cwo * 16 + j];
+        if (s != ASM_NONE) wv::atomic_or(reinterpret_cast<unsigned long long*>(&node_sup[size_t(slot_id[s]) * W + (r >> 6)]), bit);
+      }
+    }
+    wv::sync();
+    wv::fence_acquire();
+
+    // counts (:541-545: a pseudo read weighs minCoverage), seed eligibility (:679-682), links
+    for (unsigned nd = lane; nd < nNodes; nd += 64) {
+      unsigned cnt = 0;
+      for (unsigned w = 0; w < W; ++w) {
+        const uint64_t s = node_sup[size_t(nd) * W + w];
+        cnt += unsigned(wv::popc(s & normalMask(w))) + P.opt.minCoverage * unsigned(wv::popc(s & ~normalMask(w)));
+      }
+      node_cnt[nd]  = cnt;
+      const Key<KW> key = keyAt<KW>(node_key[nd]);
+      bool          selfLoop = false;
+      unsigned      indeg    = 0;
+      for (unsigned c = 0; c < 4; ++c) {
+        const unsigned s = lookup<KW>(keyShiftAppend<KW>(key, c));
+        const unsigned p = lookup<KW>(keyShiftPrepend<KW>(key, c));
+        succ[nd * 4 + c] = s;
+        pred[nd * 4 + c] = p;
+        if (s == nd) selfLoop = true;  // homopolymer (:574-577)
+        if (p != ASM_NONE && p != nd) indeg++;
+      }
+      node_flag[nd] = ((cnt >= P.opt.minCoverage) ? NF_UNUSED : 0u) | (selfLoop ? NF_REPEAT : 0u);
+      node_aux[nd]  = indeg;
+    }
+    wv::sync();
+  }
+
+  WV_DEV uint64_t normalMask(const unsigned w) const
+  {
+    const unsigned lo = w * 64;
+    if (nNormal >= lo + 64) return ~uint64_t(0);
+    if (nNormal <= lo) return 0;
+    return (uint64_t(1) << (nNormal - lo)) - 1;
+  }
+
+  /// true if the k-mer graph (self loops ignored) has a directed cycle.  Wave-parallel Kahn peel on node_aux.
+  WV_DEV bool graphHasCycle()
+  {
+    const unsigned lane = unsigned(wv::lane());
+    uint32_t*      cur  = frontier;
+    uint32_t*      nxt  = frontier + P.cap_nodes;
+    // the two frontier counters live in exact_ws[0..1]
+    uint32_t* cnt = exact_ws;
+    if (lane == 0) {
+      cnt[0] = 0;
+      cnt[1] = 0;
+    }
+    wv::sync();
+    for (unsigned nd = lane; nd < nNodes; nd += 64) {
+      if (node_aux[nd] == 0) cur[wv::atomic_add(&cnt[0], 1u)] = nd;
+    }
+    wv::sync();
+    unsigned removed = 0;
+    unsigned which   = 0;
+    while (true) {
+      const unsigned nCur = wv::first(wv::atomic_load(&cnt[which]));
+      if (nCur == 0) break;
+      removed += nCur;
+      for (unsigned i = lane; i < nCur; i += 64) {
+        const unsigned nd = cur[i];
+        for (unsigned c = 0; c < 4; ++c) {
+          const unsigned s = succ[nd * 4 + c];
+          if (s == ASM_NONE || s == nd) continue;
+          if (wv::atomic_sub(&node_aux[s], 1u) == 1u) nxt[wv::atomic_add(&cnt[which ^ 1], 1u)] = s;
+        }
+      }
+      wv::sync();
+      wv::fence_acquire();
+      if (lane == 0) cnt[which] = 0;
+      wv::sync();
+      which ^= 1;
+      uint32_t* t = cur;
+      cur         = nxt;
+      nxt         = t;
+    }
+    return removed != nNodes;
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // seed selection (:686-696): highest count among unused words, ties -> lexicographically smallest
+  // ------------------------------------------------------------------------------------------------
+  template <int KW>
+  WV_DEV unsigned selectSeed()
+  {
+    const unsigned lane = unsigned(wv::lane());
+    unsigned       best = 0;
+    for (unsigned nd = lane; nd < nNodes; nd += 64) {
+      if (node_flag[nd] & NF_UNUSED) {
+        const unsigned c = node_cnt[nd];
+        best             = (c > best) ? c : best;
+      }
+    }
+    best = waveMax(best);
+    if (best == 0) return ASM_NONE;
+    unsigned mine = ASM_NONE;
+    Key<KW>  mineKey;
+    for (int i = 0; i < KW; ++i) mineKey.w[i] = 0xffffffffu;
+    for (unsigned nd = lane; nd < nNodes; nd += 64) {
+      if ((node_flag[nd] & NF_UNUSED) && node_cnt[nd] == best) {
+        const Key<KW> key = keyAt<KW>(node_key[nd]);
+        if (mine == ASM_NONE || keyLess(key, mineKey)) {
+          mine    = nd;
+          mineKey = key;
+        }
+      }
+    }
+    for (int off = 1; off < 64; off <<= 1) {
+      const int      src = wv::lane() ^ off;
+      const unsigned on  = wv::shfl(mine, src);
+      Key<KW>        ok;
+      for (int i = 0; i < KW; ++i) ok.w[i] = wv::shfl(mineKey.w[i], src);
+      if (on != ASM_NONE && (mine == ASM_NONE || keyLess(ok, mineKey))) {
+        mine    = on;
+        mineKey = ok;
+      }
+    }
+    return mine;
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // walk (:149-501).  Lane w (< W) owns qword w of every read set; decisions are wave-uniform.
+  // ------------------------------------------------------------------------------------------------
+  WV_DEV uint64_t supWord(const unsigned node) const
+  {
+    const unsigned lane = unsigned(wv::lane());
+    return (node != ASM_NONE && lane < W) ? node_sup[size_t(node) * W + lane] : uint64_t(0);
+  }
+
+  /// four 16-bit counts packed in a qword, summed over the wave, returned wave-uniform
+  WV_DEV static uint64_t packedCountSum(const uint64_t v)
+  {
+    uint64_t s = v;
+    for (int off = 1; off < int(ASM_MAX_W); off <<= 1) s += wv::shfl(s, wv::lane() ^ off);
+    return wv::readlane(s, 0);
+  }
+
+  template <int KW>
+  WV_DEV bool walk(const unsigned seed, const unsigned serial, const unsigned candIdx)
+  {
+    const unsigned lane = unsigned(wv::lane());
+    uint64_t       S    = supWord(seed);  // contig.supportReads (:168)
+    uint64_t       Rj   = 0;              // contig.rejectReads
+    uint8_t*       outSeq  = cand_seq + size_t(candIdx) * P.max_contig_len;
+    uint64_t*      outBits = cand_bits + size_t(candIdx) * 2 * W;
+    int32_t*       meta    = cand_meta + candIdx * 4;
+
+    // node_flag is read AND written inside the walk: only lane 0 touches it, decisions are broadcast
+    unsigned seedFlag = 0;
+    if (lane == 0) seedFlag = node_flag[seed];
+    seedFlag                = wv::readlane(seedFlag, 0);
+    const bool seedIsRepeat = (seedFlag & NF_REPEAT) != 0;
+    if (lane == 0) node_flag[seed] = (seedFlag & NF_REPEAT) | (serial << 8);  // unused.erase(seed), wordsInContig
+
+    // seed k-mer text
+    const unsigned seedPb = node_key[seed];
+    for (unsigned i = lane; i < k; i += 64) {
+      const unsigned pb = seedPb + i;
+      outSeq[i]         = "ACGT"[(codes[pb >> 4] >> (30 - 2 * (pb & 15))) & 3];
+    }
+    if (seedIsRepeat) {  // :172-179
+      if (lane < W) {
+        outBits[lane]     = S;
+        outBits[W + lane] = 0;
+      }
+      if (lane == 0) {
+        meta[0] = int(k);
+        meta[1] = 0;
+        meta[2] = int(k);
+      }
+      wv::sync();
+      return true;
+    }
+
+    // reads of the unselected siblings of the seed (same (k-1)-prefix) reject the contig (:185-210)
+    {
+      const Key<KW>  key      = keyAt<KW>(seedPb);
+      const unsigned lastBase = (codes[(seedPb + k - 1) >> 4] >> (30 - 2 * ((seedPb + k - 1) & 15))) & 3;
+      for (unsigned c = 0; c < 4; ++c) {
+        if (c == lastBase) continue;
+        Key<KW> sib = key;
+        keySetBase(sib, k - 1, c);
+        const unsigned n = lookup<KW>(sib);
+        Rj |= supWord(n);
+      }
+    }
+
+    bool     isRepeatFound = false;
+    unsigned nLeft = 0, nRight = 0;
+    bool     tooLong = false;
+    int      consEnd = 0, consBegin = 0;
+    for (unsigned mode = 0; mode < 2; ++mode) {
+      const bool      isEnd = (mode == 0);
+      const uint32_t* fwd   = isEnd ? succ : pred;
+      const uint32_t* bwd   = isEnd ? pred : succ;
+      unsigned        consOffset = 0;
+      unsigned        cur        = seed;
+      while (true) {
+        unsigned cand[4];
+        uint64_t cw[4];
+        unsigned ccount[4];
+        uint64_t pk = 0;
+        for (unsigned c = 0; c < 4; ++c) {
+          cand[c]   = fwd[cur * 4 + c];
+          cw[c]     = supWord(cand[c]);
+          ccount[c] = (cand[c] != ASM_NONE) ? node_cnt[cand[c]] : 0u;
+          pk += uint64_t(wv::popc(S & cw[c])) << (16 * c);
+        }
+        pk = packedCountSum(pk);
+
+        unsigned maxBaseCount = 0, maxCnt = 0, maxNode = ASM_NONE, maxSym = 0;
+        uint64_t maxWR = 0, maxCW = 0, rm = 0, add = 0;
+        for (unsigned c = 0; c < 4; ++c) {  // :241-336
+          if (cand[c] == ASM_NONE) continue;
+          const unsigned cnt = unsigned(pk >> (16 * c)) & 0xffffu;
+          if (cnt == 0) continue;  // :280
+          const uint64_t CW = S & cw[c];
+          const uint64_t SH = maxCW & cw[c];
+          if (cnt > maxCnt) {  // :283-316
+            rm |= maxCW & ~SH;
+            add |= maxWR & ~SH;
+            maxWR        = cw[c];
+            maxCnt       = cnt;
+            maxCW        = CW;
+            maxBaseCount = ccount[c];
+            maxSym       = c;
+            maxNode      = cand[c];
+          } else {  // :317-335
+            rm |= CW & ~SH;
+            add |= cw[c] & ~SH;
+          }
+        }
+        if (maxBaseCount < P.opt.minCoverage) break;  // :343
+        unsigned maxFlag = 0;
+        if (lane == 0) maxFlag = node_flag[maxNode];
+        maxFlag = wv::readlane(maxFlag, 0);
+        if ((maxFlag >> 8) == serial) {  // :352-358
+          isRepeatFound = true;
+          break;
+        }
+        if (isEnd) {  // :363
+          if (k + nRight >= P.max_contig_len) {
+            tooLong = true;
+            break;
+          }
+          if (lane == 0) walk_right[nRight] = uint8_t("ACGT"[maxSym]);
+          nRight++;
+        } else {
+          if (k + nRight + nLeft >= P.max_contig_len) {
+            tooLong = true;
+            break;
+          }
+          if (lane == 0) walk_left[nLeft] = uint8_t("ACGT"[maxSym]);
+          nLeft++;
+        }
+        if ((consOffset != 0) || (maxBaseCount < P.opt.minConservativeCoverage)) consOffset += 1;  // :368-369
+
+        // one step backwards at the branching point (:377-427); runs every step because the reference's
+        // previousWordReads is always empty at the test (:237)
+        for (unsigned c = 0; c < 4; ++c) {
+          const unsigned n = bwd[maxNode * 4 + c];
+          if (n == cur) continue;      // the word we came from (:381)
+          if (n == maxNode) continue;  // :389
+          if (n == ASM_NONE) continue;
+          const uint64_t bw  = supWord(n);
+          const uint64_t upd = bw & ~maxCW;  // :400-414
+          add |= upd;
+          rm |= upd;
+        }
+        Rj |= add;            // :440-442
+        S |= maxWR & ~Rj;     // :458-464
+        S &= ~rm;             // :471-473
+        if (lane == 0) node_flag[maxNode] = (maxFlag & NF_REPEAT) | (serial << 8);  // :482-484
+        cur = maxNode;
+      }
+      if (isEnd)
+        consEnd = int(consOffset);  // :488-491
+      else
+        consBegin = int(consOffset);
+      if (tooLong) break;
+    }
+    if (tooLong) {
+      status = ASM_E_CONTIG_TOO_LONG;
+      return false;
+    }
+    wv::sync();
+    // assemble the text: reverse(left) + seed + right
+    const unsigned len = nLeft + k + nRight;
+    // reverse(left) + seed (re-derived from the packed reads) + right
+    for (unsigned i = lane; i < len; i += 64) {
+      uint8_t ch;
+      if (i < nLeft) {
+        ch = walk_left[nLeft - 1 - i];
+      } else if (i < nLeft + k) {
+        const unsigned pb = seedPb + (i - nLeft);
+        ch                = uint8_t("ACGT"[(codes[pb >> 4] >> (30 - 2 * (pb & 15))) & 3]);
+      } else {
+        ch = walk_right[i - nLeft - k];
+      }
+      outSeq[i] = ch;
+    }
+    if (lane < W) {
+      outBits[lane]     = S;
+      outBits[W + lane] = Rj;
+    }
+    if (lane == 0) {
+      meta[0] = int(len);
+      meta[1] = consBegin;
+      meta[2] = int(len) - consEnd;  // :498
+    }
+    wv::sync();
+    return isRepeatFound;
+  }
+
+  // defined in repeat_exact.hpp
+  template <int KW>
+  WV_DEV void exactRepeatSearch();
+
+  /// buildContigs (:644-720).  Returns isAssemblySuccess.
+  template <int KW>
+  WV_DEV bool buildContigs()
+  {
+    buildGraph<KW>();
+    if (status != ASM_OK) return true;
+    if (graphHasCycle()) {
+      cyclicIters++;
+      exactRepeatSearch<KW>();
+      if (status != ASM_OK) return true;
+    }
+    nCand        = 0;
+    bool success = true;
+    while (nCand < 2 * P.opt.maxAssemblyCount) {  // :685
+      const unsigned seed = selectSeed<KW>();
+      if (seed == ASM_NONE) break;
+      const bool rep = walk<KW>(seed, nCand + 1, nCand);
+      if (status != ASM_OK) return true;
+      if (rep) success = false;
+      nCand++;
+    }
+    return success;
+  }
+
+  WV_DEV bool buildContigsForK()
+  {
+    const unsigned kw = (k + 15) >> 4;
+    if (kw <= 2) return buildContigs<2>();
+    if (kw <= 4) return buildContigs<4>();
+    return buildContigs<8>();
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // pseudo reads (:882-910)
+  // ------------------------------------------------------------------------------------------------
+  WV_DEV unsigned appendPseudoReads()
+  {
+    const unsigned lane = unsigned(wv::lane());
+    unsigned       cw = nCodeWordsNormal, mw = nMaskWordsNormal;
+    unsigned       nPseudo = 0;
+    for (unsigned ci = 0; ci < nCand; ++ci) {
+      const unsigned len = unsigned(cand_meta[ci * 4 + 0]);
+      if (!(len > k + P.opt.wordStepSize)) continue;  // :898
+      const unsigned nCw = (len + 15) / 16 + 1, nMw = (len + 31) / 32 + 1;
+      if (cw + nCw + 2 > P.cap_words || mw + nMw + 2 > maskWordCap() || nNormal + nPseudo >= P.cap_reads) {
+        status = ASM_E_TABLE_FULL;
+        return 0;
+      }
+      const uint8_t* src = cand_seq + size_t(ci) * P.max_contig_len;
+      const unsigned r   = nNormal + nPseudo;
+      for (unsigned wi = lane; wi < nCw; wi += 64) {
+        uint32_t code = 0;
+        for (unsigned b = 0; b < 16; ++b) {
+          const unsigned i = wi * 16 + b;
+          const unsigned c = (i < len) ? baseCode(src[i]) : 0u;
+          code |= (c & 3u) << (30 - 2 * b);
+        }
+        codes[cw + wi] = code;
+      }
+      for (unsigned wi = lane; wi < nMw; wi += 64) nmask[mw + wi] = 0;
+      uint8_t* keep = pseudo_seq + size_t(nPseudo) * P.max_contig_len;
+      for (unsigned i = lane; i < len; i += 64) keep[i] = src[i];
+      if (lane == 0) {
+        rd_cw[r]            = cw;
+        rd_len[r]           = len;
+        rd_mw[r]          = mw;
+        pseudo_len[nPseudo] = len;
+      }
+      cw += nCw;
+      mw += nMw;
+      nPseudo++;
+    }
+    wv::sync();
+    return nPseudo;
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // selectContigs (:722-842) + output
+  // ------------------------------------------------------------------------------------------------
+  WV_DEV void selectAndEmit(const unsigned locus, const unsigned nPseudoFinal, const unsigned nIter)
+  {
+    const unsigned lane = unsigned(wv::lane());
+    AsmLocusOut    out;
+    out.status            = status;
+    out.n_contigs         = 0;
+    out.n_words           = W;
+    out.n_pseudo          = 0;
+    out.pseudo_off        = 0;
+    out.pseudo_len_off    = 0;
+    out.final_word_length = k;
+    out.n_iterations      = nIter;
+    out.cyclic_iterations = cyclicIters;
+    out.reserved          = 0;
+    if (status != ASM_OK) {
+      if (lane == 0) P.loci[locus] = out;
+      return;
+    }
+    // index >= nNormal <=> pseudo read (see oracle/manta_oracle.cpp selectContigs on stale indices)
+    const uint64_t pseudoMaskW = (lane < W) ? ~normalMask(lane) : 0;
+    uint64_t       used        = 0;  // lane w owns word w
+    uint64_t       alive       = (nCand >= 64) ? ~uint64_t(0) : ((uint64_t(1) << nCand) - 1);
+    unsigned       finalCount  = 0;
+    uint32_t*      chosenIdx   = frontier;  // scratch (the k-mer graph is no longer needed); same value from every lane
+    while (alive != 0 && finalCount < P.opt.maxAssemblyCount) {
+      const unsigned usedAll      = waveSum(unsigned(wv::popc(used)));
+      const unsigned usedPseudo   = waveSum(unsigned(wv::popc(used & pseudoMaskW)));
+      const unsigned unusedNormal = nNormal - (usedAll - usedPseudo);
+      if (unusedNormal < P.opt.minUnusedReads) break;  // :750 (a `return`; nothing follows the loop anyway)
+      int      selected   = -1;
+      unsigned maxSupport = 0, maxLength = 0;
+      for (unsigned ci = 0; ci < nCand; ++ci) {
+        if (!((alive >> ci) & 1)) continue;
+        const uint64_t sup    = (lane < W) ? cand_bits[size_t(ci) * 2 * W + lane] : 0;
+        const uint64_t fresh  = sup & ~used;
+        const uint64_t pk     = packedCountSum(uint64_t(wv::popc(fresh)) | (uint64_t(wv::popc(fresh & ~pseudoMaskW)) << 16));
+        const unsigned nFresh = unsigned(pk) & 0xffffu, nFreshNormal = unsigned(pk >> 16) & 0xffffu;
+        if (nFreshNormal < P.opt.minSupportReads) {  // :779-788
+          alive &= ~(uint64_t(1) << ci);
+          continue;
+        }
+        const unsigned len = unsigned(cand_meta[ci * 4 + 0]);
+        if ((nFresh > maxSupport) || ((nFresh == maxSupport) && (len > maxLength))) {  // :794-801
+          selected   = int(ci);
+          maxSupport = nFresh;
+          maxLength  = len;
+        }
+      }
+      if (maxSupport == 0) break;  // :807
+      chosenIdx[finalCount] = unsigned(selected);
+      alive &= ~(uint64_t(1) << unsigned(selected));
+      if (lane < W) used |= cand_bits[size_t(selected) * 2 * W + lane];
+      finalCount++;
+    }
+
+    // ---- reserve output space ----
+    uint64_t seqBytes = 0;
+    for (unsigned f = 0; f < finalCount; ++f) seqBytes += unsigned(cand_meta[chosenIdx[f] * 4 + 0]);
+    uint64_t pseudoBytes = 0;
+    for (unsigned p = 0; p < nPseudoFinal; ++p) pseudoBytes += pseudo_len[p];
+    const uint64_t bitsWords = uint64_t(finalCount) * 2 * W + nPseudoFinal;
+    unsigned long long seqBase = 0, bitsBase = 0;
+    if (lane == 0) {
+      seqBase  = wv::atomic_add(P.seq_used, (unsigned long long)(seqBytes + pseudoBytes));
+      bitsBase = wv::atomic_add(P.bits_used, (unsigned long long)(bitsWords));
+    }
+    seqBase  = wv::readlane(uint64_t(seqBase), 0);
+    bitsBase = wv::readlane(uint64_t(bitsBase), 0);
+    if (seqBase + seqBytes + pseudoBytes > P.seq_cap || bitsBase + bitsWords > P.bits_cap) {
+      out.status = ASM_E_OUT_CAPACITY;
+      if (lane == 0) P.loci[locus] = out;
+      return;
+    }
+    uint64_t so = seqBase, bo = bitsBase;
+    for (unsigned f = 0; f < finalCount; ++f) {
+      const unsigned ci  = chosenIdx[f];
+      const unsigned len = unsigned(cand_meta[ci * 4 + 0]);
+      const uint8_t* src = cand_seq + size_t(ci) * P.max_contig_len;
+      for (unsigned i = lane; i < len; i += 64) P.seq_arena[so + i] = src[i];
+      if (lane < 2 * W) P.bits_arena[bo + lane] = cand_bits[size_t(ci) * 2 * W + lane];
+      if (lane == 0) {
+        AsmContigOut c;
+        c.seq_off    = so;
+        c.bits_off   = bo;
+        c.seq_len    = len;
+        c.cons_begin = cand_meta[ci * 4 + 1];
+        c.cons_end   = cand_meta[ci * 4 + 2];
+        c.reserved   = 0;
+        P.contigs[size_t(locus) * P.opt.maxAssemblyCount + f] = c;
+      }
+      so += len;
+      bo += 2 * W;
+    }
+    out.pseudo_off     = so;
+    out.pseudo_len_off = bo;
+    for (unsigned p = 0; p < nPseudoFinal; ++p) {
+      const unsigned len = pseudo_len[p];
+      const uint8_t* src = pseudo_seq + size_t(p) * P.max_contig_len;
+      for (unsigned i = lane; i < len; i += 64) P.seq_arena[so + i] = src[i];
+      if (lane == 0) P.bits_arena[bo + p] = len;
+      so += len;
+    }
+    out.n_contigs = finalCount;
+    out.n_pseudo  = nPseudoFinal;
+    if (lane == 0) P.loci[locus] = out;
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // runIterativeAssembler (:844-931)
+  // ------------------------------------------------------------------------------------------------
+  WV_DEV void run(const unsigned locus)
+  {
+    const unsigned lane = unsigned(wv::lane());
+    cyclicIters         = 0;
+    nCand               = 0;
+    k                   = P.opt.minWordLength;
+    // zero the N bitmap region (filled with atomic_or)
+    for (unsigned i = lane; i < maskWordCap() + 2; i += 64) nmask[i] = 0;
+    wv::sync();
+    packNormalReads(locus);
+    wv::sync();
+    wv::fence_acquire();
+    W = (nNormal + 2 * P.opt.maxAssemblyCount + 63) / 64;
+    if (W == 0) W = 1;
+    if (status == ASM_OK && (P.opt.maxWordLength > 16u * ASM_MAX_KW || P.opt.minWordLength == 0)) status = ASM_E_WORD_TOO_LONG;
+    if (status == ASM_OK && 2 * P.opt.maxAssemblyCount > ASM_MAX_CAND) status = ASM_E_INTERNAL;
+
+    nReads            = nNormal;
+    unsigned nPseudo  = 0;
+    unsigned nIter    = 0;
+    if (status == ASM_OK) {
+      for (unsigned wl = P.opt.minWordLength; wl <= P.opt.maxWordLength; wl += P.opt.wordStepSize) {
+        k = wl;
+        nIter++;
+        const bool ok = buildContigsForK();
+        if (status != ASM_OK) break;
+        if (ok) break;  // :872-877
+        // drop the previous pseudo reads, add this iteration's contigs (:882-910)
+        nPseudo = appendPseudoReads();
+        if (status != ASM_OK) break;
+        nReads = nNormal + nPseudo;
+      }
+    }
+    selectAndEmit(locus, nPseudo, nIter);
+  }
+};
+
+}  // namespace manta_dev
+
+#include "repeat_exact.hpp"
+
+namespace manta_dev {
+
+WV_KERNEL void assemble_kernel(const AsmParams P)
+{
+  uint8_t* wsBase = P.ws + uint64_t(wv::block()) * P.ws_stride;
+  while (true) {
+    unsigned slot = 0;
+    if (wv::lane() == 0) slot = wv::atomic_add(P.counter, 1u);
+    slot = wv::first(slot);
+    if (slot >= P.n_loci) break;
+    Assembler a(P, wsBase);
+    a.run(slot);
+    wv::sync();
+  }
+}
+
+}  // namespace manta_dev

@@ -14,6 +14,7 @@
 
 #define WV_DEV __device__ __forceinline__
 #define WV_KERNEL __global__ __launch_bounds__(64)
+#define WV_HD __host__ __device__ inline
 
 extern __shared__ __attribute__((aligned(16))) char wv_dyn_lds[];
 
@@ -58,6 +59,11 @@ WV_DEV unsigned atomic_cas(unsigned* p, unsigned cmp, unsigned v) { return atomi
 WV_DEV unsigned atomic_or(unsigned* p, unsigned v) { return atomicOr(p, v); }
 WV_DEV unsigned atomic_sub(unsigned* p, unsigned v) { return atomicSub(p, v); }
 WV_DEV unsigned long long atomic_or(unsigned long long* p, unsigned long long v) { return atomicOr(p, v); }
+WV_DEV unsigned long long atomic_add(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
+/// L1-bypassing load of a word other lanes update with atomics
+WV_DEV unsigned atomic_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+/// drop this CU's (possibly stale) L1 lines: needed before plain re-reads of memory that was updated by L2 atomics
+WV_DEV void fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
 WV_DEV int popc(unsigned v) { return __popc(v); }
 WV_DEV int popc(uint64_t v) { return __popcll(v); }

@@ -17,6 +17,7 @@
 
 #define WV_DEV inline
 #define WV_KERNEL
+#define WV_HD inline
 
 namespace wv_emu {
 
@@ -181,6 +182,9 @@ inline unsigned atomic_sub(unsigned* p, unsigned v) { const unsigned o = *p; *p 
 inline unsigned atomic_cas(unsigned* p, unsigned cmp, unsigned v) { const unsigned o = *p; if (o == cmp) *p = v; return o; }
 inline unsigned atomic_or(unsigned* p, unsigned v) { const unsigned o = *p; *p = o | v; return o; }
 inline unsigned long long atomic_or(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o | v; return o; }
+inline unsigned long long atomic_add(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
+inline unsigned atomic_load(const unsigned* p) { return *p; }
+inline void fence_acquire() {}
 
 inline int popc(unsigned v) { return __builtin_popcount(v); }
 inline int popc(uint64_t v) { return __builtin_popcountll(v); }
