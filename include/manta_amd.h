@@ -143,6 +143,52 @@ int manta_assemble_batch(
     uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
     uint64_t* bits_arena_used);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Fused "small SV" locus pipeline: the arithmetic core of
+ *   SVCandidateAssemblyRefiner::getSmallSVAssembly   applications/GenerateSVCandidates/SVCandidateAssemblyRefiner.cpp:1860-2038
+ * for a batch of candidate loci:  runIterativeAssembler (:1921-1926 via SVCandidateAssembler.cpp:661-675)
+ *   -> per contig 10-mer reference trim (:1984-2011) -> GlobalLargeIndelAligner::align (:2032-2038)
+ *   -> alignment.beginPos += adjustedLeadingCut (:2039).
+ * Contigs stay on the device between the stages.  The staged form (upload / run / download) lets a caller keep
+ * inputs resident in HBM and overlap host work; manta_smallsv_run is the timed region of bench.py.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct manta_smallsv manta_smallsv_t;
+
+/* the *Cut values of SVCandidateAssemblyRefiner.cpp:1912-1915, per locus */
+typedef struct {
+  int32_t leading_cut, trailing_cut, max_leading_cut, max_trailing_cut;
+} manta_ref_cuts_t;
+
+typedef struct {
+  int32_t              adjusted_leading_cut, adjusted_trailing_cut; /* :1994-2010 */
+  manta_align_result_t align; /* begin_pos1 already includes adjusted_leading_cut (:2039) */
+} manta_smallsv_alignment_t;
+
+typedef struct {
+  float    assemble_ms, schedule_ms, align_ms, total_ms; /* HIP-event times of the last run, per stage */
+  uint32_t n_align_launches;
+  uint32_t n_alignments;
+  uint64_t ptr_matrix_bytes; /* back-pointer bytes the alignments of the last run wrote (private layout) */
+  uint64_t dp_cells;         /* sum over alignments of query_len * ref_len */
+} manta_smallsv_stats_t;
+
+int  manta_smallsv_create(manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores,
+                          int32_t large_indel_score, manta_smallsv_t** out);
+void manta_smallsv_destroy(manta_smallsv_t* b);
+/* host -> HBM.  refs/ref_off[n_loci+1]: the fetched reference window of every locus; cuts[n_loci] */
+int manta_smallsv_upload(manta_smallsv_t* b, uint32_t n_loci, const uint8_t* bases, const uint64_t* read_off,
+                         const uint32_t* locus_read_begin, const uint8_t* refs, const uint64_t* ref_off,
+                         const manta_ref_cuts_t* cuts);
+/* all three stages on the device, synchronous; inputs must have been uploaded */
+int manta_smallsv_run(manta_smallsv_t* b);
+int manta_smallsv_stats(const manta_smallsv_t* b, manta_smallsv_stats_t* stats);
+/* HBM -> host.  alignments[i] belongs to contigs[i]. */
+int manta_smallsv_download(manta_smallsv_t* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs,
+                           manta_smallsv_alignment_t* alignments, uint64_t contigs_cap, uint8_t* seq_arena,
+                           uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
+                           uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
+                           uint64_t* cigar_arena_used);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,20 @@ class AsmLocusResult(ctypes.Structure):
                 ("pseudo_len_off", ctypes.c_uint64)]
 
 
+class RefCuts(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("leading_cut", "trailing_cut", "max_leading_cut", "max_trailing_cut")]
+
+
+class SmallSvAlignment(ctypes.Structure):
+    _fields_ = [("adjusted_leading_cut", ctypes.c_int32), ("adjusted_trailing_cut", ctypes.c_int32), ("align", AlignResult)]
+
+
+class SmallSvStats(ctypes.Structure):
+    _fields_ = [("assemble_ms", ctypes.c_float), ("schedule_ms", ctypes.c_float), ("align_ms", ctypes.c_float),
+                ("total_ms", ctypes.c_float), ("n_align_launches", ctypes.c_uint32), ("n_alignments", ctypes.c_uint32),
+                ("ptr_matrix_bytes", ctypes.c_uint64), ("dp_cells", ctypes.c_uint64)]
+
+
 def _bits_members(words):
     out = []
     for wi, w in enumerate(words):
@@ -206,6 +220,111 @@ def _assemble_batch(self, opts, loci_reads, strict=True):
 
 
 Lib.assemble_batch = _assemble_batch
+
+
+class SmallSvBatch:
+    """Staged fused pipeline (manta_smallsv_*): upload once, run many times (bench), download."""
+
+    def __init__(self, lib, opts, scores, large_indel_score):
+        self.lib = lib
+        self.h = ctypes.c_void_p()
+        o, sc = AsmOptions(*opts), AlignScores(*scores)
+        self.max_asm = o.max_assembly_count
+        lib.lib.manta_smallsv_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                                 ctypes.POINTER(ctypes.c_void_p)]
+        lib.lib.manta_smallsv_destroy.argtypes = [ctypes.c_void_p]
+        for f in ("manta_smallsv_run",):
+            getattr(lib.lib, f).argtypes = [ctypes.c_void_p]
+        lib._check(lib.lib.manta_smallsv_create(lib.ctx, ctypes.byref(o), ctypes.byref(sc), large_indel_score, ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.lib.lib.manta_smallsv_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_packed(self, bases, read_off, begin, refs, ref_off, cuts):
+        """numpy arrays; cuts: int32 array (n_loci, 4)"""
+        self.n_loci = len(begin) - 1
+        self.n_reads = np.diff(begin)
+        self.total_bases = int(read_off[-1]) + int(ref_off[-1])
+        self._keep = (bases, read_off, begin, refs, ref_off, cuts)
+        self.lib._check(self.lib.lib.manta_smallsv_upload(
+            self.h, self.n_loci, bases.ctypes.data_as(ctypes.c_void_p), read_off.ctypes.data_as(ctypes.c_void_p),
+            begin.ctypes.data_as(ctypes.c_void_p), refs.ctypes.data_as(ctypes.c_void_p),
+            ref_off.ctypes.data_as(ctypes.c_void_p), cuts.ctypes.data_as(ctypes.c_void_p)))
+
+    def upload(self, loci_reads, loci_refs, cuts):
+        bases, read_off, begin = pack_loci(loci_reads)
+        rb = [_b(r) for r in loci_refs]
+        ref_off = np.zeros(len(rb) + 1, dtype=np.uint64)
+        np.cumsum([len(r) for r in rb], out=ref_off[1:])
+        refs = np.frombuffer(b"".join(rb) + b"\0", dtype=np.uint8)
+        c = np.ascontiguousarray(np.array(cuts, dtype=np.int32).reshape(len(rb), 4))
+        self.upload_packed(bases, read_off, begin, refs, ref_off, c)
+
+    def run(self):
+        self.lib._check(self.lib.lib.manta_smallsv_run(self.h))
+
+    def stats(self):
+        st = SmallSvStats()
+        self.lib._check(self.lib.lib.manta_smallsv_stats(self.h, ctypes.byref(st)))
+        return {f[0]: getattr(st, f[0]) for f in SmallSvStats._fields_}
+
+    def download(self, strict=True):
+        n = self.n_loci
+        res = (AsmLocusResult * n)()
+        ccap = n * self.max_asm + 1
+        contigs = (AsmContig * ccap)()
+        aligns = (SmallSvAlignment * ccap)()
+        seq_cap = 65536 * n + 1024
+        seq = np.zeros(seq_cap, dtype=np.uint8)
+        bits_cap = n * (self.max_asm * 2 * 16 + 64) + 64
+        bits = np.zeros(bits_cap, dtype=np.uint64)
+        cig_cap = n * self.max_asm * 512 + 4096
+        cig = np.zeros(cig_cap, dtype=np.uint32)
+        su, bu, cu = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+        rc = self.lib.lib.manta_smallsv_download(
+            self.h, res, contigs, aligns, ctypes.c_uint64(ccap), seq.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(seq_cap),
+            ctypes.byref(su), bits.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(bits_cap), ctypes.byref(bu),
+            cig.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(cig_cap), ctypes.byref(cu))
+        self.lib._check(rc, allow=() if strict else (-5, -6, -7))
+        out = []
+        for l in range(n):
+            r = res[l]
+            d = dict(status=r.status, n_reads=int(self.n_reads[l]), n_words=r.n_words, final_word_length=r.final_word_length,
+                     n_iterations=r.n_iterations, cyclic_iterations=r.cyclic_iterations, contigs=[], pseudo=[], aligns=[])
+            if r.status == 0:
+                for c in range(r.n_contigs):
+                    cc = contigs[r.first_contig + c]
+                    d["contigs"].append(dict(seq=seq[cc.seq_off:cc.seq_off + cc.seq_len].tobytes().decode("latin-1"),
+                                             seed=cc.seed_read_count, cons=(cc.conservative_begin, cc.conservative_end),
+                                             support=_bits_members(bits[cc.support_off:cc.support_off + r.n_words]),
+                                             reject=_bits_members(bits[cc.reject_off:cc.reject_off + r.n_words])))
+                    a = aligns[r.first_contig + c]
+                    d["aligns"].append(dict(status=a.align.status, lead=a.adjusted_leading_cut, trail=a.adjusted_trailing_cut,
+                                            score=a.align.score, is_jumped=a.align.is_jumped, begin1=a.align.begin_pos1,
+                                            cigar1=cigar_string(cig[a.align.cigar1_off:a.align.cigar1_off + a.align.cigar1_len])))
+                off = int(r.pseudo_seq_off)
+                for p in range(r.n_pseudo):
+                    ln = int(bits[r.pseudo_len_off + p])
+                    d["pseudo"].append(seq[off:off + ln].tobytes().decode("latin-1"))
+                    off += ln
+            out.append(d)
+        return out
+
+
+def small_sv_text(d):
+    """canonical text of ref_small_sv_locus (oracle/ref_driver.cpp) for one locus result dict"""
+    t = assembly_text(d)
+    for i, a in enumerate(d["aligns"]):
+        t += "align %d lead=%d trail=%d " % (i, a["lead"], a["trail"]) + align_text(ALIGNER_LARGE_INDEL, a)
+    return t
 
 
 def assembly_text(d):

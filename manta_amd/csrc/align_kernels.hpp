@@ -31,9 +31,11 @@ enum { OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_H = 5, OP_P = 6, OP_
 static const int ALIGN_BAD = -10000;
 
 struct AlignTaskDev {
-  uint64_t query_off, ref1_off, ref2_off;  ///< byte offsets into AlignParams::seq
-  uint32_t query_len, ref1_len, ref2_len;
-  uint32_t cigar_off;  ///< first u32 of this task's cigar region; region size = 4*query_len+16 u32
+  const uint8_t* query;  ///< device pointers (1 byte per base, exactly as the reference's std::string)
+  const uint8_t* ref1;
+  const uint8_t* ref2;
+  uint32_t       query_len, ref1_len, ref2_len;
+  uint32_t       cigar_off;  ///< first u32 of this task's cigar region; region size = 4*query_len+16 u32
 };
 
 struct AlignResultDev {
@@ -46,12 +48,12 @@ struct AlignResultDev {
 };
 
 struct AlignParams {
-  const uint8_t*      seq;
   const AlignTaskDev* tasks;
   AlignResultDev*     results;
   uint32_t*           cigar;
   const uint32_t*     task_ids;  ///< tasks of this launch (one E bucket); nullptr = identity
   uint32_t            n_tasks;
+  const uint32_t*     n_tasks_dev;  ///< if non-null, the task count is read from here (filled by an earlier kernel)
   uint32_t*           counter;  ///< work-queue head (zeroed before launch)
   uint8_t*            ptr_ws;   ///< back-pointer slabs, one per workgroup
   uint64_t            ptr_ws_stride;
@@ -716,9 +718,9 @@ struct Aligner {
 
   WV_DEV void run(const AlignTaskDev& T, AlignResultDev& res, uint8_t* ptrSlab)
   {
-    query = P.seq + T.query_off;
-    ref1  = P.seq + T.ref1_off;
-    ref2  = P.seq + T.ref2_off;
+    query = T.query;
+    ref1  = T.ref1;
+    ref2  = T.ref2;
     Q     = T.query_len;
     R1    = T.ref1_len;
     R2    = (KIND == 2) ? T.ref2_len : 0;
@@ -745,12 +747,13 @@ inline uint64_t alignPtrSlabBytes(const int kind, const int E, const uint64_t to
 template <int KIND, int E>
 WV_KERNEL void align_kernel(const AlignParams P)
 {
-  uint8_t* slab = P.ptr_ws + uint64_t(wv::block()) * P.ptr_ws_stride;
+  uint8_t*       slab   = P.ptr_ws + uint64_t(wv::block()) * P.ptr_ws_stride;
+  const unsigned nTasks = P.n_tasks_dev ? *P.n_tasks_dev : P.n_tasks;
   while (true) {
     unsigned slot = 0;
     if (wv::lane() == 0) slot = wv::atomic_add(P.counter, 1u);
     slot = wv::first(slot);
-    if (slot >= P.n_tasks) break;
+    if (slot >= nTasks) break;
     const unsigned      tid = P.task_ids ? P.task_ids[slot] : slot;
     Aligner<KIND, E>    al(P);
     al.run(P.tasks[tid], P.results[tid], slab);

@@ -12,6 +12,7 @@
 
 #include "align_kernels.hpp"
 #include "assemble_kernels.hpp"
+#include "pipeline_kernels.hpp"
 #include <unordered_map>
 #include "rt.hpp"
 
@@ -57,8 +58,6 @@ struct manta_ctx {
   int         cuCount = 0;
   // align scratch
   DevBuf dSeq, dTasks, dResults, dCigar, dTaskIds, dCounter, dPtrWs;
-  // assembler scratch
-  DevBuf aBases, aReadOff, aLocusBegin, aLoci, aContigs, aSeqArena, aBitsArena, aCounters, aWs, aGrowth;
   std::vector<uint32_t> growthSize, growthBuckets;  // libstdc++ bucket growth schedule (see repeat_exact.hpp)
 };
 
@@ -183,6 +182,221 @@ int asmStatusToAbi(int st)
   }
 }
 
+
+/// One batch of loci through assemble_kernel: sizing, staging, launch, fetch.
+struct AsmStage {
+  manta_ctx_t* ctx;
+  explicit AsmStage(manta_ctx_t* c) : ctx(c) {}
+
+  manta_asm_options_t opt{};
+  uint32_t            nLoci = 0, nReadsTotal = 0, maxContigLen = 0, wMax = 0, capWords = 0, capReads = 0, capNodes = 0, capSlots = 0;
+  uint64_t            nBases = 0, stride = 0, devSeqCap = 0, devBitsCap = 0;
+  int                 grid = 1;
+  DevBuf              bBases, bReadOff, bLocusBegin, bLoci, bContigs, bSeqArena, bBitsArena, bCounters, bWs, bGrowth;
+  uint8_t*            dBases = nullptr;
+  uint64_t*           dOff   = nullptr;
+  uint32_t*           dBegin = nullptr;
+  AsmLocusOut*        dLoci  = nullptr;
+  AsmContigOut*       dCont  = nullptr;
+  uint8_t*            dSeq   = nullptr;
+  uint64_t*           dBits  = nullptr;
+  uint64_t*           dCnt   = nullptr;
+  uint8_t*            dWs    = nullptr;
+  uint32_t*           dGrowth = nullptr;
+
+  int plan(const manta_asm_options_t& o, uint32_t n_loci, const uint64_t* read_off, const uint32_t* locus_read_begin)
+  {
+    if (o.min_word_length == 0 || o.word_step_size == 0 || o.min_coverage == 0 || o.max_assembly_count == 0)
+      return fail(ctx, MANTA_E_INVALID_ARG, "assembler options: word length, step, minCoverage and maxAssemblyCount must be >= 1");
+    if (o.max_word_length > 16u * ASM_MAX_KW) return fail(ctx, MANTA_E_UNSUPPORTED, "word lengths above 128 are not supported");
+    if (2 * o.max_assembly_count > ASM_MAX_CAND) return fail(ctx, MANTA_E_UNSUPPORTED, "maxAssemblyCount above 32 is not supported");
+    opt         = o;
+    nLoci       = n_loci;
+    nReadsTotal = locus_read_begin[n_loci];
+    nBases      = read_off[nReadsTotal];
+    uint64_t maxLocusBases = 0, maxLocusWords = 0, bitsBound = 0;
+    uint32_t maxLocusReads = 0, maxReadLen = 0;
+    for (uint32_t l = 0; l < n_loci; ++l) {
+      const uint32_t rb = locus_read_begin[l], re = locus_read_begin[l + 1];
+      if (re < rb || re > nReadsTotal) return fail(ctx, MANTA_E_INVALID_ARG, "locus_read_begin not monotone");
+      uint64_t b = 0, w = 0;
+      for (uint32_t r = rb; r < re; ++r) {
+        if (read_off[r + 1] < read_off[r]) return fail(ctx, MANTA_E_INVALID_ARG, "read_off not monotone");
+        const uint64_t len = read_off[r + 1] - read_off[r];
+        b += len;
+        w += (len + 15) / 16 + 1;
+        maxReadLen = std::max<uint32_t>(maxReadLen, uint32_t(len));
+      }
+      maxLocusBases = std::max(maxLocusBases, b);
+      maxLocusWords = std::max(maxLocusWords, w);
+      maxLocusReads = std::max(maxLocusReads, re - rb);
+      const uint64_t W = ((re - rb) + 2 * opt.max_assembly_count + 63) / 64;
+      bitsBound += uint64_t(opt.max_assembly_count) * 2 * W + 2 * opt.max_assembly_count;
+    }
+    const uint32_t nCandMax = 2 * opt.max_assembly_count;
+    wMax                    = uint32_t((maxLocusReads + nCandMax + 63) / 64);
+    if (wMax > ASM_MAX_W) return fail(ctx, MANTA_E_UNSUPPORTED, "more than ~1000 reads in one locus");
+    maxContigLen               = uint32_t(std::min<uint64_t>(maxLocusBases, 32768) + opt.max_word_length + 16);
+    const uint64_t pseudoLen   = std::min<uint64_t>(maxContigLen, 3ull * maxReadLen + opt.max_word_length);
+    const uint64_t pseudoBases = uint64_t(nCandMax) * pseudoLen;
+    capWords                   = uint32_t(maxLocusWords + pseudoBases / 16 + 2 * nCandMax + 8);
+    capReads                   = maxLocusReads + nCandMax + 1;
+    capNodes                   = uint32_t(maxLocusBases + pseudoBases + 64);
+    capSlots                   = nextPow2(2ull * capNodes);
+    const AsmWsLayout L = asmWorkspaceLayout(capSlots, capNodes, capWords, capReads, maxContigLen, wMax, opt.max_assembly_count);
+    stride              = (L.total + 255) & ~uint64_t(255);
+    const size_t wsBudget = std::min<size_t>(rt::freeBytes() / 2, size_t(64) << 30);
+    grid                  = int(std::min<uint64_t>(n_loci, uint64_t(std::max(1, ctx->cuCount * 8))));
+    grid                  = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(grid), wsBudget / stride)));
+    devSeqCap  = uint64_t(n_loci) * std::min<uint64_t>(3ull * opt.max_assembly_count * pseudoLen, 65536) + 4096;
+    devBitsCap = bitsBound + 64;
+    if (ctx->growthSize.empty()) recordGrowthSchedule(ctx->growthSize, ctx->growthBuckets, 4u << 20);
+    return MANTA_OK;
+  }
+
+  void upload(const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin)
+  {
+    dBases  = bBases.as<uint8_t>(nBases + 16);
+    dOff    = bReadOff.as<uint64_t>(nReadsTotal + 1);
+    dBegin  = bLocusBegin.as<uint32_t>(nLoci + 1);
+    dLoci   = bLoci.as<AsmLocusOut>(nLoci);
+    dCont   = bContigs.as<AsmContigOut>(uint64_t(nLoci) * opt.max_assembly_count);
+    dSeq    = bSeqArena.as<uint8_t>(devSeqCap);
+    dBits   = bBitsArena.as<uint64_t>(devBitsCap);
+    dCnt    = bCounters.as<uint64_t>(4);
+    dWs     = bWs.as<uint8_t>(stride * grid);
+    dGrowth = bGrowth.as<uint32_t>(2 * ctx->growthSize.size() + 2);
+    rt::h2d(dBases, bases, nBases);
+    rt::h2d(dOff, read_off, sizeof(uint64_t) * (nReadsTotal + 1));
+    rt::h2d(dBegin, locus_read_begin, sizeof(uint32_t) * (nLoci + 1));
+    rt::h2d(dGrowth, ctx->growthSize.data(), sizeof(uint32_t) * ctx->growthSize.size());
+    rt::h2d(dGrowth + ctx->growthSize.size(), ctx->growthBuckets.data(), sizeof(uint32_t) * ctx->growthBuckets.size());
+  }
+
+  void launch()
+  {
+    rt::dzero(dCnt, sizeof(uint64_t) * 4);
+    rt::dfill(dLoci, 0xff, sizeof(AsmLocusOut) * nLoci);
+    AsmParams P;
+    P.bases            = dBases;
+    P.read_off         = dOff;
+    P.locus_read_begin = dBegin;
+    P.n_loci           = nLoci;
+    P.opt = AsmOptsDev{opt.min_word_length, opt.max_word_length, opt.word_step_size, opt.min_coverage,
+                       opt.min_conservative_coverage, opt.min_unused_reads, opt.min_support_reads, opt.max_assembly_count};
+    P.counter        = reinterpret_cast<uint32_t*>(dCnt);
+    P.ws             = dWs;
+    P.ws_stride      = stride;
+    P.cap_slots      = capSlots;
+    P.cap_nodes      = capNodes;
+    P.cap_words      = capWords;
+    P.cap_reads      = capReads;
+    P.max_contig_len = maxContigLen;
+    P.w_max          = wMax;
+    P.loci           = dLoci;
+    P.contigs        = dCont;
+    P.seq_arena      = dSeq;
+    P.seq_cap        = devSeqCap;
+    P.seq_used       = reinterpret_cast<unsigned long long*>(dCnt + 1);
+    P.bits_arena     = dBits;
+    P.bits_cap       = devBitsCap;
+    P.bits_used      = reinterpret_cast<unsigned long long*>(dCnt + 2);
+    P.growth_size    = dGrowth;
+    P.growth_buckets = dGrowth + ctx->growthSize.size();
+    P.n_growth       = uint32_t(ctx->growthSize.size());
+    rt::launch(assemble_kernel, grid, 0, P);
+  }
+
+  int fetch(
+      manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, uint64_t contigs_cap, uint8_t* seq_arena,
+      uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used)
+  {
+    std::vector<AsmLocusOut>  hLoci(nLoci);
+    std::vector<AsmContigOut> hCont(uint64_t(nLoci) * opt.max_assembly_count);
+    uint64_t                  hCnt[4];
+    rt::d2h(hCnt, dCnt, sizeof(hCnt));
+    rt::d2h(hLoci.data(), dLoci, sizeof(AsmLocusOut) * nLoci);
+    rt::d2h(hCont.data(), dCont, sizeof(AsmContigOut) * hCont.size());
+    const uint64_t seqUsedDev = std::min<uint64_t>(hCnt[1], devSeqCap), bitsUsedDev = std::min<uint64_t>(hCnt[2], devBitsCap);
+    std::vector<uint8_t>  hSeq(seqUsedDev + 1);
+    std::vector<uint64_t> hBits(bitsUsedDev + 1);
+    rt::d2h(hSeq.data(), dSeq, seqUsedDev);
+    rt::d2h(hBits.data(), dBits, sizeof(uint64_t) * bitsUsedDev);
+
+    uint64_t seqUsed = 0, bitsUsed = 0, nContigs = 0;
+    int      worst = MANTA_OK;
+    for (uint32_t l = 0; l < nLoci; ++l) {
+      const AsmLocusOut&        h(hLoci[l]);
+      manta_asm_locus_result_t& o(loci[l]);
+      std::memset(&o, 0, sizeof(o));
+      o.status       = asmStatusToAbi(h.status);
+      o.first_contig = uint32_t(nContigs);
+      if (o.status != MANTA_OK) {
+        worst = o.status;
+        if (std::getenv("MANTA_AMD_DEBUG"))
+          std::fprintf(stderr, "manta_amd: locus %u device status %d (k=%u iter=%u)\n", l, h.status, h.final_word_length, h.n_iterations);
+        continue;
+      }
+      o.n_contigs         = h.n_contigs;
+      o.n_words           = h.n_words;
+      o.n_pseudo          = h.n_pseudo;
+      o.final_word_length = h.final_word_length;
+      o.n_iterations      = h.n_iterations;
+      o.cyclic_iterations = h.cyclic_iterations;
+      if (nContigs + h.n_contigs > contigs_cap) return fail(ctx, MANTA_E_CAPACITY, "contig array too small");
+      for (uint32_t c = 0; c < h.n_contigs; ++c) {
+        const AsmContigOut& hc(hCont[uint64_t(l) * opt.max_assembly_count + c]);
+        manta_asm_contig_t& oc(contigs[nContigs++]);
+        if (seqUsed + hc.seq_len > seq_arena_cap || bitsUsed + 2ull * h.n_words > bits_arena_cap)
+          return fail(ctx, MANTA_E_CAPACITY, "output arena too small");
+        std::memcpy(seq_arena + seqUsed, hSeq.data() + hc.seq_off, hc.seq_len);
+        std::memcpy(bits_arena + bitsUsed, hBits.data() + hc.bits_off, sizeof(uint64_t) * 2 * h.n_words);
+        oc.seq_off            = seqUsed;
+        oc.seq_len            = hc.seq_len;
+        oc.support_off        = bitsUsed;
+        oc.reject_off         = bitsUsed + h.n_words;
+        oc.seed_read_count    = 0;
+        oc.conservative_begin = hc.cons_begin;
+        oc.conservative_end   = hc.cons_end;
+        seqUsed += hc.seq_len;
+        bitsUsed += 2ull * h.n_words;
+      }
+      uint64_t pBytes = 0;
+      for (uint32_t p = 0; p < h.n_pseudo; ++p) pBytes += hBits[h.pseudo_len_off + p];
+      if (seqUsed + pBytes > seq_arena_cap || bitsUsed + h.n_pseudo > bits_arena_cap)
+        return fail(ctx, MANTA_E_CAPACITY, "output arena too small");
+      std::memcpy(seq_arena + seqUsed, hSeq.data() + h.pseudo_off, pBytes);
+      std::memcpy(bits_arena + bitsUsed, hBits.data() + h.pseudo_len_off, sizeof(uint64_t) * h.n_pseudo);
+      o.pseudo_seq_off = seqUsed;
+      o.pseudo_len_off = bitsUsed;
+      seqUsed += pBytes;
+      bitsUsed += h.n_pseudo;
+    }
+    if (seq_arena_used) *seq_arena_used = seqUsed;
+    if (bits_arena_used) *bits_arena_used = bitsUsed;
+    if (worst != MANTA_OK) return fail(ctx, worst, "one or more loci failed; see per-locus status");
+    return MANTA_OK;
+  }
+};
+
+}  // namespace
+
+struct manta_smallsv {
+  manta_ctx_t*          ctx;
+  AsmStage              asmStage;
+  manta_asm_options_t   opt{};
+  manta_align_scores_t  scores{};
+  int32_t               largeIndel = 0;
+  uint32_t              nLoci      = 0;
+  uint64_t              refBytes = 0, maxRef = 0;
+  bool                  uploaded = false, ran = false;
+  DevBuf                dRefs, dRefOff, dCuts, dTasks, dInfo, dResults, dBucketIds, dSmall, dCigar, dTable, dPtrWs;
+  rt::Event             evStart, evAsm, evSched, evAlign;
+  manta_smallsv_stats_t stats{};
+  explicit manta_smallsv(manta_ctx_t* c) : ctx(c), asmStage(c) {}
+};
+
+namespace {
 }  // namespace
 
 extern "C" {
@@ -267,9 +481,9 @@ int manta_align_batch(
         continue;
       }
       AlignTaskDev& d(dev[i]);
-      d.query_off = t.query_off;
-      d.ref1_off  = t.ref1_off;
-      d.ref2_off  = jump ? t.ref2_off : 0;
+      d.query     = reinterpret_cast<const uint8_t*>(uintptr_t(t.query_off));  // rebased onto the device arena below
+      d.ref1      = reinterpret_cast<const uint8_t*>(uintptr_t(t.ref1_off));
+      d.ref2      = reinterpret_cast<const uint8_t*>(uintptr_t(jump ? t.ref2_off : 0));
       d.query_len = t.query_len;
       d.ref1_len  = t.ref1_len;
       d.ref2_len  = jump ? t.ref2_len : 0;
@@ -287,6 +501,11 @@ int manta_align_batch(
     uint32_t*       dCigar   = ctx->dCigar.as<uint32_t>(cigarDevWords + 1);
     uint32_t*       dIds     = ctx->dTaskIds.as<uint32_t>(n_tasks);
     uint32_t*       dCounter = ctx->dCounter.as<uint32_t>(kNumESet);
+    for (AlignTaskDev& d : dev) {
+      d.query = dSeq + uintptr_t(d.query);
+      d.ref1  = dSeq + uintptr_t(d.ref1);
+      d.ref2  = dSeq + uintptr_t(d.ref2);
+    }
     rt::h2d(dSeq, seq_arena, seq_arena_bytes);
     rt::h2d(dTasks, dev.data(), sizeof(AlignTaskDev) * n_tasks);
     rt::dzero(dCounter, sizeof(uint32_t) * kNumESet);
@@ -303,12 +522,12 @@ int manta_align_batch(
       uint8_t* dWs          = ctx->dPtrWs.as<uint8_t>(stride * grid);
       rt::h2d(dIds + idsCursor, buckets[b].data(), sizeof(uint32_t) * buckets[b].size());
       AlignParams P;
-      P.seq            = dSeq;
       P.tasks          = dTasks;
       P.results        = dResults;
       P.cigar          = dCigar;
       P.task_ids       = dIds + idsCursor;
       P.n_tasks        = uint32_t(buckets[b].size());
+      P.n_tasks_dev    = nullptr;
       P.counter        = dCounter + b;
       P.ptr_ws         = dWs;
       P.ptr_ws_stride  = stride;
@@ -375,171 +594,252 @@ int manta_assemble_batch(
   if (seq_arena_used) *seq_arena_used = 0;
   if (bits_arena_used) *bits_arena_used = 0;
   if (n_loci == 0) return MANTA_OK;
-  if (opt->min_word_length == 0 || opt->word_step_size == 0 || opt->min_coverage == 0 || opt->max_assembly_count == 0)
-    return fail(ctx, MANTA_E_INVALID_ARG, "manta_assemble_batch: word length, step, minCoverage and maxAssemblyCount must be >= 1");
-  if (opt->max_word_length > 16u * ASM_MAX_KW)
-    return fail(ctx, MANTA_E_UNSUPPORTED, "manta_assemble_batch: word lengths above 128 are not supported");
-  if (2 * opt->max_assembly_count > ASM_MAX_CAND)
-    return fail(ctx, MANTA_E_UNSUPPORTED, "manta_assemble_batch: maxAssemblyCount above 32 is not supported");
-
   try {
-    const uint32_t nReadsTotal = locus_read_begin[n_loci];
-    const uint64_t nBases      = read_off[nReadsTotal];
-    // ---- workspace sizing from the batch shape ----
-    uint64_t maxLocusBases = 0, maxLocusWords = 0, bitsBound = 0;
-    uint32_t maxLocusReads = 0, maxReadLen = 0;
-    for (uint32_t l = 0; l < n_loci; ++l) {
-      const uint32_t rb = locus_read_begin[l], re = locus_read_begin[l + 1];
-      if (re < rb || re > nReadsTotal) return fail(ctx, MANTA_E_INVALID_ARG, "manta_assemble_batch: locus_read_begin not monotone");
-      uint64_t b = 0, w = 0;
-      for (uint32_t r = rb; r < re; ++r) {
-        if (read_off[r + 1] < read_off[r]) return fail(ctx, MANTA_E_INVALID_ARG, "manta_assemble_batch: read_off not monotone");
-        const uint64_t len = read_off[r + 1] - read_off[r];
-        b += len;
-        w += (len + 15) / 16 + 1;
-        maxReadLen = std::max<uint32_t>(maxReadLen, uint32_t(len));
-      }
-      maxLocusBases = std::max(maxLocusBases, b);
-      maxLocusWords = std::max(maxLocusWords, w);
-      maxLocusReads = std::max(maxLocusReads, re - rb);
-      const uint64_t W = ((re - rb) + 2 * opt->max_assembly_count + 63) / 64;
-      bitsBound += uint64_t(opt->max_assembly_count) * 2 * W + 2 * opt->max_assembly_count;
-    }
-    const uint32_t nCandMax     = 2 * opt->max_assembly_count;
-    const uint32_t wMax         = uint32_t((maxLocusReads + nCandMax + 63) / 64);
-    if (wMax > ASM_MAX_W) return fail(ctx, MANTA_E_UNSUPPORTED, "manta_assemble_batch: more than ~1000 reads in one locus");
-    const uint32_t maxContigLen = uint32_t(std::min<uint64_t>(maxLocusBases, 32768) + opt->max_word_length + 16);
-    const uint64_t pseudoLen    = std::min<uint64_t>(maxContigLen, 3ull * maxReadLen + opt->max_word_length);
-    const uint64_t pseudoBases  = uint64_t(nCandMax) * pseudoLen;
-    const uint32_t capWords     = uint32_t(maxLocusWords + pseudoBases / 16 + 2 * nCandMax + 8);
-    const uint32_t capReads     = maxLocusReads + nCandMax + 1;
-    const uint32_t capNodes     = uint32_t(maxLocusBases + pseudoBases + 64);
-    const uint32_t capSlots     = nextPow2(2ull * capNodes);
-    const AsmWsLayout L = asmWorkspaceLayout(capSlots, capNodes, capWords, capReads, maxContigLen, wMax, opt->max_assembly_count);
-    const uint64_t stride = (L.total + 255) & ~uint64_t(255);
-
-    const size_t wsBudget = std::min<size_t>(rt::freeBytes() / 2, size_t(64) << 30);
-    int          grid     = int(std::min<uint64_t>(n_loci, uint64_t(std::max(1, ctx->cuCount * 8))));
-    grid                  = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(grid), wsBudget / stride)));
-
-    // device-side output arenas
-    const uint64_t devSeqCap  = uint64_t(n_loci) * std::min<uint64_t>(3ull * opt->max_assembly_count * pseudoLen, 65536) + 4096;
-    const uint64_t devBitsCap = bitsBound + 64;
-
-    if (ctx->growthSize.empty()) recordGrowthSchedule(ctx->growthSize, ctx->growthBuckets, 4u << 20);
-
-    uint8_t*        dBases  = ctx->aBases.as<uint8_t>(nBases + 16);
-    uint64_t*       dOff    = ctx->aReadOff.as<uint64_t>(nReadsTotal + 1);
-    uint32_t*       dBegin  = ctx->aLocusBegin.as<uint32_t>(n_loci + 1);
-    AsmLocusOut*    dLoci   = ctx->aLoci.as<AsmLocusOut>(n_loci);
-    AsmContigOut*   dCont   = ctx->aContigs.as<AsmContigOut>(uint64_t(n_loci) * opt->max_assembly_count);
-    uint8_t*        dSeq    = ctx->aSeqArena.as<uint8_t>(devSeqCap);
-    uint64_t*       dBits   = ctx->aBitsArena.as<uint64_t>(devBitsCap);
-    uint64_t*       dCnt    = ctx->aCounters.as<uint64_t>(4);
-    uint8_t*        dWs     = ctx->aWs.as<uint8_t>(stride * grid);
-    uint32_t*       dGrowth = ctx->aGrowth.as<uint32_t>(2 * ctx->growthSize.size() + 2);
-    rt::h2d(dBases, bases, nBases);
-    rt::h2d(dOff, read_off, sizeof(uint64_t) * (nReadsTotal + 1));
-    rt::h2d(dBegin, locus_read_begin, sizeof(uint32_t) * (n_loci + 1));
-    rt::h2d(dGrowth, ctx->growthSize.data(), sizeof(uint32_t) * ctx->growthSize.size());
-    rt::h2d(dGrowth + ctx->growthSize.size(), ctx->growthBuckets.data(), sizeof(uint32_t) * ctx->growthBuckets.size());
-    rt::dzero(dCnt, sizeof(uint64_t) * 4);
-    rt::dfill(dLoci, 0xff, sizeof(AsmLocusOut) * n_loci);
-
-    AsmParams P;
-    P.bases            = dBases;
-    P.read_off         = dOff;
-    P.locus_read_begin = dBegin;
-    P.n_loci           = n_loci;
-    P.opt = AsmOptsDev{opt->min_word_length, opt->max_word_length, opt->word_step_size, opt->min_coverage,
-                       opt->min_conservative_coverage, opt->min_unused_reads, opt->min_support_reads, opt->max_assembly_count};
-    P.counter        = reinterpret_cast<uint32_t*>(dCnt);
-    P.ws             = dWs;
-    P.ws_stride      = stride;
-    P.cap_slots      = capSlots;
-    P.cap_nodes      = capNodes;
-    P.cap_words      = capWords;
-    P.cap_reads      = capReads;
-    P.max_contig_len = maxContigLen;
-    P.w_max          = wMax;
-    P.loci           = dLoci;
-    P.contigs        = dCont;
-    P.seq_arena      = dSeq;
-    P.seq_cap        = devSeqCap;
-    P.seq_used       = reinterpret_cast<unsigned long long*>(dCnt + 1);
-    P.bits_arena     = dBits;
-    P.bits_cap       = devBitsCap;
-    P.bits_used      = reinterpret_cast<unsigned long long*>(dCnt + 2);
-    P.growth_size    = dGrowth;
-    P.growth_buckets = dGrowth + ctx->growthSize.size();
-    P.n_growth       = uint32_t(ctx->growthSize.size());
-    rt::launch(assemble_kernel, grid, 0, P);
+    AsmStage st(ctx);
+    int      rc = st.plan(*opt, n_loci, read_off, locus_read_begin);
+    if (rc != MANTA_OK) return rc;
+    st.upload(bases, read_off, locus_read_begin);
+    st.launch();
     rt::sync();
+    return st.fetch(loci, contigs, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used);
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
+}
 
-    // ---- fetch ----
-    std::vector<AsmLocusOut>  hLoci(n_loci);
-    std::vector<AsmContigOut> hCont(uint64_t(n_loci) * opt->max_assembly_count);
-    uint64_t                  hCnt[4];
-    rt::d2h(hCnt, dCnt, sizeof(hCnt));
-    rt::d2h(hLoci.data(), dLoci, sizeof(AsmLocusOut) * n_loci);
-    rt::d2h(hCont.data(), dCont, sizeof(AsmContigOut) * hCont.size());
-    const uint64_t seqUsedDev = std::min<uint64_t>(hCnt[1], devSeqCap), bitsUsedDev = std::min<uint64_t>(hCnt[2], devBitsCap);
-    std::vector<uint8_t>  hSeq(seqUsedDev + 1);
-    std::vector<uint64_t> hBits(bitsUsedDev + 1);
-    rt::d2h(hSeq.data(), dSeq, seqUsedDev);
-    rt::d2h(hBits.data(), dBits, sizeof(uint64_t) * bitsUsedDev);
+// ------------------------------------------------------------------------------------------------------
+// fused small-SV pipeline
+// ------------------------------------------------------------------------------------------------------
+int manta_smallsv_create(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t large_indel_score,
+    manta_smallsv_t** out)
+{
+  if (!ctx) return MANTA_E_INVALID_ARG;
+  if (!opt || !scores || !out) return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_create: null argument");
+  manta_smallsv* b = new manta_smallsv(ctx);
+  b->opt           = *opt;
+  b->scores        = *scores;
+  b->largeIndel    = large_indel_score;
+  *out             = b;
+  return MANTA_OK;
+}
 
-    uint64_t seqUsed = 0, bitsUsed = 0, nContigs = 0;
-    int      worst = MANTA_OK;
+void manta_smallsv_destroy(manta_smallsv_t* b)
+{
+  delete b;
+}
+
+int manta_smallsv_upload(
+    manta_smallsv_t* b, uint32_t n_loci, const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin,
+    const uint8_t* refs, const uint64_t* ref_off, const manta_ref_cuts_t* cuts)
+{
+  if (!b) return MANTA_E_INVALID_ARG;
+  manta_ctx_t* ctx = b->ctx;
+  if (n_loci == 0 || !bases || !read_off || !locus_read_begin || !refs || !ref_off || !cuts)
+    return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_upload: null argument or empty batch");
+  try {
+    b->uploaded = false;
+    int rc      = b->asmStage.plan(b->opt, n_loci, read_off, locus_read_begin);
+    if (rc != MANTA_OK) return rc;
+    b->asmStage.upload(bases, read_off, locus_read_begin);
+    b->nLoci    = n_loci;
+    b->refBytes = ref_off[n_loci];
+    b->maxRef   = 0;
     for (uint32_t l = 0; l < n_loci; ++l) {
-      const AsmLocusOut&        h(hLoci[l]);
-      manta_asm_locus_result_t& o(loci[l]);
-      std::memset(&o, 0, sizeof(o));
-      o.status       = asmStatusToAbi(h.status);
-      o.first_contig = uint32_t(nContigs);
-      if (o.status != MANTA_OK) {
-        worst = o.status;
-        if (std::getenv("MANTA_AMD_DEBUG")) std::fprintf(stderr, "manta_amd: locus %u device status %d (k=%u iter=%u)\n", l, h.status, h.final_word_length, h.n_iterations);
-        continue;
-      }
-      o.n_contigs         = h.n_contigs;
-      o.n_words           = h.n_words;
-      o.n_pseudo          = h.n_pseudo;
-      o.final_word_length = h.final_word_length;
-      o.n_iterations      = h.n_iterations;
-      o.cyclic_iterations = h.cyclic_iterations;
-      if (nContigs + h.n_contigs > contigs_cap) return fail(ctx, MANTA_E_CAPACITY, "manta_assemble_batch: contig array too small");
-      for (uint32_t c = 0; c < h.n_contigs; ++c) {
-        const AsmContigOut& hc(hCont[uint64_t(l) * opt->max_assembly_count + c]);
-        manta_asm_contig_t& oc(contigs[nContigs++]);
-        if (seqUsed + hc.seq_len > seq_arena_cap || bitsUsed + 2ull * h.n_words > bits_arena_cap)
-          return fail(ctx, MANTA_E_CAPACITY, "manta_assemble_batch: output arena too small");
-        std::memcpy(seq_arena + seqUsed, hSeq.data() + hc.seq_off, hc.seq_len);
-        std::memcpy(bits_arena + bitsUsed, hBits.data() + hc.bits_off, sizeof(uint64_t) * 2 * h.n_words);
-        oc.seq_off            = seqUsed;
-        oc.seq_len            = hc.seq_len;
-        oc.support_off        = bitsUsed;
-        oc.reject_off         = bitsUsed + h.n_words;
-        oc.seed_read_count    = 0;
-        oc.conservative_begin = hc.cons_begin;
-        oc.conservative_end   = hc.cons_end;
-        seqUsed += hc.seq_len;
-        bitsUsed += 2ull * h.n_words;
-      }
-      uint64_t pBytes = 0;
-      for (uint32_t p = 0; p < h.n_pseudo; ++p) pBytes += hBits[h.pseudo_len_off + p];
-      if (seqUsed + pBytes > seq_arena_cap || bitsUsed + h.n_pseudo > bits_arena_cap)
-        return fail(ctx, MANTA_E_CAPACITY, "manta_assemble_batch: output arena too small");
-      std::memcpy(seq_arena + seqUsed, hSeq.data() + h.pseudo_off, pBytes);
-      std::memcpy(bits_arena + bitsUsed, hBits.data() + h.pseudo_len_off, sizeof(uint64_t) * h.n_pseudo);
-      o.pseudo_seq_off = seqUsed;
-      o.pseudo_len_off = bitsUsed;
-      seqUsed += pBytes;
-      bitsUsed += h.n_pseudo;
+      if (ref_off[l + 1] < ref_off[l]) return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_upload: ref_off not monotone");
+      b->maxRef = std::max<uint64_t>(b->maxRef, ref_off[l + 1] - ref_off[l]);
+      if (cuts[l].leading_cut < 0 || cuts[l].trailing_cut < 0 || cuts[l].max_leading_cut < 0 || cuts[l].max_trailing_cut < 0)
+        return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_upload: negative reference cut");
     }
-    if (seq_arena_used) *seq_arena_used = seqUsed;
-    if (bits_arena_used) *bits_arena_used = bitsUsed;
-    if (worst != MANTA_OK) return fail(ctx, worst, "manta_assemble_batch: one or more loci failed; see per-locus status");
+    uint8_t*  dRefs   = b->dRefs.as<uint8_t>(b->refBytes + 16);
+    uint64_t* dRefOff = b->dRefOff.as<uint64_t>(n_loci + 1);
+    auto*     dCuts   = b->dCuts.as<SmallSvCuts>(n_loci);
+    rt::h2d(dRefs, refs, b->refBytes);
+    rt::h2d(dRefOff, ref_off, sizeof(uint64_t) * (n_loci + 1));
+    static_assert(sizeof(SmallSvCuts) == sizeof(manta_ref_cuts_t), "cuts layout");
+    rt::h2d(dCuts, cuts, sizeof(SmallSvCuts) * n_loci);
+    rt::sync();
+    b->uploaded = true;
+    return MANTA_OK;
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
+}
+
+int manta_smallsv_run(manta_smallsv_t* b)
+{
+  if (!b) return MANTA_E_INVALID_ARG;
+  manta_ctx_t* ctx = b->ctx;
+  if (!b->uploaded) return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_run: nothing uploaded");
+  try {
+    const uint32_t nLoci   = b->nLoci;
+    const uint32_t maxAsm  = b->opt.max_assembly_count;
+    const uint64_t nSlots  = uint64_t(nLoci) * maxAsm;
+    AsmStage&      as(b->asmStage);
+    // ---- per-run device state ----
+    AlignTaskDev*    dTasks   = b->dTasks.as<AlignTaskDev>(nSlots);
+    SmallSvTaskInfo* dInfo    = b->dInfo.as<SmallSvTaskInfo>(nSlots);
+    AlignResultDev*  dResults = b->dResults.as<AlignResultDev>(nSlots);
+    uint32_t*        dBuckets = b->dBucketIds.as<uint32_t>(nSlots * kNumESet);
+    uint32_t*        dSmall   = b->dSmall.as<uint32_t>(64);  // [0..11] counts, [16..27] maxref, [32] sched counter, [34..35] cigar_used, [40..51] align counters
+    const uint64_t   cigarCap = nSlots * (4ull * std::min<uint64_t>(as.maxContigLen, 4096) + 16);
+    uint32_t*        dCigar   = b->dCigar.as<uint32_t>(cigarCap + 16);
+    const uint32_t   tableCap = nextPow2(2ull * as.maxContigLen);
+    const int        schedGrid = int(std::min<uint64_t>(nSlots, uint64_t(std::max(1, ctx->cuCount * 8))));
+    uint32_t*        dTable   = b->dTable.as<uint32_t>(uint64_t(tableCap) * schedGrid);
+    rt::dzero(dSmall, sizeof(uint32_t) * 64);
+    rt::dzero(dResults, sizeof(AlignResultDev) * nSlots);
+
+    b->evStart.record();
+    as.launch();
+    b->evAsm.record();
+
+    ScheduleParams S;
+    S.loci               = as.dLoci;
+    S.contigs            = as.dCont;
+    S.seq_arena          = as.dSeq;
+    S.n_loci             = nLoci;
+    S.max_assembly_count = maxAsm;
+    S.refs               = static_cast<const uint8_t*>(b->dRefs.p);
+    S.ref_off            = static_cast<const uint64_t*>(b->dRefOff.p);
+    S.cuts               = static_cast<const SmallSvCuts*>(b->dCuts.p);
+    S.tasks              = dTasks;
+    S.info               = dInfo;
+    S.bucket_ids         = dBuckets;
+    S.bucket_count       = dSmall;
+    S.bucket_maxref      = dSmall + 16;
+    S.cigar_used         = reinterpret_cast<unsigned long long*>(dSmall + 34);
+    S.cigar_cap          = cigarCap;
+    S.counter            = dSmall + 32;
+    S.table_ws           = dTable;
+    S.table_cap          = tableCap;
+    S.n_e                = kNumESet;
+    for (int i = 0; i < kNumESet; ++i) S.e_set[i] = uint32_t(kESet[i]);
+    rt::launch(smallsv_schedule_kernel, schedGrid, 0, S);
+    b->evSched.record();
+
+    // bucket sizes decide the alignment launches (one tiny D2H)
+    uint32_t hSmall[32];
+    rt::d2h(hSmall, dSmall, sizeof(hSmall));
+    b->stats.n_align_launches = 0;
+    b->stats.n_alignments     = 0;
+    b->stats.ptr_matrix_bytes = 0;
+    const int    maxWaves = std::max(1, ctx->cuCount * 8);
+    const size_t wsBudget = std::min<size_t>(rt::freeBytes() / 2, size_t(48) << 30);
+    for (int k = 0; k < kNumESet; ++k) {
+      const uint32_t cnt = hSmall[k];
+      if (cnt == 0) continue;
+      const uint64_t stride = (alignPtrSlabBytes(MANTA_ALIGNER_LARGE_INDEL, kESet[k], hSmall[16 + k]) + 255) & ~uint64_t(255);
+      int            grid   = int(std::min<size_t>(cnt, size_t(maxWaves)));
+      grid                  = int(std::max<size_t>(1, std::min<size_t>(size_t(grid), wsBudget / stride)));
+      uint8_t* dWs          = b->dPtrWs.as<uint8_t>(stride * grid);
+      AlignParams P;
+      P.tasks          = dTasks;
+      P.results        = dResults;
+      P.cigar          = dCigar;
+      P.task_ids       = dBuckets + uint64_t(k) * nSlots;
+      P.n_tasks        = cnt;
+      P.n_tasks_dev    = nullptr;
+      P.counter        = dSmall + 40 + k;
+      P.ptr_ws         = dWs;
+      P.ptr_ws_stride  = stride;
+      P.match          = b->scores.match;
+      P.mismatch       = b->scores.mismatch;
+      P.open           = b->scores.open;
+      P.extend         = b->scores.extend;
+      P.off_edge       = b->scores.off_edge;
+      P.allow_edge_ins = b->scores.is_allow_edge_insertion ? 1 : 0;
+      P.extra          = b->largeIndel;
+      launchAlignKind(MANTA_ALIGNER_LARGE_INDEL, k, grid, P);
+      b->stats.n_align_launches++;
+      b->stats.n_alignments += cnt;
+      if (k + 1 < kNumESet) rt::sync();  // the slab buffer may be re-sized for the next bucket
+    }
+    b->evAlign.record();
+    rt::sync();
+    b->stats.assemble_ms = rt::elapsedMs(b->evStart, b->evAsm);
+    b->stats.schedule_ms = rt::elapsedMs(b->evAsm, b->evSched);
+    b->stats.align_ms    = rt::elapsedMs(b->evSched, b->evAlign);
+    b->stats.total_ms    = rt::elapsedMs(b->evStart, b->evAlign);
+    b->ran               = true;
+    return MANTA_OK;
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
+}
+
+int manta_smallsv_stats(const manta_smallsv_t* b, manta_smallsv_stats_t* stats)
+{
+  if (!b || !stats) return MANTA_E_INVALID_ARG;
+  *stats = b->stats;
+  return MANTA_OK;
+}
+
+int manta_smallsv_download(
+    manta_smallsv_t* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_smallsv_alignment_t* alignments,
+    uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena,
+    uint64_t bits_arena_cap, uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
+    uint64_t* cigar_arena_used)
+{
+  if (!b) return MANTA_E_INVALID_ARG;
+  manta_ctx_t* ctx = b->ctx;
+  if (!b->ran) return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_download: run first");
+  if (!loci || !contigs || !alignments || !seq_arena || !bits_arena || !cigar_arena)
+    return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_download: null argument");
+  try {
+    int rc = b->asmStage.fetch(loci, contigs, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap,
+                               bits_arena_used);
+    if (rc != MANTA_OK && rc != MANTA_E_UNSUPPORTED && rc != MANTA_E_DEVICE_FAULT) return rc;
+    const uint32_t nLoci  = b->nLoci;
+    const uint32_t maxAsm = b->opt.max_assembly_count;
+    const uint64_t nSlots = uint64_t(nLoci) * maxAsm;
+    std::vector<AlignResultDev>  hRes(nSlots);
+    std::vector<SmallSvTaskInfo> hInfo(nSlots);
+    std::vector<AlignTaskDev>    hTasks(nSlots);
+    uint32_t                     hSmall[40];
+    rt::d2h(hRes.data(), b->dResults.p, sizeof(AlignResultDev) * nSlots);
+    rt::d2h(hInfo.data(), b->dInfo.p, sizeof(SmallSvTaskInfo) * nSlots);
+    rt::d2h(hTasks.data(), b->dTasks.p, sizeof(AlignTaskDev) * nSlots);
+    rt::d2h(hSmall, b->dSmall.p, sizeof(hSmall));
+    uint64_t cigDev = 0;
+    std::memcpy(&cigDev, hSmall + 34, sizeof(uint64_t));
+    std::vector<uint32_t> hCig(cigDev + 1);
+    rt::d2h(hCig.data(), b->dCigar.p, sizeof(uint32_t) * cigDev);
+    uint64_t used = 0, cells = 0, ptrBytes = 0;
+    int      worst = rc;
+    for (uint32_t l = 0; l < nLoci; ++l) {
+      if (loci[l].status != MANTA_OK) continue;
+      for (uint32_t c = 0; c < loci[l].n_contigs; ++c) {
+        const uint64_t             slot = uint64_t(l) * maxAsm + c;
+        manta_smallsv_alignment_t& a(alignments[loci[l].first_contig + c]);
+        std::memset(&a, 0, sizeof(a));
+        const SmallSvTaskInfo& inf(hInfo[slot]);
+        a.adjusted_leading_cut  = inf.adj_leading_cut;
+        a.adjusted_trailing_cut = inf.adj_trailing_cut;
+        if (inf.status != 0 || inf.bucket < 0 || hRes[slot].status != 0) {
+          a.align.status = (inf.status == 5) ? MANTA_E_CAPACITY : MANTA_E_UNSUPPORTED;
+          worst          = a.align.status;
+          continue;
+        }
+        const AlignResultDev& h(hRes[slot]);
+        const uint64_t        n = h.cigar1_len;
+        if (used + n > cigar_arena_cap) return fail(ctx, MANTA_E_CAPACITY, "manta_smallsv_download: cigar arena too small");
+        std::memcpy(cigar_arena + used, hCig.data() + hTasks[slot].cigar_off, sizeof(uint32_t) * n);
+        a.align.score      = h.score;
+        a.align.is_jumped  = h.is_jumped;
+        a.align.begin_pos1 = h.begin1 + inf.adj_leading_cut;  // SVCandidateAssemblyRefiner.cpp:2039
+        a.align.cigar1_len = h.cigar1_len;
+        a.align.cigar1_off = used;
+        a.align.cigar2_off = used + n;
+        used += n;
+        cells += uint64_t(hTasks[slot].query_len) * hTasks[slot].ref1_len;
+        ptrBytes += 2ull * (uint64_t(hTasks[slot].query_len) + 1) * (uint64_t(hTasks[slot].ref1_len) + 1);
+      }
+    }
+    b->stats.dp_cells         = cells;
+    b->stats.ptr_matrix_bytes = ptrBytes;
+    if (cigar_arena_used) *cigar_arena_used = used;
+    if (worst != MANTA_OK) return fail(ctx, worst, "manta_smallsv_download: one or more loci/contigs failed; see per-item status");
     return MANTA_OK;
   } catch (const std::exception& e) {
     return fail(ctx, MANTA_E_HIP, e.what());

@@ -26,6 +26,8 @@ inline void  dfill(void* d, int byte, size_t n) { if (n) std::memset(d, byte, n)
 inline void  sync() {}
 template <typename K, typename P>
 inline void launch(K kernel, int grid, size_t ldsBytes, const P& params) { wv_emu::launch(grid, ldsBytes, [&]() { kernel(params); }); }
+struct Event { void record() {} };
+inline float elapsedMs(const Event&, const Event&) { return 0.f; }
 }  // namespace rt
 #else
 #include <hip/hip_runtime.h>
@@ -80,6 +82,22 @@ inline void launch(K kernel, int grid, size_t ldsBytes, const P& params)
 {
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), ldsBytes, 0, params);
   check(hipGetLastError(), "kernel launch");
+}
+/// HIP event on the (null) stream the kernels are launched on
+struct Event {
+  hipEvent_t e = nullptr;
+  Event() { check(hipEventCreate(&e), "hipEventCreate"); }
+  ~Event() { if (e) (void)hipEventDestroy(e); }
+  Event(const Event&) = delete;
+  Event& operator=(const Event&) = delete;
+  void record() { check(hipEventRecord(e, 0), "hipEventRecord"); }
+};
+inline float elapsedMs(const Event& a, const Event& b)
+{
+  float ms = 0.f;
+  check(hipEventSynchronize(b.e), "hipEventSynchronize");
+  check(hipEventElapsedTime(&ms, a.e, b.e), "hipEventElapsedTime");
+  return ms;
 }
 }  // namespace rt
 #endif

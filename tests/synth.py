@@ -94,3 +94,40 @@ def repeat_rich_pile(seed, n_reads=12, read_len=40, alphabet=b"ACGT"):
         s = int(rng.integers(0, len(hap) - L + 1))
         reads.append(mutate(rng, hap[s:s + L], 0.02, 0.01).tobytes())
     return reads
+
+
+def config2_batch(n_loci, seed=12345, n_reads=80, read_len=150, ref_len=1800, sub_rate=0.003):
+    """Vectorised config-2 generator: returns packed arrays ready for manta_smallsv_upload:
+    bases(uint8), read_off(uint64), locus_read_begin(uint32), refs(uint8), ref_off(uint64), cuts(int32 n x 4).
+    Per locus: ref = random ACGT; alt = ref with a deletion of U{10..60} (or an insertion of random bases, 50/50) at the
+    middle; reads sampled from alt so that each overlaps the breakpoint by >= 10 bp; substitutions at `sub_rate`."""
+    rng = np.random.default_rng(seed)
+    code = rng.integers(0, 4, size=(n_loci, ref_len), dtype=np.uint8)
+    bp = ref_len // 2
+    size = rng.integers(10, 61, size=n_loci)
+    is_del = rng.random(n_loci) < 0.5
+    ins = rng.integers(0, 4, size=(n_loci, 60), dtype=np.uint8)
+    reads = np.empty((n_loci, n_reads, read_len), dtype=np.uint8)
+    for l in range(n_loci):
+        s = int(size[l])
+        alt = np.concatenate([code[l, :bp], code[l, bp + s:]]) if is_del[l] else np.concatenate([code[l, :bp], ins[l, :s], code[l, bp:]])
+        lo, hi = max(0, bp - read_len + 10), min(len(alt) - read_len, bp - 10)
+        starts = rng.integers(lo, hi + 1, size=n_reads)
+        idx = starts[:, None] + np.arange(read_len)[None, :]
+        reads[l] = alt[idx]
+    m = rng.random(reads.shape) < sub_rate
+    reads = np.where(m, (reads + rng.integers(1, 4, size=reads.shape, dtype=np.uint8)) & 3, reads).astype(np.uint8)
+    bases = ACGT[reads].reshape(-1)
+    refs = ACGT[code].reshape(-1)
+    read_off = (np.arange(n_loci * n_reads + 1, dtype=np.uint64) * np.uint64(read_len))
+    begin = (np.arange(n_loci + 1, dtype=np.uint32) * np.uint32(n_reads))
+    ref_off = (np.arange(n_loci + 1, dtype=np.uint64) * np.uint64(ref_len))
+    cuts = np.tile(np.array([100, 100, 800, 800], dtype=np.int32), (n_loci, 1))
+    return (np.ascontiguousarray(bases), read_off, begin, np.ascontiguousarray(refs), ref_off, np.ascontiguousarray(cuts))
+
+
+def unpack_locus(batch, l):
+    """(reads list, ref bytes, cuts tuple) of locus l of a packed batch"""
+    bases, read_off, begin, refs, ref_off, cuts = batch
+    reads = [bases[int(read_off[r]):int(read_off[r + 1])].tobytes() for r in range(int(begin[l]), int(begin[l + 1]))]
+    return reads, refs[int(ref_off[l]):int(ref_off[l + 1])].tobytes(), tuple(int(x) for x in cuts[l])
