@@ -180,14 +180,23 @@ def main():
         }
         # ---- CPU baseline: the reference's own sources (oracle/_ref) on this box's host cores ----
         if world == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 1
             kind, cpu = ("reference", RefLib()) if have_ref() else ("port", orc)
-            n_s = args.cpu_sample or min(args.loci, max(64, 24 * cores))
+            # bounded sample: ~32 ms/locus/thread (BASELINE.md probe) -> about 10-20 s of CPU work in total
+            n_1 = 96
+            sb1 = config2_batch(n_1, seed=12345)
+            secs1 = cpu.bench_small_sv(opts, SCORES, LARGE_INDEL, sb1[0], sb1[1], sb1[2], sb1[3], sb1[4], (100, 100, 800, 800), 1)
+            n_s = args.cpu_sample or min(args.loci, max(128, 8 * cores))
             sb = config2_batch(n_s, seed=12345)
             secs = cpu.bench_small_sv(opts, SCORES, LARGE_INDEL, sb[0], sb[1], sb[2], sb[3], sb[4], (100, 100, 800, 800), cores)
             out["cpu_baseline"] = {"value": round(n_s / secs, 2), "unit": "loci/s", "cores": cores, "kind": kind,
-                                   "sample": "%d loci of the same workload, %d host threads (one aligner per thread), %.1f s wall"
-                                             % (n_s, cores, secs)}
+                                   "sample": "%d loci of the same workload on %d host threads (one aligner per thread, as "
+                                             "GenerateSVCandidates.cpp:232-266), %.1f s wall; single thread: %d loci in %.1f s"
+                                             % (n_s, cores, secs, n_1, secs1),
+                                   "single_thread_value": round(n_1 / secs1, 2)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -116,6 +116,11 @@ void launchAlignKind(int kind, int eIdx, int grid, const AlignParams& P)
     launchAlignE<2>(eIdx, grid, P);
 }
 
+int alignWavesPerCu()
+{
+  return std::getenv("MANTA_AMD_ALIGN_WAVES_PER_CU") ? std::atoi(std::getenv("MANTA_AMD_ALIGN_WAVES_PER_CU")) : 16;
+}
+
 /// bucket_count() transitions of the libstdc++ this library is linked against, recorded from a live
 /// std::unordered_map (the reference's repeat search iterates such maps: assembly/IterativeAssembler.cpp:630-641)
 void recordGrowthSchedule(std::vector<uint32_t>& sizes, std::vector<uint32_t>& buckets, const uint32_t upTo)
@@ -246,8 +251,9 @@ struct AsmStage {
     const AsmWsLayout L = asmWorkspaceLayout(capSlots, capNodes, capWords, capReads, maxContigLen, wMax, opt.max_assembly_count);
     stride              = (L.total + 255) & ~uint64_t(255);
     const size_t wsBudget = std::min<size_t>(rt::freeBytes() / 2, size_t(64) << 30);
-    grid                  = int(std::min<uint64_t>(n_loci, uint64_t(std::max(1, ctx->cuCount * 8))));
-    grid                  = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(grid), wsBudget / stride)));
+    const int wavesPerCu  = std::getenv("MANTA_AMD_ASM_WAVES_PER_CU") ? std::atoi(std::getenv("MANTA_AMD_ASM_WAVES_PER_CU")) : 16;
+    grid                  = int(std::min<uint64_t>(n_loci, uint64_t(std::max(1, ctx->cuCount * wavesPerCu))));
+    grid                  = rt::roundGrid(int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(grid), wsBudget / stride))));
     devSeqCap  = uint64_t(n_loci) * std::min<uint64_t>(3ull * opt.max_assembly_count * pseudoLen, 65536) + 4096;
     devBitsCap = bitsBound + 64;
     if (ctx->growthSize.empty()) recordGrowthSchedule(ctx->growthSize, ctx->growthBuckets, 4u << 20);
@@ -263,7 +269,7 @@ struct AsmStage {
     dCont   = bContigs.as<AsmContigOut>(uint64_t(nLoci) * opt.max_assembly_count);
     dSeq    = bSeqArena.as<uint8_t>(devSeqCap);
     dBits   = bBitsArena.as<uint64_t>(devBitsCap);
-    dCnt    = bCounters.as<uint64_t>(4);
+    dCnt    = bCounters.as<uint64_t>(16);
     dWs     = bWs.as<uint8_t>(stride * grid);
     dGrowth = bGrowth.as<uint32_t>(2 * ctx->growthSize.size() + 2);
     rt::h2d(dBases, bases, nBases);
@@ -275,7 +281,7 @@ struct AsmStage {
 
   void launch()
   {
-    rt::dzero(dCnt, sizeof(uint64_t) * 4);
+    rt::dzero(dCnt, sizeof(uint64_t) * 16);
     rt::dfill(dLoci, 0xff, sizeof(AsmLocusOut) * nLoci);
     AsmParams P;
     P.bases            = dBases;
@@ -301,6 +307,7 @@ struct AsmStage {
     P.bits_arena     = dBits;
     P.bits_cap       = devBitsCap;
     P.bits_used      = reinterpret_cast<unsigned long long*>(dCnt + 2);
+    P.phase_cycles   = reinterpret_cast<unsigned long long*>(dCnt + 4);
     P.growth_size    = dGrowth;
     P.growth_buckets = dGrowth + ctx->growthSize.size();
     P.n_growth       = uint32_t(ctx->growthSize.size());
@@ -313,8 +320,16 @@ struct AsmStage {
   {
     std::vector<AsmLocusOut>  hLoci(nLoci);
     std::vector<AsmContigOut> hCont(uint64_t(nLoci) * opt.max_assembly_count);
-    uint64_t                  hCnt[4];
+    uint64_t                  hCnt[16];
     rt::d2h(hCnt, dCnt, sizeof(hCnt));
+    if (std::getenv("MANTA_AMD_PROFILE")) {
+      static const char* names[8] = {"pack", "table", "links", "cycle-check", "exact", "seed", "walk", "select+emit"};
+      uint64_t           tot = 0;
+      for (int i = 0; i < 8; ++i) tot += hCnt[4 + i];
+      std::fprintf(stderr, "manta_amd assemble_kernel phase share (shader clocks summed over %u loci, grid %d):", nLoci, grid);
+      for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s=%.1f%%", names[i], tot ? 100.0 * double(hCnt[4 + i]) / double(tot) : 0.0);
+      std::fprintf(stderr, " | avg clocks/locus=%.0f\n", double(tot) / nLoci);
+    }
     rt::d2h(hLoci.data(), dLoci, sizeof(AsmLocusOut) * nLoci);
     rt::d2h(hCont.data(), dCont, sizeof(AsmContigOut) * hCont.size());
     const uint64_t seqUsedDev = std::min<uint64_t>(hCnt[1], devSeqCap), bitsUsedDev = std::min<uint64_t>(hCnt[2], devBitsCap);
@@ -511,7 +526,7 @@ int manta_align_batch(
     rt::dzero(dCounter, sizeof(uint32_t) * kNumESet);
     rt::dzero(dResults, sizeof(AlignResultDev) * n_tasks);
 
-    const int    maxWaves  = std::max(1, ctx->cuCount * 8);
+    const int    maxWaves  = std::max(1, ctx->cuCount * alignWavesPerCu());
     const size_t wsBudget  = std::min<size_t>(rt::freeBytes() / 2, size_t(24) << 30);
     size_t       idsCursor = 0;
     for (int b = 0; b < kNumESet; ++b) {
@@ -519,6 +534,7 @@ int manta_align_batch(
       const uint64_t stride = (alignPtrSlabBytes(kind, kESet[b], bucketMaxRef[b]) + 255) & ~uint64_t(255);
       int            grid   = int(std::min<size_t>(buckets[b].size(), size_t(maxWaves)));
       grid                  = int(std::max<size_t>(1, std::min<size_t>(size_t(grid), wsBudget / stride)));
+      grid                  = rt::roundGrid(grid);
       uint8_t* dWs          = ctx->dPtrWs.as<uint8_t>(stride * grid);
       rt::h2d(dIds + idsCursor, buckets[b].data(), sizeof(uint32_t) * buckets[b].size());
       AlignParams P;
@@ -685,7 +701,7 @@ int manta_smallsv_run(manta_smallsv_t* b)
     const uint64_t   cigarCap = nSlots * (4ull * std::min<uint64_t>(as.maxContigLen, 4096) + 16);
     uint32_t*        dCigar   = b->dCigar.as<uint32_t>(cigarCap + 16);
     const uint32_t   tableCap = nextPow2(2ull * as.maxContigLen);
-    const int        schedGrid = int(std::min<uint64_t>(nSlots, uint64_t(std::max(1, ctx->cuCount * 8))));
+    const int        schedGrid = rt::roundGrid(int(std::min<uint64_t>(nSlots, uint64_t(std::max(1, ctx->cuCount * 16)))));
     uint32_t*        dTable   = b->dTable.as<uint32_t>(uint64_t(tableCap) * schedGrid);
     rt::dzero(dSmall, sizeof(uint32_t) * 64);
     rt::dzero(dResults, sizeof(AlignResultDev) * nSlots);
@@ -724,7 +740,7 @@ int manta_smallsv_run(manta_smallsv_t* b)
     b->stats.n_align_launches = 0;
     b->stats.n_alignments     = 0;
     b->stats.ptr_matrix_bytes = 0;
-    const int    maxWaves = std::max(1, ctx->cuCount * 8);
+    const int    maxWaves = std::max(1, ctx->cuCount * alignWavesPerCu());
     const size_t wsBudget = std::min<size_t>(rt::freeBytes() / 2, size_t(48) << 30);
     for (int k = 0; k < kNumESet; ++k) {
       const uint32_t cnt = hSmall[k];
@@ -732,6 +748,7 @@ int manta_smallsv_run(manta_smallsv_t* b)
       const uint64_t stride = (alignPtrSlabBytes(MANTA_ALIGNER_LARGE_INDEL, kESet[k], hSmall[16 + k]) + 255) & ~uint64_t(255);
       int            grid   = int(std::min<size_t>(cnt, size_t(maxWaves)));
       grid                  = int(std::max<size_t>(1, std::min<size_t>(size_t(grid), wsBudget / stride)));
+      grid                  = rt::roundGrid(grid);
       uint8_t* dWs          = b->dPtrWs.as<uint8_t>(stride * grid);
       AlignParams P;
       P.tasks          = dTasks;

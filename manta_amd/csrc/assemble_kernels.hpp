@@ -93,6 +93,7 @@ struct AsmParams {
   uint64_t            bits_cap;
   unsigned long long* bits_used;
   // libstdc++ bucket growth schedule for the exact repeat search (host records it from the live library)
+  unsigned long long* phase_cycles;  ///< optional [8]: pack, table, links, cycle-check, exact, seed, walk, select (summed over loci)
   const uint32_t* growth_size;     ///< map.size() right before the insertion that rehashes
   const uint32_t* growth_buckets;  ///< bucket count after it
   uint32_t        n_growth;
@@ -194,6 +195,8 @@ struct Assembler {
   unsigned codeWordsUsed, maskWordsUsed;
   int      status;
   unsigned cyclicIters;
+  uint64_t tPhase[8];
+  uint64_t tMark;
 
   WV_DEV Assembler(const AsmParams& p, uint8_t* wsBase) : P(p), ws(wsBase)
   {
@@ -222,6 +225,20 @@ struct Assembler {
     pseudo_seq = ws + L.pseudo_seq;
     pseudo_len = reinterpret_cast<uint32_t*>(ws + L.pseudo_len);
     exact_ws   = reinterpret_cast<uint32_t*>(ws + L.exact);
+  }
+
+  /// optional per-phase shader-clock profile (compiled in with -DMANTA_ASM_PROFILE; costs registers)
+  WV_DEV void tick(const int phase)
+  {
+#ifdef MANTA_ASM_PROFILE
+    const uint64_t now = wv::clock();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i == phase) tPhase[i] += now - tMark;
+    tMark = now;
+#else
+    (void)phase;
+#endif
   }
 
   // ------------------------------------------------------------------------------------------------
@@ -530,6 +547,7 @@ struct Assembler {
     }
     wv::sync();
     wv::fence_acquire();
+    tick(1);
 
     // counts (:541-545: a pseudo read weighs minCoverage), seed eligibility (:679-682), links
     for (unsigned nd = lane; nd < nNodes; nd += 64) {
@@ -554,6 +572,7 @@ struct Assembler {
       node_aux[nd]  = indeg;
     }
     wv::sync();
+    tick(2);
   }
 
   WV_DEV uint64_t normalMask(const unsigned w) const
@@ -852,17 +871,22 @@ struct Assembler {
   {
     buildGraph<KW>();
     if (status != ASM_OK) return true;
-    if (graphHasCycle()) {
+    const bool cyclic = graphHasCycle();
+    tick(3);
+    if (cyclic) {
       cyclicIters++;
       exactRepeatSearch<KW>();
+      tick(4);
       if (status != ASM_OK) return true;
     }
     nCand        = 0;
     bool success = true;
     while (nCand < 2 * P.opt.maxAssemblyCount) {  // :685
       const unsigned seed = selectSeed<KW>();
+      tick(5);
       if (seed == ASM_NONE) break;
       const bool rep = walk<KW>(seed, nCand + 1, nCand);
+      tick(6);
       if (status != ASM_OK) return true;
       if (rep) success = false;
       nCand++;
@@ -1038,6 +1062,8 @@ struct Assembler {
   WV_DEV void run(const unsigned locus)
   {
     const unsigned lane = unsigned(wv::lane());
+    for (int i = 0; i < 8; ++i) tPhase[i] = 0;
+    tMark               = wv::clock();
     cyclicIters         = 0;
     nCand               = 0;
     k                   = P.opt.minWordLength;
@@ -1047,6 +1073,7 @@ struct Assembler {
     packNormalReads(locus);
     wv::sync();
     wv::fence_acquire();
+    tick(0);
     W = (nNormal + 2 * P.opt.maxAssemblyCount + 63) / 64;
     if (W == 0) W = 1;
     if (status == ASM_OK && (P.opt.maxWordLength > 16u * ASM_MAX_KW || P.opt.minWordLength == 0)) status = ASM_E_WORD_TOO_LONG;
@@ -1069,6 +1096,13 @@ struct Assembler {
       }
     }
     selectAndEmit(locus, nPseudo, nIter);
+    tick(7);
+#ifdef MANTA_ASM_PROFILE
+    if (P.phase_cycles && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wv::atomic_add(&P.phase_cycles[i], (unsigned long long)tPhase[i]);
+    }
+#endif
   }
 };
 
@@ -1078,7 +1112,7 @@ struct Assembler {
 
 namespace manta_dev {
 
-WV_KERNEL void assemble_kernel(const AsmParams P)
+WV_KERNEL_OCC(4) void assemble_kernel(const AsmParams P)
 {
   uint8_t* wsBase = P.ws + uint64_t(wv::block()) * P.ws_stride;
   while (true) {

@@ -26,6 +26,7 @@ inline void  dfill(void* d, int byte, size_t n) { if (n) std::memset(d, byte, n)
 inline void  sync() {}
 template <typename K, typename P>
 inline void launch(K kernel, int grid, size_t ldsBytes, const P& params) { wv_emu::launch(grid, ldsBytes, [&]() { kernel(params); }); }
+inline int roundGrid(int waves) { return waves; }
 struct Event { void record() {} };
 inline float elapsedMs(const Event&, const Event&) { return 0.f; }
 }  // namespace rt
@@ -80,9 +81,11 @@ inline void sync() { check(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
 template <typename K, typename P>
 inline void launch(K kernel, int grid, size_t ldsBytes, const P& params)
 {
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), ldsBytes, 0, params);
+  // `grid` counts WAVEFRONTS and must be a multiple of WV_WAVES_PER_WG (see roundGrid); ldsBytes is per wave
+  hipLaunchKernelGGL(kernel, dim3(grid / WV_WAVES_PER_WG), dim3(64 * WV_WAVES_PER_WG), ldsBytes * WV_WAVES_PER_WG, 0, params);
   check(hipGetLastError(), "kernel launch");
 }
+inline int roundGrid(int waves) { return ((waves + WV_WAVES_PER_WG - 1) / WV_WAVES_PER_WG) * WV_WAVES_PER_WG; }
 /// HIP event on the (null) stream the kernels are launched on
 struct Event {
   hipEvent_t e = nullptr;

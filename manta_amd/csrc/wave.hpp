@@ -13,17 +13,25 @@
 #include <hip/hip_runtime.h>
 
 #define WV_DEV __device__ __forceinline__
-#define WV_KERNEL __global__ __launch_bounds__(64)
+// Workgroups are 4 INDEPENDENT wavefronts (256 threads): the hardware admits only ~8 workgroups per CU, so
+// single-wave workgroups would cap residency at 8 waves/CU.  The waves of a workgroup never synchronise with each
+// other; every "block" below is one wavefront.
+#define WV_WAVES_PER_WG 4
+#define WV_KERNEL __global__ __launch_bounds__(64 * WV_WAVES_PER_WG)
+// same, additionally asking the register allocator for at least `w` resident waves per SIMD
+#define WV_KERNEL_OCC(w) __global__ __launch_bounds__(64 * WV_WAVES_PER_WG, w)
 #define WV_HD __host__ __device__ inline
 
 extern __shared__ __attribute__((aligned(16))) char wv_dyn_lds[];
 
 namespace wv {
 
-WV_DEV int lane() { return int(threadIdx.x); }
-WV_DEV int block() { return int(blockIdx.x); }
-WV_DEV int nblocks() { return int(gridDim.x); }
-WV_DEV char* lds() { return wv_dyn_lds; }
+WV_DEV int lane() { return int(threadIdx.x & 63u); }
+/// index of this wavefront among all wavefronts of the launch (its workspace slot)
+WV_DEV int block() { return int(blockIdx.x) * WV_WAVES_PER_WG + __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)); }
+WV_DEV int nblocks() { return int(gridDim.x) * WV_WAVES_PER_WG; }
+/// this wavefront's share of the dynamic LDS (ldsBytes passed to rt::launch is PER WAVE)
+WV_DEV char* lds(const unsigned bytesPerWave) { return wv_dyn_lds + size_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))) * bytesPerWave; }
 
 /// lane l receives lane (l-1)'s value; lane 0 receives `fill`   (v_mov_b32_dpp wave_shr:1)
 WV_DEV int shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
@@ -51,8 +59,14 @@ WV_DEV unsigned first(unsigned v) { return unsigned(__builtin_amdgcn_readfirstla
 WV_DEV uint64_t ballot(bool p) { return __ballot(p); }
 WV_DEV bool any(bool p) { return __ballot(p) != 0; }
 
-/// makes this wave's earlier LDS/global writes visible to its other lanes (block == wave)
-WV_DEV void sync() { __syncthreads(); }
+/// makes this wave's earlier LDS/global writes visible to its other lanes.  A wavefront executes in lock step, so no
+/// s_barrier is needed (and none may be used: sibling wavefronts of the workgroup run unrelated work items);
+/// the fence drains this wave's outstanding memory operations.
+WV_DEV void sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
 
 WV_DEV unsigned atomic_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 WV_DEV unsigned atomic_cas(unsigned* p, unsigned cmp, unsigned v) { return atomicCAS(p, cmp, v); }
@@ -64,6 +78,9 @@ WV_DEV unsigned long long atomic_add(unsigned long long* p, unsigned long long v
 WV_DEV unsigned atomic_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 /// drop this CU's (possibly stale) L1 lines: needed before plain re-reads of memory that was updated by L2 atomics
 WV_DEV void fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+
+/// shader-clock timestamp (s_memtime) for the optional per-phase profile
+WV_DEV uint64_t clock() { return uint64_t(__builtin_readcyclecounter()); }
 
 WV_DEV int popc(unsigned v) { return __popc(v); }
 WV_DEV int popc(uint64_t v) { return __popcll(v); }

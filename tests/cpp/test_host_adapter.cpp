@@ -1,0 +1,175 @@
+// Host-adapter parity tests, written the way the reference's own Boost.Test cases read
+// (alignment/test/Global*AlignerTest.cpp, assembly/test/IterativeAssemblerTest.cpp): same call sequence, same
+// expectations (the vectors are the reference's published test data), through manta_amd/host/manta_amd.hpp.
+// Linked against libmanta_amd.so (GPU) or tests/emu/libmanta_amd_emu.so (CPU tier).
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <sstream>
+
+#include "../../manta_amd/host/manta_amd.hpp"
+
+using namespace manta_amd;
+using ALIGNPATH::apath_to_cigar;
+
+static int g_fail = 0, g_checks = 0;
+#define REQUIRE_EQUAL(a, b)                                                                      \
+  do {                                                                                           \
+    ++g_checks;                                                                                  \
+    std::ostringstream _sa, _sb;                                                                 \
+    _sa << (a);                                                                                  \
+    _sb << (b);                                                                                  \
+    if (_sa.str() != _sb.str()) {                                                                \
+      ++g_fail;                                                                                  \
+      std::cerr << __FILE__ << ":" << __LINE__ << ": " #a " == " #b " failed: " << _sa.str() << " vs " << _sb.str() << "\n"; \
+    }                                                                                            \
+  } while (0)
+#define REQUIRE(a) REQUIRE_EQUAL(bool(a), true)
+
+static void test_GlobalLargeIndelAligner()
+{
+  AlignmentScores<int>         scores(2, -4, -5, -1, -4);
+  GlobalLargeIndelAligner<int> aligner(scores, -10);
+  AlignmentResult<int>         result;
+  {
+    const std::string seq("BCDEFHIKLM"), ref("ABCDEFGGGGGGGGGGGGGGGGGGGGGGGGGGHIKLMN");
+    aligner.align(seq.begin(), seq.end(), ref.begin(), ref.end(), result);
+    REQUIRE_EQUAL(apath_to_cigar(result.align.apath), "5=26D5=");
+    REQUIRE_EQUAL(result.align.beginPos, 1);
+    REQUIRE_EQUAL(result.score, 10);
+  }
+  {
+    const std::string seq("BCDEFXHIKLM"), ref("ABCDEFGGGGGGGGGGGGGGGGGGGGGGGGGGHIKLMN");
+    aligner.align(seq.begin(), seq.end(), ref.begin(), ref.end(), result);
+    REQUIRE_EQUAL(apath_to_cigar(result.align.apath), "5=1I26D5=");
+    REQUIRE_EQUAL(result.score, 9);
+  }
+  {
+    const std::string seq("ABCDEFFFFFGHIJKL"), ref("ABCDEFFFFFFGHIJKL");  // left-shift within a repeat
+    aligner.align(seq.begin(), seq.end(), ref.begin(), ref.end(), result);
+    REQUIRE_EQUAL(apath_to_cigar(result.align.apath), "5=1D11=");
+    REQUIRE_EQUAL(result.align.beginPos, 0);
+  }
+  {
+    const std::string seq("ABCD"), ref("B");
+    aligner.align(seq.begin(), seq.end(), ref.begin(), ref.end(), result);
+    REQUIRE_EQUAL(apath_to_cigar(result.align.apath), "1S1=2S");
+    REQUIRE_EQUAL(result.score, -10);
+  }
+}
+
+static void test_GlobalAligner()
+{
+  {
+    AlignmentScores<int> scores(2, -4, -5, -1, -1000, true);
+    GlobalAligner<int>   aligner(scores);
+    AlignmentResult<int> result;
+    const std::string    seq("12ABCDEFFFFFFFGHIJKL12"), ref("ABCDEFFFFFFFGHIJKL");
+    aligner.align(seq.begin(), seq.end(), ref.begin(), ref.end(), result);
+    REQUIRE_EQUAL(apath_to_cigar(result.align.apath), "2I18=2I");
+  }
+  {
+    AlignmentScores<int> scores(2, -4, -5, -1, -4);
+    GlobalAligner<int>   aligner(scores);
+    AlignmentResult<int> result;
+    const std::string    seq("AABCC"), ref("ZZBYY");
+    aligner.align(seq.begin(), seq.end(), ref.begin(), ref.end(), result);
+    REQUIRE_EQUAL(apath_to_cigar(result.align.apath), "2X1=2X");
+    bool threw = false;
+    try {
+      const std::string empty;
+      aligner.align(empty.begin(), empty.end(), ref.begin(), ref.end(), result);
+    } catch (const GeneralException&) {
+      threw = true;
+    }
+    REQUIRE(threw);
+  }
+}
+
+static void test_GlobalJumpAligner()
+{
+  AlignmentScores<int>     scores(2, -4, -5, -1, -1);
+  GlobalJumpAligner<int>   aligner(scores, -3);
+  JumpAlignmentResult<int> result;
+  {
+    const std::string seq("ABABACDCDC"), ref1("dslfjfkjaslABABAlsjfkdsflsk"), ref2("sdfldsklkjdCDCDCfsdlkjfslk");
+    aligner.align(seq.begin(), seq.end(), ref1.begin(), ref1.end(), ref2.begin(), ref2.end(), result);
+    REQUIRE_EQUAL(apath_to_cigar(result.align1.apath), "5=");
+    REQUIRE_EQUAL(result.align1.beginPos, 11);
+    REQUIRE_EQUAL(apath_to_cigar(result.align2.apath), "5=");
+    REQUIRE_EQUAL(result.align2.beginPos, 11);
+  }
+  {
+    const std::string seq("ABABABABABA1234CDCDCDCDCDC"), ref1("xABABABABABAx"), ref2("xCDCDCDCDCDCDCx");  // breakend insertion
+    aligner.align(seq.begin(), seq.end(), ref1.begin(), ref1.end(), ref2.begin(), ref2.end(), result);
+    REQUIRE_EQUAL(apath_to_cigar(result.align1.apath), "11=");
+    REQUIRE_EQUAL(result.align1.beginPos, 1);
+    REQUIRE_EQUAL(apath_to_cigar(result.align2.apath), "11=");
+    REQUIRE_EQUAL(result.align2.beginPos, 1);
+    REQUIRE_EQUAL(result.jumpInsertSize, 4u);
+  }
+}
+
+static void test_IterativeAssembler()
+{
+  {  // single word size, two alleles sharing a trunk
+    IterativeAssemblerOptions assembleOpt;
+    assembleOpt.minWordLength   = 6;
+    assembleOpt.maxWordLength   = 6;
+    assembleOpt.minCoverage     = 1;
+    assembleOpt.minSupportReads = 1;
+    assembleOpt.minUnusedReads  = 1;
+    AssemblyReadInput reads;
+    reads.emplace_back("ATATAGACGATG");
+    reads.emplace_back("ACGATGTCTATCTT");
+    reads.emplace_back("ACGATGTTGGCCTT");
+    AssemblyReadOutput readInfo;
+    Assembly           contigs;
+    runIterativeAssembler(assembleOpt, reads, readInfo, contigs);
+    REQUIRE_EQUAL(contigs.size(), 2u);
+    REQUIRE_EQUAL(contigs[0].seq, "ATATAGACGATGTCTATCTT");
+    REQUIRE_EQUAL(contigs[1].seq, "ATATAGACGATGTTGGCCTT");
+    REQUIRE(readInfo[0].isUsed);
+    REQUIRE_EQUAL(readInfo[0].contigIds[0], 0u);
+    REQUIRE_EQUAL(readInfo[0].contigIds[1], 1u);
+    REQUIRE_EQUAL(readInfo[1].contigIds[0], 0u);
+    REQUIRE_EQUAL(readInfo[2].contigIds[0], 1u);
+  }
+  {  // word size iteration through a cyclic k-mer graph; contigs come back as pseudo reads
+    IterativeAssemblerOptions assembleOpt;
+    assembleOpt.minWordLength   = 3;
+    assembleOpt.maxWordLength   = 9;
+    assembleOpt.wordStepSize    = 3;
+    assembleOpt.minCoverage     = 1;
+    assembleOpt.minSupportReads = 1;
+    assembleOpt.minUnusedReads  = 1;
+    AssemblyReadInput reads;
+    reads.emplace_back("ACACACACGATG");
+    reads.emplace_back("GATGGCCCCCCC");
+    reads.emplace_back("GATGTCTCTCTC");
+    AssemblyReadOutput readInfo;
+    Assembly           contigs;
+    runIterativeAssembler(assembleOpt, reads, readInfo, contigs);
+    REQUIRE_EQUAL(contigs.size(), 2u);
+    REQUIRE_EQUAL(contigs[0].seq, "ACACACACGATGGCCCCCCC");
+    REQUIRE_EQUAL(contigs[1].seq, "ACACACACGATGTCTCTCTC");
+    REQUIRE_EQUAL(reads.size(), 5u);  // two pseudo reads stay appended (IterativeAssembler.cpp:902)
+    REQUIRE(readInfo[3].isPseudo);
+    REQUIRE_EQUAL(readInfo[2].contigIds[0], 1u);
+  }
+}
+
+int main()
+{
+  try {
+    test_GlobalLargeIndelAligner();
+    test_GlobalAligner();
+    test_GlobalJumpAligner();
+    test_IterativeAssembler();
+  } catch (const std::exception& e) {
+    std::cerr << "EXCEPTION: " << e.what() << "\n";
+    return 2;
+  }
+  std::printf("host adapter: %d checks, %d failures\n", g_checks, g_fail);
+  return g_fail ? 1 : 0;
+}

@@ -17,6 +17,8 @@
 
 #define WV_DEV inline
 #define WV_KERNEL
+#define WV_KERNEL_OCC(w)
+#define WV_WAVES_PER_WG 1
 #define WV_HD inline
 
 namespace wv_emu {
@@ -131,7 +133,7 @@ namespace wv {
 inline int lane() { return wv_emu::W()->cur; }
 inline int block() { return wv_emu::W()->block; }
 inline int nblocks() { return wv_emu::W()->nblocks; }
-inline char* lds()
+inline char* lds(const unsigned)
 {
   char* p = wv_emu::W()->ldsMem.data();
   return p + ((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15);
@@ -186,6 +188,7 @@ inline unsigned long long atomic_add(unsigned long long* p, unsigned long long v
 inline unsigned atomic_load(const unsigned* p) { return *p; }
 inline void fence_acquire() {}
 
+inline uint64_t clock() { return 0; }
 inline int popc(unsigned v) { return __builtin_popcount(v); }
 inline int popc(uint64_t v) { return __builtin_popcountll(v); }
 inline int ctz(uint64_t v) { return __builtin_ctzll(v); }
