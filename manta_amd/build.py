@@ -21,6 +21,18 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_profile_variant(verbose=True):
+    """developer tool: same library with the per-phase shader-clock counters of assemble_kernel compiled in
+    (tools/profile_phases.py); never used by tests, bench.py or the product path"""
+    out = os.path.join(HERE, "libmanta_amd_prof.so")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "-DMANTA_ASM_PROFILE",
+           "-I", CSRC, "-o", out] + sources()
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
@@ -33,4 +45,7 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--profile" in sys.argv:
+        build_profile_variant()
+    else:
+        build(force="--force" in sys.argv)

@@ -311,6 +311,7 @@ struct AsmStage {
     P.growth_size    = dGrowth;
     P.growth_buckets = dGrowth + ctx->growthSize.size();
     P.n_growth       = uint32_t(ctx->growthSize.size());
+    P.flags          = std::getenv("MANTA_AMD_SERIAL_WALK") ? ASM_FLAG_SERIAL_WALK : 0u;
     rt::launch(assemble_kernel, grid, 0, P);
   }
 

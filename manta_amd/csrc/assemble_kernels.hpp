@@ -36,10 +36,13 @@ enum {
   ASM_E_INTERNAL       = 7
 };
 
+static const unsigned ASM_FLAG_SERIAL_WALK = 1u;  // debug/A-B knob: build contigs one at a time even for small read sets
 static const unsigned ASM_NONE     = 0xffffffffu;
 static const int      ASM_MAX_KW   = 8;    // k <= 128
 static const unsigned ASM_MAX_W    = 16;   // <= 1024 reads incl. pseudo reads
 static const unsigned ASM_MAX_CAND = 64;   // 2*maxAssemblyCount must not exceed this
+static const unsigned TENT_CAP     = 256;  // tentative-seed list capacity of one speculative round
+static const unsigned WQ_MAX       = 4;    // lane-private walks hold read sets of up to 4 qwords (<= 256 reads) in registers
 
 struct AsmOptsDev {
   uint32_t minWordLength, maxWordLength, wordStepSize, minCoverage, minConservativeCoverage, minUnusedReads,
@@ -97,19 +100,28 @@ struct AsmParams {
   const uint32_t* growth_size;     ///< map.size() right before the insertion that rehashes
   const uint32_t* growth_buckets;  ///< bucket count after it
   uint32_t        n_growth;
+  uint32_t        flags;  ///< ASM_FLAG_*
 };
 
 // --------------------------------------------------------------------------------------------------
 // per-workgroup workspace carve (host and device agree through asmWorkspaceLayout)
 // --------------------------------------------------------------------------------------------------
 struct AsmWsLayout {
-  uint64_t codes, nmask, rd_cw, rd_mw, rd_len, slots, slot_id, inst_slot, node_key, node_cnt, node_flag, node_aux, node_sup,
-      succ, pred, frontier, cand_seq, cand_bits, cand_meta, walk_left, walk_right, pseudo_seq, pseudo_len, exact, total;
+  uint64_t codes, nmask, rd_cw, rd_mw, rd_len, slots, slot_id, inst_slot, node_key, node_cnt, node_flag, node_aux, rec,
+      frontier, cand_seq, cand_bits, cand_meta, walk_left, walk_right, pseudo_seq, pseudo_len, exact, node_k32, tent, lane_seq,
+      lane_bits, lane_meta, lane_vis, total;
 };
 
 WV_HD uint64_t asmAlign16(uint64_t v)
 {
   return (v + 15) & ~uint64_t(15);
+}
+
+/// bytes of one node record: succ[4] | pred[4] | count,pad[3] | support[W qwords]; one 64-byte line for W <= 2
+WV_HD uint32_t asmRecStride(const uint32_t W)
+{
+  const uint32_t b = 48 + 8 * W;
+  return (b < 64) ? 64u : ((b + 15u) & ~15u);
 }
 
 WV_HD uint64_t asmPut(uint64_t& cursor, const uint64_t bytes)
@@ -138,9 +150,7 @@ WV_HD AsmWsLayout asmWorkspaceLayout(
   L.node_cnt   = asmPut(o, 4ull * cap_nodes);
   L.node_flag  = asmPut(o, 4ull * cap_nodes);
   L.node_aux   = asmPut(o, 4ull * cap_nodes);
-  L.node_sup   = asmPut(o, 8ull * cap_nodes * w_max);
-  L.succ       = asmPut(o, 16ull * cap_nodes);
-  L.pred       = asmPut(o, 16ull * cap_nodes);
+  L.rec        = asmPut(o, uint64_t(cap_nodes) * asmRecStride(w_max));
   L.frontier   = asmPut(o, 8ull * cap_nodes + 256);
   L.cand_seq   = asmPut(o, nCand * max_contig_len);
   L.cand_bits  = asmPut(o, nCand * 2 * 8ull * w_max);
@@ -150,6 +160,12 @@ WV_HD AsmWsLayout asmWorkspaceLayout(
   L.pseudo_seq = asmPut(o, nCand * max_contig_len);
   L.pseudo_len = asmPut(o, nCand * 4);
   L.exact      = asmPut(o, 4ull * (14ull * cap_nodes + 256));
+  L.node_k32   = asmPut(o, 4ull * cap_nodes);
+  L.tent       = asmPut(o, 4ull * 2 * TENT_CAP);
+  L.lane_seq   = asmPut(o, 64ull * 2 * max_contig_len);
+  L.lane_bits  = asmPut(o, 64ull * 2 * WQ_MAX * 8);
+  L.lane_meta  = asmPut(o, 64ull * 8 * 4);
+  L.lane_vis   = asmPut(o, 64ull * 4 * ((cap_nodes + 31) / 32));
   L.total      = asmAlign16(o);
   return L;
 }
@@ -172,6 +188,11 @@ WV_DEV uint32_t hashMix(uint32_t h, const uint32_t v)
   return h;
 }
 
+/// 16-byte vector for one-instruction loads of a link quad / count block / support pair
+struct alignas(16) u32x4 {
+  uint32_t x, y, z, w;
+};
+
 template <int KW>
 struct Key {
   uint32_t w[KW];
@@ -183,13 +204,18 @@ struct Assembler {
   AsmWsLayout      L;
   // workspace views
   uint32_t *codes, *nmask, *rd_cw, *rd_mw, *rd_len, *slots, *slot_id, *inst_slot, *node_key, *node_cnt, *node_flag, *node_aux;
-  uint64_t* node_sup;
-  uint32_t *succ, *pred, *frontier;
+  uint8_t*  rec;        // node records (see asmRecStride)
+  unsigned  recStride;
+  uint32_t* frontier;
   uint8_t * cand_seq, *walk_left, *walk_right, *pseudo_seq;
   uint64_t* cand_bits;
   int32_t*  cand_meta;  // per candidate: len, consBegin, consEnd, pad
   uint32_t* pseudo_len;
   uint32_t* exact_ws;
+  uint32_t *node_k32, *tent_raw, *tent_sorted, *lane_vis;
+  uint8_t*  lane_seq;
+  uint64_t* lane_bits;
+  int32_t*  lane_meta;
   // per-locus state (wave-uniform)
   unsigned nNormal, nReads, W, k, nNodes, nCodeWordsNormal, nMaskWordsNormal, nCand;
   unsigned codeWordsUsed, maskWordsUsed;
@@ -213,9 +239,8 @@ struct Assembler {
     node_cnt   = reinterpret_cast<uint32_t*>(ws + L.node_cnt);
     node_flag  = reinterpret_cast<uint32_t*>(ws + L.node_flag);
     node_aux   = reinterpret_cast<uint32_t*>(ws + L.node_aux);
-    node_sup   = reinterpret_cast<uint64_t*>(ws + L.node_sup);
-    succ       = reinterpret_cast<uint32_t*>(ws + L.succ);
-    pred       = reinterpret_cast<uint32_t*>(ws + L.pred);
+    rec        = ws + L.rec;
+    recStride  = 64;
     frontier   = reinterpret_cast<uint32_t*>(ws + L.frontier);
     cand_seq   = ws + L.cand_seq;
     cand_bits  = reinterpret_cast<uint64_t*>(ws + L.cand_bits);
@@ -225,6 +250,13 @@ struct Assembler {
     pseudo_seq = ws + L.pseudo_seq;
     pseudo_len = reinterpret_cast<uint32_t*>(ws + L.pseudo_len);
     exact_ws   = reinterpret_cast<uint32_t*>(ws + L.exact);
+    node_k32   = reinterpret_cast<uint32_t*>(ws + L.node_k32);
+    tent_raw   = reinterpret_cast<uint32_t*>(ws + L.tent);
+    tent_sorted = tent_raw + TENT_CAP;
+    lane_seq   = ws + L.lane_seq;
+    lane_bits  = reinterpret_cast<uint64_t*>(ws + L.lane_bits);
+    lane_meta  = reinterpret_cast<int32_t*>(ws + L.lane_meta);
+    lane_vis   = reinterpret_cast<uint32_t*>(ws + L.lane_vis);
   }
 
   /// optional per-phase shader-clock profile (compiled in with -DMANTA_ASM_PROFILE; costs registers)
@@ -240,6 +272,11 @@ struct Assembler {
     (void)phase;
 #endif
   }
+
+  WV_DEV uint32_t* recSucc(const unsigned n) const { return reinterpret_cast<uint32_t*>(rec + size_t(n) * recStride); }
+  WV_DEV uint32_t* recPred(const unsigned n) const { return recSucc(n) + 4; }
+  WV_DEV uint32_t& recCnt(const unsigned n) const { return recSucc(n)[8]; }
+  WV_DEV uint64_t* recSup(const unsigned n) const { return reinterpret_cast<uint64_t*>(rec + size_t(n) * recStride + 48); }
 
   // ------------------------------------------------------------------------------------------------
   // wave helpers (all lanes must call)
@@ -531,7 +568,7 @@ struct Assembler {
       status = ASM_E_TABLE_FULL;
       return;
     }
-    for (unsigned i = lane; i < nNodes * W; i += 64) node_sup[i] = 0;
+    for (unsigned i = lane; i < nNodes * W; i += 64) recSup(i / W)[i % W] = 0;
     wv::sync();
 
     // pass 3: supporting reads (:544-548)
@@ -542,7 +579,7 @@ struct Assembler {
       const uint64_t bit = uint64_t(1) << (r & 63);
       for (unsigned j = lane; j + k <= len; j += 64) {
         const unsigned s = inst_slot[cwo * 16 + j];
-        if (s != ASM_NONE) wv::atomic_or(reinterpret_cast<unsigned long long*>(&node_sup[size_t(slot_id[s]) * W + (r >> 6)]), bit);
+        if (s != ASM_NONE) wv::atomic_or(reinterpret_cast<unsigned long long*>(&recSup(slot_id[s])[r >> 6]), bit);
       }
     }
     wv::sync();
@@ -553,18 +590,20 @@ struct Assembler {
     for (unsigned nd = lane; nd < nNodes; nd += 64) {
       unsigned cnt = 0;
       for (unsigned w = 0; w < W; ++w) {
-        const uint64_t s = node_sup[size_t(nd) * W + w];
+        const uint64_t s = recSup(nd)[w];
         cnt += unsigned(wv::popc(s & normalMask(w))) + P.opt.minCoverage * unsigned(wv::popc(s & ~normalMask(w)));
       }
       node_cnt[nd]  = cnt;
+      recCnt(nd)    = cnt;
       const Key<KW> key = keyAt<KW>(node_key[nd]);
+      node_k32[nd]  = key.w[0];
       bool          selfLoop = false;
       unsigned      indeg    = 0;
       for (unsigned c = 0; c < 4; ++c) {
         const unsigned s = lookup<KW>(keyShiftAppend<KW>(key, c));
         const unsigned p = lookup<KW>(keyShiftPrepend<KW>(key, c));
-        succ[nd * 4 + c] = s;
-        pred[nd * 4 + c] = p;
+        recSucc(nd)[c] = s;
+        recPred(nd)[c] = p;
         if (s == nd) selfLoop = true;  // homopolymer (:574-577)
         if (p != ASM_NONE && p != nd) indeg++;
       }
@@ -583,21 +622,37 @@ struct Assembler {
     return (uint64_t(1) << (nNormal - lo)) - 1;
   }
 
-  /// true if the k-mer graph (self loops ignored) has a directed cycle.  Wave-parallel Kahn peel on node_aux.
+  /// true if the k-mer graph (self loops ignored) has a directed cycle.  Wave-parallel peel of sources (in-degree 0,
+  /// counters in node_aux) AND sinks (out-degree 0): what
+  /// survives has in- and out-degree >= 1 inside the survivor set, i.e. contains a cycle.  Peeling from both ends
+  /// halves the number of rounds on the (mostly linear) graphs.
   WV_DEV bool graphHasCycle()
   {
     const unsigned lane = unsigned(wv::lane());
     uint32_t*      cur  = frontier;
     uint32_t*      nxt  = frontier + P.cap_nodes;
-    // the two frontier counters live in exact_ws[0..1]
-    uint32_t* cnt = exact_ws;
+    uint32_t*      outdeg = exact_ws + 64;  // scratch of the exact search, not live yet
+    uint32_t*      gone   = inst_slot; // 1 = already peeled (either way); >= cap_nodes words
+    uint32_t*      cnt    = exact_ws;  // frontier sizes [0],[1]
     if (lane == 0) {
       cnt[0] = 0;
       cnt[1] = 0;
     }
+    for (unsigned nd = lane; nd < nNodes; nd += 64) {
+      unsigned od = 0;
+      for (unsigned c = 0; c < 4; ++c) {
+        const unsigned s = recSucc(nd)[c];
+        if (s != ASM_NONE && s != nd) od++;
+      }
+      outdeg[nd] = od;
+      gone[nd]   = 0;
+    }
     wv::sync();
     for (unsigned nd = lane; nd < nNodes; nd += 64) {
-      if (node_aux[nd] == 0) cur[wv::atomic_add(&cnt[0], 1u)] = nd;
+      if (node_aux[nd] == 0 || outdeg[nd] == 0) {
+        gone[nd] = 1;
+        cur[wv::atomic_add(&cnt[0], 1u)] = nd;
+      }
     }
     wv::sync();
     unsigned removed = 0;
@@ -609,13 +664,17 @@ struct Assembler {
       for (unsigned i = lane; i < nCur; i += 64) {
         const unsigned nd = cur[i];
         for (unsigned c = 0; c < 4; ++c) {
-          const unsigned s = succ[nd * 4 + c];
-          if (s == ASM_NONE || s == nd) continue;
-          if (wv::atomic_sub(&node_aux[s], 1u) == 1u) nxt[wv::atomic_add(&cnt[which ^ 1], 1u)] = s;
+          const unsigned s = recSucc(nd)[c];
+          if (s != ASM_NONE && s != nd && wv::atomic_sub(&node_aux[s], 1u) == 1u) {
+            if (wv::atomic_cas(&gone[s], 0u, 1u) == 0u) nxt[wv::atomic_add(&cnt[which ^ 1], 1u)] = s;
+          }
+          const unsigned p = recPred(nd)[c];
+          if (p != ASM_NONE && p != nd && wv::atomic_sub(&outdeg[p], 1u) == 1u) {
+            if (wv::atomic_cas(&gone[p], 0u, 1u) == 0u) nxt[wv::atomic_add(&cnt[which ^ 1], 1u)] = p;
+          }
         }
       }
       wv::sync();
-      wv::fence_acquire();
       if (lane == 0) cnt[which] = 0;
       wv::sync();
       which ^= 1;
@@ -673,7 +732,7 @@ struct Assembler {
   WV_DEV uint64_t supWord(const unsigned node) const
   {
     const unsigned lane = unsigned(wv::lane());
-    return (node != ASM_NONE && lane < W) ? node_sup[size_t(node) * W + lane] : uint64_t(0);
+    return (node != ASM_NONE && lane < W) ? recSup(node)[lane] : uint64_t(0);
   }
 
   /// four 16-bit counts packed in a qword, summed over the wave, returned wave-uniform
@@ -740,8 +799,7 @@ struct Assembler {
     int      consEnd = 0, consBegin = 0;
     for (unsigned mode = 0; mode < 2; ++mode) {
       const bool      isEnd = (mode == 0);
-      const uint32_t* fwd   = isEnd ? succ : pred;
-      const uint32_t* bwd   = isEnd ? pred : succ;
+      const unsigned  fwdOff = isEnd ? 0u : 4u, bwdOff = isEnd ? 4u : 0u;  // succ[4] | pred[4] inside a node record
       unsigned        consOffset = 0;
       unsigned        cur        = seed;
       while (true) {
@@ -750,7 +808,7 @@ struct Assembler {
         unsigned ccount[4];
         uint64_t pk = 0;
         for (unsigned c = 0; c < 4; ++c) {
-          cand[c]   = fwd[cur * 4 + c];
+          cand[c]   = recSucc(cur)[fwdOff + c];
           cw[c]     = supWord(cand[c]);
           ccount[c] = (cand[c] != ASM_NONE) ? node_cnt[cand[c]] : 0u;
           pk += uint64_t(wv::popc(S & cw[c])) << (16 * c);
@@ -807,7 +865,7 @@ struct Assembler {
         // one step backwards at the branching point (:377-427); runs every step because the reference's
         // previousWordReads is always empty at the test (:237)
         for (unsigned c = 0; c < 4; ++c) {
-          const unsigned n = bwd[maxNode * 4 + c];
+          const unsigned n = recSucc(maxNode)[bwdOff + c];
           if (n == cur) continue;      // the word we came from (:381)
           if (n == maxNode) continue;  // :389
           if (n == ASM_NONE) continue;
@@ -864,6 +922,13 @@ struct Assembler {
   // defined in repeat_exact.hpp
   template <int KW>
   WV_DEV void exactRepeatSearch();
+  // defined in walk_lanes.hpp
+  template <int KW>
+  WV_DEV unsigned selectTentative(const unsigned T);
+  template <int KW, int WQ>
+  WV_DEV void walkLanes(const unsigned nT);
+  template <int KW, int WQ>
+  WV_DEV bool contigRounds();
 
   /// buildContigs (:644-720).  Returns isAssemblySuccess.
   template <int KW>
@@ -879,6 +944,12 @@ struct Assembler {
       tick(4);
       if (status != ASM_OK) return true;
     }
+    if (!(P.flags & ASM_FLAG_SERIAL_WALK)) {
+      if (W <= 1) return contigRounds<KW, 1>();
+      if (W <= 2) return contigRounds<KW, 2>();
+      if (W <= 4) return contigRounds<KW, 4>();
+    }
+    // more than 256 reads (or forced): one contig at a time, lanes spread over the qwords of the read sets
     nCand        = 0;
     bool success = true;
     while (nCand < 2 * P.opt.maxAssemblyCount) {  // :685
@@ -1076,6 +1147,7 @@ struct Assembler {
     tick(0);
     W = (nNormal + 2 * P.opt.maxAssemblyCount + 63) / 64;
     if (W == 0) W = 1;
+    recStride = asmRecStride(W);
     if (status == ASM_OK && (P.opt.maxWordLength > 16u * ASM_MAX_KW || P.opt.minWordLength == 0)) status = ASM_E_WORD_TOO_LONG;
     if (status == ASM_OK && 2 * P.opt.maxAssemblyCount > ASM_MAX_CAND) status = ASM_E_INTERNAL;
 
@@ -1109,6 +1181,7 @@ struct Assembler {
 }  // namespace manta_dev
 
 #include "repeat_exact.hpp"
+#include "walk_lanes.hpp"
 
 namespace manta_dev {
 

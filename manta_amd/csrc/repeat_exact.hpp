@@ -156,7 +156,7 @@ WV_DEV void Assembler::exactRepeatSearch()
   for (unsigned nd = lane; nd < n; nd += 64) {
     unsigned fr = 0;
     for (unsigned w = 0; w < W; ++w) {
-      const uint64_t s = node_sup[size_t(nd) * W + w];
+      const uint64_t s = recSup(nd)[w];
       if (s) {
         fr = w * 64 + unsigned(wv::ctz(s));
         break;
@@ -225,7 +225,7 @@ WV_DEV void Assembler::exactRepeatSearch()
         const unsigned sym = f & 7;
         if (sym < 4) {
           frames[fp - 1]   = f + 1;
-          const unsigned s = succ[nd * 4 + sym];
+          const unsigned s = recSucc(nd)[sym];
           if (s == nd) {  // homopolymer (:574-577)
             node_flag[nd] |= NF_REPEAT;
             continue;

@@ -116,3 +116,16 @@ def test_gpu_assembler_config5_batch(gpu, oracle):
         res = gpu.assemble_batch(o, loci)
         for reads, r in zip(loci, res):
             assert assembly_text(r) == oracle.assemble(o, reads), k
+
+
+def test_emulated_assembler_many_reads_uses_wide_sets(emu, oracle):
+    """> 256 reads: read sets no longer fit lane-private registers -> contigs are built one at a time (wide-set path)"""
+    reads, _ = small_indel_locus(11, n_reads=300, read_len=40, ref_len=300, sub_rate=0.01)
+    assert _check(emu, oracle, [(asm_opts(minWordLength=15, maxWordLength=25), reads)]) == 1
+
+
+def test_emulated_serial_and_speculative_walks_agree(emu, oracle, monkeypatch):
+    cases = _mid_cases(range(100, 112))
+    assert _check(emu, oracle, cases) == len(cases)
+    monkeypatch.setenv("MANTA_AMD_SERIAL_WALK", "1")
+    assert _check(emu, oracle, cases) == len(cases)
