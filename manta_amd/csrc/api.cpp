@@ -312,7 +312,7 @@ struct AsmStage {
     P.growth_buckets = dGrowth + ctx->growthSize.size();
     P.n_growth       = uint32_t(ctx->growthSize.size());
     P.flags          = std::getenv("MANTA_AMD_SERIAL_WALK") ? ASM_FLAG_SERIAL_WALK : 0u;
-    rt::launch(assemble_kernel, grid, 0, P);
+    rt::launch(assemble_kernel, grid, ASM_LDS_BYTES, P);
   }
 
   int fetch(
@@ -732,7 +732,7 @@ int manta_smallsv_run(manta_smallsv_t* b)
     S.table_cap          = tableCap;
     S.n_e                = kNumESet;
     for (int i = 0; i < kNumESet; ++i) S.e_set[i] = uint32_t(kESet[i]);
-    rt::launch(smallsv_schedule_kernel, schedGrid, 0, S);
+    rt::launch(smallsv_schedule_kernel, schedGrid, SCHED_LDS_BYTES, S);
     b->evSched.record();
 
     // bucket sizes decide the alignment launches (one tiny D2H)

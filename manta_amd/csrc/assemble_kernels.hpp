@@ -42,6 +42,7 @@ static const int      ASM_MAX_KW   = 8;    // k <= 128
 static const unsigned ASM_MAX_W    = 16;   // <= 1024 reads incl. pseudo reads
 static const unsigned ASM_MAX_CAND = 64;   // 2*maxAssemblyCount must not exceed this
 static const unsigned TENT_CAP     = 256;  // tentative-seed list capacity of one speculative round
+static const unsigned ASM_LDS_BYTES = 10240;  // dynamic LDS per wavefront (visited bitmaps of a speculative round)
 static const unsigned WQ_MAX       = 4;    // lane-private walks hold read sets of up to 4 qwords (<= 256 reads) in registers
 
 struct AsmOptsDev {
@@ -162,7 +163,7 @@ WV_HD AsmWsLayout asmWorkspaceLayout(
   L.exact      = asmPut(o, 4ull * (14ull * cap_nodes + 256));
   L.node_k32   = asmPut(o, 4ull * cap_nodes);
   L.tent       = asmPut(o, 4ull * 2 * TENT_CAP);
-  L.lane_seq   = asmPut(o, 64ull * 2 * max_contig_len);
+  L.lane_seq   = asmPut(o, 64ull * 2 * 4 * (max_contig_len / 16 + 2));
   L.lane_bits  = asmPut(o, 64ull * 2 * WQ_MAX * 8);
   L.lane_meta  = asmPut(o, 64ull * 8 * 4);
   L.lane_vis   = asmPut(o, 64ull * 4 * ((cap_nodes + 31) / 32));
@@ -466,11 +467,15 @@ struct Assembler {
     nMaskWordsNormal = mw;
     wv::sync();
     bool badAlphabet = false;
-    for (unsigned r = 0; r < nNormal; ++r) {
+    // 8 lanes per read, 8 reads per pass: lane (g, i) converts code dwords i, i+8, ... of read (base + g)
+    const unsigned lane = unsigned(wv::lane());
+    for (unsigned base = 0; base < nNormal; base += 8) {
+      const unsigned r = base + (lane >> 3);
+      if (r >= nNormal) continue;
       const uint8_t* src = P.bases + P.read_off[rBegin + r];
       const unsigned len = rd_len[r], cwo = rd_cw[r], mwo = rd_mw[r];
       const unsigned nCw = (len + 15) / 16 + 1;
-      for (unsigned wi = unsigned(wv::lane()); wi < nCw; wi += 64) {
+      for (unsigned wi = (lane & 7); wi < nCw; wi += 8) {
         uint32_t code = 0, nbits = 0;
         for (unsigned b = 0; b < 16; ++b) {
           const unsigned i = wi * 16 + b;
@@ -622,37 +627,40 @@ struct Assembler {
     return (uint64_t(1) << (nNormal - lo)) - 1;
   }
 
-  /// true if the k-mer graph (self loops ignored) has a directed cycle.  Wave-parallel peel of sources (in-degree 0,
-  /// counters in node_aux) AND sinks (out-degree 0): what
-  /// survives has in- and out-degree >= 1 inside the survivor set, i.e. contains a cycle.  Peeling from both ends
-  /// halves the number of rounds on the (mostly linear) graphs.
+  /// true if the k-mer graph (self loops ignored) has a directed cycle.  Wave-parallel peel of sources (in-degree 0)
+  /// AND sinks (out-degree 0): what survives has in- and out-degree >= 1 inside the survivor set, i.e. contains a
+  /// cycle.  Peeling from both ends halves the number of rounds on the (mostly linear) graphs.
+  /// Per-node state = one 16-bit field {in-degree:4, out-degree:4, peeled:1}, two nodes per dword, updated with
+  /// atomics; it lives in LDS when the graph is small enough (<= ASM_LDS_BYTES/2 nodes), else in global scratch.
   WV_DEV bool graphHasCycle()
   {
-    const unsigned lane = unsigned(wv::lane());
-    uint32_t*      cur  = frontier;
-    uint32_t*      nxt  = frontier + P.cap_nodes;
-    uint32_t*      outdeg = exact_ws + 64;  // scratch of the exact search, not live yet
-    uint32_t*      gone   = inst_slot; // 1 = already peeled (either way); >= cap_nodes words
+    const unsigned lane   = unsigned(wv::lane());
+    uint32_t*      cur    = frontier;
+    uint32_t*      nxt    = frontier + P.cap_nodes;
     uint32_t*      cnt    = exact_ws;  // frontier sizes [0],[1]
+    const bool     inLds  = (nNodes * 2 <= ASM_LDS_BYTES);
+    uint32_t*      st     = inLds ? reinterpret_cast<uint32_t*>(wv::lds(ASM_LDS_BYTES)) : (exact_ws + 64);
+    const unsigned nWords = (nNodes + 1) / 2;
     if (lane == 0) {
       cnt[0] = 0;
       cnt[1] = 0;
     }
-    for (unsigned nd = lane; nd < nNodes; nd += 64) {
-      unsigned od = 0;
-      for (unsigned c = 0; c < 4; ++c) {
-        const unsigned s = recSucc(nd)[c];
-        if (s != ASM_NONE && s != nd) od++;
+    for (unsigned w = lane; w < nWords; w += 64) {
+      uint32_t v = 0;
+      for (unsigned h = 0; h < 2; ++h) {
+        const unsigned nd = w * 2 + h;
+        if (nd >= nNodes) continue;
+        unsigned od = 0;
+        for (unsigned c = 0; c < 4; ++c) {
+          const unsigned s = recSucc(nd)[c];
+          if (s != ASM_NONE && s != nd) od++;
+        }
+        const unsigned id  = node_aux[nd];
+        const bool     src = (id == 0 || od == 0);
+        v |= (id | (od << 4) | (src ? 0x100u : 0u)) << (16 * h);
+        if (src) cur[wv::atomic_add(&cnt[0], 1u)] = nd;
       }
-      outdeg[nd] = od;
-      gone[nd]   = 0;
-    }
-    wv::sync();
-    for (unsigned nd = lane; nd < nNodes; nd += 64) {
-      if (node_aux[nd] == 0 || outdeg[nd] == 0) {
-        gone[nd] = 1;
-        cur[wv::atomic_add(&cnt[0], 1u)] = nd;
-      }
+      st[w] = v;
     }
     wv::sync();
     unsigned removed = 0;
@@ -665,12 +673,18 @@ struct Assembler {
         const unsigned nd = cur[i];
         for (unsigned c = 0; c < 4; ++c) {
           const unsigned s = recSucc(nd)[c];
-          if (s != ASM_NONE && s != nd && wv::atomic_sub(&node_aux[s], 1u) == 1u) {
-            if (wv::atomic_cas(&gone[s], 0u, 1u) == 0u) nxt[wv::atomic_add(&cnt[which ^ 1], 1u)] = s;
+          if (s != ASM_NONE && s != nd) {
+            const unsigned sh  = 16 * (s & 1);
+            const unsigned old = wv::atomic_sub(&st[s >> 1], 1u << sh) >> sh;
+            if ((old & 0xfu) == 1u && !(wv::atomic_or(&st[s >> 1], 0x100u << sh) & (0x100u << sh)))
+              nxt[wv::atomic_add(&cnt[which ^ 1], 1u)] = s;
           }
           const unsigned p = recPred(nd)[c];
-          if (p != ASM_NONE && p != nd && wv::atomic_sub(&outdeg[p], 1u) == 1u) {
-            if (wv::atomic_cas(&gone[p], 0u, 1u) == 0u) nxt[wv::atomic_add(&cnt[which ^ 1], 1u)] = p;
+          if (p != ASM_NONE && p != nd) {
+            const unsigned sh  = 16 * (p & 1);
+            const unsigned old = wv::atomic_sub(&st[p >> 1], 0x10u << sh) >> sh;
+            if ((old & 0xf0u) == 0x10u && !(wv::atomic_or(&st[p >> 1], 0x100u << sh) & (0x100u << sh)))
+              nxt[wv::atomic_add(&cnt[which ^ 1], 1u)] = p;
           }
         }
       }

@@ -9,7 +9,8 @@
 
 namespace manta_dev {
 
-static const int SMALLSV_MER = 10;  // SVCandidateAssemblyRefiner.cpp:1986
+static const int      SMALLSV_MER       = 10;    // SVCandidateAssemblyRefiner.cpp:1986
+static const unsigned SCHED_LDS_BYTES   = 8192;  // per wavefront: 10-mer table of contigs up to 1024 bp lives in LDS
 
 struct SmallSvCuts {
   int32_t leadingCut, trailingCut, maxLeadingCut, maxTrailingCut;  // :1912-1915
@@ -75,7 +76,8 @@ WV_DEV bool merLookup(const uint32_t* table, const unsigned mask, const unsigned
 WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
 {
   const unsigned lane  = unsigned(wv::lane());
-  uint32_t*      table = P.table_ws + size_t(wv::block()) * P.table_cap;
+  uint32_t*      gtable = P.table_ws + size_t(wv::block()) * P.table_cap;
+  uint32_t*      ltable = reinterpret_cast<uint32_t*>(wv::lds(SCHED_LDS_BYTES));
   const unsigned total = P.n_loci * P.max_assembly_count;
   while (true) {
     unsigned slot = 0;
@@ -105,7 +107,8 @@ WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
     // hash set of the contig's 10-mers (:1987-1991)
     unsigned tcap = 64;
     while (tcap < 2 * clen) tcap <<= 1;
-    const unsigned mask = tcap - 1;
+    const unsigned mask  = tcap - 1;
+    uint32_t*      table = (tcap * 4 <= SCHED_LDS_BYTES) ? ltable : gtable;
     for (unsigned i = lane; i < tcap; i += 64) table[i] = 0;
     wv::sync();
     for (unsigned i = lane; i + SMALLSV_MER <= clen; i += 64) {
@@ -120,7 +123,7 @@ WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
       }
     }
     wv::sync();
-    wv::fence_acquire();
+    if (table == gtable) wv::fence_acquire();
 
     const int minRefIndex    = cuts.leadingCut;
     const int maxRefIndex    = refSize - (cuts.trailingCut + SMALLSV_MER);

@@ -17,31 +17,50 @@
 namespace manta_dev {
 
 /// Fills tent_sorted[0..nT) with the next <= T unused words in exact seed order; returns nT (0: none left).
+/// Order = count descending, k-mer ascending (the reference's scan of the ordered `unusedWords` set with a strict
+/// '>' on the count, :689-696).  Top-T selection without a sort: compact the unused words once, find the count level
+/// and then the 16-base-prefix threshold that cut off T words by two binary searches over coalesced arrays, gather
+/// the (about T) survivors and order only those exactly.
 template <int KW>
 WV_DEV unsigned Assembler::selectTentative(const unsigned T)
 {
   const unsigned lane = unsigned(wv::lane());
-  // unused population and its largest count
-  unsigned myU = 0, myMax = 0;
-  for (unsigned nd = lane; nd < nNodes; nd += 64) {
-    if (node_flag[nd] & NF_UNUSED) {
-      myU++;
-      const unsigned c = node_cnt[nd];
-      myMax            = (c > myMax) ? c : myMax;
-    }
+  if (T == 1) {
+    const unsigned s = selectSeed<KW>();
+    if (s == ASM_NONE) return 0;
+    if (lane == 0) tent_sorted[0] = s;
+    wv::sync();
+    return 1;
   }
-  const unsigned U = waveSum(myU);
+  // compact list of unused words: node id, count, 16-base prefix (scratch of the exact repeat search, free by now)
+  uint32_t* uNode = exact_ws + 64;
+  uint32_t* uCnt  = uNode + P.cap_nodes;
+  uint32_t* uK32  = uCnt + P.cap_nodes;
+  unsigned  U = 0, myMax = 0;
+  for (unsigned base = 0; base < nNodes; base += 64) {
+    const unsigned nd  = base + lane;
+    const bool     sel = (nd < nNodes) && (node_flag[nd] & NF_UNUSED);
+    const uint64_t m   = wv::ballot(sel);
+    if (sel) {
+      const unsigned pos = U + unsigned(wv::popc(m & ((uint64_t(1) << lane) - 1)));
+      const unsigned c   = node_cnt[nd];
+      uNode[pos]         = nd;
+      uCnt[pos]          = c;
+      uK32[pos]          = node_k32[nd];
+      myMax              = (c > myMax) ? c : myMax;
+    }
+    U += unsigned(wv::popc(m));
+  }
+  wv::sync();
   if (U == 0) return 0;
   unsigned cStar = 1, pStar = 0xffffffffu;
   if (U > T) {
     const unsigned cmax = waveMax(myMax);
-    // largest c with #{unused, cnt >= c} >= T
-    unsigned lo = 1, hi = cmax;
+    unsigned       lo = 1, hi = cmax;  // largest c with #{cnt >= c} >= T
     while (lo < hi) {
       const unsigned mid = lo + (hi - lo + 1) / 2;
       unsigned       n   = 0;
-      for (unsigned nd = lane; nd < nNodes; nd += 64)
-        if ((node_flag[nd] & NF_UNUSED) && node_cnt[nd] >= mid) n++;
+      for (unsigned i = lane; i < U; i += 64) n += (uCnt[i] >= mid) ? 1u : 0u;
       if (waveSum(n) >= T)
         lo = mid;
       else
@@ -49,16 +68,13 @@ WV_DEV unsigned Assembler::selectTentative(const unsigned T)
     }
     cStar = lo;
     unsigned above = 0;
-    for (unsigned nd = lane; nd < nNodes; nd += 64)
-      if ((node_flag[nd] & NF_UNUSED) && node_cnt[nd] > cStar) above++;
+    for (unsigned i = lane; i < U; i += 64) above += (uCnt[i] > cStar) ? 1u : 0u;
     const unsigned need = T - waveSum(above);  // >= 1 words wanted from the tie level
-    // smallest 16-base prefix p with #{unused, cnt == cStar, k32 <= p} >= need
-    unsigned plo = 0, phi = 0xffffffffu;
+    unsigned       plo = 0, phi = 0xffffffffu;  // smallest prefix p with #{cnt == cStar, k32 <= p} >= need
     while (plo < phi) {
       const unsigned mid = plo + (phi - plo) / 2;
       unsigned       n   = 0;
-      for (unsigned nd = lane; nd < nNodes; nd += 64)
-        if ((node_flag[nd] & NF_UNUSED) && node_cnt[nd] == cStar && node_k32[nd] <= mid) n++;
+      for (unsigned i = lane; i < U; i += 64) n += (uCnt[i] == cStar && uK32[i] <= mid) ? 1u : 0u;
       if (waveSum(n) >= need)
         phi = mid;
       else
@@ -68,16 +84,16 @@ WV_DEV unsigned Assembler::selectTentative(const unsigned T)
   }
   // gather (every word outside this list sorts after every word inside it)
   unsigned total = 0;
-  for (unsigned base = 0; base < nNodes; base += 64) {
-    const unsigned nd  = base + lane;
+  for (unsigned base = 0; base < U; base += 64) {
+    const unsigned i   = base + lane;
     bool           sel = false;
-    if (nd < nNodes && (node_flag[nd] & NF_UNUSED)) {
-      const unsigned c = node_cnt[nd];
-      sel              = (U <= T) || (c > cStar) || (c == cStar && node_k32[nd] <= pStar);
+    if (i < U) {
+      const unsigned c = uCnt[i];
+      sel              = (U <= T) || (c > cStar) || (c == cStar && uK32[i] <= pStar);
     }
     const uint64_t m   = wv::ballot(sel);
     const unsigned pos = total + unsigned(wv::popc(m & ((uint64_t(1) << lane) - 1)));
-    if (sel && pos < TENT_CAP) tent_raw[pos] = nd;
+    if (sel && pos < TENT_CAP) tent_raw[pos] = uNode[i];
     total += unsigned(wv::popc(m));
   }
   wv::sync();
@@ -107,21 +123,40 @@ WV_DEV unsigned Assembler::selectTentative(const unsigned T)
   return (total < T) ? total : T;
 }
 
+/// candidate-word data a walk step needs, fetched as whole-record 16-byte blocks (one 64-byte line per word, W <= 2)
+template <int WQ>
+struct StepData {
+  unsigned node[4];
+  u32x4    fwd[4], bwd[4];  // the candidate's own links in / against the walking direction
+  unsigned count[4];
+  uint64_t sup[4][WQ];
+  unsigned visWord[4];
+};
+
 /// One round: lane t < nT walks tent_sorted[t] with private state (assembly/IterativeAssembler.cpp:149-501).
+/// The step loop is software-pipelined: the records of the NEXT step's candidates are requested as soon as the
+/// current step has chosen its word, together with the (<= 3) records of the backward check, so a step costs about
+/// one memory round trip.  The private visited bitmaps live in LDS when they fit.
 template <int KW, int WQ>
 WV_DEV void Assembler::walkLanes(const unsigned nT)
 {
   const unsigned lane     = unsigned(wv::lane());
   const unsigned visWords = (P.cap_nodes + 31) / 32;
   const unsigned useWords = (nNodes + 31) / 32;
-  for (unsigned i = lane; i < nT * useWords; i += 64) lane_vis[size_t(i / useWords) * visWords + (i % useWords)] = 0;
+  const bool     visInLds = (nT * useWords * 4 <= ASM_LDS_BYTES);
+  uint32_t*      visBase  = visInLds ? reinterpret_cast<uint32_t*>(wv::lds(ASM_LDS_BYTES)) : lane_vis;
+  const unsigned visStride = visInLds ? useWords : visWords;
+  for (unsigned i = lane; i < nT * useWords; i += 64) visBase[size_t(i / useWords) * visStride + (i % useWords)] = 0;
   wv::sync();
 
   const bool     has  = lane < nT;
   const unsigned seed = has ? tent_sorted[lane] : 0u;
-  uint32_t*      vis  = lane_vis + size_t(lane) * visWords;
-  uint8_t*       rightBuf = lane_seq + size_t(lane) * 2 * P.max_contig_len;
-  uint8_t*       leftBuf  = rightBuf + P.max_contig_len;
+  uint32_t*      vis  = visBase + size_t(has ? lane : 0) * visStride;
+  // appended / prepended bases are collected 2 bits each and stored one dword per 16 bases
+  const unsigned seqWords = P.max_contig_len / 16 + 2;
+  uint32_t*      rightBuf = reinterpret_cast<uint32_t*>(lane_seq) + size_t(lane) * 2 * seqWords;
+  uint32_t*      leftBuf  = rightBuf + seqWords;
+  uint32_t       accR = 0, accL = 0;
   uint64_t       S[WQ], Rj[WQ];
   for (int w = 0; w < WQ; ++w) {
     S[w]  = (has && unsigned(w) < W) ? recSup(seed)[w] : 0;
@@ -152,60 +187,76 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
     }
   }
 
+  // fetch everything a step needs about the four words `q` (ASM_NONE entries stay zero)
+  auto fetch = [&](const u32x4 q, const unsigned fwdOff, const unsigned bwdOff, StepData<WQ>& d) {
+    d.node[0] = q.x;
+    d.node[1] = q.y;
+    d.node[2] = q.z;
+    d.node[3] = q.w;
+    for (unsigned c = 0; c < 4; ++c) {
+      d.count[c]   = 0;
+      d.visWord[c] = 0;
+      d.fwd[c] = d.bwd[c] = u32x4{ASM_NONE, ASM_NONE, ASM_NONE, ASM_NONE};
+      for (int w = 0; w < WQ; ++w) d.sup[c][w] = 0;
+      const unsigned n = d.node[c];
+      if (n != ASM_NONE) {
+        const uint32_t* r = recSucc(n);
+        d.fwd[c]          = *reinterpret_cast<const u32x4*>(r + fwdOff);
+        d.bwd[c]          = *reinterpret_cast<const u32x4*>(r + bwdOff);
+        d.count[c]        = r[8];
+        const uint64_t* sp = reinterpret_cast<const uint64_t*>(r + 12);
+        for (int w = 0; w < WQ; ++w)
+          if (unsigned(w) < W) d.sup[c][w] = sp[w];
+        d.visWord[c] = vis[n >> 5];
+      }
+    }
+  };
+
+  StepData<WQ> D;
+  if (active) fetch(*reinterpret_cast<const u32x4*>(recSucc(cur)), 0u, 4u, D);
+
   while (wv::any(active)) {
     if (!active) continue;
     const bool     isEnd  = (mode == 0);
     const unsigned fwdOff = isEnd ? 0u : 4u, bwdOff = isEnd ? 4u : 0u;  // succ[4] | pred[4] inside a node record
-    // the four candidate words: one 16-byte load of the current word's links, then per candidate its
-    // {count} and {support} 16-byte blocks -- all inside that candidate's single 64-byte record (W <= 2)
-    const u32x4    links = *reinterpret_cast<const u32x4*>(recSucc(cur) + fwdOff);
-    const unsigned cand[4] = {links.x, links.y, links.z, links.w};
-    uint64_t       cw[4][WQ];
-    unsigned       ccount[4], cnt[4];
+    unsigned       cnt[4];
     for (unsigned c = 0; c < 4; ++c) {
-      ccount[c] = 0;
-      cnt[c]    = 0;
-      for (int w = 0; w < WQ; ++w) cw[c][w] = 0;
-      if (cand[c] != ASM_NONE) {
-        ccount[c]          = recCnt(cand[c]);
-        const uint64_t* sp = recSup(cand[c]);
-        for (int w = 0; w < WQ; ++w) {
-          if (unsigned(w) < W) {
-            cw[c][w] = sp[w];
-            cnt[c] += unsigned(wv::popc(S[w] & cw[c][w]));
-          }
-        }
-      }
+      cnt[c] = 0;
+      for (int w = 0; w < WQ; ++w) cnt[c] += unsigned(wv::popc(S[w] & D.sup[c][w]));
     }
-    unsigned maxBaseCount = 0, maxCnt = 0, maxNode = ASM_NONE, maxSym = 0;
+    unsigned maxBaseCount = 0, maxCnt = 0, maxNode = ASM_NONE, maxSym = 0, maxVis = 0;
+    u32x4    maxFwd = {ASM_NONE, ASM_NONE, ASM_NONE, ASM_NONE}, maxBwd = maxFwd;
     uint64_t maxWR[WQ], maxCW[WQ], rm[WQ], add[WQ];
     for (int w = 0; w < WQ; ++w) maxWR[w] = maxCW[w] = rm[w] = add[w] = 0;
     for (unsigned c = 0; c < 4; ++c) {  // :241-336
-      if (cand[c] == ASM_NONE || cnt[c] == 0) continue;
+      if (D.node[c] == ASM_NONE || cnt[c] == 0) continue;
       if (cnt[c] > maxCnt) {
         for (int w = 0; w < WQ; ++w) {
-          const uint64_t SH = maxCW[w] & cw[c][w];
+          const uint64_t SH = maxCW[w] & D.sup[c][w];
           rm[w] |= maxCW[w] & ~SH;
           add[w] |= maxWR[w] & ~SH;
-          maxWR[w] = cw[c][w];
-          maxCW[w] = S[w] & cw[c][w];
+          maxWR[w] = D.sup[c][w];
+          maxCW[w] = S[w] & D.sup[c][w];
         }
         maxCnt       = cnt[c];
-        maxBaseCount = ccount[c];
+        maxBaseCount = D.count[c];
         maxSym       = c;
-        maxNode      = cand[c];
+        maxNode      = D.node[c];
+        maxFwd       = D.fwd[c];
+        maxBwd       = D.bwd[c];
+        maxVis       = D.visWord[c];
       } else {
         for (int w = 0; w < WQ; ++w) {
-          const uint64_t SH = maxCW[w] & cw[c][w];
-          rm[w] |= (S[w] & cw[c][w]) & ~SH;
-          add[w] |= cw[c][w] & ~SH;
+          const uint64_t SH = maxCW[w] & D.sup[c][w];
+          rm[w] |= (S[w] & D.sup[c][w]) & ~SH;
+          add[w] |= D.sup[c][w] & ~SH;
         }
       }
     }
     bool stop = false;
     if (maxBaseCount < P.opt.minCoverage) {  // :343
       stop = true;
-    } else if (vis[maxNode >> 5] & (1u << (maxNode & 31))) {  // :352-358
+    } else if (maxVis & (1u << (maxNode & 31))) {  // :352-358
       rep  = true;
       stop = true;
     } else if (k + nRight + nLeft + 1 >= P.max_contig_len) {
@@ -213,23 +264,39 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
       active  = false;
       continue;
     } else {
-      if (isEnd)
-        rightBuf[nRight++] = uint8_t("ACGT"[maxSym]);  // :363
-      else
-        leftBuf[nLeft++] = uint8_t("ACGT"[maxSym]);
+      // requests first: the backward-check records (:377-427) and the next step's candidates
+      const unsigned bnode[4] = {maxBwd.x, maxBwd.y, maxBwd.z, maxBwd.w};
+      uint64_t       bsup[4][WQ];
+      for (unsigned c = 0; c < 4; ++c) {
+        const unsigned n     = bnode[c];
+        const bool     take  = !(n == cur || n == maxNode || n == ASM_NONE);
+        for (int w = 0; w < WQ; ++w) bsup[c][w] = (take && unsigned(w) < W) ? recSup(n)[w] : 0;
+      }
+      vis[maxNode >> 5] = maxVis | (1u << (maxNode & 31));  // :482-484 (before the next fetch reads the bitmap)
+      StepData<WQ> N;
+      fetch(maxFwd, fwdOff, bwdOff, N);
+
+      if (isEnd) {  // :363
+        accR |= maxSym << (2 * (nRight & 15));
+        if ((nRight & 15) == 15) {
+          rightBuf[nRight >> 4] = accR;
+          accR                  = 0;
+        }
+        nRight++;
+      } else {
+        accL |= maxSym << (2 * (nLeft & 15));
+        if ((nLeft & 15) == 15) {
+          leftBuf[nLeft >> 4] = accL;
+          accL                = 0;
+        }
+        nLeft++;
+      }
       if ((consOffset != 0) || (maxBaseCount < P.opt.minConservativeCoverage)) consOffset += 1;  // :368-369
-      const u32x4    blinks = *reinterpret_cast<const u32x4*>(recSucc(maxNode) + bwdOff);
-      const unsigned bnode[4] = {blinks.x, blinks.y, blinks.z, blinks.w};
-      for (unsigned c = 0; c < 4; ++c) {  // one step backwards at the branching point (:377-427)
-        const unsigned n = bnode[c];
-        if (n == cur || n == maxNode || n == ASM_NONE) continue;
-        const uint64_t* sp = recSup(n);
+      for (unsigned c = 0; c < 4; ++c) {
         for (int w = 0; w < WQ; ++w) {
-          if (unsigned(w) < W) {
-            const uint64_t upd = sp[w] & ~maxCW[w];
-            add[w] |= upd;
-            rm[w] |= upd;
-          }
+          const uint64_t upd = bsup[c][w] & ~maxCW[w];  // :400-414
+          add[w] |= upd;
+          rm[w] |= upd;
         }
       }
       for (int w = 0; w < WQ; ++w) {
@@ -237,8 +304,8 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
         S[w] |= maxWR[w] & ~Rj[w];   // :458-464
         S[w] &= ~rm[w];              // :471-473
       }
-      vis[maxNode >> 5] |= (1u << (maxNode & 31));  // :482-484
       cur = maxNode;
+      D   = N;
     }
     if (stop) {
       if (mode == 0) {  // :488-491
@@ -246,6 +313,7 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
         mode       = 1;
         cur        = seed;
         consOffset = 0;
+        fetch(*reinterpret_cast<const u32x4*>(recPred(cur)), 4u, 0u, D);
       } else {
         consBegin = int(consOffset);
         active    = false;
@@ -258,6 +326,8 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
       lane_bits[size_t(lane) * 2 * WQ_MAX + w]          = S[w];
       lane_bits[size_t(lane) * 2 * WQ_MAX + WQ_MAX + w] = Rj[w];
     }
+    if (nRight & 15) rightBuf[nRight >> 4] = accR;
+    if (nLeft & 15) leftBuf[nLeft >> 4] = accL;
     int32_t* m = lane_meta + lane * 8;
     m[0]       = int(nLeft);
     m[1]       = int(nRight);
@@ -266,6 +336,9 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
     m[4]       = rep ? 1 : 0;
     m[5]       = tooLong ? 1 : 0;
     m[6]       = seedRepeat ? 1 : 0;
+    // the visited set must be readable by every lane during acceptance
+    if (visInLds)
+      for (unsigned w = 0; w < useWords; ++w) lane_vis[size_t(lane) * visWords + w] = vis[w];
   }
   wv::sync();
 }
@@ -305,19 +378,22 @@ WV_DEV bool Assembler::contigRounds()
       const unsigned len    = nLeft + k + nRight;
       const unsigned seedPb = node_key[seed];
       uint8_t*       outSeq = cand_seq + size_t(nCand) * P.max_contig_len;
-      const uint8_t* rightBuf = lane_seq + size_t(t) * 2 * P.max_contig_len;
-      const uint8_t* leftBuf  = rightBuf + P.max_contig_len;
+      const unsigned  seqWords = P.max_contig_len / 16 + 2;
+      const uint32_t* rightBuf = reinterpret_cast<const uint32_t*>(lane_seq) + size_t(t) * 2 * seqWords;
+      const uint32_t* leftBuf  = rightBuf + seqWords;
       for (unsigned i = lane; i < len; i += 64) {
-        uint8_t ch;
+        unsigned code;
         if (i < nLeft) {
-          ch = leftBuf[nLeft - 1 - i];
+          const unsigned j = nLeft - 1 - i;
+          code             = (leftBuf[j >> 4] >> (2 * (j & 15))) & 3;
         } else if (i < nLeft + k) {
           const unsigned pb = seedPb + (i - nLeft);
-          ch                = uint8_t("ACGT"[(codes[pb >> 4] >> (30 - 2 * (pb & 15))) & 3]);
+          code              = (codes[pb >> 4] >> (30 - 2 * (pb & 15))) & 3;
         } else {
-          ch = rightBuf[i - nLeft - k];
+          const unsigned j = i - nLeft - k;
+          code             = (rightBuf[j >> 4] >> (2 * (j & 15))) & 3;
         }
-        outSeq[i] = ch;
+        outSeq[i] = uint8_t("ACGT"[code]);
       }
       if (lane < 2 * W) {
         const unsigned half = lane / W, w = lane % W;
