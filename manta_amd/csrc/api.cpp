@@ -247,6 +247,7 @@ struct AsmStage {
     capWords                   = uint32_t(maxLocusWords + pseudoBases / 16 + 2 * nCandMax + 8);
     capReads                   = maxLocusReads + nCandMax + 1;
     capNodes                   = uint32_t(maxLocusBases + pseudoBases + 64);
+    if (capNodes >= LINK_NONE21) return fail(ctx, MANTA_E_UNSUPPORTED, "a locus with more than ~2M read bases is not supported");
     capSlots                   = nextPow2(2ull * capNodes);
     const AsmWsLayout L = asmWorkspaceLayout(capSlots, capNodes, capWords, capReads, maxContigLen, wMax, opt.max_assembly_count);
     stride              = (L.total + 255) & ~uint64_t(255);

@@ -108,7 +108,7 @@ struct AsmParams {
 // per-workgroup workspace carve (host and device agree through asmWorkspaceLayout)
 // --------------------------------------------------------------------------------------------------
 struct AsmWsLayout {
-  uint64_t codes, nmask, rd_cw, rd_mw, rd_len, slots, slot_id, inst_slot, node_key, node_cnt, node_flag, node_aux, rec,
+  uint64_t codes, nmask, rd_cw, rd_mw, rd_len, slots, slot_id, inst_slot, node_key, node_cnt, node_flag, node_aux, rec, links,
       frontier, cand_seq, cand_bits, cand_meta, walk_left, walk_right, pseudo_seq, pseudo_len, exact, node_k32, tent, lane_seq,
       lane_bits, lane_meta, lane_vis, total;
 };
@@ -118,12 +118,19 @@ WV_HD uint64_t asmAlign16(uint64_t v)
   return (v + 15) & ~uint64_t(15);
 }
 
-/// bytes of one node record: succ[4] | pred[4] | count,pad[3] | support[W qwords]; one 64-byte line for W <= 2
+/// bytes of one node record, the unit the contig walks fetch:
+///   [ 0,16) successors  : four 21-bit node ids + the word's count (11 bits), see packLinks
+///   [16,32) predecessors: same packing
+///   [32, ..) read-support bitset, W qwords
+/// -> exactly one 64-byte line for W <= 4 (up to 256 reads incl. pseudo reads)
 WV_HD uint32_t asmRecStride(const uint32_t W)
 {
-  const uint32_t b = 48 + 8 * W;
+  const uint32_t b = 32 + 8 * W;
   return (b < 64) ? 64u : ((b + 15u) & ~15u);
 }
+
+static const uint32_t LINK_NONE21 = 0x1fffffu;  // packed form of ASM_NONE; node ids must stay below it
+static const uint32_t LINK_CNT_MAX = 0x7ffu;    // counts are stored saturated; 0x7ff means "read node_cnt"
 
 WV_HD uint64_t asmPut(uint64_t& cursor, const uint64_t bytes)
 {
@@ -152,6 +159,7 @@ WV_HD AsmWsLayout asmWorkspaceLayout(
   L.node_flag  = asmPut(o, 4ull * cap_nodes);
   L.node_aux   = asmPut(o, 4ull * cap_nodes);
   L.rec        = asmPut(o, uint64_t(cap_nodes) * asmRecStride(w_max));
+  L.links      = asmPut(o, 32ull * cap_nodes);
   L.frontier   = asmPut(o, 8ull * cap_nodes + 256);
   L.cand_seq   = asmPut(o, nCand * max_contig_len);
   L.cand_bits  = asmPut(o, nCand * 2 * 8ull * w_max);
@@ -207,6 +215,7 @@ struct Assembler {
   uint32_t *codes, *nmask, *rd_cw, *rd_mw, *rd_len, *slots, *slot_id, *inst_slot, *node_key, *node_cnt, *node_flag, *node_aux;
   uint8_t*  rec;        // node records (see asmRecStride)
   unsigned  recStride;
+  uint32_t* links;      // succ[4] | pred[4] per node, plain 32-bit ids (cycle test, exact repeat search, wide-set walk)
   uint32_t* frontier;
   uint8_t * cand_seq, *walk_left, *walk_right, *pseudo_seq;
   uint64_t* cand_bits;
@@ -219,7 +228,7 @@ struct Assembler {
   int32_t*  lane_meta;
   // per-locus state (wave-uniform)
   unsigned nNormal, nReads, W, k, nNodes, nCodeWordsNormal, nMaskWordsNormal, nCand;
-  unsigned codeWordsUsed, maskWordsUsed;
+  unsigned codeWordsUsed, maskWordsUsed, slotMask;
   int      status;
   unsigned cyclicIters;
   uint64_t tPhase[8];
@@ -242,6 +251,7 @@ struct Assembler {
     node_aux   = reinterpret_cast<uint32_t*>(ws + L.node_aux);
     rec        = ws + L.rec;
     recStride  = 64;
+    links      = reinterpret_cast<uint32_t*>(ws + L.links);
     frontier   = reinterpret_cast<uint32_t*>(ws + L.frontier);
     cand_seq   = ws + L.cand_seq;
     cand_bits  = reinterpret_cast<uint64_t*>(ws + L.cand_bits);
@@ -274,10 +284,31 @@ struct Assembler {
 #endif
   }
 
-  WV_DEV uint32_t* recSucc(const unsigned n) const { return reinterpret_cast<uint32_t*>(rec + size_t(n) * recStride); }
-  WV_DEV uint32_t* recPred(const unsigned n) const { return recSucc(n) + 4; }
-  WV_DEV uint32_t& recCnt(const unsigned n) const { return recSucc(n)[8]; }
-  WV_DEV uint64_t* recSup(const unsigned n) const { return reinterpret_cast<uint64_t*>(rec + size_t(n) * recStride + 48); }
+  WV_DEV uint32_t* recSucc(const unsigned n) const { return links + size_t(n) * 8; }
+  WV_DEV uint32_t* recPred(const unsigned n) const { return links + size_t(n) * 8 + 4; }
+  WV_DEV uint64_t* recPacked(const unsigned n, const unsigned dirOff16) const  // dirOff16: 0 = successors, 16 = predecessors
+  {
+    return reinterpret_cast<uint64_t*>(rec + size_t(n) * recStride + dirOff16);
+  }
+  WV_DEV uint64_t* recSup(const unsigned n) const { return reinterpret_cast<uint64_t*>(rec + size_t(n) * recStride + 32); }
+  /// four node ids (ASM_NONE -> LINK_NONE21) + saturated count in 128 bits
+  WV_DEV static void packLinks(const unsigned id[4], const unsigned cnt, uint64_t& lo, uint64_t& hi)
+  {
+    uint64_t v[4];
+    for (int i = 0; i < 4; ++i) v[i] = (id[i] == ASM_NONE) ? uint64_t(LINK_NONE21) : uint64_t(id[i]);
+    lo = v[0] | (v[1] << 21) | (v[2] << 42);
+    hi = v[3] | (uint64_t(cnt < LINK_CNT_MAX ? cnt : LINK_CNT_MAX) << 21);
+  }
+  WV_DEV static void unpackLinks(const uint64_t lo, const uint64_t hi, unsigned id[4], unsigned& cnt)
+  {
+    id[0] = unsigned(lo) & LINK_NONE21;
+    id[1] = unsigned(lo >> 21) & LINK_NONE21;
+    id[2] = unsigned(lo >> 42) & LINK_NONE21;
+    id[3] = unsigned(hi) & LINK_NONE21;
+    for (int i = 0; i < 4; ++i)
+      if (id[i] == LINK_NONE21) id[i] = ASM_NONE;
+    cnt = unsigned(hi >> 21) & LINK_CNT_MAX;
+  }
 
   // ------------------------------------------------------------------------------------------------
   // wave helpers (all lanes must call)
@@ -331,11 +362,14 @@ struct Assembler {
     return key;
   }
 
+  /// hashes only the dwords the k-mer occupies, so the value does not depend on the KW instantiation
   template <int KW>
-  WV_DEV static uint32_t keyHash(const Key<KW>& key)
+  WV_DEV uint32_t keyHash(const Key<KW>& key) const
   {
-    uint32_t h = 0x811C9DC5u;
-    for (int i = 0; i < KW; ++i) h = hashMix(h, key.w[i]);
+    const unsigned kw = (k + 15) >> 4;
+    uint32_t       h  = 0x811C9DC5u;
+    for (int i = 0; i < KW; ++i)
+      if (unsigned(i) < kw) h = hashMix(h, key.w[i]);
     h ^= h >> 13;
     return h;
   }
@@ -411,9 +445,9 @@ struct Assembler {
   template <int KW>
   WV_DEV unsigned lookup(const Key<KW>& key) const
   {
-    const unsigned mask = P.cap_slots - 1;
+    const unsigned mask = slotMask;
     unsigned       s    = keyHash(key) & mask;
-    for (unsigned probe = 0; probe < P.cap_slots; ++probe) {
+    for (unsigned probe = 0; probe <= mask; ++probe) {
       const uint32_t cur = slots[s];
       if (cur == ASM_NONE) return ASM_NONE;
       if (keyEq(keyAt<KW>(cur), key)) return slot_id[s];
@@ -511,84 +545,89 @@ struct Assembler {
   WV_DEV void buildGraph()
   {
     const unsigned lane = unsigned(wv::lane());
-    for (unsigned s = lane; s < P.cap_slots; s += 64) slots[s] = ASM_NONE;
+    // table sized for this locus and word length: 2x the k-mer instances, rounded up to a power of two
+    unsigned inst = 0;
+    for (unsigned r = lane; r < nReads; r += 64) {
+      const unsigned len = rd_len[r];
+      inst += (len >= k) ? (len - k + 1) : 0u;
+    }
+    inst = waveSum(inst);
+    unsigned tableSlots = 64;
+    while (tableSlots < 2 * inst && tableSlots < P.cap_slots) tableSlots <<= 1;
+    slotMask = tableSlots - 1;
+    for (unsigned s = lane; s < tableSlots; s += 64) slots[s] = ASM_NONE;
     wv::sync();
 
-    // pass 1: distinct k-mers (assembly/IterativeAssembler.cpp:516-534); per-read de-dup is implicit (sets)
-    bool full = false;
-    const unsigned mask = P.cap_slots - 1;
-    for (unsigned r = 0; r < nReads; ++r) {
-      const unsigned len = rd_len[r];
-      if (len < k) continue;  // :522
-      const unsigned cwo = rd_cw[r], mwo = rd_mw[r];
-      for (unsigned j = lane; j + k <= len; j += 64) {
-        const unsigned pb = cwo * 16 + j;
-        unsigned       slot = ASM_NONE;
-        if (!windowHasN(mwo, j)) {  // :531
-          const Key<KW> key = keyAt<KW>(pb);
-          unsigned      s   = keyHash(key) & mask;
-          for (unsigned probe = 0; probe < P.cap_slots; ++probe) {
-            uint32_t cur = slots[s];
-            if (cur == ASM_NONE) {
-              cur = wv::atomic_cas(&slots[s], ASM_NONE, pb);
+    // one fused pass over the k-mer instances (assembly/IterativeAssembler.cpp:516-548):
+    //   claim-or-find the word's slot with one atomicCAS; the claimers of this step get dense node ids from a
+    //   ballot prefix and initialise their node; after a wave-local fence every instance ORs its read into the
+    //   word's support set.  Per-read de-dup is implicit (sets).
+    bool           full = false;
+    const unsigned mask = slotMask;
+    nNodes              = 0;
+    for (unsigned rBase = 0; rBase < nReads; rBase += 64) {
+      // read descriptors of up to 64 reads live in lane registers; v_readlane hands them out per read
+      const unsigned rMine = rBase + lane;
+      const unsigned lenV  = (rMine < nReads) ? rd_len[rMine] : 0u;
+      const unsigned cwoV  = (rMine < nReads) ? rd_cw[rMine] : 0u;
+      const unsigned mwoV  = (rMine < nReads) ? rd_mw[rMine] : 0u;
+      const unsigned rEnd  = (nReads - rBase < 64) ? (nReads - rBase) : 64u;
+      for (unsigned ri = 0; ri < rEnd; ++ri) {
+        const unsigned r   = rBase + ri;
+        const unsigned len = wv::readlane(lenV, int(ri));
+        if (len < k) continue;  // :522
+        const unsigned cwo = wv::readlane(cwoV, int(ri)), mwo = wv::readlane(mwoV, int(ri));
+        const uint64_t bit = uint64_t(1) << (r & 63);
+        for (unsigned j0 = 0; j0 + k <= len; j0 += 64) {
+          const unsigned j    = j0 + lane;
+          const unsigned pb   = cwo * 16 + j;
+          unsigned       slot = ASM_NONE;
+          bool           won  = false;
+          if (j + k <= len && !windowHasN(mwo, j)) {  // :531
+            const Key<KW> key = keyAt<KW>(pb);
+            unsigned      s   = keyHash(key) & mask;
+            for (unsigned probe = 0; probe <= mask; ++probe) {
+              uint32_t cur = wv::atomic_load(&slots[s]);
               if (cur == ASM_NONE) {
+                cur = wv::atomic_cas(&slots[s], ASM_NONE, pb);
+                if (cur == ASM_NONE) {
+                  slot = s;
+                  won  = true;
+                  break;
+                }
+              }
+              if (keyEq(keyAt<KW>(cur), key)) {
                 slot = s;
                 break;
               }
+              s = (s + 1) & mask;
             }
-            if (keyEq(keyAt<KW>(cur), key)) {
-              slot = s;
-              break;
-            }
-            s = (s + 1) & mask;
+            if (slot == ASM_NONE) full = true;
           }
-          if (slot == ASM_NONE) full = true;
+          const uint64_t m  = wv::ballot(won);
+          const unsigned id = nNodes + unsigned(wv::popc(m & ((uint64_t(1) << lane) - 1)));
+          nNodes += unsigned(wv::popc(m));
+          if (nNodes > P.cap_nodes) {
+            status = ASM_E_TABLE_FULL;
+            return;
+          }
+          if (won) {
+            slot_id[slot] = id;
+            node_key[id]  = pb;
+            for (unsigned w = 0; w < W; ++w) recSup(id)[w] = 0;
+          }
+          wv::sync();
+          if (slot != ASM_NONE)
+            wv::atomic_or(reinterpret_cast<unsigned long long*>(&recSup(wv::atomic_load(&slot_id[slot]))[r >> 6]), bit);
         }
-        inst_slot[pb] = slot;
       }
     }
     wv::sync();
-    wv::fence_acquire();  // slots[] was filled by L2 atomics: drop any stale L1 lines before plain re-reads
+    wv::fence_acquire();  // slots / supports were filled by L2 atomics: drop stale L1 lines before plain re-reads
     if (wv::any(full)) {
       status = ASM_E_TABLE_FULL;
       return;
     }
-
-    // pass 2: dense node ids
-    unsigned n = 0;
-    for (unsigned base = 0; base < P.cap_slots; base += 64) {
-      const unsigned s   = base + lane;
-      const uint32_t pb  = slots[s];
-      const bool     occ = (pb != ASM_NONE);
-      const uint64_t m   = wv::ballot(occ);
-      const unsigned id  = n + unsigned(wv::popc(m & ((uint64_t(1) << lane) - 1)));
-      if (occ && id < P.cap_nodes) {
-        slot_id[s]   = id;
-        node_key[id] = pb;
-      }
-      n += unsigned(wv::popc(m));
-    }
-    nNodes = n;
-    if (nNodes > P.cap_nodes) {
-      status = ASM_E_TABLE_FULL;
-      return;
-    }
-    for (unsigned i = lane; i < nNodes * W; i += 64) recSup(i / W)[i % W] = 0;
-    wv::sync();
-
-    // pass 3: supporting reads (:544-548)
-    for (unsigned r = 0; r < nReads; ++r) {
-      const unsigned len = rd_len[r];
-      if (len < k) continue;
-      const unsigned cwo = rd_cw[r];
-      const uint64_t bit = uint64_t(1) << (r & 63);
-      for (unsigned j = lane; j + k <= len; j += 64) {
-        const unsigned s = inst_slot[cwo * 16 + j];
-        if (s != ASM_NONE) wv::atomic_or(reinterpret_cast<unsigned long long*>(&recSup(slot_id[s])[r >> 6]), bit);
-      }
-    }
-    wv::sync();
-    wv::fence_acquire();
     tick(1);
 
     // counts (:541-545: a pseudo read weighs minCoverage), seed eligibility (:679-682), links
@@ -599,19 +638,23 @@ struct Assembler {
         cnt += unsigned(wv::popc(s & normalMask(w))) + P.opt.minCoverage * unsigned(wv::popc(s & ~normalMask(w)));
       }
       node_cnt[nd]  = cnt;
-      recCnt(nd)    = cnt;
       const Key<KW> key = keyAt<KW>(node_key[nd]);
       node_k32[nd]  = key.w[0];
       bool          selfLoop = false;
       unsigned      indeg    = 0;
+      unsigned      sIds[4], pIds[4];
       for (unsigned c = 0; c < 4; ++c) {
         const unsigned s = lookup<KW>(keyShiftAppend<KW>(key, c));
         const unsigned p = lookup<KW>(keyShiftPrepend<KW>(key, c));
-        recSucc(nd)[c] = s;
-        recPred(nd)[c] = p;
+        sIds[c]          = s;
+        pIds[c]          = p;
+        recSucc(nd)[c]   = s;
+        recPred(nd)[c]   = p;
         if (s == nd) selfLoop = true;  // homopolymer (:574-577)
         if (p != ASM_NONE && p != nd) indeg++;
       }
+      packLinks(sIds, cnt, recPacked(nd, 0)[0], recPacked(nd, 0)[1]);
+      packLinks(pIds, cnt, recPacked(nd, 16)[0], recPacked(nd, 16)[1]);
       node_flag[nd] = ((cnt >= P.opt.minCoverage) ? NF_UNUSED : 0u) | (selfLoop ? NF_REPEAT : 0u);
       node_aux[nd]  = indeg;
     }
@@ -702,9 +745,9 @@ struct Assembler {
   // ------------------------------------------------------------------------------------------------
   // seed selection (:686-696): highest count among unused words, ties -> lexicographically smallest
   // ------------------------------------------------------------------------------------------------
-  template <int KW>
   WV_DEV unsigned selectSeed()
   {
+    typedef Key<ASM_MAX_KW> GKey;
     const unsigned lane = unsigned(wv::lane());
     unsigned       best = 0;
     for (unsigned nd = lane; nd < nNodes; nd += 64) {
@@ -715,12 +758,17 @@ struct Assembler {
     }
     best = waveMax(best);
     if (best == 0) return ASM_NONE;
+    // smallest 16-base prefix among the best-count words, then the full k-mer only among prefix ties
+    unsigned minPre = 0xffffffffu;
+    for (unsigned nd = lane; nd < nNodes; nd += 64)
+      if ((node_flag[nd] & NF_UNUSED) && node_cnt[nd] == best) minPre = (node_k32[nd] < minPre) ? node_k32[nd] : minPre;
+    minPre = ~waveMax(~minPre);
     unsigned mine = ASM_NONE;
-    Key<KW>  mineKey;
-    for (int i = 0; i < KW; ++i) mineKey.w[i] = 0xffffffffu;
+    GKey     mineKey;
+    for (int i = 0; i < ASM_MAX_KW; ++i) mineKey.w[i] = 0xffffffffu;
     for (unsigned nd = lane; nd < nNodes; nd += 64) {
-      if ((node_flag[nd] & NF_UNUSED) && node_cnt[nd] == best) {
-        const Key<KW> key = keyAt<KW>(node_key[nd]);
+      if ((node_flag[nd] & NF_UNUSED) && node_cnt[nd] == best && node_k32[nd] == minPre) {
+        const GKey key = keyAt<ASM_MAX_KW>(node_key[nd]);
         if (mine == ASM_NONE || keyLess(key, mineKey)) {
           mine    = nd;
           mineKey = key;
@@ -730,8 +778,8 @@ struct Assembler {
     for (int off = 1; off < 64; off <<= 1) {
       const int      src = wv::lane() ^ off;
       const unsigned on  = wv::shfl(mine, src);
-      Key<KW>        ok;
-      for (int i = 0; i < KW; ++i) ok.w[i] = wv::shfl(mineKey.w[i], src);
+      GKey           ok;
+      for (int i = 0; i < ASM_MAX_KW; ++i) ok.w[i] = wv::shfl(mineKey.w[i], src);
       if (on != ASM_NONE && (mine == ASM_NONE || keyLess(ok, mineKey))) {
         mine    = on;
         mineKey = ok;
@@ -757,9 +805,9 @@ struct Assembler {
     return wv::readlane(s, 0);
   }
 
-  template <int KW>
   WV_DEV bool walk(const unsigned seed, const unsigned serial, const unsigned candIdx)
   {
+    static const int KW = ASM_MAX_KW;  // generic key width: this path is the wide-read-set fallback, not the hot one
     const unsigned lane = unsigned(wv::lane());
     uint64_t       S    = supWord(seed);  // contig.supportReads (:168)
     uint64_t       Rj   = 0;              // contig.rejectReads
@@ -934,43 +982,46 @@ struct Assembler {
   }
 
   // defined in repeat_exact.hpp
-  template <int KW>
   WV_DEV void exactRepeatSearch();
   // defined in walk_lanes.hpp
-  template <int KW>
   WV_DEV unsigned selectTentative(const unsigned T);
-  template <int KW, int WQ>
+  template <int WQ>
   WV_DEV void walkLanes(const unsigned nT);
-  template <int KW, int WQ>
+  template <int WQ>
   WV_DEV bool contigRounds();
 
-  /// buildContigs (:644-720).  Returns isAssemblySuccess.
+  /// buildContigs (:644-720).  Returns isAssemblySuccess.  Only the graph build is specialised on the key width;
+  /// everything after it works on node ids / links and uses the generic key width for its few k-mer compares.
   template <int KW>
   WV_DEV bool buildContigs()
   {
     buildGraph<KW>();
     if (status != ASM_OK) return true;
+    return contigsFromGraph();
+  }
+
+  WV_DEV bool contigsFromGraph()
+  {
     const bool cyclic = graphHasCycle();
     tick(3);
     if (cyclic) {
       cyclicIters++;
-      exactRepeatSearch<KW>();
+      exactRepeatSearch();
       tick(4);
       if (status != ASM_OK) return true;
     }
     if (!(P.flags & ASM_FLAG_SERIAL_WALK)) {
-      if (W <= 1) return contigRounds<KW, 1>();
-      if (W <= 2) return contigRounds<KW, 2>();
-      if (W <= 4) return contigRounds<KW, 4>();
+      if (W <= 2) return contigRounds<2>();
+      if (W <= 4) return contigRounds<4>();
     }
     // more than 256 reads (or forced): one contig at a time, lanes spread over the qwords of the read sets
     nCand        = 0;
     bool success = true;
     while (nCand < 2 * P.opt.maxAssemblyCount) {  // :685
-      const unsigned seed = selectSeed<KW>();
+      const unsigned seed = selectSeed();
       tick(5);
       if (seed == ASM_NONE) break;
-      const bool rep = walk<KW>(seed, nCand + 1, nCand);
+      const bool rep = walk(seed, nCand + 1, nCand);
       tick(6);
       if (status != ASM_OK) return true;
       if (rep) success = false;

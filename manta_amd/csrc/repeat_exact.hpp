@@ -118,9 +118,9 @@ WV_DEV void unorderedOrderSerial(
   for (uint32_t p = head; p != NIL; p = next[p]) seqOut[m++] = p;
 }
 
-template <int KW>
 WV_DEV void Assembler::exactRepeatSearch()
 {
+  static const int KW = ASM_MAX_KW;
   const unsigned lane = unsigned(wv::lane());
   const unsigned n    = nNodes;
   // carve (u32 units) out of the `exact` workspace region: 14 * cap_nodes + 64 words

@@ -21,12 +21,12 @@ namespace manta_dev {
 /// '>' on the count, :689-696).  Top-T selection without a sort: compact the unused words once, find the count level
 /// and then the 16-base-prefix threshold that cut off T words by two binary searches over coalesced arrays, gather
 /// the (about T) survivors and order only those exactly.
-template <int KW>
 WV_DEV unsigned Assembler::selectTentative(const unsigned T)
 {
+  static const int KW = ASM_MAX_KW;
   const unsigned lane = unsigned(wv::lane());
   if (T == 1) {
-    const unsigned s = selectSeed<KW>();
+    const unsigned s = selectSeed();
     if (s == ASM_NONE) return 0;
     if (lane == 0) tent_sorted[0] = s;
     wv::sync();
@@ -99,7 +99,7 @@ WV_DEV unsigned Assembler::selectTentative(const unsigned T)
   wv::sync();
   if (total > TENT_CAP) {
     // pathological tie group (hundreds of words sharing a 16-base prefix): take one exact seed the slow way
-    const unsigned s = selectSeed<KW>();
+    const unsigned s = selectSeed();
     if (s == ASM_NONE) return 0;
     if (lane == 0) tent_sorted[0] = s;
     wv::sync();
@@ -123,23 +123,36 @@ WV_DEV unsigned Assembler::selectTentative(const unsigned T)
   return (total < T) ? total : T;
 }
 
-/// candidate-word data a walk step needs, fetched as whole-record 16-byte blocks (one 64-byte line per word, W <= 2)
+/// The (<= 4) existing candidate words of a walk step, compacted in alphabet order, with everything the step needs:
+/// per candidate three 16-byte blocks of its 64-byte record (links in walking direction + count, links against it,
+/// read support) and the lane's visited-bitmap word.
+static const unsigned WALK_NPRE = 2;  // candidate slots fetched ahead; a 3rd/4th candidate (rare) is fetched on demand
 template <int WQ>
 struct StepData {
-  unsigned node[4];
-  u32x4    fwd[4], bwd[4];  // the candidate's own links in / against the walking direction
-  unsigned count[4];
-  uint64_t sup[4][WQ];
-  unsigned visWord[4];
+  unsigned m;        // number of candidates
+  unsigned node[4];  // compacted, alphabet order
+  unsigned syms;     // their symbols, 2 bits each
+  uint64_t flo[WALK_NPRE], fhi[WALK_NPRE], blo[WALK_NPRE], bhi[WALK_NPRE];
+  uint64_t sup[WALK_NPRE][WQ];
+  unsigned visWord[WALK_NPRE];
 };
 
 /// One round: lane t < nT walks tent_sorted[t] with private state (assembly/IterativeAssembler.cpp:149-501).
-/// The step loop is software-pipelined: the records of the NEXT step's candidates are requested as soon as the
-/// current step has chosen its word, together with the (<= 3) records of the backward check, so a step costs about
-/// one memory round trip.  The private visited bitmaps live in LDS when they fit.
-template <int KW, int WQ>
+///
+/// The per-CU vector-memory pipe, not HBM, bounds this loop (a gather instruction costs the same whether 1 or 64
+/// lanes are live), so the step is built to issue as few memory instructions as possible:
+///   * most words have ONE successor: the existing candidates are compacted per lane and candidate slot i is only
+///     fetched if some lane has more than i candidates;
+///   * a candidate costs three 16-byte loads from its single 64-byte record (packed links carry the count);
+///   * the step is software-pipelined: right after the choice, the backward-check supports (:377-427) and the next
+///     step's candidates are requested together, so a step is about one memory round trip;
+///   * the lane-private visited bitmaps live in LDS when they fit.
+/// All lanes execute the same instruction stream (finished lanes are predicated off), so the wave-level votes that
+/// skip empty candidate slots are convergent.
+template <int WQ>
 WV_DEV void Assembler::walkLanes(const unsigned nT)
 {
+  static const int KW = ASM_MAX_KW;
   const unsigned lane     = unsigned(wv::lane());
   const unsigned visWords = (P.cap_nodes + 31) / 32;
   const unsigned useWords = (nNodes + 31) / 32;
@@ -187,95 +200,179 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
     }
   }
 
-  // fetch everything a step needs about the four words `q` (ASM_NONE entries stay zero)
-  auto fetch = [&](const u32x4 q, const unsigned fwdOff, const unsigned bwdOff, StepData<WQ>& d) {
-    d.node[0] = q.x;
-    d.node[1] = q.y;
-    d.node[2] = q.z;
-    d.node[3] = q.w;
-    for (unsigned c = 0; c < 4; ++c) {
-      d.count[c]   = 0;
-      d.visWord[c] = 0;
-      d.fwd[c] = d.bwd[c] = u32x4{ASM_NONE, ASM_NONE, ASM_NONE, ASM_NONE};
-      for (int w = 0; w < WQ; ++w) d.sup[c][w] = 0;
-      const unsigned n = d.node[c];
-      if (n != ASM_NONE) {
-        const uint32_t* r = recSucc(n);
-        d.fwd[c]          = *reinterpret_cast<const u32x4*>(r + fwdOff);
-        d.bwd[c]          = *reinterpret_cast<const u32x4*>(r + bwdOff);
-        d.count[c]        = r[8];
-        const uint64_t* sp = reinterpret_cast<const uint64_t*>(r + 12);
+  // Fetch the step data for the candidates named by the packed link block (lo,hi); `on` predicates the lane.
+  // fdir16 / bdir16: byte offset of the links in / against the walking direction inside a record (0 or 16).
+  auto fetch = [&](const bool on, const uint64_t lo, const uint64_t hi, const unsigned fdir16, const unsigned bdir16,
+                   StepData<WQ>& d) {
+    unsigned ids[4], cntUnused;
+    unpackLinks(lo, hi, ids, cntUnused);
+    d.m    = 0;
+    d.syms = 0;
+    for (unsigned i = 0; i < 4; ++i) d.node[i] = ASM_NONE;
+    if (on) {
+      for (unsigned c = 0; c < 4; ++c) {  // stable compaction keeps the reference's A,C,G,T evaluation order
+        if (ids[c] == ASM_NONE) continue;
+        for (unsigned i = 0; i < 4; ++i)
+          if (i == d.m) d.node[i] = ids[c];
+        d.syms |= c << (2 * d.m);
+        d.m++;
+      }
+    }
+    for (unsigned i = 0; i < WALK_NPRE; ++i) {
+      d.flo[i] = d.fhi[i] = d.blo[i] = d.bhi[i] = 0;
+      d.visWord[i] = 0;
+      for (int w = 0; w < WQ; ++w) d.sup[i][w] = 0;
+      if (!wv::any(i < d.m)) continue;  // nobody has an (i+1)-th candidate: no memory instructions at all
+      if (i < d.m) {
+        const unsigned  n  = d.node[i];
+        const uint64_t* f  = recPacked(n, fdir16);
+        const uint64_t* b  = recPacked(n, bdir16);
+        const uint64_t* sp = recSup(n);
+        d.flo[i] = f[0];
+        d.fhi[i] = f[1];
+        d.blo[i] = b[0];
+        d.bhi[i] = b[1];
         for (int w = 0; w < WQ; ++w)
-          if (unsigned(w) < W) d.sup[c][w] = sp[w];
-        d.visWord[c] = vis[n >> 5];
+          if (unsigned(w) < W) d.sup[i][w] = sp[w];
+        d.visWord[i] = vis[n >> 5];
       }
     }
   };
 
   StepData<WQ> D;
-  if (active) fetch(*reinterpret_cast<const u32x4*>(recSucc(cur)), 0u, 4u, D);
+  {
+    uint64_t lo = 0, hi = 0;
+    if (active) {
+      lo = recPacked(cur, 0)[0];
+      hi = recPacked(cur, 0)[1];
+    }
+    fetch(active, lo, hi, 0u, 16u, D);
+  }
 
   while (wv::any(active)) {
-    if (!active) continue;
     const bool     isEnd  = (mode == 0);
-    const unsigned fwdOff = isEnd ? 0u : 4u, bwdOff = isEnd ? 4u : 0u;  // succ[4] | pred[4] inside a node record
-    unsigned       cnt[4];
-    for (unsigned c = 0; c < 4; ++c) {
-      cnt[c] = 0;
-      for (int w = 0; w < WQ; ++w) cnt[c] += unsigned(wv::popc(S[w] & D.sup[c][w]));
-    }
+    const unsigned fdir16 = isEnd ? 0u : 16u, bdir16 = isEnd ? 16u : 0u;
+    // ---- choose the extension among the candidates (:241-336) ----
     unsigned maxBaseCount = 0, maxCnt = 0, maxNode = ASM_NONE, maxSym = 0, maxVis = 0;
-    u32x4    maxFwd = {ASM_NONE, ASM_NONE, ASM_NONE, ASM_NONE}, maxBwd = maxFwd;
+    uint64_t maxFlo = 0, maxFhi = 0, maxBlo = 0, maxBhi = 0;
     uint64_t maxWR[WQ], maxCW[WQ], rm[WQ], add[WQ];
     for (int w = 0; w < WQ; ++w) maxWR[w] = maxCW[w] = rm[w] = add[w] = 0;
-    for (unsigned c = 0; c < 4; ++c) {  // :241-336
-      if (D.node[c] == ASM_NONE || cnt[c] == 0) continue;
-      if (cnt[c] > maxCnt) {
+    for (unsigned i = 0; i < 4; ++i) {
+      const bool live = active && i < D.m;
+      uint64_t   cflo, cfhi, cblo, cbhi, csup[WQ];
+      unsigned   cvis;
+      if (i < WALK_NPRE) {
+        cflo = D.flo[i];
+        cfhi = D.fhi[i];
+        cblo = D.blo[i];
+        cbhi = D.bhi[i];
+        cvis = D.visWord[i];
+        for (int w = 0; w < WQ; ++w) csup[w] = D.sup[i][w];
+      } else {
+        cflo = cfhi = cblo = cbhi = 0;
+        cvis = 0;
+        for (int w = 0; w < WQ; ++w) csup[w] = 0;
+        if (!wv::any(live)) continue;  // a third / fourth candidate is rare: fetched only when some lane has one
+        if (live) {
+          const unsigned  n  = D.node[i];
+          const uint64_t* f  = recPacked(n, fdir16);
+          const uint64_t* b  = recPacked(n, bdir16);
+          const uint64_t* sp = recSup(n);
+          cflo = f[0];
+          cfhi = f[1];
+          cblo = b[0];
+          cbhi = b[1];
+          for (int w = 0; w < WQ; ++w)
+            if (unsigned(w) < W) csup[w] = sp[w];
+          cvis = vis[n >> 5];
+        }
+      }
+      if (!live) continue;
+      unsigned cnt = 0;
+      for (int w = 0; w < WQ; ++w) cnt += unsigned(wv::popc(S[w] & csup[w]));
+      if (cnt == 0) continue;  // :280
+      if (cnt > maxCnt) {      // :283-316
         for (int w = 0; w < WQ; ++w) {
-          const uint64_t SH = maxCW[w] & D.sup[c][w];
+          const uint64_t SH = maxCW[w] & csup[w];
           rm[w] |= maxCW[w] & ~SH;
           add[w] |= maxWR[w] & ~SH;
-          maxWR[w] = D.sup[c][w];
-          maxCW[w] = S[w] & D.sup[c][w];
+          maxWR[w] = csup[w];
+          maxCW[w] = S[w] & csup[w];
         }
-        maxCnt       = cnt[c];
-        maxBaseCount = D.count[c];
-        maxSym       = c;
-        maxNode      = D.node[c];
-        maxFwd       = D.fwd[c];
-        maxBwd       = D.bwd[c];
-        maxVis       = D.visWord[c];
-      } else {
+        maxCnt  = cnt;
+        maxSym  = (D.syms >> (2 * i)) & 3;
+        maxNode = D.node[i];
+        maxFlo  = cflo;
+        maxFhi  = cfhi;
+        maxBlo  = cblo;
+        maxBhi  = cbhi;
+        maxVis  = cvis;
+      } else {  // :317-335
         for (int w = 0; w < WQ; ++w) {
-          const uint64_t SH = maxCW[w] & D.sup[c][w];
-          rm[w] |= (S[w] & D.sup[c][w]) & ~SH;
-          add[w] |= D.sup[c][w] & ~SH;
+          const uint64_t SH = maxCW[w] & csup[w];
+          rm[w] |= (S[w] & csup[w]) & ~SH;
+          add[w] |= csup[w] & ~SH;
         }
       }
     }
-    bool stop = false;
-    if (maxBaseCount < P.opt.minCoverage) {  // :343
-      stop = true;
-    } else if (maxVis & (1u << (maxNode & 31))) {  // :352-358
-      rep  = true;
-      stop = true;
-    } else if (k + nRight + nLeft + 1 >= P.max_contig_len) {
-      tooLong = true;
-      active  = false;
-      continue;
-    } else {
-      // requests first: the backward-check records (:377-427) and the next step's candidates
-      const unsigned bnode[4] = {maxBwd.x, maxBwd.y, maxBwd.z, maxBwd.w};
-      uint64_t       bsup[4][WQ];
-      for (unsigned c = 0; c < 4; ++c) {
-        const unsigned n     = bnode[c];
-        const bool     take  = !(n == cur || n == maxNode || n == ASM_NONE);
-        for (int w = 0; w < WQ; ++w) bsup[c][w] = (take && unsigned(w) < W) ? recSup(n)[w] : 0;
+    if (maxNode != ASM_NONE) {
+      maxBaseCount = unsigned(maxFhi >> 21) & LINK_CNT_MAX;
+      if (maxBaseCount == LINK_CNT_MAX) maxBaseCount = node_cnt[maxNode];  // saturated: the exact count is in the SoA copy
+    }
+    bool stop = false, extend = false;
+    if (active) {
+      if (maxBaseCount < P.opt.minCoverage) {  // :343 (also "no candidate")
+        stop = true;
+      } else if (maxVis & (1u << (maxNode & 31))) {  // :352-358
+        rep  = true;
+        stop = true;
+      } else if (k + nRight + nLeft + 1 >= P.max_contig_len) {
+        tooLong = true;
+        active  = false;
+      } else {
+        extend = true;
       }
-      vis[maxNode >> 5] = maxVis | (1u << (maxNode & 31));  // :482-484 (before the next fetch reads the bitmap)
-      StepData<WQ> N;
-      fetch(maxFwd, fwdOff, bwdOff, N);
+    }
+    // ---- requests: backward-check supports of the chosen word (:377-427) ... ----
+    unsigned bIds[4], bCntUnused;
+    unpackLinks(maxBlo, maxBhi, bIds, bCntUnused);
+    unsigned bn[3] = {ASM_NONE, ASM_NONE, ASM_NONE};
+    unsigned bm    = 0;
+    if (extend) {
+      for (unsigned c = 0; c < 4; ++c) {
+        const unsigned n = bIds[c];
+        if (n == cur || n == maxNode || n == ASM_NONE) continue;  // :381, :389
+        for (unsigned i = 0; i < 3; ++i)
+          if (i == bm) bn[i] = n;
+        bm++;
+      }
+    }
+    uint64_t bsup[3][WQ];
+    for (unsigned i = 0; i < 3; ++i) {
+      for (int w = 0; w < WQ; ++w) bsup[i][w] = 0;
+      if (!wv::any(i < bm)) continue;
+      if (i < bm) {
+        const uint64_t* sp = recSup(bn[i]);
+        for (int w = 0; w < WQ; ++w)
+          if (unsigned(w) < W) bsup[i][w] = sp[w];
+      }
+    }
+    // ---- ... and the next step's candidates (or, on a direction switch, the seed's predecessors) ----
+    if (extend) vis[maxNode >> 5] = maxVis | (1u << (maxNode & 31));  // :482-484, before the next fetch reads the bitmap
+    const bool toLeft = stop && (mode == 0);  // :488-491
+    uint64_t   nlo = maxFlo, nhi = maxFhi;
+    unsigned   nf = fdir16, nb = bdir16;
+    if (toLeft) {
+      nlo = recPacked(seed, 16)[0];
+      nhi = recPacked(seed, 16)[1];
+      nf  = 16u;
+      nb  = 0u;
+    }
+    StepData<WQ> N;
+    fetch(extend || toLeft, nlo, nhi, nf, nb, N);
 
+    // ---- finish this step ----
+    if (extend) {
       if (isEnd) {  // :363
         accR |= maxSym << (2 * (nRight & 15));
         if ((nRight & 15) == 15) {
@@ -292,9 +389,9 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
         nLeft++;
       }
       if ((consOffset != 0) || (maxBaseCount < P.opt.minConservativeCoverage)) consOffset += 1;  // :368-369
-      for (unsigned c = 0; c < 4; ++c) {
+      for (unsigned i = 0; i < 3; ++i) {
         for (int w = 0; w < WQ; ++w) {
-          const uint64_t upd = bsup[c][w] & ~maxCW[w];  // :400-414
+          const uint64_t upd = bsup[i][w] & ~maxCW[w];  // :400-414
           add[w] |= upd;
           rm[w] |= upd;
         }
@@ -305,20 +402,19 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
         S[w] &= ~rm[w];              // :471-473
       }
       cur = maxNode;
-      D   = N;
     }
     if (stop) {
-      if (mode == 0) {  // :488-491
+      if (mode == 0) {
         consEnd    = int(consOffset);
         mode       = 1;
         cur        = seed;
         consOffset = 0;
-        fetch(*reinterpret_cast<const u32x4*>(recPred(cur)), 4u, 0u, D);
       } else {
         consBegin = int(consOffset);
         active    = false;
       }
     }
+    D = N;
   }
 
   if (has) {
@@ -344,7 +440,7 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
 }
 
 /// buildContigs' contig loop (:685-713) by speculative rounds.  Returns isAssemblySuccess.
-template <int KW, int WQ>
+template <int WQ>
 WV_DEV bool Assembler::contigRounds()
 {
   const unsigned lane     = unsigned(wv::lane());
@@ -358,10 +454,10 @@ WV_DEV bool Assembler::contigRounds()
     // first round); later rounds: what is still needed plus a margin for invalidated tentative seeds
     unsigned T = (nCand == 0) ? 1u : (capCand - nCand) + (capCand - nCand) / 4 + 2;
     if (T > 64) T = 64;
-    const unsigned nT = selectTentative<KW>(T);
+    const unsigned nT = selectTentative(T);
     tick(5);
     if (nT == 0) break;
-    walkLanes<KW, WQ>(nT);
+    walkLanes<WQ>(nT);
     tick(6);
     for (unsigned t = 0; t < nT && nCand < capCand; ++t) {
       const unsigned seed = tent_sorted[t];
