@@ -745,7 +745,7 @@ struct Assembler {
   // ------------------------------------------------------------------------------------------------
   // seed selection (:686-696): highest count among unused words, ties -> lexicographically smallest
   // ------------------------------------------------------------------------------------------------
-  WV_DEV unsigned selectSeed()
+  WV_DEV_COLD unsigned selectSeed()
   {
     typedef Key<ASM_MAX_KW> GKey;
     const unsigned lane = unsigned(wv::lane());
@@ -805,7 +805,7 @@ struct Assembler {
     return wv::readlane(s, 0);
   }
 
-  WV_DEV bool walk(const unsigned seed, const unsigned serial, const unsigned candIdx)
+  WV_DEV_COLD bool walk(const unsigned seed, const unsigned serial, const unsigned candIdx)
   {
     static const int KW = ASM_MAX_KW;  // generic key width: this path is the wide-read-set fallback, not the hot one
     const unsigned lane = unsigned(wv::lane());
@@ -982,7 +982,7 @@ struct Assembler {
   }
 
   // defined in repeat_exact.hpp
-  WV_DEV void exactRepeatSearch();
+  WV_DEV_COLD void exactRepeatSearch();
   // defined in walk_lanes.hpp
   WV_DEV unsigned selectTentative(const unsigned T);
   template <int WQ>
@@ -1041,7 +1041,7 @@ struct Assembler {
   // ------------------------------------------------------------------------------------------------
   // pseudo reads (:882-910)
   // ------------------------------------------------------------------------------------------------
-  WV_DEV unsigned appendPseudoReads()
+  WV_DEV_COLD unsigned appendPseudoReads()
   {
     const unsigned lane = unsigned(wv::lane());
     unsigned       cw = nCodeWordsNormal, mw = nMaskWordsNormal;
@@ -1085,7 +1085,7 @@ struct Assembler {
   // ------------------------------------------------------------------------------------------------
   // selectContigs (:722-842) + output
   // ------------------------------------------------------------------------------------------------
-  WV_DEV void selectAndEmit(const unsigned locus, const unsigned nPseudoFinal, const unsigned nIter)
+  WV_DEV_COLD void selectAndEmit(const unsigned locus, const unsigned nPseudoFinal, const unsigned nIter)
   {
     const unsigned lane = unsigned(wv::lane());
     AsmLocusOut    out;

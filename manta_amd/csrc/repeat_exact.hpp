@@ -118,7 +118,7 @@ WV_DEV void unorderedOrderSerial(
   for (uint32_t p = head; p != NIL; p = next[p]) seqOut[m++] = p;
 }
 
-WV_DEV void Assembler::exactRepeatSearch()
+WV_DEV_COLD void Assembler::exactRepeatSearch()
 {
   static const int KW = ASM_MAX_KW;
   const unsigned lane = unsigned(wv::lane());

@@ -21,6 +21,8 @@
 // same, additionally asking the register allocator for at least `w` resident waves per SIMD
 #define WV_KERNEL_OCC(w) __global__ __launch_bounds__(64 * WV_WAVES_PER_WG, w)
 #define WV_HD __host__ __device__ inline
+// cold paths (measured: real out-of-line calls cost more than they save on gfx950, so this is still inline)
+#define WV_DEV_COLD __device__ __forceinline__
 
 extern __shared__ __attribute__((aligned(16))) char wv_dyn_lds[];
 

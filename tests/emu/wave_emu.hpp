@@ -20,6 +20,7 @@
 #define WV_KERNEL_OCC(w)
 #define WV_WAVES_PER_WG 1
 #define WV_HD inline
+#define WV_DEV_COLD inline
 
 namespace wv_emu {
 
