@@ -78,6 +78,8 @@ struct KindTraits<2> {
   typedef uint8_t cell_t;
 };
 
+WV_DEV int imax(const int a, const int b) { return (a > b) ? a : b; }
+
 /// strict-'>' running arg-max step
 WV_DEV void amax(int& best, int& ptr, const int v, const int idx)
 {
@@ -127,6 +129,7 @@ struct Aligner {
   typedef typename KT::cell_t       cell_t;
   static const int                  NS = KT::NS;
   static const int                  BITS = KT::BITS;
+  static const int                  FMASK = (1 << KT::BITS) - 1;  // a stored field is (7 - state) & FMASK
 
   const AlignParams& P;
   const uint8_t*     query;
@@ -152,7 +155,7 @@ struct Aligner {
     }
     const unsigned l = (q - 1) / E, e = (q - 1) % E;
     const uint64_t idx = (uint64_t(g + l) * E + e) * 64 + l;
-    return (int(ptr[idx]) >> (state * BITS)) & ((1 << BITS) - 1);
+    return (7 - ((int(ptr[idx]) >> (state * BITS)) & FMASK)) & FMASK;
   }
 
   // ------------------------------------------------------------------------------------------------
@@ -264,82 +267,71 @@ struct Aligner {
         for (int s = 0; s < NS; ++s) up[s] = st[s][e];
         const bool firstCol = (e == 0) && (lane == 0);
         const int  sub      = (unsigned(qc[e]) == rc) ? P.match : P.mismatch;
-        int        nv[NS], np[NS];
-
+        int        nv[NS];
+        unsigned   code = 0;
+        // Arg-max with "lowest state index wins ties" (the reference's strict-'>' scan) in ONE integer max per
+        // candidate: candidate i is scored as value*8 + (7-i), so equal values order by state index; v_max3_i32
+        // folds three at a time; value = max >> 3, and the low bits (= 7 - winning state) go straight into the
+        // stored back-pointer field (ptrField undoes the 7-x).  |scores| < 2^27, so the shift cannot overflow.
+#define MANTA_PK(v, idx) (((v) << 3) + (7 - (idx)))
+#define MANTA_PKA(v, add, idx) (((v) << 3) + (((add) << 3) + (7 - (idx))))
         // match
         {
-          int b = diag[ST_MATCH], p = 0;
-          amax(b, p, diag[ST_DELETE], 1);
-          amax(b, p, diag[ST_INSERT], 2);
-          if (KIND == 1) {
-            amax(b, p, diag[ST_JUMP], 3);
-            amax(b, p, diag[ST_JUMPINS], 4);
-          }
-          if (KIND == 2 && inRef2) amax(b, p, diag[ST_JUMP], 3);
-          nv[ST_MATCH] = b + sub;
-          np[ST_MATCH] = p;
+          int m = imax(imax(MANTA_PK(diag[ST_MATCH], 0), MANTA_PK(diag[ST_DELETE], 1)), MANTA_PK(diag[ST_INSERT], 2));
+          if (KIND == 1) m = imax(imax(m, MANTA_PK(diag[ST_JUMP], 3)), MANTA_PK(diag[ST_JUMPINS], 4));
+          if (KIND == 2 && inRef2) m = imax(m, MANTA_PK(diag[ST_JUMP], 3));
+          nv[ST_MATCH] = (m >> 3) + sub;
+          code |= unsigned(m & FMASK) << (ST_MATCH * BITS);
         }
         // delete
         {
-          int b = up[ST_MATCH] + open, p = 0;
-          amax(b, p, up[ST_DELETE], 1);
-          amax(b, p, up[ST_INSERT], 2);
-          if (KIND == 1) {
-            amax(b, p, ALIGN_BAD, 3);
-            amax(b, p, up[ST_JUMPINS], 4);
-          }
-          b += extend;
+          int m = imax(imax(MANTA_PKA(up[ST_MATCH], open, 0), MANTA_PK(up[ST_DELETE], 1)), MANTA_PK(up[ST_INSERT], 2));
+          if (KIND == 1) m = imax(imax(m, MANTA_PK(ALIGN_BAD, 3)), MANTA_PK(up[ST_JUMPINS], 4));
+          int b = (m >> 3) + extend;
           if (firstCol && !inRef2) b = ALIGN_BAD;  // no reset in ref2 (GlobalJumpAlignerImpl.hpp:240-246)
           nv[ST_DELETE] = b;
-          np[ST_DELETE] = p;
+          code |= unsigned(m & FMASK) << (ST_DELETE * BITS);
         }
         // insert
         {
-          int b = left[ST_MATCH] + open, p = 0;
-          amax(b, p, ALIGN_BAD, 1);
-          amax(b, p, left[ST_INSERT], 2);
-          if (KIND == 2 && inRef2) amax(b, p, left[ST_JUMP], 3);  // jump->ins pays no open (:251-256)
-          b += extend;
+          int m = imax(imax(MANTA_PKA(left[ST_MATCH], open, 0), MANTA_PK(ALIGN_BAD, 1)), MANTA_PK(left[ST_INSERT], 2));
+          if (KIND == 2 && inRef2) m = imax(m, MANTA_PK(left[ST_JUMP], 3));  // jump->ins pays no open (:251-256)
+          int b = (m >> 3) + extend;
           if (firstCol && !inRef2) b = ALIGN_BAD;
           nv[ST_INSERT] = b;
-          np[ST_INSERT] = p;
+          code |= unsigned(m & FMASK) << (ST_INSERT * BITS);
         }
         if (KIND == 1) {
           {  // jumpDel (GlobalLargeIndelAlignerImpl.hpp:148-166)
-            int b = up[ST_MATCH] + L, p = 0;
-            amax(b, p, ALIGN_BAD, 1);
-            amax(b, p, up[ST_INSERT] + L - open, 2);
-            amax(b, p, up[ST_JUMP], 3);
-            amax(b, p, up[ST_JUMPINS] + L, 4);
+            int m = imax(imax(MANTA_PKA(up[ST_MATCH], L, 0), MANTA_PK(ALIGN_BAD, 1)), MANTA_PKA(up[ST_INSERT], L - open, 2));
+            m     = imax(imax(m, MANTA_PK(up[ST_JUMP], 3)), MANTA_PKA(up[ST_JUMPINS], L, 4));
+            int b = m >> 3;
             if (firstCol) b = ALIGN_BAD;
             nv[ST_JUMP] = b;
-            np[ST_JUMP] = p;
+            code |= unsigned(m & FMASK) << (ST_JUMP * BITS);
           }
           {  // jumpIns (:169-176)
-            int b = left[ST_MATCH] + L, p = 0;
-            amax(b, p, ALIGN_BAD, 1);
-            amax(b, p, left[ST_JUMPINS], 4);
+            int m = imax(imax(MANTA_PKA(left[ST_MATCH], L, 0), MANTA_PK(ALIGN_BAD, 1)), MANTA_PK(left[ST_JUMPINS], 4));
+            int b = m >> 3;
             if (firstCol) b = ALIGN_BAD;
             nv[ST_JUMPINS] = b;
-            np[ST_JUMPINS] = p;
+            code |= unsigned(m & FMASK) << (ST_JUMPINS * BITS);
           }
         }
         if (KIND == 2) {
           if (!inRef2) {  // uses THIS cell's final match / ins (GlobalJumpAlignerImpl.hpp:153-161)
-            int b = nv[ST_MATCH] + L, p = 0;
-            amax(b, p, ALIGN_BAD, 1);
-            amax(b, p, nv[ST_INSERT] + L, 2);
-            amax(b, p, up[ST_JUMP], 3);
-            nv[ST_JUMP] = b;
-            np[ST_JUMP] = p;
-          } else {  // :262-267
+            int m = imax(imax(MANTA_PKA(nv[ST_MATCH], L, 0), MANTA_PK(ALIGN_BAD, 1)), MANTA_PKA(nv[ST_INSERT], L, 2));
+            m     = imax(m, MANTA_PK(up[ST_JUMP], 3));
+            nv[ST_JUMP] = m >> 3;
+            code |= unsigned(m & FMASK) << (ST_JUMP * BITS);
+          } else {  // :262-267: pointer = JUMP
             nv[ST_JUMP] = up[ST_JUMP];
-            np[ST_JUMP] = ST_JUMP;
+            code |= unsigned((7 - ST_JUMP) & FMASK) << (ST_JUMP * BITS);
           }
         }
-        unsigned code = 0;
+#undef MANTA_PK
+#undef MANTA_PKA
         for (int s = 0; s < NS; ++s) {
-          code |= unsigned(np[s]) << (s * BITS);
           diag[s]  = up[s];
           left[s]  = nv[s];
           st[s][e] = nv[s];

@@ -62,6 +62,31 @@ WV_DEV unsigned merCode(const uint8_t* p, bool& valid)
   return code;
 }
 
+/// 10-mer codes of 55 consecutive positions with ONE byte load per lane: lane l loads base p0+l, then the codes of
+/// bases l..l+9 are assembled by doubling with four lane shuffles (2, 4, 8, 10 bases).  Lane l (<= 54) returns the
+/// code of the 10-mer starting at p0+l; `valid` is false if the 10-mer leaves [0,len) or holds a non-ACGT base.
+/// All 64 lanes must call.
+static const int MER_BATCH = 55;
+WV_DEV unsigned merCodes55(const uint8_t* seq, const int len, const int p0, bool& valid)
+{
+  const int      l   = wv::lane();
+  const int      pos = p0 + l;
+  unsigned       c   = 4;
+  if (pos >= 0 && pos < len) c = baseCode(seq[pos]);
+  unsigned bad = (c > 3) ? 1u : 0u;
+  unsigned w1  = c & 3u;
+  const unsigned w2 = (w1 << 2) | wv::shfl(w1, (l + 1) & 63);
+  const unsigned b2 = bad | wv::shfl(bad, (l + 1) & 63);
+  const unsigned w4 = (w2 << 4) | wv::shfl(w2, (l + 2) & 63);
+  const unsigned b4 = b2 | wv::shfl(b2, (l + 2) & 63);
+  const unsigned w8 = (w4 << 8) | wv::shfl(w4, (l + 4) & 63);
+  const unsigned b8 = b4 | wv::shfl(b4, (l + 4) & 63);
+  const unsigned w10 = (w8 << 4) | wv::shfl(w2, (l + 8) & 63);
+  const unsigned b10 = b8 | wv::shfl(b2, (l + 8) & 63);
+  valid = (l < MER_BATCH) && (b10 == 0);
+  return w10;
+}
+
 WV_DEV bool merLookup(const uint32_t* table, const unsigned mask, const unsigned code)
 {
   unsigned s = (code * 2654435761u) & mask;
@@ -111,9 +136,9 @@ WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
     uint32_t*      table = (tcap * 4 <= SCHED_LDS_BYTES) ? ltable : gtable;
     for (unsigned i = lane; i < tcap; i += 64) table[i] = 0;
     wv::sync();
-    for (unsigned i = lane; i + SMALLSV_MER <= clen; i += 64) {
+    for (int p0 = 0; p0 + SMALLSV_MER <= int(clen); p0 += MER_BATCH) {
       bool           valid;
-      const unsigned code = merCode(contig + i, valid);
+      const unsigned code = merCodes55(contig, int(clen), p0, valid);
       if (!valid) continue;
       unsigned s = (code * 2654435761u) & mask;
       while (true) {
@@ -131,35 +156,30 @@ WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
     // first hit scanning forward (:1997-2001)
     int adjLead = maxFwdRefIndex + 1;
     if (adjLead < minRefIndex) adjLead = minRefIndex;  // empty scan range: the loop variable keeps its initial value
-    for (int base = minRefIndex; base <= maxFwdRefIndex; base += 64) {
-      const int i   = base + int(lane);
-      bool      hit = false;
-      if (i <= maxFwdRefIndex && i >= 0 && i + SMALLSV_MER <= refSize) {
-        bool           valid;
-        const unsigned code = merCode(ref + i, valid);
-        hit                 = valid && merLookup(table, mask, code);
-      }
-      const uint64_t m = wv::ballot(hit);
+    for (int base = minRefIndex; base <= maxFwdRefIndex; base += MER_BATCH) {
+      bool           valid;
+      const unsigned code = merCodes55(ref, refSize, base, valid);
+      const int      i    = base + int(lane);
+      const bool     hit  = valid && i <= maxFwdRefIndex && merLookup(table, mask, code);
+      const uint64_t m    = wv::ballot(hit);
       if (m) {
         adjLead = base + wv::ctz(m);
         break;
       }
     }
-    // last hit scanning backward (:2004-2008)
+    // last hit scanning backward (:2004-2008): windows of 55 start positions, highest window first
     const int minRevRefIndex = (minRefIndex > refSize - cuts.maxTrailingCut) ? minRefIndex : (refSize - cuts.maxTrailingCut);
     int       revIndex       = minRevRefIndex - 1;
     if (revIndex > maxRefIndex) revIndex = maxRefIndex;  // empty scan range
-    for (int base = maxRefIndex; base >= minRevRefIndex; base -= 64) {
-      const int i   = base - int(lane);
-      bool      hit = false;
-      if (i >= minRevRefIndex && i >= 0 && i + SMALLSV_MER <= refSize) {
-        bool           valid;
-        const unsigned code = merCode(ref + i, valid);
-        hit                 = valid && merLookup(table, mask, code);
-      }
-      const uint64_t m = wv::ballot(hit);
+    for (int top = maxRefIndex; top >= minRevRefIndex; top -= MER_BATCH) {
+      const int      base = top - (MER_BATCH - 1);
+      bool           valid;
+      const unsigned code = merCodes55(ref, refSize, base, valid);
+      const int      i    = base + int(lane);
+      const bool     hit  = valid && i >= minRevRefIndex && i <= top && merLookup(table, mask, code);
+      const uint64_t m    = wv::ballot(hit);
       if (m) {
-        revIndex = base - wv::ctz(m);
+        revIndex = base + (63 - wv::clz(m));
         break;
       }
     }

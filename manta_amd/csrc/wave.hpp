@@ -87,6 +87,7 @@ WV_DEV uint64_t clock() { return uint64_t(__builtin_readcyclecounter()); }
 WV_DEV int popc(unsigned v) { return __popc(v); }
 WV_DEV int popc(uint64_t v) { return __popcll(v); }
 WV_DEV int ctz(uint64_t v) { return __builtin_ctzll(v); }  // v != 0
+WV_DEV int clz(uint64_t v) { return __builtin_clzll(v); }  // v != 0
 
 }  // namespace wv
 #endif

@@ -193,5 +193,6 @@ inline uint64_t clock() { return 0; }
 inline int popc(unsigned v) { return __builtin_popcount(v); }
 inline int popc(uint64_t v) { return __builtin_popcountll(v); }
 inline int ctz(uint64_t v) { return __builtin_ctzll(v); }
+inline int clz(uint64_t v) { return __builtin_clzll(v); }
 
 }  // namespace wv
