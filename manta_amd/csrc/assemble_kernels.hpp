@@ -108,7 +108,7 @@ struct AsmParams {
 // per-workgroup workspace carve (host and device agree through asmWorkspaceLayout)
 // --------------------------------------------------------------------------------------------------
 struct AsmWsLayout {
-  uint64_t codes, nmask, rd_cw, rd_mw, rd_len, slots, slot_id, inst_slot, node_key, node_cnt, node_flag, node_aux, rec, links,
+  uint64_t codes, nmask, rd_cw, rd_mw, rd_len, rd_hasn, slots, slot_id, inst_slot, node_key, node_cnt, node_flag, node_aux, rec, links,
       frontier, cand_seq, cand_bits, cand_meta, walk_left, walk_right, pseudo_seq, pseudo_len, exact, node_k32, tent, lane_seq,
       lane_bits, lane_meta, lane_vis, total;
 };
@@ -151,6 +151,7 @@ WV_HD AsmWsLayout asmWorkspaceLayout(
   L.rd_cw      = asmPut(o, 4ull * (cap_reads + 1));
   L.rd_mw      = asmPut(o, 4ull * (cap_reads + 1));
   L.rd_len     = asmPut(o, 4ull * (cap_reads + 1));
+  L.rd_hasn    = asmPut(o, 4ull * (cap_reads + 1));
   L.slots      = asmPut(o, 4ull * cap_slots);
   L.slot_id    = asmPut(o, 4ull * cap_slots);
   L.inst_slot  = asmPut(o, 4ull * 16 * (cap_words + 2));
@@ -212,7 +213,7 @@ struct Assembler {
   uint8_t*         ws;
   AsmWsLayout      L;
   // workspace views
-  uint32_t *codes, *nmask, *rd_cw, *rd_mw, *rd_len, *slots, *slot_id, *inst_slot, *node_key, *node_cnt, *node_flag, *node_aux;
+  uint32_t *codes, *nmask, *rd_cw, *rd_mw, *rd_len, *rd_hasn, *slots, *slot_id, *inst_slot, *node_key, *node_cnt, *node_flag, *node_aux;
   uint8_t*  rec;        // node records (see asmRecStride)
   unsigned  recStride;
   uint32_t* links;      // succ[4] | pred[4] per node, plain 32-bit ids (cycle test, exact repeat search, wide-set walk)
@@ -242,6 +243,7 @@ struct Assembler {
     rd_cw      = reinterpret_cast<uint32_t*>(ws + L.rd_cw);
     rd_mw      = reinterpret_cast<uint32_t*>(ws + L.rd_mw);
     rd_len     = reinterpret_cast<uint32_t*>(ws + L.rd_len);
+    rd_hasn    = reinterpret_cast<uint32_t*>(ws + L.rd_hasn);
     slots      = reinterpret_cast<uint32_t*>(ws + L.slots);
     slot_id    = reinterpret_cast<uint32_t*>(ws + L.slot_id);
     inst_slot  = reinterpret_cast<uint32_t*>(ws + L.inst_slot);
@@ -350,10 +352,22 @@ struct Assembler {
   {
     Key<KW>        key;
     const unsigned kw = (k + 15) >> 4;
+    const unsigned wi = pb >> 4, sh = (pb & 15) * 2;
+    uint32_t       raw[KW + 1];
+    if (KW <= 4) {
+      // one wide (dword-aligned) load of KW+1 code dwords; the slab is padded, over-reading is harmless
+      struct __attribute__((packed, aligned(4))) Raw {
+        uint32_t v[KW + 1];
+      };
+      const Raw r = *reinterpret_cast<const Raw*>(codes + wi);
+      for (int i = 0; i <= KW; ++i) raw[i] = r.v[i];
+    } else {
+      for (int i = 0; i <= KW; ++i) raw[i] = (unsigned(i) <= kw) ? codes[wi + i] : 0u;
+    }
     for (int i = 0; i < KW; ++i) {
       uint32_t v = 0;
       if (unsigned(i) < kw) {
-        v                   = codes16(pb + 16u * unsigned(i));
+        v = uint32_t((((uint64_t(raw[i]) << 32) | raw[i + 1]) << sh) >> 32);  // funnel shift (v_alignbit_b32)
         const unsigned have = k - 16u * unsigned(i);  // bases that belong to the word in this dword
         if (have < 16) v &= ~((1u << (32 - 2 * have)) - 1u);
       }
@@ -488,6 +502,7 @@ struct Assembler {
       if (r < nNormal) {
         rd_cw[r]               = cw + sc - myC;
         rd_len[r]              = len;
+        rd_hasn[r]             = 0;
         rd_mw[r]               = mw + sm - myM;
       }
       cw += wv::readlane(sc, 63);
@@ -531,6 +546,7 @@ struct Assembler {
           wv::atomic_or(mp, nbits << 16);
         else
           wv::atomic_or(mp, nbits);
+        if (nbits) wv::atomic_or(&rd_hasn[r], 1u);
       }
     }
     if (wv::any(badAlphabet)) status = ASM_E_ALPHABET;
@@ -571,19 +587,21 @@ struct Assembler {
       const unsigned lenV  = (rMine < nReads) ? rd_len[rMine] : 0u;
       const unsigned cwoV  = (rMine < nReads) ? rd_cw[rMine] : 0u;
       const unsigned mwoV  = (rMine < nReads) ? rd_mw[rMine] : 0u;
+      const unsigned hasnV = (rMine < nReads) ? rd_hasn[rMine] : 0u;
       const unsigned rEnd  = (nReads - rBase < 64) ? (nReads - rBase) : 64u;
       for (unsigned ri = 0; ri < rEnd; ++ri) {
         const unsigned r   = rBase + ri;
         const unsigned len = wv::readlane(lenV, int(ri));
         if (len < k) continue;  // :522
         const unsigned cwo = wv::readlane(cwoV, int(ri)), mwo = wv::readlane(mwoV, int(ri));
+        const bool     rdHasN = wv::readlane(hasnV, int(ri)) != 0;  // most reads have no 'N': skip the bitmap test
         const uint64_t bit = uint64_t(1) << (r & 63);
         for (unsigned j0 = 0; j0 + k <= len; j0 += 64) {
           const unsigned j    = j0 + lane;
           const unsigned pb   = cwo * 16 + j;
           unsigned       slot = ASM_NONE;
           bool           won  = false;
-          if (j + k <= len && !windowHasN(mwo, j)) {  // :531
+          if (j + k <= len && !(rdHasN && windowHasN(mwo, j))) {  // :531
             const Key<KW> key = keyAt<KW>(pb);
             unsigned      s   = keyHash(key) & mask;
             for (unsigned probe = 0; probe <= mask; ++probe) {
@@ -712,6 +730,7 @@ struct Assembler {
       const unsigned nCur = wv::first(wv::atomic_load(&cnt[which]));
       if (nCur == 0) break;
       removed += nCur;
+      // (measured: letting a lane chase the chain it is peeling is slower than these wave-wide rounds)
       for (unsigned i = lane; i < nCur; i += 64) {
         const unsigned nd = cur[i];
         for (unsigned c = 0; c < 4; ++c) {
@@ -1072,6 +1091,7 @@ struct Assembler {
         rd_cw[r]            = cw;
         rd_len[r]           = len;
         rd_mw[r]          = mw;
+        rd_hasn[r]        = 0;
         pseudo_len[nPseudo] = len;
       }
       cw += nCw;

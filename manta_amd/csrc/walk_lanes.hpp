@@ -105,17 +105,23 @@ WV_DEV unsigned Assembler::selectTentative(const unsigned T)
     wv::sync();
     return 1;
   }
-  // exact order inside the list: rank by counting (the list is ~T long)
+  // exact order inside the list: rank by counting (the list is ~T long); count, then 16-base prefix, then -- only
+  // on a prefix tie -- the full k-mer
   for (unsigned i = lane; i < total; i += 64) {
-    const unsigned x   = tent_raw[i];
-    const unsigned cx  = node_cnt[x];
-    const Key<KW>  kx  = keyAt<KW>(node_key[x]);
+    const unsigned x    = tent_raw[i];
+    const unsigned cx   = node_cnt[x];
+    const unsigned px   = node_k32[x];
     unsigned       rank = 0;
     for (unsigned j = 0; j < total; ++j) {
       if (j == i) continue;
       const unsigned y  = tent_raw[j];
       const unsigned cy = node_cnt[y];
-      if (cy > cx || (cy == cx && keyLess(keyAt<KW>(node_key[y]), kx))) rank++;
+      bool           before = (cy > cx);
+      if (cy == cx) {
+        const unsigned py = node_k32[y];
+        before            = (py < px) || (py == px && keyLess(keyAt<KW>(node_key[y]), keyAt<KW>(node_key[x])));
+      }
+      if (before) rank++;
     }
     tent_sorted[rank] = x;
   }
