@@ -1,0 +1,38 @@
+"""N>1 path on CPU: world_size-2 gloo run of the sharded pipeline (emulator) == single-process oracle, in locus order."""
+import json
+import os
+import subprocess
+import sys
+
+from manta_amd.shard import shard_bounds
+from oracle_lib import asm_opts
+from synth import small_indel_locus
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_cover_and_balance():
+    costs = [5, 1, 1, 1, 8, 2, 2, 4]
+    for world in (1, 2, 3, 8, 11):
+        cuts = [shard_bounds(costs, world, r) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == len(costs)
+        for a, b in zip(cuts, cuts[1:]):
+            assert a[1] == b[0] and a[0] <= a[1]
+    assert shard_bounds([], 4, 2) == (0, 0)
+    b = [shard_bounds([1] * 100, 4, r) for r in range(4)]
+    assert [e - s for s, e in b] == [25, 25, 25, 25]
+
+
+def test_two_rank_gloo_pipeline_matches_oracle(emu, oracle, tmp_path):
+    n_loci = 5
+    out = str(tmp_path / "gathered.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                           "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "tests", "multi_rank_worker.py"), out,
+                           str(n_loci)], env=env, timeout=600)
+    got = json.load(open(out))
+    assert got["world"] == 2 and len(got["texts"]) == n_loci
+    opts, sc, cuts = asm_opts(minWordLength=17, maxWordLength=32), [2, -8, -24, -1, -1, 0], (40, 40, 200, 200)
+    for s, text in enumerate(got["texts"]):
+        reads, ref = small_indel_locus(100 + s, n_reads=16 + 4 * (s % 3), read_len=50, ref_len=400)
+        assert text == oracle.small_sv_locus(opts, sc, -100, reads, ref, cuts), s
