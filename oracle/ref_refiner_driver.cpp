@@ -156,3 +156,181 @@ REF_EXPORT int ref_extended_contig_jump(
   getFwdStrandInsertSegment(ja, query, isBp1Reversed != 0, ins);
   return emit(ext + " insert=" + ins, out, cap);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The WHOLE refiner: the reference's own SVCandidateAssemblyRefiner::getCandidateAssemblyData (unmodified, from the
+// #included .cpp) run on in-memory inputs.  Only its file I/O is replaced by test doubles defined here:
+//   * SVCandidateAssembler's BAM scan (getBreakendReads) -> the read pile handed in by the caller; the double still
+//     calls the reference's real runIterativeAssembler exactly as manta/SVCandidateAssembler.cpp:661-698 does;
+//   * get_standardized_region_seq (htsapi/samtools_fasta_util.cpp, faidx) -> substrings of in-memory chromosomes;
+//     manta/SVReferenceUtil.cpp itself (trim / clipping logic) is the real source file;
+//   * constructors of ChromDepthFilterUtil / SVLocusScanner (stats + depth files) -> empty objects (never consulted).
+// ------------------------------------------------------------------------------------------------------------------
+#include "assembly/IterativeAssembler.hpp"
+#include "htsapi/samtools_fasta_util.hpp"
+
+namespace {
+struct RefinerLocusInputs {
+  std::vector<std::string> chroms;
+  AssemblyReadInput        complexReads;   // pile handed to assembleComplexSVCandidate
+  AssemblyReadInput        spanningReads;  // pile handed to assembleSpanningSVCandidate (already oriented, bp1 reads first)
+};
+thread_local RefinerLocusInputs* g_locus = nullptr;
+}  // namespace
+
+void get_standardized_region_seq(
+    const std::string&, const std::string& chrom, const int begin_pos, const int end_pos, std::string& ref_seq)
+{
+  const std::string& c(g_locus->chroms.at(std::stoul(chrom)));
+  ref_seq = c.substr(begin_pos, end_pos - begin_pos + 1);
+}
+
+ChromDepthFilterUtil::ChromDepthFilterUtil(const std::string&, const double, const bam_header_info&) : _isMaxDepthFilter(false) {}
+
+SVLocusScanner::SVLocusScanner(const ReadScannerOptions& opt, const std::string&, const std::vector<std::string>&, const bool)
+  : _opt(opt), _dopt(opt, false)
+{
+}
+
+SVCandidateAssembler::SVCandidateAssembler(
+    const ReadScannerOptions& scanOpt, const AssemblerOptions& assembleOpt, const AlignmentFileOptions& alignFileOpt,
+    const std::string&, const std::string& statsFilename, const std::string& chromDepthFilename, const bam_header_info& bamHeader,
+    const AllSampleReadCounts&, const bool isRNA, TimeTracker& remoteReadRetrievalTime)
+  : _scanOpt(scanOpt), _assembleOpt(assembleOpt), _isAlignmentTumor(alignFileOpt.isAlignmentTumor),
+    _dFilter(chromDepthFilename, scanOpt.maxDepthFactor, bamHeader),
+    _dFilterLocalDepthForRemoteReadRetrieval(chromDepthFilename, scanOpt.maxLocalDepthFactorForRemoteReadRetrieval, bamHeader),
+    _readScanner(_scanOpt, statsFilename, alignFileOpt.alignmentFilenames, isRNA), _remoteReadRetrievalTime(remoteReadRetrievalTime)
+{
+}
+
+void SVCandidateAssembler::assembleComplexSVCandidate(
+    const SVBreakend&, const reference_contig_segment&, const bool, RemoteReadCache&, Assembly& as) const
+{
+  AssemblyReadInput  reads(g_locus->complexReads);
+  AssemblyReadOutput readInfo;
+  runIterativeAssembler(_assembleOpt, reads, readInfo, as);
+}
+
+void SVCandidateAssembler::assembleSpanningSVCandidate(
+    const SVBreakend&, const SVBreakend&, const bool, const bool, const reference_contig_segment&, const reference_contig_segment&,
+    Assembly& as) const
+{
+  AssemblyReadInput  reads(g_locus->spanningReads);
+  AssemblyReadOutput readInfo;
+  runIterativeAssembler(_assembleOpt, reads, readInfo, as);
+}
+
+namespace {
+const char* stateName(const SVBreakendState::index_t s)
+{
+  return SVBreakendState::label(s);
+}
+void dumpAlign(std::ostream& os, const Alignment& a)
+{
+  os << a.beginPos << ":" << ALIGNPATH::apath_to_cigar(a.apath);
+}
+std::string dumpAssemblyData(const SVCandidateAssemblyData& d)
+{
+  std::ostringstream os;
+  os << "isCandidateSpanning=" << d.isCandidateSpanning << " isSpanning=" << d.isSpanning << " isOverlapSkip=" << d.isOverlapSkip
+     << " best=" << d.bestAlignmentIndex << " orient=" << d.bporient.isBp2AlignedFirst << d.bporient.isBp1Reversed
+     << d.bporient.isBp2Reversed << d.bporient.isBp1First << "\n";
+  os << "bp1ref=" << d.bp1ref.get_offset() << "+" << d.bp1ref.seq().size() << " bp2ref=" << d.bp2ref.get_offset() << "+"
+     << d.bp2ref.seq().size() << "\n";
+  for (size_t i = 0; i < d.contigs.size(); ++i) {
+    const AssembledContig& c(d.contigs[i]);
+    os << "contig " << i << " " << c.seq << " seed=" << c.seedReadCount << " cons=" << c.conservativeRange.begin_pos() << ","
+       << c.conservativeRange.end_pos() << " sup=";
+    for (const unsigned r : c.supportReads) os << r << ",";
+    os << "\n";
+  }
+  for (size_t i = 0; i < d.smallSVAlignments.size(); ++i) {
+    const auto& a(d.smallSVAlignments[i]);
+    os << "small " << i << " score=" << a.score << " jumped=" << a.isJumped << " ";
+    dumpAlign(os, a.align);
+    os << " seg=" << (i < d.smallSVSegments.size() ? segText(d.smallSVSegments[i]) : std::string("-"));
+    if (i < d.largeInsertInfo.size()) {
+      const LargeInsertionInfo& li(d.largeInsertInfo[i]);
+      os << " li=" << li.isLeftCandidate << li.isRightCandidate << "," << li.contigOffset << "," << li.refOffset << "," << li.score;
+    }
+    os << "\n";
+  }
+  for (size_t i = 0; i < d.spanningAlignments.size(); ++i) {
+    const auto& a(d.spanningAlignments[i]);
+    os << "span " << i << " score=" << a.score << " ins=" << a.jumpInsertSize << " range=" << a.jumpRange << " ";
+    dumpAlign(os, a.align1);
+    os << " ";
+    dumpAlign(os, a.align2);
+    os << "\n";
+  }
+  for (size_t i = 0; i < d.extendedContigs.size(); ++i) os << "ext " << i << " " << d.extendedContigs[i] << "\n";
+  for (size_t i = 0; i < d.svs.size(); ++i) {
+    const SVCandidate& sv(d.svs[i]);
+    os << "sv " << i << " imprecise=" << sv.isImprecise() << " align=" << sv.assemblyAlignIndex << "/" << sv.assemblySegmentIndex
+       << " bp1=" << stateName(sv.bp1.state) << ":" << sv.bp1.interval.tid << ":" << sv.bp1.interval.range.begin_pos() << "-"
+       << sv.bp1.interval.range.end_pos() << " bp2=" << stateName(sv.bp2.state) << ":" << sv.bp2.interval.tid << ":"
+       << sv.bp2.interval.range.begin_pos() << "-" << sv.bp2.interval.range.end_pos() << " insertSeq=" << sv.insertSeq
+       << " insertAlignment=" << ALIGNPATH::apath_to_cigar(sv.insertAlignment) << " unknownSizeInsertion=" << sv.isUnknownSizeInsertion
+       << " L=" << sv.unknownSizeInsertionLeftSeq << " R=" << sv.unknownSizeInsertionRightSeq << "\n";
+  }
+  return os.str();
+}
+}  // namespace
+
+/// POD view of one refiner call; all sequences are NUL-terminated ACGTN text
+struct ref_refine_input_t {
+  int32_t            n_chrom;
+  const char* const* chrom_seq;
+  int32_t            bp_state[2];      ///< SVBreakendState::index_t
+  int32_t            bp_tid[2];
+  int32_t            bp_begin[2], bp_end[2];
+  int32_t            is_find_large_insertions;
+  int32_t            n_reads;          ///< reads[0..n_reads) go to whichever assembler the refiner picks
+  const char* const* reads;
+  int32_t            small_word[3];    ///< min/max/step word length of smallSVAssembleOpt (<=0: reference default)
+  int32_t            spanning_word[3];
+  int32_t            n_calls;          ///< >1: repeat the identical call (exercises _spanToComplexAssmRegions)
+};
+
+REF_EXPORT int ref_get_candidate_assembly_data(const ref_refine_input_t* in, char* out, int cap)
+{
+  try {
+    RefinerLocusInputs locus;
+    for (int i = 0; i < in->n_chrom; ++i) locus.chroms.emplace_back(in->chrom_seq[i]);
+    for (int i = 0; i < in->n_reads; ++i) locus.complexReads.emplace_back(in->reads[i]);
+    locus.spanningReads = locus.complexReads;
+    g_locus             = &locus;
+
+    bam_header_info header;
+    for (int i = 0; i < in->n_chrom; ++i) header.chrom_data.emplace_back(std::to_string(i).c_str(), unsigned(locus.chroms[i].size()));
+    GSCOptions options;
+    auto setWords = [](IterativeAssemblerOptions& o, const int32_t* w) {
+      if (w[0] > 0) o.minWordLength = w[0];
+      if (w[1] > 0) o.maxWordLength = w[1];
+      if (w[2] > 0) o.wordStepSize = w[2];
+    };
+    setWords(options.refineOpt.smallSVAssembleOpt, in->small_word);
+    setWords(options.refineOpt.spanningAssembleOpt, in->spanning_word);
+    AllSampleReadCounts counts;
+    auto                edgeTrackerPtr(std::make_shared<EdgeRuntimeTracker>(std::string("/dev/null")));
+    const SVCandidateAssemblyRefiner refiner(options, header, counts, edgeTrackerPtr);
+
+    SVCandidate sv;
+    sv.bp1.state    = static_cast<SVBreakendState::index_t>(in->bp_state[0]);
+    sv.bp1.interval = GenomeInterval(in->bp_tid[0], in->bp_begin[0], in->bp_end[0]);
+    sv.bp2.state    = static_cast<SVBreakendState::index_t>(in->bp_state[1]);
+    sv.bp2.interval = GenomeInterval(in->bp_tid[1], in->bp_begin[1], in->bp_end[1]);
+
+    std::string text;
+    for (int c = 0; c < std::max(1, in->n_calls); ++c) {
+      SVCandidateAssemblyData data;
+      refiner.getCandidateAssemblyData(sv, in->is_find_large_insertions != 0, data);
+      text += dumpAssemblyData(data);
+    }
+    g_locus = nullptr;
+    return emit(text, out, cap);
+  } catch (const std::exception& e) {
+    g_locus = nullptr;
+    return emit(std::string("EXCEPTION ") + e.what(), out, cap);
+  }
+}
