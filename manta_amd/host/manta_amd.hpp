@@ -54,11 +54,25 @@ inline manta_ctx_t* threadContext()
 // ------------------------------------------------------------------------------------------------------
 // assembly
 // ------------------------------------------------------------------------------------------------------
-struct known_pos_range2 {  // blt_util/known_pos_range2.hpp (subset used by AssembledContig)
+struct known_pos_range2 {  // blt_util/known_pos_range2.hpp:33-135 (the members the path uses)
+  known_pos_range2() {}
+  known_pos_range2(const pos_t b, const pos_t e) : _begin(b), _end(e) {}
   void  set_begin_pos(pos_t p) { _begin = p; }
   void  set_end_pos(pos_t p) { _end = p; }
-  pos_t begin_pos() const { return _begin; }
-  pos_t end_pos() const { return _end; }
+  void  set_range(pos_t b, pos_t e)
+  {
+    _begin = b;
+    _end   = e;
+  }
+  pos_t    begin_pos() const { return _begin; }
+  pos_t    end_pos() const { return _end; }
+  unsigned size() const { return unsigned(_end > _begin ? _end - _begin : 0); }
+  bool     is_range_intersect(const known_pos_range2& pr) const { return (pr._end > _begin) && (pr._begin < _end); }
+  void     merge_range(const known_pos_range2& kpr)
+  {
+    if (kpr._begin < _begin) _begin = kpr._begin;
+    if (kpr._end > _end) _end = kpr._end;
+  }
   pos_t _begin = 0, _end = 0;
 };
 

@@ -1,0 +1,183 @@
+// Test-only C surface over manta_amd/host/refiner.hpp (the product's SVCandidateAssemblyRefiner) with the same POD
+// input and the same text dump as ref_get_candidate_assembly_data in oracle/ref_refiner_driver.cpp (the reference's
+// own refiner run in memory).  Linked against the emulator build (CPU tier) or libmanta_amd.so (GPU tier).
+#include <cstdint>
+#include <cstring>
+#include <sstream>
+
+#include "refiner.hpp"
+
+using namespace manta_amd;
+#define MINE_EXPORT extern "C" __attribute__((visibility("default")))
+
+struct ref_refine_input_t {
+  int32_t            n_chrom;
+  const char* const* chrom_seq;
+  int32_t            bp_state[2];
+  int32_t            bp_tid[2];
+  int32_t            bp_begin[2], bp_end[2];
+  int32_t            is_find_large_insertions;
+  int32_t            n_reads;
+  const char* const* reads;
+  int32_t            small_word[3];
+  int32_t            spanning_word[3];
+  int32_t            n_calls;
+};
+
+namespace {
+int emit(const std::string& s, char* out, int cap)
+{
+  const int n = static_cast<int>(s.size());
+  if (out != nullptr && cap > 0) {
+    const int m = (n < cap - 1) ? n : (cap - 1);
+    std::memcpy(out, s.data(), m);
+    out[m] = '\0';
+  }
+  return n;
+}
+std::string segText(const std::vector<std::pair<unsigned, unsigned>>& segs)
+{
+  std::ostringstream os;
+  for (size_t i = 0; i < segs.size(); ++i) os << (i ? "," : "") << segs[i].first << "-" << segs[i].second;
+  return os.str();
+}
+void dumpAlign(std::ostream& os, const Alignment& a) { os << a.beginPos << ":" << ALIGNPATH::apath_to_cigar(a.apath); }
+std::string dumpAssemblyData(const SVCandidateAssemblyData& d)
+{
+  std::ostringstream os;
+  os << "isCandidateSpanning=" << d.isCandidateSpanning << " isSpanning=" << d.isSpanning << " isOverlapSkip=" << d.isOverlapSkip
+     << " best=" << d.bestAlignmentIndex << " orient=" << d.bporient.isBp2AlignedFirst << d.bporient.isBp1Reversed
+     << d.bporient.isBp2Reversed << d.bporient.isBp1First << "\n";
+  os << "bp1ref=" << d.bp1ref.get_offset() << "+" << d.bp1ref.seq().size() << " bp2ref=" << d.bp2ref.get_offset() << "+"
+     << d.bp2ref.seq().size() << "\n";
+  for (size_t i = 0; i < d.contigs.size(); ++i) {
+    const AssembledContig& c(d.contigs[i]);
+    os << "contig " << i << " " << c.seq << " seed=" << c.seedReadCount << " cons=" << c.conservativeRange.begin_pos() << ","
+       << c.conservativeRange.end_pos() << " sup=";
+    for (const unsigned r : c.supportReads) os << r << ",";
+    os << "\n";
+  }
+  for (size_t i = 0; i < d.smallSVAlignments.size(); ++i) {
+    const auto& a(d.smallSVAlignments[i]);
+    os << "small " << i << " score=" << a.score << " jumped=" << a.isJumped << " ";
+    dumpAlign(os, a.align);
+    os << " seg=" << (i < d.smallSVSegments.size() ? segText(d.smallSVSegments[i]) : std::string("-"));
+    if (i < d.largeInsertInfo.size()) {
+      const LargeInsertionInfo& li(d.largeInsertInfo[i]);
+      os << " li=" << li.isLeftCandidate << li.isRightCandidate << "," << li.contigOffset << "," << li.refOffset << "," << li.score;
+    }
+    os << "\n";
+  }
+  for (size_t i = 0; i < d.spanningAlignments.size(); ++i) {
+    const auto& a(d.spanningAlignments[i]);
+    os << "span " << i << " score=" << a.score << " ins=" << a.jumpInsertSize << " range=" << a.jumpRange << " ";
+    dumpAlign(os, a.align1);
+    os << " ";
+    dumpAlign(os, a.align2);
+    os << "\n";
+  }
+  for (size_t i = 0; i < d.extendedContigs.size(); ++i) os << "ext " << i << " " << d.extendedContigs[i] << "\n";
+  for (size_t i = 0; i < d.svs.size(); ++i) {
+    const SVCandidate& sv(d.svs[i]);
+    os << "sv " << i << " imprecise=" << sv.isImprecise() << " align=" << sv.assemblyAlignIndex << "/" << sv.assemblySegmentIndex
+       << " bp1=" << SVBreakendState::label(sv.bp1.state) << ":" << sv.bp1.interval.tid << ":" << sv.bp1.interval.range.begin_pos() << "-"
+       << sv.bp1.interval.range.end_pos() << " bp2=" << SVBreakendState::label(sv.bp2.state) << ":" << sv.bp2.interval.tid << ":"
+       << sv.bp2.interval.range.begin_pos() << "-" << sv.bp2.interval.range.end_pos() << " insertSeq=" << sv.insertSeq
+       << " insertAlignment=" << ALIGNPATH::apath_to_cigar(sv.insertAlignment) << " unknownSizeInsertion=" << sv.isUnknownSizeInsertion
+       << " L=" << sv.unknownSizeInsertionLeftSeq << " R=" << sv.unknownSizeInsertionRightSeq << "\n";
+  }
+  return os.str();
+}
+
+/// in-memory chromosomes; read piles keyed by the first breakend that asks for them
+struct MemorySource : RefinerInputSource {
+  std::vector<std::string> chroms;
+  struct Pile {
+    int32_t           tid;
+    pos_t             pos;
+    AssemblyReadInput reads;
+  };
+  std::vector<Pile> piles;
+  void getReferenceSeq(const std::string& chrom, pos_t beginPos, pos_t endPos, std::string& seq) override
+  {
+    seq = chroms.at(std::stoul(chrom)).substr(size_t(beginPos), size_t(endPos - beginPos + 1));
+  }
+  void getBreakendReads(const SVBreakend& bp, bool, const reference_contig_segment&, AssemblyReadInput& reads) override
+  {
+    if (!reads.empty()) return;  // the pile holds both breakends' reads already, in final order
+    for (const Pile& p : piles)
+      if (p.tid == bp.interval.tid && p.pos >= bp.interval.range.begin_pos() && p.pos < bp.interval.range.end_pos()) {
+        reads = p.reads;
+        return;
+      }
+  }
+};
+
+SVCandidate makeSV(const ref_refine_input_t& in)
+{
+  SVCandidate sv;
+  sv.bp1.state    = static_cast<SVBreakendState::index_t>(in.bp_state[0]);
+  sv.bp1.interval = GenomeInterval(in.bp_tid[0], in.bp_begin[0], in.bp_end[0]);
+  sv.bp2.state    = static_cast<SVBreakendState::index_t>(in.bp_state[1]);
+  sv.bp2.interval = GenomeInterval(in.bp_tid[1], in.bp_begin[1], in.bp_end[1]);
+  return sv;
+}
+void setOptions(const ref_refine_input_t& in, GSCOptions& options)
+{
+  auto setWords = [](IterativeAssemblerOptions& o, const int32_t* w) {
+    if (w[0] > 0) o.minWordLength = unsigned(w[0]);
+    if (w[1] > 0) o.maxWordLength = unsigned(w[1]);
+    if (w[2] > 0) o.wordStepSize = unsigned(w[2]);
+  };
+  setWords(options.refineOpt.smallSVAssembleOpt, in.small_word);
+  setWords(options.refineOpt.spanningAssembleOpt, in.spanning_word);
+}
+}  // namespace
+
+/// n inputs that share chromosomes/options (those of inputs[0]); is_batched != 0 -> ONE getCandidateAssemblyDataBatch
+/// call, else consecutive single calls on the same refiner object.  Text = the dumps in order.
+MINE_EXPORT int mine_get_candidate_assembly_data_multi(const ref_refine_input_t* inputs, int n, int is_batched, char* out, int cap)
+{
+  try {
+    MemorySource    source;
+    bam_header_info header;
+    for (int i = 0; i < inputs[0].n_chrom; ++i) {
+      source.chroms.emplace_back(inputs[0].chrom_seq[i]);
+      header.chrom_data.emplace_back(std::to_string(i).c_str(), unsigned(source.chroms.back().size()));
+    }
+    GSCOptions options;
+    setOptions(inputs[0], options);
+    std::vector<SVCandidate> svs;
+    for (int k = 0; k < n; ++k) {
+      const ref_refine_input_t& in(inputs[k]);
+      MemorySource::Pile        pile;
+      pile.tid = in.bp_tid[0];
+      pile.pos = in.bp_begin[0];
+      for (int i = 0; i < in.n_reads; ++i) pile.reads.emplace_back(in.reads[i]);
+      source.piles.push_back(pile);
+      for (int c = 0; c < std::max(1, in.n_calls); ++c) svs.push_back(makeSV(in));
+    }
+    const SVCandidateAssemblyRefiner refiner(options, header, source);
+    const bool                       large = inputs[0].is_find_large_insertions != 0;
+    std::string                      text;
+    if (is_batched) {
+      std::vector<SVCandidateAssemblyData> data;
+      refiner.getCandidateAssemblyDataBatch(svs, large, data);
+      for (const auto& d : data) text += dumpAssemblyData(d);
+    } else {
+      for (const SVCandidate& sv : svs) {
+        SVCandidateAssemblyData data;
+        refiner.getCandidateAssemblyData(sv, large, data);
+        text += dumpAssemblyData(data);
+      }
+    }
+    return emit(text, out, cap);
+  } catch (const std::exception& e) {
+    return emit(std::string("EXCEPTION ") + e.what(), out, cap);
+  }
+}
+
+MINE_EXPORT int mine_get_candidate_assembly_data(const ref_refine_input_t* in, char* out, int cap)
+{
+  return mine_get_candidate_assembly_data_multi(in, 1, 0, out, cap);
+}

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/refiner_helpers.json: outputs of the UNMODIFIED reference helper statics
+(oracle/_ref/libmanta_ref_refiner.so, built by `make -C oracle ref` from /root/reference) on the seeded cases of
+tests/refiner_cases.py.  Run in the build container only (needs /root/reference)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from refiner_cases import HelperLib, make_cases  # noqa: E402
+
+SEED, N = 777, 900
+subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+ref = HelperLib(os.path.join(ROOT, "oracle", "_ref", "libmanta_ref_refiner.so"), "ref")
+lines = [ref.evaluate(c) for c in make_cases(SEED, N)]
+json.dump({"seed": SEED, "n": N, "source": "oracle/_ref/libmanta_ref_refiner.so (reference statics, unmodified)", "lines": lines},
+          open(os.path.join(ROOT, "tests", "golden", "refiner_helpers.json"), "w"), indent=0)
+print("wrote", len(lines), "lines")
