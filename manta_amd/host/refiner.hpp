@@ -440,6 +440,12 @@ struct SVCandidateAssemblyRefiner {
 
   void clearEdgeData() { _spanToComplexAssmRegions.clear(); }
 
+  /// work counters of this refiner object (no reference counterpart; for logs and tests)
+  struct Stats {
+    uint64_t smallLoci = 0, spanningLoci = 0, contigAlignments = 0, realignedContigs = 0, largeInsertionAlignments = 0;
+  };
+  const Stats& stats() const { return _stats; }
+
   /// The same call for a whole list of candidates (one edge's worth, or many edges' worth: the only cross-candidate
   /// state is the geometric _spanToComplexAssmRegions filter, applied here in list order exactly as consecutive
   /// single calls would).  Every device stage runs once over the whole list.
@@ -582,6 +588,7 @@ private:
       cuts.push_back(manta_ref_cuts_t{plans[i].leadingCut, plans[i].trailingCut, plans[i].maxLeadingCut, plans[i].maxTrailingCut});
     }
     if (which.empty()) return;
+    _stats.smallLoci += which.size();
     detail::SmallSvOutput dev;
     detail::smallSvBatch(_opt.refineOpt.smallSVAssembleOpt, _opt.refineOpt.largeSVAlignScores, _opt.refineOpt.largeGapOpenScore, packed,
                          refs, cuts, dev);
@@ -591,6 +598,7 @@ private:
       const Plan&              p(plans[which[w]]);
       SVCandidateAssemblyData& data(out[which[w]]);
       dev.toContigs(unsigned(w), data.contigs);
+      _stats.contigAlignments += data.contigs.size();
       const std::string& align1RefStr(data.bp1ref.seq());
       const unsigned     contigCount = unsigned(data.contigs.size());
       data.smallSVAlignments.resize(contigCount);
@@ -699,6 +707,7 @@ private:
     // large-insertion completion: one GlobalAligner batch over every locus that found a left/right pair
     std::vector<detail::AlignJob*> jobs;
     for (auto& w : liWork) jobs.push_back(&w->job);
+    _stats.largeInsertionAlignments += jobs.size();
     detail::alignBatch(MANTA_ALIGNER_GLOBAL, _opt.refineOpt.largeInsertCompleteAlignScores, 0, jobs);
     for (auto& w : liWork) finishLargeInsertion(plans[w->planIndex], *w, out[w->planIndex]);
   }
@@ -809,6 +818,7 @@ private:
       packed.addLocus(plans[i].reads, maxAsm);
     }
     if (loci.empty()) return;
+    _stats.spanningLoci += loci.size();
     detail::AsmOutput dev;
     detail::assembleBatch(_opt.refineOpt.spanningAssembleOpt, packed, dev);
 
@@ -842,6 +852,7 @@ private:
     }
     for (SpanningLocus& sl : loci)
       for (detail::AlignJob& j : sl.jobs) jobs.push_back(&j);
+    _stats.contigAlignments += jobs.size();
     detail::alignBatch(MANTA_ALIGNER_JUMP, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, jobs);
 
     // round 2 (:1682-1713): the first contig whose junction holds an insertion AND lies within 5 bases of the cut edge
@@ -867,6 +878,7 @@ private:
     }
     for (SpanningLocus& sl : loci)
       for (detail::AlignJob& j : sl.rejobs) jobs.push_back(&j);
+    _stats.realignedContigs += jobs.size();
     detail::alignBatch(MANTA_ALIGNER_JUMP, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, jobs);
 
     for (SpanningLocus& sl : loci) {
@@ -922,6 +934,7 @@ private:
   const bam_header_info         _header;
   RefinerInputSource&           _source;
   mutable GenomeIntervalTracker _spanToComplexAssmRegions;
+  mutable Stats                 _stats;
 };
 
 }  // namespace manta_amd

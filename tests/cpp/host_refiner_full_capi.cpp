@@ -134,6 +134,8 @@ void setOptions(const ref_refine_input_t& in, GSCOptions& options)
 }
 }  // namespace
 
+thread_local SVCandidateAssemblyRefiner::Stats g_stats;
+
 /// n inputs that share chromosomes/options (those of inputs[0]); is_batched != 0 -> ONE getCandidateAssemblyDataBatch
 /// call, else consecutive single calls on the same refiner object.  Text = the dumps in order.
 MINE_EXPORT int mine_get_candidate_assembly_data_multi(const ref_refine_input_t* inputs, int n, int is_batched, char* out, int cap)
@@ -171,10 +173,21 @@ MINE_EXPORT int mine_get_candidate_assembly_data_multi(const ref_refine_input_t*
         text += dumpAssemblyData(data);
       }
     }
+    g_stats = refiner.stats();
     return emit(text, out, cap);
   } catch (const std::exception& e) {
     return emit(std::string("EXCEPTION ") + e.what(), out, cap);
   }
+}
+
+/// counters of the last call: small loci, spanning loci, contig alignments, re-aligned contigs, large-insertion alignments
+MINE_EXPORT void mine_last_stats(uint64_t* out)
+{
+  out[0] = g_stats.smallLoci;
+  out[1] = g_stats.spanningLoci;
+  out[2] = g_stats.contigAlignments;
+  out[3] = g_stats.realignedContigs;
+  out[4] = g_stats.largeInsertionAlignments;
 }
 
 MINE_EXPORT int mine_get_candidate_assembly_data(const ref_refine_input_t* in, char* out, int cap)

@@ -18,3 +18,14 @@ lines = [ref.evaluate(c) for c in make_cases(SEED, N)]
 json.dump({"seed": SEED, "n": N, "source": "oracle/_ref/libmanta_ref_refiner.so (reference statics, unmodified)", "lines": lines},
           open(os.path.join(ROOT, "tests", "golden", "refiner_helpers.json"), "w"), indent=0)
 print("wrote", len(lines), "lines")
+
+# ---- whole refiner calls (tests/test_refiner.py) ----
+from refiner_loci import RefinerLib  # noqa: E402
+from test_refiner import scenario_cases  # noqa: E402
+
+rl = RefinerLib(os.path.join(ROOT, "oracle", "_ref", "libmanta_ref_refiner.so"), "ref")
+cases = scenario_cases(4242)
+json.dump({"seed": 4242, "names": [n for n, _ in cases], "source": "reference SVCandidateAssemblyRefiner::getCandidateAssemblyData "
+           "(unmodified) via oracle/ref_refiner_driver.cpp", "texts": [rl.run(c) for _, c in cases]},
+          open(os.path.join(ROOT, "tests", "golden", "refiner_calls.json"), "w"), indent=0)
+print("wrote", len(cases), "refiner calls")

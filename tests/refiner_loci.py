@@ -42,6 +42,11 @@ class RefinerLib:
         self.single.restype = ctypes.c_int
         self.multi = getattr(self.lib, prefix + "_get_candidate_assembly_data_multi", None)
 
+    def last_stats(self):
+        out = (ctypes.c_uint64 * 5)()
+        self.lib.mine_last_stats(out)
+        return dict(zip(("small", "spanning", "aligned", "realigned", "large_insertion"), list(out)))
+
     def run(self, case):
         keep, inp = [], RefineInput()
         fill(inp, case, keep)
@@ -126,7 +131,10 @@ def spanning_case(rng, orient="RL", same_chrom=False, ins_len=0, n_reads=40, hom
     """a breakend pair.  orient: states of (bp1, bp2), R = RIGHT_OPEN, L = LEFT_OPEN."""
     c0 = rand_seq(rng, chrom_len)
     c1 = c0 if same_chrom else rand_seq(rng, chrom_len)
-    p1 = rng.randint(120, 200) if near_edge else rng.randint(1000, chrom_len - 1000)
+    if same_chrom and far:
+        chrom_len += 3000
+        c0 = c1 = rand_seq(rng, chrom_len)
+    p1 = rng.randint(120, 200) if near_edge else rng.randint(1000, (chrom_len - 4000) if (same_chrom and far) else (chrom_len - 1000))
     if same_chrom:
         p2 = p1 + (rng.randint(1500, 2500) if far else rng.randint(60, 300))
     else:
