@@ -708,9 +708,18 @@ int manta_smallsv_run(manta_smallsv_t* b)
     rt::dzero(dSmall, sizeof(uint32_t) * 64);
     rt::dzero(dResults, sizeof(AlignResultDev) * nSlots);
 
+    const bool dbg = std::getenv("MANTA_AMD_DEBUG") != nullptr;
+    auto       stage = [&](const char* what) {
+      if (!dbg) return;
+      rt::sync();
+      std::fprintf(stderr, "manta_amd: smallsv_run %s\n", what);
+      std::fflush(stderr);
+    };
+    stage("start");
     b->evStart.record();
     as.launch();
     b->evAsm.record();
+    stage("assembled");
 
     ScheduleParams S;
     S.loci               = as.dLoci;
@@ -735,6 +744,7 @@ int manta_smallsv_run(manta_smallsv_t* b)
     for (int i = 0; i < kNumESet; ++i) S.e_set[i] = uint32_t(kESet[i]);
     rt::launch(smallsv_schedule_kernel, schedGrid, SCHED_LDS_BYTES, S);
     b->evSched.record();
+    stage("scheduled");
 
     // bucket sizes decide the alignment launches (one tiny D2H)
     uint32_t hSmall[32];
@@ -776,6 +786,7 @@ int manta_smallsv_run(manta_smallsv_t* b)
     }
     b->evAlign.record();
     rt::sync();
+    stage("aligned");
     b->stats.assemble_ms = rt::elapsedMs(b->evStart, b->evAsm);
     b->stats.schedule_ms = rt::elapsedMs(b->evAsm, b->evSched);
     b->stats.align_ms    = rt::elapsedMs(b->evSched, b->evAlign);

@@ -17,7 +17,8 @@ inline void  init(int) {}
 inline std::string deviceName() { return "wave-emulator (test infrastructure)"; }
 inline int   cuCount() { return 2; }
 inline size_t freeBytes() { return size_t(1) << 30; }
-inline void* dmalloc(size_t n) { void* p = std::malloc(n ? n : 1); if (!p) throw Error("emu malloc failed"); std::memset(p, 0xab, n); return p; }
+inline int   poisonByte() { const char* e = std::getenv("MANTA_EMU_POISON"); return e ? std::atoi(e) : 0xab; }  // "uninitialised" memory pattern
+inline void* dmalloc(size_t n) { void* p = std::malloc(n ? n : 1); if (!p) throw Error("emu malloc failed"); std::memset(p, poisonByte(), n); return p; }
 inline void  dfree(void* p) { std::free(p); }
 inline void  h2d(void* d, const void* h, size_t n) { if (n) std::memcpy(d, h, n); }
 inline void  d2h(void* h, const void* d, size_t n) { if (n) std::memcpy(h, d, n); }

@@ -83,3 +83,23 @@ def test_gpu_pipeline_planted_indel_recovered_at_full_size(gpu):
                     hit = True
         ok += hit
     assert ok >= 9950, ok
+
+
+def _contigless_loci():
+    full = small_indel_locus(5, n_reads=24, read_len=60, ref_len=500)
+    return [(full[0][:2], full[1]), ([], full[1]), (full[0][:1], full[1]), full]
+
+
+def test_emulated_pipeline_loci_without_contigs(emu, oracle):
+    _run(emu, oracle, _contigless_loci(), asm_opts(minWordLength=21, maxWordLength=41), (40, 40, 200, 200))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(120)
+def test_gpu_pipeline_loci_without_contigs(gpu, oracle):
+    """piles of 0-2 reads assemble to nothing.  Regression: the schedule kernel once spun forever on such batches on
+    hardware only (lane-divergent loop exit produced by the compiler, see pipeline_kernels.hpp scheduleSlot)."""
+    loci = _contigless_loci()
+    _run(gpu, oracle, loci[:1], asm_opts(minWordLength=21, maxWordLength=41), (40, 40, 200, 200))
+    _run(gpu, oracle, loci[:3], asm_opts(minWordLength=21, maxWordLength=41), (40, 40, 200, 200))
+    _run(gpu, oracle, loci, asm_opts(minWordLength=21, maxWordLength=41), (40, 40, 200, 200))
