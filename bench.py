@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--loci", type=int, default=10000, help="loci per GPU (config 2 = 10k)")
+    ap.add_argument("--workload", choices=("smallsv", "spanning"), default="smallsv",
+                    help="smallsv = BASELINE config[1] (the metric's configuration, default); spanning = config[4] shape "
+                         "(breakend loci, 200 reads x 250 bp, mixed k), an extra measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="loci in the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
@@ -78,6 +81,9 @@ def main():
     from manta_amd._capi import Lib, SmallSvBatch, small_sv_text
     from oracle_lib import asm_opts
     from synth import config2_batch, unpack_locus
+
+    if args.workload == "spanning":
+        return spanning_main(args, torch, dist, rank, local_rank, world)
 
     lib = Lib(device=local_rank)
     opts = asm_opts(**ASM_K)
@@ -197,6 +203,112 @@ def main():
                                              "GenerateSVCandidates.cpp:232-266), %.1f s wall; single thread: %d loci in %.1f s"
                                              % (n_s, cores, secs, n_1, secs1),
                                    "single_thread_value": round(n_1 / secs1, 2)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def spanning_main(args, torch, dist, rank, local_rank, world):
+    """BASELINE config[4] shape (SURVEY.md 8d "C5"): breakend loci, 200 reads x 250 bp, 0.5 % substitutions, 1 % N, 10 % of
+    the loci with a tandem repeat, minWordLength drawn from {25,30,..,75}; GlobalJumpAligner (2,-8,-12,-1,-1;-100) on
+    ref[100..800) windows with the re-align rule.  One step = one pass of the fused spanning pipeline over all 11 word
+    length groups (the ABI takes one option set per batch)."""
+    import re
+    from manta_amd._capi import Lib, SpanningBatch
+    from oracle_lib import asm_opts, OracleLib
+    from synth import breakend_locus
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+    lib = Lib(device=local_rank)
+    ks = list(range(25, 80, 5))
+    per_group = max(1, args.loci // len(ks))
+    distinct = 24
+    SPAN_SC = [2, -8, -12, -1, -1, 0]
+    groups = []
+    for gi, k in enumerate(ks):
+        base = [breakend_locus(1000003 * rank + 1000 * gi + s) for s in range(distinct)]
+        loci = [base[i % distinct] for i in range(per_group)]
+        o = asm_opts(minWordLength=k, maxWordLength=max(76, k), minContigLength=75)
+        b = SpanningBatch(lib, o, SPAN_SC, -100)
+        b.upload([l[0] for l in loci], [l[1] for l in loci], [l[2] for l in loci], [(100, 100, 100, 100)] * per_group)
+        groups.append((k, o, base, b))
+    n_loci = per_group * len(ks)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        for g in groups:
+            g[3].run()
+    barrier()
+    t0 = time.perf_counter()
+    asm_ms = sched_ms = align_ms = 0.0
+    for _ in range(args.steps):
+        for g in groups:
+            g[3].run()
+            st = g[3].stats()
+            asm_ms += st["assemble_ms"]
+            sched_ms += st["schedule_ms"]
+            align_ms += st["align_ms"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        from test_spanning_pipeline import oracle_locus
+        orc = OracleLib()
+        b_in = b_ptr = b_out = n_contigs = cells = 0
+        mism = 0
+        for k, o, base, b in groups:
+            res = b.download()
+            st = b.stats()
+            cells += st["dp_cells"]
+            for i, r in enumerate(res):
+                reads, ref1, ref2 = base[i % distinct]
+                b_in += sum(len(x) for x in reads) + len(ref1) + len(ref2)
+                b_out += len(reads) * 8
+                for c, a in zip(r["contigs"], r["aligns"]):
+                    q = len(c["seq"])
+                    span = (len(ref1) + len(ref2)) if a["is_uncut"] else (len(ref1) + len(ref2) - 400)
+                    b_ptr += (q + 1) * (span + 2)  # 1 B cells, the reference's own jump pointer matrix (GlobalJumpAligner.hpp:81-115)
+                    b_out += q + 2 * ((len(reads) + 7) // 8) + 64
+                n_contigs += len(r["contigs"])
+            for i in (0, distinct // 2):  # parity spot check against the oracle (checker only)
+                reads, ref1, ref2 = base[i]
+                _, want = oracle_locus(orc, o, reads, ref1, ref2, (100, 100, 100, 100))
+                got = [(a["score"], a["jump_insert_size"], a["jump_range"], a["begin1"], a["cigar1"], a["begin2"], a["cigar2"], a["is_uncut"])
+                       for a in res[i]["aligns"]]
+                mism += got != want
+        if mism:
+            raise SystemExit("PARITY FAILURE: %d sampled spanning loci differ from the oracle" % mism)
+        steps = args.steps
+        value = n_loci * world * steps / elapsed
+        asm_avg, align_avg = asm_ms / steps, align_ms / steps
+        asm_bytes = b_in + b_out
+        dom, dom_bytes, dom_ms = ("assemble_kernel", asm_bytes, asm_avg) if asm_avg >= align_avg else ("align_kernel<JUMP>", b_ptr, align_avg)
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out = {"metric": "candidate SV loci assembled+aligned per second (whole node)", "value": round(value, 1), "unit": "loci/s",
+               "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+               "config": {"workload": "BASELINE config[4] shape (NOT the metric's configuration): breakend loci, 200 reads x 250 bp, 1 % N, "
+                                      "10 % tandem-repeat loci, minWordLength in {25..75} (11 batches per step), assemble + "
+                                      "GlobalJumpAligner(2,-8,-12,-1,-1;-100) on 700+700 bp windows + re-align rule",
+                          "loci_per_gpu": n_loci, "distinct_loci": distinct * len(ks), "contigs_per_locus": round(n_contigs / n_loci, 3),
+                          "parallelism": "loci sharded, %d rank(s)" % world},
+               "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "algorithmic_bytes_per_launch": dom_bytes,
+                            "avg_launch_ms": round(dom_ms, 3), "note": "summed over the 11 launches of a step"},
+               "kernels_ms_per_step": {"assemble_kernel": round(asm_avg, 3), "spanning_schedule_kernel": round(sched_ms / steps, 3),
+                                       "align+realign": round(align_avg, 3)},
+               "algorithmic_bytes_per_locus": {"in": b_in / n_loci, "ptr": b_ptr / n_loci, "out": b_out / n_loci},
+               "dp_gcups": round(cells * world * steps / elapsed / 1e9, 2),
+               "cpu_baseline": None}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

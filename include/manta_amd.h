@@ -189,6 +189,44 @@ int manta_smallsv_download(manta_smallsv_t* b, manta_asm_locus_result_t* loci, m
                            uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
                            uint64_t* cigar_arena_used);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Fused "spanning" locus pipeline: the arithmetic core of
+ *   SVCandidateAssemblyRefiner::getJumpAssembly      applications/GenerateSVCandidates/SVCandidateAssemblyRefiner.cpp:1745-1849
+ * for a batch of breakend-pair candidates (DNA):  runIterativeAssembler (via assembleJumpContigs :1504-1511 ->
+ * manta/SVCandidateAssembler.cpp:677-698) -> alignJumpContigs (:1525-1743): GlobalJumpAligner::align of every contig
+ * against the CUT references (:1663-1670), the re-align rule on the uncut references (:1672-1713, including its
+ * carry-over to the later contigs of the locus), and beginPos += leading cut (:1716-1717).
+ * Inputs per locus are what alignJumpContigs holds after its orientation step (:1533-1550): the two reference strings
+ * in alignment order (align1RefStr / align2RefStr, reverse-complemented where the breakend is reversed) and the four
+ * cuts in the same order.  Same staging and download conventions as manta_smallsv_*.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct manta_spanning manta_spanning_t;
+
+typedef struct {
+  int32_t align1_leading_cut, align1_trailing_cut, align2_leading_cut, align2_trailing_cut; /* AlignData :1400-1411 */
+} manta_jump_cuts_t;
+
+typedef struct {
+  int32_t              is_uncut; /* 1: the alignment is the re-alignment against the uncut references (:1699-1712) */
+  int32_t              reserved;
+  manta_align_result_t align;    /* begin_pos1/2 already include the leading cuts that applied (:1716-1717) */
+} manta_spanning_alignment_t;
+
+int  manta_spanning_create(manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores,
+                           int32_t jump_score, manta_spanning_t** out);
+void manta_spanning_destroy(manta_spanning_t* b);
+int  manta_spanning_upload(manta_spanning_t* b, uint32_t n_loci, const uint8_t* bases, const uint64_t* read_off,
+                           const uint32_t* locus_read_begin, const uint8_t* refs1, const uint64_t* ref1_off,
+                           const uint8_t* refs2, const uint64_t* ref2_off, const manta_jump_cuts_t* cuts);
+int  manta_spanning_run(manta_spanning_t* b);
+/* align_ms covers both alignment rounds and the re-align decision kernel */
+int  manta_spanning_stats(const manta_spanning_t* b, manta_smallsv_stats_t* stats);
+int  manta_spanning_download(manta_spanning_t* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs,
+                             manta_spanning_alignment_t* alignments, uint64_t contigs_cap, uint8_t* seq_arena,
+                             uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
+                             uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
+                             uint64_t* cigar_arena_used);
+
 #ifdef __cplusplus
 }
 #endif

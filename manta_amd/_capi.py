@@ -350,3 +350,108 @@ def align_text(kind, r):
         return "score=%d jumpInsertSize=%d jumpRange=%d begin1=%d cigar1=%s begin2=%d cigar2=%s\n" % (
             r["score"], r["jump_insert_size"], r["jump_range"], r["begin1"], r["cigar1"], r["begin2"], r["cigar2"])
     return "score=%d jumped=%d begin=%d cigar=%s\n" % (r["score"], r["is_jumped"], r["begin1"], r["cigar1"])
+
+
+class JumpCuts(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("align1_leading_cut", "align1_trailing_cut", "align2_leading_cut", "align2_trailing_cut")]
+
+
+class SpanningAlignment(ctypes.Structure):
+    _fields_ = [("is_uncut", ctypes.c_int32), ("reserved", ctypes.c_int32), ("align", AlignResult)]
+
+
+class SpanningBatch:
+    """Staged fused spanning pipeline (manta_spanning_*): assemble -> jump-align on cut references -> re-align rule."""
+
+    def __init__(self, lib, opts, scores, jump_score):
+        self.lib = lib
+        self.h = ctypes.c_void_p()
+        o, sc = AsmOptions(*opts), AlignScores(*scores)
+        self.max_asm = o.max_assembly_count
+        L = lib.lib
+        L.manta_spanning_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
+        L.manta_spanning_destroy.argtypes = [ctypes.c_void_p]
+        L.manta_spanning_run.argtypes = [ctypes.c_void_p]
+        lib._check(L.manta_spanning_create(lib.ctx, ctypes.byref(o), ctypes.byref(sc), jump_score, ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.lib.lib.manta_spanning_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, loci_reads, refs1, refs2, cuts):
+        """cuts: per locus (a1Lead, a1Trail, a2Lead, a2Trail)"""
+        bases, read_off, begin = pack_loci(loci_reads)
+        self.n_loci = len(begin) - 1
+        self.n_reads = np.diff(begin)
+
+        def pack(refs):
+            rb = [_b(r) for r in refs]
+            off = np.zeros(len(rb) + 1, dtype=np.uint64)
+            np.cumsum([len(r) for r in rb], out=off[1:])
+            return np.frombuffer(b"".join(rb) + b"\0", dtype=np.uint8), off
+        r1, o1 = pack(refs1)
+        r2, o2 = pack(refs2)
+        c = np.ascontiguousarray(np.array(cuts, dtype=np.int32).reshape(self.n_loci, 4))
+        self._keep = (bases, read_off, begin, r1, o1, r2, o2, c)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self.lib._check(self.lib.lib.manta_spanning_upload(self.h, self.n_loci, p(bases), p(read_off), p(begin), p(r1), p(o1), p(r2), p(o2), p(c)))
+
+    def run(self):
+        self.lib._check(self.lib.lib.manta_spanning_run(self.h))
+
+    def stats(self):
+        st = SmallSvStats()
+        self.lib._check(self.lib.lib.manta_spanning_stats(self.h, ctypes.byref(st)))
+        return {f[0]: getattr(st, f[0]) for f in SmallSvStats._fields_}
+
+    def download(self, strict=True):
+        n = self.n_loci
+        res = (AsmLocusResult * n)()
+        ccap = n * self.max_asm + 1
+        contigs = (AsmContig * ccap)()
+        aligns = (SpanningAlignment * ccap)()
+        total_bases = int(self._keep[1][-1])
+        seq_cap = 4 * total_bases + 65536 * min(n, 64) + 4096 * n
+        seq = np.zeros(seq_cap, dtype=np.uint8)
+        bits_cap = int(sum(self.max_asm * 2 * ((int(r) + 2 * self.max_asm + 63) // 64) + 2 * self.max_asm + 8 for r in self.n_reads)) + 64
+        bits = np.zeros(bits_cap, dtype=np.uint64)
+        cig_cap = n * self.max_asm * 512 + 4096
+        cig = np.zeros(cig_cap, dtype=np.uint32)
+        su, bu, cu = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+        rc = self.lib.lib.manta_spanning_download(
+            self.h, res, contigs, aligns, ctypes.c_uint64(ccap), seq.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(seq_cap),
+            ctypes.byref(su), bits.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(bits_cap), ctypes.byref(bu),
+            cig.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(cig_cap), ctypes.byref(cu))
+        self.lib._check(rc, allow=() if strict else (-4, -5, -6, -7))
+        out = []
+        for l in range(n):
+            r = res[l]
+            d = dict(status=r.status, n_reads=int(self.n_reads[l]), n_words=r.n_words, final_word_length=r.final_word_length,
+                     n_iterations=r.n_iterations, cyclic_iterations=r.cyclic_iterations, contigs=[], pseudo=[], aligns=[])
+            if r.status == 0:
+                for c in range(r.n_contigs):
+                    cc = contigs[r.first_contig + c]
+                    d["contigs"].append(dict(seq=seq[cc.seq_off:cc.seq_off + cc.seq_len].tobytes().decode("latin-1"),
+                                             seed=cc.seed_read_count, cons=(cc.conservative_begin, cc.conservative_end),
+                                             support=_bits_members(bits[cc.support_off:cc.support_off + r.n_words]),
+                                             reject=_bits_members(bits[cc.reject_off:cc.reject_off + r.n_words])))
+                    a = aligns[r.first_contig + c]
+                    d["aligns"].append(dict(status=a.align.status, is_uncut=a.is_uncut, score=a.align.score, begin1=a.align.begin_pos1,
+                                            begin2=a.align.begin_pos2, jump_insert_size=a.align.jump_insert_size,
+                                            jump_range=a.align.jump_range,
+                                            cigar1=cigar_string(cig[a.align.cigar1_off:a.align.cigar1_off + a.align.cigar1_len]),
+                                            cigar2=cigar_string(cig[a.align.cigar2_off:a.align.cigar2_off + a.align.cigar2_len])))
+                off = int(r.pseudo_seq_off)
+                for p in range(r.n_pseudo):
+                    ln = int(bits[r.pseudo_len_off + p])
+                    d["pseudo"].append(seq[off:off + ln].tobytes().decode("latin-1"))
+                    off += ln
+            out.append(d)
+        return out

@@ -413,8 +413,22 @@ struct manta_smallsv {
   explicit manta_smallsv(manta_ctx_t* c) : ctx(c), asmStage(c) {}
 };
 
-namespace {
-}  // namespace
+
+struct manta_spanning {
+  manta_ctx_t*          ctx;
+  AsmStage              asmStage;
+  manta_asm_options_t   opt{};
+  manta_align_scores_t  scores{};
+  int32_t               jumpScore = 0;
+  uint32_t              nLoci     = 0;
+  uint64_t              ref1Bytes = 0, ref2Bytes = 0;
+  bool                  uploaded = false, ran = false;
+  DevBuf                dRefs1, dRef1Off, dRefs2, dRef2Off, dCuts, dTasks, dTasks2, dInfo, dResults, dResults2, dBucketIds, dBucketIds2, dSmall,
+      dCigar, dPtrWs;
+  rt::Event             evStart, evAsm, evSched, evAlign;
+  manta_smallsv_stats_t stats{};
+  explicit manta_spanning(manta_ctx_t* c) : ctx(c), asmStage(c) {}
+};
 
 extern "C" {
 
@@ -556,8 +570,13 @@ int manta_align_batch(
       P.off_edge       = scores->off_edge;
       P.allow_edge_ins = scores->is_allow_edge_insertion ? 1 : 0;
       P.extra          = extra_score;
+      rt::Event e0, e1;
+      e0.record();
       launchAlignKind(kind, b, grid, P);
+      e1.record();
       rt::sync();  // dPtrWs may be re-sized by the next bucket
+      if (std::getenv("MANTA_AMD_DEBUG"))
+        std::fprintf(stderr, "manta_amd: align_kernel kind %d E=%d %zu tasks %.3f ms\n", kind, kESet[b], buckets[b].size(), rt::elapsedMs(e0, e1));
       idsCursor += buckets[b].size();
     }
 
@@ -617,8 +636,13 @@ int manta_assemble_batch(
     int      rc = st.plan(*opt, n_loci, read_off, locus_read_begin);
     if (rc != MANTA_OK) return rc;
     st.upload(bases, read_off, locus_read_begin);
+    rt::Event e0, e1;
+    e0.record();
     st.launch();
+    e1.record();
     rt::sync();
+    if (std::getenv("MANTA_AMD_DEBUG"))
+      std::fprintf(stderr, "manta_amd: assemble_kernel %u loci %.3f ms\n", n_loci, rt::elapsedMs(e0, e1));
     return st.fetch(loci, contigs, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used);
   } catch (const std::exception& e) {
     return fail(ctx, MANTA_E_HIP, e.what());
@@ -870,6 +894,280 @@ int manta_smallsv_download(
     b->stats.ptr_matrix_bytes = ptrBytes;
     if (cigar_arena_used) *cigar_arena_used = used;
     if (worst != MANTA_OK) return fail(ctx, worst, "manta_smallsv_download: one or more loci/contigs failed; see per-item status");
+    return MANTA_OK;
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fused spanning pipeline
+// ------------------------------------------------------------------------------------------------------
+int manta_spanning_create(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t jump_score, manta_spanning_t** out)
+{
+  if (!ctx) return MANTA_E_INVALID_ARG;
+  if (!opt || !scores || !out) return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_create: null argument");
+  if (scores->is_allow_edge_insertion)
+    return fail(ctx, MANTA_E_INVALID_ARG, "GlobalJumpAligner does not support isAllowEdgeInsertion");
+  manta_spanning* b = new manta_spanning(ctx);
+  b->opt            = *opt;
+  b->scores         = *scores;
+  b->jumpScore      = jump_score;
+  *out              = b;
+  return MANTA_OK;
+}
+
+void manta_spanning_destroy(manta_spanning_t* b)
+{
+  delete b;
+}
+
+int manta_spanning_upload(
+    manta_spanning_t* b, uint32_t n_loci, const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin,
+    const uint8_t* refs1, const uint64_t* ref1_off, const uint8_t* refs2, const uint64_t* ref2_off, const manta_jump_cuts_t* cuts)
+{
+  if (!b) return MANTA_E_INVALID_ARG;
+  manta_ctx_t* ctx = b->ctx;
+  if (n_loci == 0 || !bases || !read_off || !locus_read_begin || !refs1 || !ref1_off || !refs2 || !ref2_off || !cuts)
+    return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_upload: null argument or empty batch");
+  try {
+    b->uploaded = false;
+    int rc      = b->asmStage.plan(b->opt, n_loci, read_off, locus_read_begin);
+    if (rc != MANTA_OK) return rc;
+    b->asmStage.upload(bases, read_off, locus_read_begin);
+    b->nLoci     = n_loci;
+    b->ref1Bytes = ref1_off[n_loci];
+    b->ref2Bytes = ref2_off[n_loci];
+    for (uint32_t l = 0; l < n_loci; ++l) {
+      if (ref1_off[l + 1] < ref1_off[l] || ref2_off[l + 1] < ref2_off[l])
+        return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_upload: reference offsets not monotone");
+      const manta_jump_cuts_t& c(cuts[l]);
+      if (c.align1_leading_cut < 0 || c.align1_trailing_cut < 0 || c.align2_leading_cut < 0 || c.align2_trailing_cut < 0)
+        return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_upload: negative reference cut");
+    }
+    static_assert(sizeof(JumpCuts) == sizeof(manta_jump_cuts_t), "cuts layout");
+    rt::h2d(b->dRefs1.as<uint8_t>(b->ref1Bytes + 16), refs1, b->ref1Bytes);
+    rt::h2d(b->dRef1Off.as<uint64_t>(n_loci + 1), ref1_off, sizeof(uint64_t) * (n_loci + 1));
+    rt::h2d(b->dRefs2.as<uint8_t>(b->ref2Bytes + 16), refs2, b->ref2Bytes);
+    rt::h2d(b->dRef2Off.as<uint64_t>(n_loci + 1), ref2_off, sizeof(uint64_t) * (n_loci + 1));
+    rt::h2d(b->dCuts.as<JumpCuts>(n_loci), cuts, sizeof(JumpCuts) * n_loci);
+    rt::sync();
+    b->uploaded = true;
+    return MANTA_OK;
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
+}
+
+int manta_spanning_run(manta_spanning_t* b)
+{
+  if (!b) return MANTA_E_INVALID_ARG;
+  manta_ctx_t* ctx = b->ctx;
+  if (!b->uploaded) return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_run: nothing uploaded");
+  try {
+    const uint32_t nLoci  = b->nLoci;
+    const uint32_t maxAsm = b->opt.max_assembly_count;
+    const uint64_t nSlots = uint64_t(nLoci) * maxAsm;
+    AsmStage&      as(b->asmStage);
+    AlignTaskDev*   dTasks    = b->dTasks.as<AlignTaskDev>(nSlots);
+    AlignTaskDev*   dTasks2   = b->dTasks2.as<AlignTaskDev>(nSlots);
+    SpanTaskInfo*   dInfo     = b->dInfo.as<SpanTaskInfo>(nSlots);
+    AlignResultDev* dResults  = b->dResults.as<AlignResultDev>(nSlots);
+    AlignResultDev* dResults2 = b->dResults2.as<AlignResultDev>(nSlots);
+    uint32_t*       dBuckets  = b->dBucketIds.as<uint32_t>(nSlots * kNumESet);
+    uint32_t*       dBuckets2 = b->dBucketIds2.as<uint32_t>(nSlots * kNumESet);
+    // [0..15] counts, [16..31] maxref, [32..47] counts2, [48..63] maxref2, [64..65] cigar_used, [72..87] / [88..103] align counters
+    uint32_t*      dSmall   = b->dSmall.as<uint32_t>(128);
+    const uint64_t cigarCap = 2 * nSlots * (4ull * std::min<uint64_t>(as.maxContigLen, 4096) + 16);
+    uint32_t*      dCigar   = b->dCigar.as<uint32_t>(cigarCap + 16);
+    rt::dzero(dSmall, sizeof(uint32_t) * 128);
+    rt::dzero(dResults, sizeof(AlignResultDev) * nSlots);
+    rt::dzero(dResults2, sizeof(AlignResultDev) * nSlots);
+
+    const bool dbg   = std::getenv("MANTA_AMD_DEBUG") != nullptr;
+    auto       stage = [&](const char* what) {
+      if (!dbg) return;
+      rt::sync();
+      std::fprintf(stderr, "manta_amd: spanning_run %s\n", what);
+      std::fflush(stderr);
+    };
+    b->evStart.record();
+    as.launch();
+    b->evAsm.record();
+    stage("assembled");
+
+    SpanParams S;
+    S.loci               = as.dLoci;
+    S.contigs            = as.dCont;
+    S.seq_arena          = as.dSeq;
+    S.n_loci             = nLoci;
+    S.max_assembly_count = maxAsm;
+    S.refs1              = static_cast<const uint8_t*>(b->dRefs1.p);
+    S.ref1_off           = static_cast<const uint64_t*>(b->dRef1Off.p);
+    S.refs2              = static_cast<const uint8_t*>(b->dRefs2.p);
+    S.ref2_off           = static_cast<const uint64_t*>(b->dRef2Off.p);
+    S.cuts               = static_cast<const JumpCuts*>(b->dCuts.p);
+    S.tasks              = dTasks;
+    S.tasks2             = dTasks2;
+    S.info               = dInfo;
+    S.bucket_ids         = dBuckets;
+    S.bucket_count       = dSmall;
+    S.bucket_maxref      = dSmall + 16;
+    S.bucket_ids2        = dBuckets2;
+    S.bucket_count2      = dSmall + 32;
+    S.bucket_maxref2     = dSmall + 48;
+    S.cigar_used         = reinterpret_cast<unsigned long long*>(dSmall + 64);
+    S.cigar_cap          = cigarCap;
+    S.results            = dResults;
+    S.cigar              = dCigar;
+    S.n_e                = kNumESet;
+    for (int i = 0; i < kNumESet; ++i) S.e_set[i] = uint32_t(kESet[i]);
+    const int glueGrid = rt::roundGrid(int(std::min<uint64_t>((nSlots + 63) / 64, uint64_t(std::max(1, ctx->cuCount * 8)))));
+    rt::launch(spanning_schedule_kernel, glueGrid, 0, S);
+    b->evSched.record();
+    stage("scheduled");
+
+    b->stats.n_align_launches = 0;
+    b->stats.n_alignments     = 0;
+    const int    maxWaves = std::max(1, ctx->cuCount * alignWavesPerCu());
+    const size_t wsBudget = std::min<size_t>(rt::freeBytes() / 2, size_t(48) << 30);
+    auto alignRound = [&](const uint32_t* hCounts, const uint32_t* hMaxref, const AlignTaskDev* tasks, AlignResultDev* results,
+                          const uint32_t* bucketIds, uint32_t* counters) {
+      for (int k = 0; k < kNumESet; ++k) {
+        const uint32_t cnt = hCounts[k];
+        if (cnt == 0) continue;
+        const uint64_t stride = (alignPtrSlabBytes(MANTA_ALIGNER_JUMP, kESet[k], hMaxref[k]) + 255) & ~uint64_t(255);
+        int            grid   = int(std::min<size_t>(cnt, size_t(maxWaves)));
+        grid                  = int(std::max<size_t>(1, std::min<size_t>(size_t(grid), wsBudget / stride)));
+        grid                  = rt::roundGrid(grid);
+        uint8_t* dWs          = b->dPtrWs.as<uint8_t>(stride * grid);
+        AlignParams P;
+        P.tasks          = tasks;
+        P.results        = results;
+        P.cigar          = dCigar;
+        P.task_ids       = bucketIds + uint64_t(k) * nSlots;
+        P.n_tasks        = cnt;
+        P.n_tasks_dev    = nullptr;
+        P.counter        = counters + k;
+        P.ptr_ws         = dWs;
+        P.ptr_ws_stride  = stride;
+        P.match          = b->scores.match;
+        P.mismatch       = b->scores.mismatch;
+        P.open           = b->scores.open;
+        P.extend         = b->scores.extend;
+        P.off_edge       = b->scores.off_edge;
+        P.allow_edge_ins = 0;
+        P.extra          = b->jumpScore;
+        launchAlignKind(MANTA_ALIGNER_JUMP, k, grid, P);
+        b->stats.n_align_launches++;
+        b->stats.n_alignments += cnt;
+        rt::sync();  // the slab buffer may be re-sized for the next bucket
+      }
+    };
+    uint32_t hSmall[64];
+    rt::d2h(hSmall, dSmall, sizeof(hSmall));
+    alignRound(hSmall, hSmall + 16, dTasks, dResults, dBuckets, dSmall + 72);
+    stage("aligned round 1");
+    rt::launch(spanning_realign_kernel, rt::roundGrid(int(std::min<uint64_t>((nLoci + 63) / 64, uint64_t(std::max(1, ctx->cuCount * 8))))), 0, S);
+    rt::d2h(hSmall, dSmall, sizeof(hSmall));
+    alignRound(hSmall + 32, hSmall + 48, dTasks2, dResults2, dBuckets2, dSmall + 88);
+    b->evAlign.record();
+    rt::sync();
+    stage("aligned round 2");
+    b->stats.assemble_ms = rt::elapsedMs(b->evStart, b->evAsm);
+    b->stats.schedule_ms = rt::elapsedMs(b->evAsm, b->evSched);
+    b->stats.align_ms    = rt::elapsedMs(b->evSched, b->evAlign);
+    b->stats.total_ms    = rt::elapsedMs(b->evStart, b->evAlign);
+    b->ran               = true;
+    return MANTA_OK;
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
+}
+
+int manta_spanning_stats(const manta_spanning_t* b, manta_smallsv_stats_t* stats)
+{
+  if (!b || !stats) return MANTA_E_INVALID_ARG;
+  *stats = b->stats;
+  return MANTA_OK;
+}
+
+int manta_spanning_download(
+    manta_spanning_t* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_spanning_alignment_t* alignments,
+    uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena,
+    uint64_t bits_arena_cap, uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
+    uint64_t* cigar_arena_used)
+{
+  if (!b) return MANTA_E_INVALID_ARG;
+  manta_ctx_t* ctx = b->ctx;
+  if (!b->ran) return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_download: run first");
+  if (!loci || !contigs || !alignments || !seq_arena || !bits_arena || !cigar_arena)
+    return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_download: null argument");
+  try {
+    int rc = b->asmStage.fetch(loci, contigs, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap,
+                               bits_arena_used);
+    if (rc != MANTA_OK && rc != MANTA_E_UNSUPPORTED && rc != MANTA_E_DEVICE_FAULT) return rc;
+    const uint32_t nLoci  = b->nLoci;
+    const uint32_t maxAsm = b->opt.max_assembly_count;
+    const uint64_t nSlots = uint64_t(nLoci) * maxAsm;
+    std::vector<AlignResultDev> hRes(nSlots), hRes2(nSlots);
+    std::vector<SpanTaskInfo>   hInfo(nSlots);
+    std::vector<AlignTaskDev>   hTasks(nSlots), hTasks2(nSlots);
+    std::vector<JumpCuts>       hCuts(nLoci);
+    uint32_t                    hSmall[72];
+    rt::d2h(hRes.data(), b->dResults.p, sizeof(AlignResultDev) * nSlots);
+    rt::d2h(hRes2.data(), b->dResults2.p, sizeof(AlignResultDev) * nSlots);
+    rt::d2h(hInfo.data(), b->dInfo.p, sizeof(SpanTaskInfo) * nSlots);
+    rt::d2h(hTasks.data(), b->dTasks.p, sizeof(AlignTaskDev) * nSlots);
+    rt::d2h(hTasks2.data(), b->dTasks2.p, sizeof(AlignTaskDev) * nSlots);
+    rt::d2h(hCuts.data(), b->dCuts.p, sizeof(JumpCuts) * nLoci);
+    rt::d2h(hSmall, b->dSmall.p, sizeof(hSmall));
+    uint64_t cigDev = 0;
+    std::memcpy(&cigDev, hSmall + 64, sizeof(uint64_t));
+    std::vector<uint32_t> hCig(cigDev + 1);
+    rt::d2h(hCig.data(), b->dCigar.p, sizeof(uint32_t) * cigDev);
+    uint64_t used = 0, cells = 0, ptrBytes = 0;
+    int      worst = rc;
+    for (uint32_t l = 0; l < nLoci; ++l) {
+      if (loci[l].status != MANTA_OK) continue;
+      for (uint32_t c = 0; c < loci[l].n_contigs; ++c) {
+        const uint64_t              slot = uint64_t(l) * maxAsm + c;
+        manta_spanning_alignment_t& a(alignments[loci[l].first_contig + c]);
+        std::memset(&a, 0, sizeof(a));
+        const SpanTaskInfo&   inf(hInfo[slot]);
+        const bool            uncut = inf.is_uncut != 0;
+        const AlignResultDev& h(uncut ? hRes2[slot] : hRes[slot]);
+        const AlignTaskDev&   t(uncut ? hTasks2[slot] : hTasks[slot]);
+        a.is_uncut = uncut ? 1 : 0;
+        if (inf.status != 0 || h.status != 0 || (uncut ? inf.bucket2 : inf.bucket) < 0) {
+          a.align.status = (inf.status == 5) ? MANTA_E_CAPACITY : (inf.status == 6) ? MANTA_E_EMPTY_SEQ : MANTA_E_UNSUPPORTED;
+          worst          = a.align.status;
+          continue;
+        }
+        const uint64_t n = uint64_t(h.cigar1_len) + h.cigar2_len;
+        if (used + n > cigar_arena_cap) return fail(ctx, MANTA_E_CAPACITY, "manta_spanning_download: cigar arena too small");
+        std::memcpy(cigar_arena + used, hCig.data() + t.cigar_off, sizeof(uint32_t) * n);
+        a.align.score            = h.score;
+        a.align.is_jumped        = h.is_jumped;
+        a.align.begin_pos1       = h.begin1 + (uncut ? 0 : hCuts[l].a1Lead);  // SVCandidateAssemblyRefiner.cpp:1716-1717
+        a.align.begin_pos2       = h.begin2 + (uncut ? 0 : hCuts[l].a2Lead);
+        a.align.jump_insert_size = h.jump_insert_size;
+        a.align.jump_range       = h.jump_range;
+        a.align.cigar1_len       = h.cigar1_len;
+        a.align.cigar2_len       = h.cigar2_len;
+        a.align.cigar1_off       = used;
+        a.align.cigar2_off       = used + h.cigar1_len;
+        used += n;
+        const uint64_t refLen = uint64_t(t.ref1_len) + t.ref2_len;
+        cells += uint64_t(t.query_len) * refLen;
+        ptrBytes += (uint64_t(t.query_len) + 1) * (refLen + 2);
+      }
+    }
+    b->stats.dp_cells         = cells;
+    b->stats.ptr_matrix_bytes = ptrBytes;
+    if (cigar_arena_used) *cigar_arena_used = used;
+    if (worst != MANTA_OK) return fail(ctx, worst, "manta_spanning_download: one or more loci/contigs failed; see per-item status");
     return MANTA_OK;
   } catch (const std::exception& e) {
     return fail(ctx, MANTA_E_HIP, e.what());

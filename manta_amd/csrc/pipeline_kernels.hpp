@@ -248,4 +248,165 @@ WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fused "spanning" locus pipeline (SVCandidateAssemblyRefiner::getJumpAssembly -> alignJumpContigs, DNA branch,
+// applications/GenerateSVCandidates/SVCandidateAssemblyRefiner.cpp:1525-1743):
+//   assemble_kernel -> spanning_schedule_kernel (round 1: every contig against the CUT references, :1663-1670)
+//   -> align_kernel<JUMP,E> -> spanning_realign_kernel (the re-align rule, :1672-1713) -> align_kernel<JUMP,E> (round 2).
+// Both glue kernels are one LANE per item: a few loads, compares and atomics each.
+// ------------------------------------------------------------------------------------------------------------------
+struct JumpCuts {
+  int32_t a1Lead, a1Trail, a2Lead, a2Trail;  // AlignData after the orientation swaps (:1533-1550)
+};
+
+struct SpanTaskInfo {
+  int32_t status;   // 0 ok; 4 contig longer than the widest aligner bucket; 5 CIGAR workspace exhausted; 6 empty cut window
+  int32_t bucket;   // round-1 E bucket (-1: no contig in this slot)
+  int32_t bucket2;  // round-2 E bucket (-1: not re-aligned)
+  int32_t is_uncut; // final alignment is the round-2 one (references without cuts, begin positions without offset)
+};
+
+struct SpanParams {
+  const AsmLocusOut*  loci;
+  const AsmContigOut* contigs;
+  const uint8_t*      seq_arena;
+  uint32_t            n_loci, max_assembly_count;
+  const uint8_t*      refs1;
+  const uint64_t*     ref1_off;  // n_loci + 1
+  const uint8_t*      refs2;
+  const uint64_t*     ref2_off;
+  const JumpCuts*     cuts;
+  AlignTaskDev*       tasks;   // round 1, n_loci * max_assembly_count
+  AlignTaskDev*       tasks2;  // round 2
+  SpanTaskInfo*       info;
+  uint32_t*           bucket_ids;     // n_buckets * n_slots
+  uint32_t*           bucket_count;   // n_buckets
+  uint32_t*           bucket_maxref;  // n_buckets
+  uint32_t*           bucket_ids2;
+  uint32_t*           bucket_count2;
+  uint32_t*           bucket_maxref2;
+  unsigned long long* cigar_used;  // bump allocator (u32 units), shared by both rounds
+  uint64_t            cigar_cap;
+  const AlignResultDev* results;   // round-1 results (read by the re-align kernel)
+  const uint32_t*       cigar;
+  uint32_t            e_set[16];
+  uint32_t            n_e;
+};
+
+WV_DEV void spanAtomicMax(uint32_t* p, const unsigned v)
+{
+  unsigned cur = wv::atomic_load(p);
+  while (cur < v) {
+    const unsigned old = wv::atomic_cas(p, cur, v);
+    if (old == cur) break;
+    cur = old;
+  }
+}
+
+/// files one jump-alignment task; returns the E bucket or a negative status
+WV_DEV int spanFileTask(
+    const SpanParams& P, const unsigned slot, const unsigned total, const AsmContigOut& co, const uint8_t* r1, const int r1Len,
+    const uint8_t* r2, const int r2Len, AlignTaskDev* tasks, uint32_t* bucketIds, uint32_t* bucketCount, uint32_t* bucketMaxref)
+{
+  if (r1Len <= 0 || r2Len <= 0) return -6;
+  const unsigned need = (co.seq_len + 63) / 64;
+  int            bucket = -1;
+  for (unsigned b = 0; b < P.n_e; ++b)
+    if (P.e_set[b] >= need) {
+      bucket = int(b);
+      break;
+    }
+  if (bucket < 0) return -4;
+  const unsigned long long words = 4ull * co.seq_len + 16;
+  const unsigned long long cig   = wv::atomic_add(P.cigar_used, words);
+  if (cig + words > P.cigar_cap) return -5;
+  AlignTaskDev t;
+  t.query     = P.seq_arena + co.seq_off;
+  t.ref1      = r1;
+  t.ref2      = r2;
+  t.query_len = co.seq_len;
+  t.ref1_len  = unsigned(r1Len);
+  t.ref2_len  = unsigned(r2Len);
+  t.cigar_off = uint32_t(cig);
+  tasks[slot] = t;
+  const unsigned pos = wv::atomic_add(&bucketCount[bucket], 1u);
+  bucketIds[size_t(bucket) * total + pos] = slot;
+  spanAtomicMax(&bucketMaxref[bucket], unsigned(r1Len + r2Len));
+  return bucket;
+}
+
+WV_KERNEL void spanning_schedule_kernel(const SpanParams P)
+{
+  const unsigned total = P.n_loci * P.max_assembly_count;
+  for (unsigned slot = unsigned(wv::block()) * 64u + unsigned(wv::lane()); slot < total; slot += unsigned(wv::nblocks()) * 64u) {
+    const unsigned    locus = slot / P.max_assembly_count, ci = slot % P.max_assembly_count;
+    const AsmLocusOut lo    = P.loci[locus];
+    SpanTaskInfo      info  = {0, -1, -1, 0};
+    if (lo.status == ASM_OK && ci < lo.n_contigs) {
+      const JumpCuts c    = P.cuts[locus];
+      const int      len1 = int(P.ref1_off[locus + 1] - P.ref1_off[locus]), len2 = int(P.ref2_off[locus + 1] - P.ref2_off[locus]);
+      const int      b    = spanFileTask(P, slot, total, P.contigs[slot], P.refs1 + P.ref1_off[locus] + c.a1Lead, len1 - c.a1Lead - c.a1Trail,
+                                         P.refs2 + P.ref2_off[locus] + c.a2Lead, len2 - c.a2Lead - c.a2Trail, P.tasks, P.bucket_ids,
+                                         P.bucket_count, P.bucket_maxref);
+      if (b >= 0)
+        info.bucket = b;
+      else
+        info.status = -b;
+    } else if (lo.status != ASM_OK) {
+      info.status = 1;
+    }
+    P.info[slot] = info;
+  }
+}
+
+/// the re-align rule (:1672-1713), one lane per locus: the first contig (in contig order) whose junction holds an
+/// insertion while a breakend sits within 5 bases of a cut edge zeroes the cuts -- for itself and, because the
+/// reference's AlignData is shared by the contig loop, for every later contig of the locus.
+WV_KERNEL void spanning_realign_kernel(const SpanParams P)
+{
+  const unsigned total = P.n_loci * P.max_assembly_count;
+  for (unsigned locus = unsigned(wv::block()) * 64u + unsigned(wv::lane()); locus < P.n_loci; locus += unsigned(wv::nblocks()) * 64u) {
+    const AsmLocusOut lo = P.loci[locus];
+    if (lo.status != ASM_OK) continue;
+    const JumpCuts c    = P.cuts[locus];
+    const int      len1 = int(P.ref1_off[locus + 1] - P.ref1_off[locus]), len2 = int(P.ref2_off[locus + 1] - P.ref2_off[locus]);
+    unsigned       firstUncut = lo.n_contigs;
+    for (unsigned ci = 0; ci < lo.n_contigs; ++ci) {
+      const unsigned slot = locus * P.max_assembly_count + ci;
+      if (P.info[slot].status != 0) continue;
+      const AlignResultDev r = P.results[slot];
+      if (r.status != 0 || r.jump_insert_size == 0) continue;
+      // reference length of align1's path: '=' (7), 'X' (8), 'D' (2), 'N' (3) segments
+      const uint32_t* cig    = P.cigar + P.tasks[slot].cigar_off;
+      int             refLen = 0;
+      for (unsigned i = 0; i < r.cigar1_len; ++i) {
+        const unsigned op = cig[i] & 15u;
+        if (op == 7 || op == 8 || op == 2 || op == 3 || op == 0) refLen += int(cig[i] >> 4);
+      }
+      const int ref1EndPos   = len1 - c.a1Lead - c.a1Trail - 1;
+      const int align1EndPos = r.begin1 + refLen;
+      if ((ref1EndPos - align1EndPos < 5) || (r.begin2 < 5)) {
+        firstUncut = ci;
+        break;
+      }
+    }
+    for (unsigned ci = firstUncut; ci < lo.n_contigs; ++ci) {
+      const unsigned slot = locus * P.max_assembly_count + ci;
+      SpanTaskInfo   info = P.info[slot];
+      info.is_uncut       = 1;
+      if (info.status == 0) {
+        const int b = spanFileTask(P, slot, total, P.contigs[slot], P.refs1 + P.ref1_off[locus], len1, P.refs2 + P.ref2_off[locus], len2,
+                                   P.tasks2, P.bucket_ids2, P.bucket_count2, P.bucket_maxref2);
+        if (b >= 0) {
+          info.bucket2 = b;
+          info.status  = 0;
+        } else {
+          info.status = -b;
+        }
+      }
+      P.info[slot] = info;
+    }
+  }
+}
+
 }  // namespace manta_dev

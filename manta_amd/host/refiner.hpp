@@ -3,7 +3,7 @@
 //   (/root/reference/src/c++/lib/applications/GenerateSVCandidates/SVCandidateAssemblyRefiner.hpp:41-99)
 // plus a batched form of the same call.  All assembly and all DP run in the HIP kernels behind include/manta_amd.h:
 //   complex ("small SV") candidates -> manta_smallsv_*  (assemble -> 10-mer trim -> GlobalLargeIndelAligner, fused on device)
-//   spanning candidates             -> manta_assemble_batch + manta_align_batch(MANTA_ALIGNER_JUMP) (+ the re-align round)
+//   spanning candidates             -> manta_spanning_* (assemble -> GlobalJumpAligner on the cut references -> re-align rule, fused)
 //   large-insertion completion      -> manta_align_batch(MANTA_ALIGNER_GLOBAL)
 // The host code here is the refiner's own glue (SVCandidateAssemblyRefiner.cpp:59-86, 677-1007, 1210-1250, 1364-1398,
 // 1422-1849, 1860-2303; manta/SVReferenceUtil.cpp:56-205), restated over sv_types.hpp.  The two I/O seams of the
@@ -421,6 +421,62 @@ inline void smallSvBatch(
   manta_smallsv_destroy(b);
 }
 
+struct SpanningOutput : AsmOutput {
+  std::vector<manta_spanning_alignment_t> aligns;
+  std::vector<uint32_t>                   cigar;
+};
+
+/// the fused device pipeline for a batch of spanning loci (references already oriented, in alignment order)
+inline void spanningBatch(
+    const IterativeAssemblerOptions& opt, const AlignmentScores<int>& scores, const int jumpScore, PackedReads& in,
+    const std::vector<const std::string*>& refs1, const std::vector<const std::string*>& refs2, const std::vector<manta_jump_cuts_t>& cuts,
+    SpanningOutput& out)
+{
+  if (in.nLoci() == 0) return;
+  manta_ctx_t*               ctx = threadContext();
+  const manta_asm_options_t  o   = toAbi(opt);
+  const manta_align_scores_t sc  = toAbi(scores);
+  std::vector<uint8_t>       ref1Bytes, ref2Bytes;
+  std::vector<uint64_t>      ref1Off{0}, ref2Off{0};
+  for (size_t i = 0; i < refs1.size(); ++i) {
+    ref1Bytes.insert(ref1Bytes.end(), refs1[i]->begin(), refs1[i]->end());
+    ref1Off.push_back(ref1Bytes.size());
+    ref2Bytes.insert(ref2Bytes.end(), refs2[i]->begin(), refs2[i]->end());
+    ref2Off.push_back(ref2Bytes.size());
+  }
+  ref1Bytes.push_back(0);
+  ref2Bytes.push_back(0);
+  in.bases.push_back(0);
+  manta_spanning_t* b = nullptr;
+  auto              check = [&](const int rc) {
+    if (rc == MANTA_OK) return;
+    const std::string msg(manta_last_error(ctx));
+    if (b) manta_spanning_destroy(b);
+    throw GeneralException("manta_amd spanning pipeline: " + msg, rc);
+  };
+  check(manta_spanning_create(ctx, &o, &sc, jumpScore, &b));
+  check(manta_spanning_upload(b, in.nLoci(), in.bases.data(), in.readOff.data(), in.locusBegin.data(), ref1Bytes.data(), ref1Off.data(),
+                              ref2Bytes.data(), ref2Off.data(), cuts.data()));
+  check(manta_spanning_run(b));
+  in.bases.pop_back();
+  for (unsigned attempt = 0;; ++attempt) {
+    out.reserveFor(in, o.max_assembly_count, attempt);
+    out.aligns.resize(out.contigs.size());
+    out.cigar.resize((out.contigs.size() * 64 + out.seq.size() / 4 + 4096) << attempt);
+    uint64_t  su = 0, bu = 0, cu = 0;
+    const int rc = manta_spanning_download(b, out.loci.data(), out.contigs.data(), out.aligns.data(), out.contigs.size(), out.seq.data(),
+                                           out.seq.size(), &su, out.bits.data(), out.bits.size(), &bu, out.cigar.data(), out.cigar.size(), &cu);
+    if (rc == MANTA_E_CAPACITY && attempt < 6) continue;
+    if (rc == MANTA_E_EMPTY_SEQ) {  // the reference throws from GlobalJumpAligner::align (GlobalJumpAlignerImpl.hpp:50-58)
+      manta_spanning_destroy(b);
+      throw GeneralException("Unexpected empty reference sequence");
+    }
+    check(rc);
+    break;
+  }
+  manta_spanning_destroy(b);
+}
+
 }  // namespace detail
 
 struct SVCandidateAssemblyRefiner {
@@ -797,13 +853,10 @@ private:
   // generateRefinedVCFSVCandidateFromJumpAlignment (:1175-1250)
   // ---------------------------------------------------------------------------------------------------------------
   struct SpanningLocus {
-    size_t      planIndex = 0;
-    std::string bp1refSeq, bp2refSeq;  ///< orientation applied
+    size_t             planIndex = 0;
+    std::string        bp1refSeq, bp2refSeq;  ///< orientation applied
     const std::string *align1Ref = nullptr, *align2Ref = nullptr;
-    pos_t       a1Lead = 0, a1Trail = 0, a2Lead = 0, a2Trail = 0;
-    std::vector<detail::AlignJob> jobs;     ///< first round, one per contig
-    std::vector<detail::AlignJob> rejobs;   ///< second round (uncut references), contigs [firstUncut, contigCount)
-    unsigned    firstUncut = 0;
+    pos_t              a1Lead = 0, a1Trail = 0, a2Lead = 0, a2Trail = 0;
   };
 
   void runSpanning(const std::vector<Plan>& plans, std::vector<SVCandidateAssemblyData>& out) const
@@ -819,16 +872,13 @@ private:
     }
     if (loci.empty()) return;
     _stats.spanningLoci += loci.size();
-    detail::AsmOutput dev;
-    detail::assembleBatch(_opt.refineOpt.spanningAssembleOpt, packed, dev);
 
-    // round 1: every contig against the cut references
-    std::vector<detail::AlignJob*> jobs;
-    for (size_t l = 0; l < loci.size(); ++l) {
-      SpanningLocus&           sl(loci[l]);
-      const Plan&              p(plans[sl.planIndex]);
-      SVCandidateAssemblyData& data(out[sl.planIndex]);
-      dev.toContigs(unsigned(l), data.contigs);
+    // orientation step of alignJumpContigs (:1533-1550)
+    std::vector<const std::string*> refs1, refs2;
+    std::vector<manta_jump_cuts_t>  cuts;
+    for (SpanningLocus& sl : loci) {
+      const Plan&                    p(plans[sl.planIndex]);
+      const SVCandidateAssemblyData& data(out[sl.planIndex]);
       sl.bp1refSeq = data.bp1ref.seq();
       sl.bp2refSeq = data.bp2ref.seq();
       sl.a1Lead = p.align1LeadingCut, sl.a1Trail = p.align1TrailingCut, sl.a2Lead = p.align2LeadingCut, sl.a2Trail = p.align2TrailingCut;
@@ -847,51 +897,39 @@ private:
         std::swap(sl.a1Lead, sl.a2Lead);
         std::swap(sl.a1Trail, sl.a2Trail);
       }
-      sl.jobs.resize(data.contigs.size());
-      for (size_t c = 0; c < data.contigs.size(); ++c) setJob(sl, data.contigs[c].seq, true, sl.jobs[c]);
     }
-    for (SpanningLocus& sl : loci)
-      for (detail::AlignJob& j : sl.jobs) jobs.push_back(&j);
-    _stats.contigAlignments += jobs.size();
-    detail::alignBatch(MANTA_ALIGNER_JUMP, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, jobs);
-
-    // round 2 (:1682-1713): the first contig whose junction holds an insertion AND lies within 5 bases of the cut edge
-    // zeroes the cuts -- for itself (re-alignment) and, because alignData is shared by the loop, for every later contig
-    jobs.clear();
-    for (SpanningLocus& sl : loci) {
-      const SVCandidateAssemblyData& data(out[sl.planIndex]);
-      const unsigned                 contigCount = unsigned(data.contigs.size());
-      sl.firstUncut = contigCount;
-      for (unsigned c = 0; c < contigCount; ++c) {
-        JumpAlignmentResult<int> alignment;
-        detail::toResult(sl.jobs[c], alignment);
-        const pos_t minAlignBuffer(5);
-        const pos_t ref1EndPos   = pos_t(sl.align1Ref->size()) - sl.a1Lead - sl.a1Trail - 1;
-        const pos_t align1EndPos = alignment.align1.beginPos + pos_t(ALIGNPATH::apath_ref_length(alignment.align1.apath));
-        if (alignment.jumpInsertSize > 0 && ((ref1EndPos - align1EndPos < minAlignBuffer) || (alignment.align2.beginPos < minAlignBuffer))) {
-          sl.firstUncut = c;
-          break;
-        }
-      }
-      sl.rejobs.resize(contigCount - sl.firstUncut);
-      for (unsigned c = sl.firstUncut; c < contigCount; ++c) setJob(sl, data.contigs[c].seq, false, sl.rejobs[c - sl.firstUncut]);
+    for (const SpanningLocus& sl : loci) {  // pointers taken only now: `loci` no longer reallocates
+      refs1.push_back(sl.align1Ref);
+      refs2.push_back(sl.align2Ref);
+      cuts.push_back(manta_jump_cuts_t{sl.a1Lead, sl.a1Trail, sl.a2Lead, sl.a2Trail});
     }
-    for (SpanningLocus& sl : loci)
-      for (detail::AlignJob& j : sl.rejobs) jobs.push_back(&j);
-    _stats.realignedContigs += jobs.size();
-    detail::alignBatch(MANTA_ALIGNER_JUMP, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, jobs);
 
-    for (SpanningLocus& sl : loci) {
+    // assemble -> jump-align (cut references) -> re-align rule -> jump-align (uncut), all on the device
+    detail::SpanningOutput dev;
+    detail::spanningBatch(_opt.refineOpt.spanningAssembleOpt, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, packed, refs1,
+                          refs2, cuts, dev);
+
+    for (size_t l = 0; l < loci.size(); ++l) {
+      const SpanningLocus&     sl(loci[l]);
       const Plan&              p(plans[sl.planIndex]);
       SVCandidateAssemblyData& data(out[sl.planIndex]);
-      const unsigned           contigCount = unsigned(data.contigs.size());
+      dev.toContigs(unsigned(l), data.contigs);
+      const unsigned contigCount = unsigned(data.contigs.size());
+      _stats.contigAlignments += contigCount;
       data.spanningAlignments.resize(contigCount);
       for (unsigned c = 0; c < contigCount; ++c) {
-        JumpAlignmentResult<int>& alignment(data.spanningAlignments[c]);
-        const bool                uncut = (c >= sl.firstUncut);
-        detail::toResult(uncut ? sl.rejobs[c - sl.firstUncut] : sl.jobs[c], alignment);
-        alignment.align1.beginPos += uncut ? 0 : sl.a1Lead;
-        alignment.align2.beginPos += uncut ? 0 : sl.a2Lead;
+        JumpAlignmentResult<int>&         alignment(data.spanningAlignments[c]);
+        const manta_spanning_alignment_t& da(dev.aligns[dev.loci[l].first_contig + c]);
+        if (da.align.status != MANTA_OK) throw GeneralException("manta_amd spanning pipeline: contig alignment failed on the device", da.align.status);
+        _stats.realignedContigs += da.is_uncut ? 1 : 0;
+        alignment.clear();
+        alignment.score           = da.align.score;
+        alignment.jumpInsertSize  = da.align.jump_insert_size;
+        alignment.jumpRange       = da.align.jump_range;
+        alignment.align1.beginPos = da.align.begin_pos1;  // leading cuts already added on the device side (:1716-1717)
+        alignment.align2.beginPos = da.align.begin_pos2;
+        detail::toPath(dev.cigar.data() + da.align.cigar1_off, da.align.cigar1_len, alignment.align1.apath);
+        detail::toPath(dev.cigar.data() + da.align.cigar2_off, da.align.cigar2_len, alignment.align2.apath);
         std::string extendedContig;
         getExtendedContig(alignment, data.contigs[c].seq, *sl.align1Ref, *sl.align2Ref, extendedContig);
         data.extendedContigs.push_back(extendedContig);
@@ -918,16 +956,6 @@ private:
       if (_opt.isOutputContig) sv.contigSeq = data.contigs[data.bestAlignmentIndex].seq;
       detail::addCigarToSpanningAlignment(sv);
     }
-  }
-
-  static void setJob(const SpanningLocus& sl, const std::string& contigSeq, const bool isCut, detail::AlignJob& job)
-  {
-    const pos_t l1 = isCut ? sl.a1Lead : 0, t1 = isCut ? sl.a1Trail : 0, l2 = isCut ? sl.a2Lead : 0, t2 = isCut ? sl.a2Trail : 0;
-    job.query   = &contigSeq;
-    job.ref1    = sl.align1Ref->data() + l1;
-    job.ref1Len = sl.align1Ref->size() - size_t(l1) - size_t(t1);
-    job.ref2    = sl.align2Ref->data() + l2;
-    job.ref2Len = sl.align2Ref->size() - size_t(l2) - size_t(t2);
   }
 
   const GSCOptions              _opt;
