@@ -569,7 +569,7 @@ struct Assembler {
     }
     inst = waveSum(inst);
     unsigned tableSlots = 64;
-    while (tableSlots < 2 * inst && tableSlots < P.cap_slots) tableSlots <<= 1;
+    while (tableSlots < ((2 * inst) >> ((P.flags >> 8) & 7u)) && tableSlots < P.cap_slots) tableSlots <<= 1;
     slotMask = tableSlots - 1;
     for (unsigned s = lane; s < tableSlots; s += 64) slots[s] = ASM_NONE;
     wv::sync();

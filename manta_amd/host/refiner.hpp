@@ -12,13 +12,23 @@
 // tests/test_refiner.py.  DNA only: GSCOptions::isRNA is refused (the intron-aware aligner is not on this path).
 #pragma once
 
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <sstream>
+#include <thread>
 
 #include "sv_types.hpp"
 
 namespace manta_amd {
+
+/// wall-clock split of the last getCandidateAssemblyDataBatch call, seconds (no reference counterpart; for logs)
+struct RefinerTimes {
+  double plan = 0, pack = 0, device = 0, post = 0;
+};
 
 /// the refiner's two input seams
 struct RefinerInputSource {
@@ -230,6 +240,38 @@ inline bool isFinishedLargeInsertAlignment(
   std::reverse(rev.begin(), rev.end());
   info.isRightCandidate = isLargeInsertSegment(scores, rev, info.contigOffset, info.refOffset, info.score, middleSize);
   return info.isLeftCandidate && info.isRightCandidate;
+}
+
+/// the per-locus host glue after a device batch is independent across loci: spread it over host threads
+template <typename F>
+void parallelFor(const size_t n, unsigned threads, F&& body)
+{
+  if (threads > n) threads = unsigned(n);
+  if (threads <= 1) {
+    for (size_t i = 0; i < n; ++i) body(i);
+    return;
+  }
+  std::atomic<size_t> next(0);
+  std::exception_ptr  firstError;
+  std::mutex          errorLock;
+  auto                worker = [&]() {
+    try {
+      while (true) {
+        const size_t begin = next.fetch_add(16);
+        if (begin >= n) return;
+        for (size_t i = begin; i < std::min(n, begin + 16); ++i) body(i);
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> g(errorLock);
+      if (!firstError) firstError = std::current_exception();
+      next.store(n);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < threads; ++t) pool.emplace_back(worker);
+  worker();
+  for (std::thread& t : pool) t.join();
+  if (firstError) std::rethrow_exception(firstError);
 }
 
 // ---- batched device calls ------------------------------------------------------------------------------------------
@@ -496,11 +538,15 @@ struct SVCandidateAssemblyRefiner {
 
   void clearEdgeData() { _spanToComplexAssmRegions.clear(); }
 
+  /// host threads used for the per-locus glue after each device batch (default: all hardware threads, at most 64)
+  void setHostThreads(const unsigned n) { _hostThreads = (n == 0) ? 1 : n; }
+
   /// work counters of this refiner object (no reference counterpart; for logs and tests)
   struct Stats {
     uint64_t smallLoci = 0, spanningLoci = 0, contigAlignments = 0, realignedContigs = 0, largeInsertionAlignments = 0;
   };
-  const Stats& stats() const { return _stats; }
+  const Stats&        stats() const { return _stats; }
+  const RefinerTimes& times() const { return _times; }
 
   /// The same call for a whole list of candidates (one edge's worth, or many edges' worth: the only cross-candidate
   /// state is the geometric _spanToComplexAssmRegions filter, applied here in list order exactly as consecutive
@@ -511,12 +557,17 @@ struct SVCandidateAssemblyRefiner {
     const size_t n = svs.size();
     out.assign(n, SVCandidateAssemblyData());
     std::vector<Plan> plans(n);
+    _times = RefinerTimes();
+    const double t0 = now();
     for (size_t i = 0; i < n; ++i) plan(svs[i], plans[i], out[i]);
+    _times.plan = now() - t0;
     runSmall(plans, isFindLargeInsertions, out);
     runSpanning(plans, out);
   }
 
 private:
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
   struct Plan {
     enum Kind { NONE, SMALL, SPANNING } kind = NONE;
     SVCandidate       sv;  ///< the candidate as the chosen sub-path sees it (single-region form after a transfer)
@@ -631,6 +682,7 @@ private:
 
   void runSmall(const std::vector<Plan>& plans, const bool isFindLargeInsertions, std::vector<SVCandidateAssemblyData>& out) const
   {
+    const double                    tStart = now();
     std::vector<size_t>             which;
     detail::PackedReads             packed;
     std::vector<const std::string*> refs;
@@ -645,16 +697,21 @@ private:
     }
     if (which.empty()) return;
     _stats.smallLoci += which.size();
+    const double          tPacked = now();
+    _times.pack += tPacked - tStart;
     detail::SmallSvOutput dev;
     detail::smallSvBatch(_opt.refineOpt.smallSVAssembleOpt, _opt.refineOpt.largeSVAlignScores, _opt.refineOpt.largeGapOpenScore, packed,
                          refs, cuts, dev);
+    const double tDevice = now();
+    _times.device += tDevice - tPacked;
 
-    std::vector<std::unique_ptr<LargeInsertionWork>> liWork;
-    for (size_t w = 0; w < which.size(); ++w) {
+    std::vector<std::unique_ptr<LargeInsertionWork>> liWorkByLocus(which.size());
+    std::atomic<uint64_t>                            nContigs(0);
+    detail::parallelFor(which.size(), _hostThreads, [&](const size_t w) {
       const Plan&              p(plans[which[w]]);
       SVCandidateAssemblyData& data(out[which[w]]);
       dev.toContigs(unsigned(w), data.contigs);
-      _stats.contigAlignments += data.contigs.size();
+      nContigs += data.contigs.size();
       const std::string& align1RefStr(data.bp1ref.seq());
       const unsigned     contigCount = unsigned(data.contigs.size());
       data.smallSVAlignments.resize(contigCount);
@@ -755,10 +812,14 @@ private:
         if (planLargeInsertion(p, data, largeInsertionCandidateIndex, *work)) {
           work->planIndex = which[w];
           work->insPos    = insPos;
-          liWork.push_back(std::move(work));
+          liWorkByLocus[w] = std::move(work);
         }
       }
-    }
+    });
+    _stats.contigAlignments += nContigs;
+    std::vector<std::unique_ptr<LargeInsertionWork>> liWork;
+    for (auto& w : liWorkByLocus)
+      if (w) liWork.push_back(std::move(w));
 
     // large-insertion completion: one GlobalAligner batch over every locus that found a left/right pair
     std::vector<detail::AlignJob*> jobs;
@@ -766,6 +827,7 @@ private:
     _stats.largeInsertionAlignments += jobs.size();
     detail::alignBatch(MANTA_ALIGNER_GLOBAL, _opt.refineOpt.largeInsertCompleteAlignScores, 0, jobs);
     for (auto& w : liWork) finishLargeInsertion(plans[w->planIndex], *w, out[w->planIndex]);
+    _times.post += now() - tDevice;
   }
 
   /// processLargeInsertion, first half (:833-935): choose the left/right pair and set up the fake-contig alignment
@@ -861,6 +923,7 @@ private:
 
   void runSpanning(const std::vector<Plan>& plans, std::vector<SVCandidateAssemblyData>& out) const
   {
+    const double               tStart = now();
     std::vector<SpanningLocus> loci;
     detail::PackedReads        packed;
     const unsigned             maxAsm = _opt.refineOpt.spanningAssembleOpt.maxAssemblyCount;
@@ -905,23 +968,28 @@ private:
     }
 
     // assemble -> jump-align (cut references) -> re-align rule -> jump-align (uncut), all on the device
+    const double           tPacked = now();
+    _times.pack += tPacked - tStart;
     detail::SpanningOutput dev;
     detail::spanningBatch(_opt.refineOpt.spanningAssembleOpt, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, packed, refs1,
                           refs2, cuts, dev);
+    const double tDevice = now();
+    _times.device += tDevice - tPacked;
 
-    for (size_t l = 0; l < loci.size(); ++l) {
+    std::atomic<uint64_t> nContigs(0), nRealigned(0);
+    detail::parallelFor(loci.size(), _hostThreads, [&](const size_t l) {
       const SpanningLocus&     sl(loci[l]);
       const Plan&              p(plans[sl.planIndex]);
       SVCandidateAssemblyData& data(out[sl.planIndex]);
       dev.toContigs(unsigned(l), data.contigs);
       const unsigned contigCount = unsigned(data.contigs.size());
-      _stats.contigAlignments += contigCount;
+      nContigs += contigCount;
       data.spanningAlignments.resize(contigCount);
       for (unsigned c = 0; c < contigCount; ++c) {
         JumpAlignmentResult<int>&         alignment(data.spanningAlignments[c]);
         const manta_spanning_alignment_t& da(dev.aligns[dev.loci[l].first_contig + c]);
         if (da.align.status != MANTA_OK) throw GeneralException("manta_amd spanning pipeline: contig alignment failed on the device", da.align.status);
-        _stats.realignedContigs += da.is_uncut ? 1 : 0;
+        nRealigned += da.is_uncut ? 1 : 0;
         alignment.clear();
         alignment.score           = da.align.score;
         alignment.jumpInsertSize  = da.align.jump_insert_size;
@@ -935,7 +1003,7 @@ private:
         data.extendedContigs.push_back(extendedContig);
       }
       const int best = selectJumpContigDNA(data.spanningAlignments, _opt.refineOpt.contigFilterScores);
-      if (best < 0) continue;  // bestAlignmentIndex stays 0, no refined candidate (:1392-1397, 1829)
+      if (best < 0) return;  // bestAlignmentIndex stays 0, no refined candidate (:1392-1397, 1829)
       data.bestAlignmentIndex = unsigned(best);
       data.svs.push_back(p.sv);
       SVCandidate&                    sv(data.svs.back());
@@ -955,7 +1023,10 @@ private:
         getFwdStrandInsertSegment(align, data.contigs[data.bestAlignmentIndex].seq, data.bporient.isBp1Reversed, sv.insertSeq);
       if (_opt.isOutputContig) sv.contigSeq = data.contigs[data.bestAlignmentIndex].seq;
       detail::addCigarToSpanningAlignment(sv);
-    }
+    });
+    _stats.contigAlignments += nContigs;
+    _stats.realignedContigs += nRealigned;
+    _times.post += now() - tDevice;
   }
 
   const GSCOptions              _opt;
@@ -963,6 +1034,8 @@ private:
   RefinerInputSource&           _source;
   mutable GenomeIntervalTracker _spanToComplexAssmRegions;
   mutable Stats                 _stats;
+  mutable RefinerTimes          _times;
+  unsigned                      _hostThreads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
 };
 
 }  // namespace manta_amd

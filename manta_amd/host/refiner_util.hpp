@@ -318,12 +318,21 @@ inline int getQuerySeqMatchCount(const std::string& targetSeq, const std::string
 {
   const unsigned querySize = unsigned(querySeq.size()), targetSize = unsigned(targetSeq.size());
   if (querySize > targetSize) return 0;
-  unsigned hits = 0;
+  // smallest mismatch count that already fails the reference's float test `mismatches/querySize <= maxMismatchRate`
+  // (monotone in the count): a placement is abandoned as soon as it gets there -- same verdicts, far fewer compares
+  unsigned failCount = 0;
+  while (failCount <= querySize && float(failCount) / float(querySize) <= maxMismatchRate) ++failCount;
+  const char* q = querySeq.data();
+  unsigned    hits = 0;
   for (unsigned i = 0; i + querySize <= targetSize; ++i) {
-    unsigned mismatches = 0;
-    for (unsigned j = 0; j < querySize; ++j)
-      if (querySeq[j] != targetSeq[i + j] || querySeq[j] == 'N') ++mismatches;
-    if (float(mismatches) / float(querySize) <= maxMismatchRate) ++hits;
+    const char* t = targetSeq.data() + i;
+    unsigned    mismatches = 0;
+    for (unsigned j = 0; j < querySize; ++j) {
+      if (q[j] != t[j] || q[j] == 'N') {
+        if (++mismatches >= failCount) break;
+      }
+    }
+    if (mismatches < failCount) ++hits;
   }
   return int(hits);
 }

@@ -1,0 +1,116 @@
+// Whole-call throughput of manta_amd::SVCandidateAssemblyRefiner::getCandidateAssemblyDataBatch (host glue included) on
+// config-2 shaped complex candidates and config-5 shaped breakend pairs.  Build: see tools/perf_refiner.sh
+#include <chrono>
+#include <cstdio>
+#include <random>
+
+#include "refiner.hpp"
+
+using namespace manta_amd;
+
+struct Source : RefinerInputSource {
+  std::vector<std::string> chroms;
+  struct Pile {
+    int32_t           tid;
+    pos_t             pos;
+    AssemblyReadInput reads;
+  };
+  std::vector<Pile> piles;  // sorted by (tid,pos) in generation order == query order
+  size_t            cursor = 0;
+  void getReferenceSeq(const std::string& chrom, pos_t b, pos_t e, std::string& seq) override
+  {
+    seq = chroms[std::stoul(chrom)].substr(size_t(b), size_t(e - b + 1));
+  }
+  void getBreakendReads(const SVBreakend& bp, bool, const reference_contig_segment&, AssemblyReadInput& reads) override
+  {
+    if (!reads.empty()) return;
+    for (size_t i = 0; i < piles.size(); ++i) {
+      const Pile& p(piles[(cursor + i) % piles.size()]);
+      if (p.tid == bp.interval.tid && p.pos >= bp.interval.range.begin_pos() && p.pos < bp.interval.range.end_pos()) {
+        reads  = p.reads;
+        cursor = (cursor + i) % piles.size();
+        return;
+      }
+    }
+  }
+};
+
+static std::string randSeq(std::mt19937& g, size_t n)
+{
+  std::string s(n, 'A');
+  for (char& c : s) c = "ACGT"[g() & 3];
+  return s;
+}
+
+int main(int argc, char** argv)
+{
+  const int    n       = argc > 1 ? atoi(argv[1]) : 2000;
+  const bool   span    = argc > 2 && atoi(argv[2]) != 0;
+  std::mt19937 g(12345);
+  Source       src;
+  const size_t spacing = 4000;
+  src.chroms.push_back(randSeq(g, size_t(n) * spacing + 8000));
+  src.chroms.push_back(randSeq(g, size_t(n) * spacing + 8000));
+  std::vector<SVCandidate> svs;
+  for (int i = 0; i < n; ++i) {
+    const pos_t      pos = pos_t(2000 + size_t(i) * spacing);
+    Source::Pile     pile;
+    pile.tid = 0;
+    pile.pos = pos;
+    SVCandidate sv;
+    std::string hap;
+    size_t      junction;
+    if (!span) {
+      const int d = 10 + int(g() % 50);
+      hap         = src.chroms[0].substr(size_t(pos) - 400, 400) + src.chroms[0].substr(size_t(pos) + d, 400);
+      junction    = 400;
+      sv.bp1.state    = SVBreakendState::COMPLEX;
+      sv.bp1.interval = GenomeInterval(0, pos - 20, pos + 20);
+      sv.bp2.state    = SVBreakendState::UNKNOWN;
+      sv.bp2.interval = sv.bp1.interval;
+    } else {
+      const pos_t p2 = pos + 137;
+      hap            = src.chroms[0].substr(size_t(pos) - 450, 450) + src.chroms[1].substr(size_t(p2), 450);
+      junction       = 450;
+      sv.bp1.state    = SVBreakendState::RIGHT_OPEN;
+      sv.bp1.interval = GenomeInterval(0, pos - 30, pos + 30);
+      sv.bp2.state    = SVBreakendState::LEFT_OPEN;
+      sv.bp2.interval = GenomeInterval(1, p2 - 30, p2 + 30);
+    }
+    const int nReads = span ? 200 : 80, readLen = span ? 250 : 150;
+    for (int r = 0; r < nReads; ++r) {
+      const size_t lo = junction - size_t(readLen) + 15, hi = junction - 15;
+      const size_t s  = lo + g() % (hi - lo);
+      std::string  rd = hap.substr(s, size_t(readLen));
+      for (char& c : rd)
+        if (g() % 333 == 0) c = "ACGT"[g() & 3];
+      pile.reads.push_back(rd);
+    }
+    src.piles.push_back(pile);
+    svs.push_back(sv);
+  }
+  bam_header_info header;
+  header.chrom_data.emplace_back("0", unsigned(src.chroms[0].size()));
+  header.chrom_data.emplace_back("1", unsigned(src.chroms[1].size()));
+  GSCOptions opt;
+  if (!span) opt.refineOpt.smallSVAssembleOpt.minWordLength = 31;
+  SVCandidateAssemblyRefiner           refiner(opt, header, src);
+  std::vector<SVCandidateAssemblyData> out;
+  for (int rep = 0; rep < 3; ++rep) {
+    src.cursor    = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    refiner.getCandidateAssemblyDataBatch(svs, false, out);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    size_t       nsv = 0, ncontig = 0;
+    for (const auto& d : out) {
+      nsv += d.svs.size();
+      ncontig += d.contigs.size();
+    }
+    std::printf("%s n=%d  %.3f s  %.0f candidates/s  (refined SVs %zu, contigs %zu)\n", span ? "spanning" : "complex", n, dt, n / dt, nsv,
+                ncontig);
+    const RefinerTimes& t(refiner.times());
+    std::printf("   plan(host, incl. read/ref callbacks) %.3f  pack %.3f  device(upload+run+download) %.3f  post(host glue) %.3f\n", t.plan, t.pack,
+                t.device, t.post);
+  }
+  return 0;
+}
