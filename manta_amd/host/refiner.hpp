@@ -351,15 +351,30 @@ struct PackedReads {
   std::vector<uint64_t> readOff{0};
   std::vector<uint32_t> locusBegin{0};
   std::vector<uint64_t> bitsBound;  ///< per locus
+  std::vector<const AssemblyReadInput*> piles;
   void addLocus(const AssemblyReadInput& reads, const unsigned maxAssemblyCount)
   {
+    uint64_t off = readOff.back();
     for (const std::string& r : reads) {
-      bases.insert(bases.end(), r.begin(), r.end());
-      readOff.push_back(bases.size());
+      off += r.size();
+      readOff.push_back(off);
     }
     locusBegin.push_back(uint32_t(readOff.size() - 1));
+    piles.push_back(&reads);
     const uint64_t W = (reads.size() + 2ull * maxAssemblyCount + 63) / 64;
     bitsBound.push_back(uint64_t(maxAssemblyCount) * 2 * W + 2ull * maxAssemblyCount + 8);
+  }
+  /// flatten the piles into `bases` (the copy is spread over host threads)
+  void finish(const unsigned threads)
+  {
+    bases.resize(readOff.back());
+    parallelFor(piles.size(), threads, [&](const size_t l) {
+      size_t r = locusBegin[l];
+      for (const std::string& rd : *piles[l]) {
+        std::copy(rd.begin(), rd.end(), bases.begin() + readOff[r]);
+        ++r;
+      }
+    });
   }
   uint32_t nLoci() const { return uint32_t(locusBegin.size() - 1); }
 };
@@ -396,25 +411,6 @@ struct AsmOutput {
   }
 };
 
-inline void assembleBatch(const IterativeAssemblerOptions& opt, PackedReads& in, AsmOutput& out)
-{
-  if (in.nLoci() == 0) return;
-  manta_ctx_t*              ctx = threadContext();
-  const manta_asm_options_t o   = toAbi(opt);
-  in.bases.push_back(0);
-  for (unsigned attempt = 0;; ++attempt) {
-    out.reserveFor(in, o.max_assembly_count, attempt);
-    uint64_t  seqUsed = 0, bitsUsed = 0;
-    const int rc = manta_assemble_batch(
-        ctx, &o, in.nLoci(), in.bases.data(), in.readOff.data(), in.locusBegin.data(), out.loci.data(), out.contigs.data(),
-        out.contigs.size(), out.seq.data(), out.seq.size(), &seqUsed, out.bits.data(), out.bits.size(), &bitsUsed);
-    if (rc == MANTA_E_CAPACITY && attempt < 6) continue;
-    in.bases.pop_back();
-    if (rc != MANTA_OK) throw GeneralException(std::string("manta_amd assembler: ") + manta_last_error(ctx), rc);
-    return;
-  }
-}
-
 struct SmallSvOutput : AsmOutput {
   std::vector<manta_smallsv_alignment_t> aligns;
   std::vector<uint32_t>                  cigar;
@@ -422,8 +418,8 @@ struct SmallSvOutput : AsmOutput {
 
 /// the fused device pipeline for a batch of complex loci
 inline void smallSvBatch(
-    const IterativeAssemblerOptions& opt, const AlignmentScores<int>& scores, const int largeIndelScore, PackedReads& in,
-    const std::vector<const std::string*>& refs, const std::vector<manta_ref_cuts_t>& cuts, SmallSvOutput& out)
+    manta_smallsv_t*& b, const IterativeAssemblerOptions& opt, const AlignmentScores<int>& scores, const int largeIndelScore,
+    PackedReads& in, const std::vector<const std::string*>& refs, const std::vector<manta_ref_cuts_t>& cuts, SmallSvOutput& out)
 {
   if (in.nLoci() == 0) return;
   manta_ctx_t*               ctx = threadContext();
@@ -437,14 +433,11 @@ inline void smallSvBatch(
   }
   refBytes.push_back(0);
   in.bases.push_back(0);
-  manta_smallsv_t* b = nullptr;
-  auto             check = [&](const int rc) {
+  auto check = [&](const int rc) {
     if (rc == MANTA_OK) return;
-    const std::string msg(manta_last_error(ctx));
-    if (b) manta_smallsv_destroy(b);
-    throw GeneralException("manta_amd small-SV pipeline: " + msg, rc);
+    throw GeneralException("manta_amd small-SV pipeline: " + std::string(manta_last_error(ctx)), rc);
   };
-  check(manta_smallsv_create(ctx, &o, &sc, largeIndelScore, &b));
+  if (!b) check(manta_smallsv_create(ctx, &o, &sc, largeIndelScore, &b));  // kept by the caller: device buffers are reused
   check(manta_smallsv_upload(b, in.nLoci(), in.bases.data(), in.readOff.data(), in.locusBegin.data(), refBytes.data(), refOff.data(),
                              cuts.data()));
   check(manta_smallsv_run(b));
@@ -460,7 +453,6 @@ inline void smallSvBatch(
     check(rc);
     break;
   }
-  manta_smallsv_destroy(b);
 }
 
 struct SpanningOutput : AsmOutput {
@@ -470,7 +462,7 @@ struct SpanningOutput : AsmOutput {
 
 /// the fused device pipeline for a batch of spanning loci (references already oriented, in alignment order)
 inline void spanningBatch(
-    const IterativeAssemblerOptions& opt, const AlignmentScores<int>& scores, const int jumpScore, PackedReads& in,
+    manta_spanning_t*& b, const IterativeAssemblerOptions& opt, const AlignmentScores<int>& scores, const int jumpScore, PackedReads& in,
     const std::vector<const std::string*>& refs1, const std::vector<const std::string*>& refs2, const std::vector<manta_jump_cuts_t>& cuts,
     SpanningOutput& out)
 {
@@ -489,14 +481,11 @@ inline void spanningBatch(
   ref1Bytes.push_back(0);
   ref2Bytes.push_back(0);
   in.bases.push_back(0);
-  manta_spanning_t* b = nullptr;
-  auto              check = [&](const int rc) {
+  auto check = [&](const int rc) {
     if (rc == MANTA_OK) return;
-    const std::string msg(manta_last_error(ctx));
-    if (b) manta_spanning_destroy(b);
-    throw GeneralException("manta_amd spanning pipeline: " + msg, rc);
+    throw GeneralException("manta_amd spanning pipeline: " + std::string(manta_last_error(ctx)), rc);
   };
-  check(manta_spanning_create(ctx, &o, &sc, jumpScore, &b));
+  if (!b) check(manta_spanning_create(ctx, &o, &sc, jumpScore, &b));  // kept by the caller: device buffers are reused
   check(manta_spanning_upload(b, in.nLoci(), in.bases.data(), in.readOff.data(), in.locusBegin.data(), ref1Bytes.data(), ref1Off.data(),
                               ref2Bytes.data(), ref2Off.data(), cuts.data()));
   check(manta_spanning_run(b));
@@ -509,14 +498,11 @@ inline void spanningBatch(
     const int rc = manta_spanning_download(b, out.loci.data(), out.contigs.data(), out.aligns.data(), out.contigs.size(), out.seq.data(),
                                            out.seq.size(), &su, out.bits.data(), out.bits.size(), &bu, out.cigar.data(), out.cigar.size(), &cu);
     if (rc == MANTA_E_CAPACITY && attempt < 6) continue;
-    if (rc == MANTA_E_EMPTY_SEQ) {  // the reference throws from GlobalJumpAligner::align (GlobalJumpAlignerImpl.hpp:50-58)
-      manta_spanning_destroy(b);
+    if (rc == MANTA_E_EMPTY_SEQ)  // the reference throws from GlobalJumpAligner::align (GlobalJumpAlignerImpl.hpp:50-58)
       throw GeneralException("Unexpected empty reference sequence");
-    }
     check(rc);
     break;
   }
-  manta_spanning_destroy(b);
 }
 
 }  // namespace detail
@@ -527,6 +513,14 @@ struct SVCandidateAssemblyRefiner {
   {
     if (opt.isRNA) throw GeneralException("manta_amd::SVCandidateAssemblyRefiner: the RNA (intron-aware) spanning path is not supported");
   }
+
+  ~SVCandidateAssemblyRefiner()
+  {
+    if (_smallPipe) manta_smallsv_destroy(_smallPipe);
+    if (_spanPipe) manta_spanning_destroy(_spanPipe);
+  }
+  SVCandidateAssemblyRefiner(const SVCandidateAssemblyRefiner&) = delete;
+  SVCandidateAssemblyRefiner& operator=(const SVCandidateAssemblyRefiner&) = delete;
 
   /// SVCandidateAssemblyRefiner.hpp:56-57 -- a batch of one
   void getCandidateAssemblyData(const SVCandidate& sv, const bool isFindLargeInsertions, SVCandidateAssemblyData& assemblyData) const
@@ -696,11 +690,12 @@ private:
       cuts.push_back(manta_ref_cuts_t{plans[i].leadingCut, plans[i].trailingCut, plans[i].maxLeadingCut, plans[i].maxTrailingCut});
     }
     if (which.empty()) return;
+    packed.finish(_hostThreads);
     _stats.smallLoci += which.size();
     const double          tPacked = now();
     _times.pack += tPacked - tStart;
     detail::SmallSvOutput dev;
-    detail::smallSvBatch(_opt.refineOpt.smallSVAssembleOpt, _opt.refineOpt.largeSVAlignScores, _opt.refineOpt.largeGapOpenScore, packed,
+    detail::smallSvBatch(_smallPipe, _opt.refineOpt.smallSVAssembleOpt, _opt.refineOpt.largeSVAlignScores, _opt.refineOpt.largeGapOpenScore, packed,
                          refs, cuts, dev);
     const double tDevice = now();
     _times.device += tDevice - tPacked;
@@ -934,6 +929,7 @@ private:
       packed.addLocus(plans[i].reads, maxAsm);
     }
     if (loci.empty()) return;
+    packed.finish(_hostThreads);
     _stats.spanningLoci += loci.size();
 
     // orientation step of alignJumpContigs (:1533-1550)
@@ -971,7 +967,7 @@ private:
     const double           tPacked = now();
     _times.pack += tPacked - tStart;
     detail::SpanningOutput dev;
-    detail::spanningBatch(_opt.refineOpt.spanningAssembleOpt, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, packed, refs1,
+    detail::spanningBatch(_spanPipe, _opt.refineOpt.spanningAssembleOpt, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, packed, refs1,
                           refs2, cuts, dev);
     const double tDevice = now();
     _times.device += tDevice - tPacked;
@@ -1035,6 +1031,8 @@ private:
   mutable GenomeIntervalTracker _spanToComplexAssmRegions;
   mutable Stats                 _stats;
   mutable RefinerTimes          _times;
+  mutable manta_smallsv_t*      _smallPipe = nullptr;  ///< device pipelines of this refiner (and of the thread that
+  mutable manta_spanning_t*     _spanPipe  = nullptr;  ///< first used it: one ABI context per host thread)
   unsigned                      _hostThreads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
 };
 
