@@ -182,6 +182,10 @@ int manta_smallsv_upload(manta_smallsv_t* b, uint32_t n_loci, const uint8_t* bas
 /* all three stages on the device, synchronous; inputs must have been uploaded */
 int manta_smallsv_run(manta_smallsv_t* b);
 int manta_smallsv_stats(const manta_smallsv_t* b, manta_smallsv_stats_t* stats);
+/* sizes that manta_smallsv_download will need after this run (upper bounds): contig records, sequence bytes, bitset
+ * qwords, cigar u32 words -- so that the caller can size its arenas exactly */
+int manta_smallsv_output_sizes(const manta_smallsv_t* b, uint64_t* contigs, uint64_t* seq_bytes, uint64_t* bits_words,
+                               uint64_t* cigar_words);
 /* HBM -> host.  alignments[i] belongs to contigs[i]. */
 int manta_smallsv_download(manta_smallsv_t* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs,
                            manta_smallsv_alignment_t* alignments, uint64_t contigs_cap, uint8_t* seq_arena,
@@ -221,6 +225,8 @@ int  manta_spanning_upload(manta_spanning_t* b, uint32_t n_loci, const uint8_t* 
 int  manta_spanning_run(manta_spanning_t* b);
 /* align_ms covers both alignment rounds and the re-align decision kernel */
 int  manta_spanning_stats(const manta_spanning_t* b, manta_smallsv_stats_t* stats);
+int  manta_spanning_output_sizes(const manta_spanning_t* b, uint64_t* contigs, uint64_t* seq_bytes, uint64_t* bits_words,
+                                 uint64_t* cigar_words);
 int  manta_spanning_download(manta_spanning_t* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs,
                              manta_spanning_alignment_t* alignments, uint64_t contigs_cap, uint8_t* seq_arena,
                              uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,

@@ -235,6 +235,7 @@ class SmallSvBatch:
         lib.lib.manta_smallsv_destroy.argtypes = [ctypes.c_void_p]
         for f in ("manta_smallsv_run",):
             getattr(lib.lib, f).argtypes = [ctypes.c_void_p]
+        lib.lib.manta_smallsv_output_sizes.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_uint64)] * 4
         lib._check(lib.lib.manta_smallsv_create(lib.ctx, ctypes.byref(o), ctypes.byref(sc), large_indel_score, ctypes.byref(self.h)))
 
     def close(self):
@@ -279,14 +280,13 @@ class SmallSvBatch:
     def download(self, strict=True):
         n = self.n_loci
         res = (AsmLocusResult * n)()
-        ccap = n * self.max_asm + 1
+        sizes = [ctypes.c_uint64(0) for _ in range(4)]
+        self.lib._check(self.lib.lib.manta_smallsv_output_sizes(self.h, *[ctypes.byref(x) for x in sizes]))
+        ccap, seq_cap, bits_cap, cig_cap = [int(x.value) for x in sizes]
         contigs = (AsmContig * ccap)()
         aligns = (SmallSvAlignment * ccap)()
-        seq_cap = 65536 * n + 1024
         seq = np.zeros(seq_cap, dtype=np.uint8)
-        bits_cap = n * (self.max_asm * 2 * 16 + 64) + 64
         bits = np.zeros(bits_cap, dtype=np.uint64)
-        cig_cap = n * self.max_asm * 512 + 4096
         cig = np.zeros(cig_cap, dtype=np.uint32)
         su, bu, cu = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
         rc = self.lib.lib.manta_smallsv_download(
@@ -372,6 +372,7 @@ class SpanningBatch:
         L.manta_spanning_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
         L.manta_spanning_destroy.argtypes = [ctypes.c_void_p]
         L.manta_spanning_run.argtypes = [ctypes.c_void_p]
+        L.manta_spanning_output_sizes.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_uint64)] * 4
         lib._check(L.manta_spanning_create(lib.ctx, ctypes.byref(o), ctypes.byref(sc), jump_score, ctypes.byref(self.h)))
 
     def close(self):
@@ -414,15 +415,13 @@ class SpanningBatch:
     def download(self, strict=True):
         n = self.n_loci
         res = (AsmLocusResult * n)()
-        ccap = n * self.max_asm + 1
+        sizes = [ctypes.c_uint64(0) for _ in range(4)]
+        self.lib._check(self.lib.lib.manta_spanning_output_sizes(self.h, *[ctypes.byref(x) for x in sizes]))
+        ccap, seq_cap, bits_cap, cig_cap = [int(x.value) for x in sizes]
         contigs = (AsmContig * ccap)()
         aligns = (SpanningAlignment * ccap)()
-        total_bases = int(self._keep[1][-1])
-        seq_cap = 4 * total_bases + 65536 * min(n, 64) + 4096 * n
         seq = np.zeros(seq_cap, dtype=np.uint8)
-        bits_cap = int(sum(self.max_asm * 2 * ((int(r) + 2 * self.max_asm + 63) // 64) + 2 * self.max_asm + 8 for r in self.n_reads)) + 64
         bits = np.zeros(bits_cap, dtype=np.uint64)
-        cig_cap = n * self.max_asm * 512 + 4096
         cig = np.zeros(cig_cap, dtype=np.uint32)
         su, bu, cu = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
         rc = self.lib.lib.manta_spanning_download(

@@ -317,6 +317,16 @@ struct AsmStage {
     rt::launch(assemble_kernel, grid, ASM_LDS_BYTES, P);
   }
 
+  /// upper bounds of what fetch() writes into the caller's arenas
+  void outputSizes(uint64_t& nContigs, uint64_t& seqBytes, uint64_t& bitsWords) const
+  {
+    uint64_t hCnt[3];
+    rt::d2h(hCnt, dCnt, sizeof(hCnt));
+    nContigs  = uint64_t(nLoci) * opt.max_assembly_count + 1;
+    seqBytes  = std::min<uint64_t>(hCnt[1], devSeqCap) + 64;
+    bitsWords = std::min<uint64_t>(hCnt[2], devBitsCap) + 64;
+  }
+
   int fetch(
       manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, uint64_t contigs_cap, uint8_t* seq_arena,
       uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used)
@@ -830,6 +840,23 @@ int manta_smallsv_stats(const manta_smallsv_t* b, manta_smallsv_stats_t* stats)
   return MANTA_OK;
 }
 
+int manta_smallsv_output_sizes(const manta_smallsv_t* b, uint64_t* contigs, uint64_t* seq_bytes, uint64_t* bits_words, uint64_t* cigar_words)
+{
+  if (!b || !contigs || !seq_bytes || !bits_words || !cigar_words) return MANTA_E_INVALID_ARG;
+  if (!b->ran) return fail(b->ctx, MANTA_E_INVALID_ARG, "manta_smallsv_output_sizes: run first");
+  try {
+    b->asmStage.outputSizes(*contigs, *seq_bytes, *bits_words);
+    uint32_t hSmall[40];
+    rt::d2h(hSmall, b->dSmall.p, sizeof(hSmall));
+    uint64_t cig = 0;
+    std::memcpy(&cig, hSmall + 34, sizeof(uint64_t));
+    *cigar_words = cig + 64;
+    return MANTA_OK;
+  } catch (const std::exception& e) {
+    return fail(b->ctx, MANTA_E_HIP, e.what());
+  }
+}
+
 int manta_smallsv_download(
     manta_smallsv_t* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_smallsv_alignment_t* alignments,
     uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena,
@@ -1092,6 +1119,23 @@ int manta_spanning_stats(const manta_spanning_t* b, manta_smallsv_stats_t* stats
   if (!b || !stats) return MANTA_E_INVALID_ARG;
   *stats = b->stats;
   return MANTA_OK;
+}
+
+int manta_spanning_output_sizes(const manta_spanning_t* b, uint64_t* contigs, uint64_t* seq_bytes, uint64_t* bits_words, uint64_t* cigar_words)
+{
+  if (!b || !contigs || !seq_bytes || !bits_words || !cigar_words) return MANTA_E_INVALID_ARG;
+  if (!b->ran) return fail(b->ctx, MANTA_E_INVALID_ARG, "manta_spanning_output_sizes: run first");
+  try {
+    b->asmStage.outputSizes(*contigs, *seq_bytes, *bits_words);
+    uint32_t hSmall[72];
+    rt::d2h(hSmall, b->dSmall.p, sizeof(hSmall));
+    uint64_t cig = 0;
+    std::memcpy(&cig, hSmall + 64, sizeof(uint64_t));
+    *cigar_words = cig + 64;
+    return MANTA_OK;
+  } catch (const std::exception& e) {
+    return fail(b->ctx, MANTA_E_HIP, e.what());
+  }
 }
 
 int manta_spanning_download(

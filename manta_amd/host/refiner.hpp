@@ -384,14 +384,12 @@ struct AsmOutput {
   std::vector<manta_asm_contig_t>       contigs;
   std::vector<uint8_t>                  seq;
   std::vector<uint64_t>                 bits;
-  void reserveFor(const PackedReads& in, const unsigned maxAssemblyCount, const unsigned attempt)
+  void sizeTo(const uint32_t nLoci, const uint64_t nContigs, const uint64_t seqBytes, const uint64_t bitsWords)
   {
-    loci.resize(in.nLoci());
-    contigs.resize(size_t(in.nLoci()) * maxAssemblyCount + 1);
-    seq.resize(((in.bases.size() * 4 + size_t(in.nLoci()) * 4096 + 65536)) << attempt);
-    uint64_t b = 64;
-    for (const uint64_t x : in.bitsBound) b += x;
-    bits.resize(b << attempt);
+    loci.resize(nLoci);
+    contigs.resize(nContigs);
+    seq.resize(seqBytes);
+    bits.resize(bitsWords);
   }
   void toContigs(const unsigned locus, Assembly& out) const
   {
@@ -442,17 +440,14 @@ inline void smallSvBatch(
                              cuts.data()));
   check(manta_smallsv_run(b));
   in.bases.pop_back();
-  for (unsigned attempt = 0;; ++attempt) {
-    out.reserveFor(in, o.max_assembly_count, attempt);
-    out.aligns.resize(out.contigs.size());
-    out.cigar.resize((out.contigs.size() * 64 + out.seq.size() / 8 + 4096) << attempt);
-    uint64_t  su = 0, bu = 0, cu = 0;
-    const int rc = manta_smallsv_download(b, out.loci.data(), out.contigs.data(), out.aligns.data(), out.contigs.size(), out.seq.data(),
-                                          out.seq.size(), &su, out.bits.data(), out.bits.size(), &bu, out.cigar.data(), out.cigar.size(), &cu);
-    if (rc == MANTA_E_CAPACITY && attempt < 6) continue;
-    check(rc);
-    break;
-  }
+  uint64_t nc = 0, sb = 0, bw = 0, cw = 0;
+  check(manta_smallsv_output_sizes(b, &nc, &sb, &bw, &cw));
+  out.sizeTo(in.nLoci(), nc, sb, bw);
+  out.aligns.resize(nc);
+  out.cigar.resize(cw);
+  uint64_t su = 0, bu = 0, cu = 0;
+  check(manta_smallsv_download(b, out.loci.data(), out.contigs.data(), out.aligns.data(), out.contigs.size(), out.seq.data(), out.seq.size(),
+                               &su, out.bits.data(), out.bits.size(), &bu, out.cigar.data(), out.cigar.size(), &cu));
 }
 
 struct SpanningOutput : AsmOutput {
@@ -490,19 +485,17 @@ inline void spanningBatch(
                               ref2Bytes.data(), ref2Off.data(), cuts.data()));
   check(manta_spanning_run(b));
   in.bases.pop_back();
-  for (unsigned attempt = 0;; ++attempt) {
-    out.reserveFor(in, o.max_assembly_count, attempt);
-    out.aligns.resize(out.contigs.size());
-    out.cigar.resize((out.contigs.size() * 64 + out.seq.size() / 4 + 4096) << attempt);
-    uint64_t  su = 0, bu = 0, cu = 0;
-    const int rc = manta_spanning_download(b, out.loci.data(), out.contigs.data(), out.aligns.data(), out.contigs.size(), out.seq.data(),
-                                           out.seq.size(), &su, out.bits.data(), out.bits.size(), &bu, out.cigar.data(), out.cigar.size(), &cu);
-    if (rc == MANTA_E_CAPACITY && attempt < 6) continue;
-    if (rc == MANTA_E_EMPTY_SEQ)  // the reference throws from GlobalJumpAligner::align (GlobalJumpAlignerImpl.hpp:50-58)
-      throw GeneralException("Unexpected empty reference sequence");
-    check(rc);
-    break;
-  }
+  uint64_t nc = 0, sb = 0, bw = 0, cw = 0;
+  check(manta_spanning_output_sizes(b, &nc, &sb, &bw, &cw));
+  out.sizeTo(in.nLoci(), nc, sb, bw);
+  out.aligns.resize(nc);
+  out.cigar.resize(cw);
+  uint64_t  su = 0, bu = 0, cu = 0;
+  const int rc = manta_spanning_download(b, out.loci.data(), out.contigs.data(), out.aligns.data(), out.contigs.size(), out.seq.data(),
+                                         out.seq.size(), &su, out.bits.data(), out.bits.size(), &bu, out.cigar.data(), out.cigar.size(), &cu);
+  if (rc == MANTA_E_EMPTY_SEQ)  // the reference throws from GlobalJumpAligner::align (GlobalJumpAlignerImpl.hpp:50-58)
+    throw GeneralException("Unexpected empty reference sequence");
+  check(rc);
 }
 
 }  // namespace detail
