@@ -74,6 +74,8 @@ WV_DEV unsigned atomic_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 WV_DEV unsigned atomic_cas(unsigned* p, unsigned cmp, unsigned v) { return atomicCAS(p, cmp, v); }
 WV_DEV unsigned atomic_or(unsigned* p, unsigned v) { return atomicOr(p, v); }
 WV_DEV unsigned atomic_sub(unsigned* p, unsigned v) { return atomicSub(p, v); }
+WV_DEV unsigned atomic_exch(unsigned* p, unsigned v) { return atomicExch(p, v); }
+WV_DEV unsigned atomic_min(unsigned* p, unsigned v) { return atomicMin(p, v); }
 WV_DEV unsigned long long atomic_or(unsigned long long* p, unsigned long long v) { return atomicOr(p, v); }
 WV_DEV unsigned long long atomic_add(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 /// L1-bypassing load of a word other lanes update with atomics

@@ -182,6 +182,8 @@ inline void sync() { wv_emu::yieldLane("sync"); }
 
 inline unsigned atomic_add(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
 inline unsigned atomic_sub(unsigned* p, unsigned v) { const unsigned o = *p; *p = o - v; return o; }
+inline unsigned atomic_exch(unsigned* p, unsigned v) { const unsigned o = *p; *p = v; return o; }
+inline unsigned atomic_min(unsigned* p, unsigned v) { const unsigned o = *p; if (v < o) *p = v; return o; }
 inline unsigned atomic_cas(unsigned* p, unsigned cmp, unsigned v) { const unsigned o = *p; if (o == cmp) *p = v; return o; }
 inline unsigned atomic_or(unsigned* p, unsigned v) { const unsigned o = *p; *p = o | v; return o; }
 inline unsigned long long atomic_or(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o | v; return o; }
