@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_<tag>/ (written by tools/profile_round.sh on the GPU box) -> profiles/<tag>_*: the bench line, the
+rocprofv3 kernel-stats table, one PMC row per kernel, and profiles/traffic.json (HBM-side bytes per launch that bench.py
+reports as roofline.traffic)."""
+import csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+
+
+def short(name):
+    n = name.replace("manta_dev::", "").replace("void ", "")
+    return n.split("(")[0]
+
+
+line = open(os.path.join(src, "bench_line.json")).read().strip().splitlines()[-1]
+json.loads(line)
+open(os.path.join(dst, tag + "_bench_line.json"), "w").write(line + "\n")
+sp = os.path.join(src, "bench_spanning_line.json")
+if os.path.exists(sp) and os.path.getsize(sp):
+    open(os.path.join(dst, tag + "_bench_spanning_line.json"), "w").write(open(sp).read().strip().splitlines()[-1] + "\n")
+stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    open(os.path.join(dst, tag + "_bench_kernel_stats.csv"), "w").write(open(stats[0]).read())
+per = {}
+for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for f in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = short(row["Kernel_Name"])
+            if "rocclr" in k:
+                continue
+            per.setdefault(k, {}).setdefault(row["Counter_Name"], 0.0)
+            per[k][row["Counter_Name"]] += float(row["Counter_Value"])
+cols = sorted({c for v in per.values() for c in v})
+with open(os.path.join(dst, tag + "_pmc_summary.csv"), "w") as out:
+    out.write("# rocprofv3 --pmc passes over `python bench.py --steps 1 --warmup 0 --no-cpu-baseline` (10k loci, config 2), summed per kernel\n")
+    out.write("# over the launches of that one step.  FETCH_SIZE / WRITE_SIZE are KiB as rocprofv3 reports them (separate passes; see\n")
+    out.write("# MI355X_MICROARCH.md HBM section: FETCH_SIZE can under-count wide coalesced reads by 2x on gfx950; these reads are narrow and\n")
+    out.write("# scattered, so the value is reported raw).\n")
+    out.write("kernel," + ",".join(cols) + "\n")
+    for k in sorted(per):
+        out.write('"%s",' % k + ",".join("%.0f" % per[k].get(c, 0) for c in cols) + "\n")
+traffic = {"loci": 10000, "note": "HBM-side bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB * 1024, rocprofv3 --pmc, separate passes, raw "
+           "(no gfx950 x2 read correction: narrow scattered reads)"}
+agg = {}
+for k, v in per.items():
+    name = "align_kernel<LARGE_INDEL>" if k.startswith("align_kernel<1") else k
+    agg[name] = agg.get(name, 0) + (v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024
+for k, v in agg.items():
+    traffic[k] = int(v)
+json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1))
+print(line[:300])
