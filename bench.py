@@ -220,6 +220,7 @@ def spanning_main(args, torch, dist, rank, local_rank, world):
     from synth import breakend_locus
     sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+    os.environ.setdefault("MANTA_AMD_WS_BUDGET_GB", "12")  # 11 resident batches share the HBM
     lib = Lib(device=local_rank)
     ks = list(range(25, 80, 5))
     per_group = max(1, args.loci // len(ks))

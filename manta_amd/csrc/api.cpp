@@ -251,7 +251,10 @@ struct AsmStage {
     capSlots                   = nextPow2(2ull * capNodes);
     const AsmWsLayout L = asmWorkspaceLayout(capSlots, capNodes, capWords, capReads, maxContigLen, wMax, opt.max_assembly_count);
     stride              = (L.total + 255) & ~uint64_t(255);
-    const size_t wsBudget = std::min<size_t>(rt::freeBytes() / 2, size_t(64) << 30);
+    // per-wave workspaces: at most half of the free HBM, 64 GiB by default (MANTA_AMD_WS_BUDGET_GB lowers it for callers
+    // that keep several batches resident at once)
+    const size_t wsCapGb  = std::getenv("MANTA_AMD_WS_BUDGET_GB") ? size_t(std::max(1, std::atoi(std::getenv("MANTA_AMD_WS_BUDGET_GB")))) : size_t(64);
+    const size_t wsBudget = std::min<size_t>(rt::freeBytes() / 2, wsCapGb << 30);
     const int wavesPerCu  = std::getenv("MANTA_AMD_ASM_WAVES_PER_CU") ? std::atoi(std::getenv("MANTA_AMD_ASM_WAVES_PER_CU")) : 16;
     grid                  = int(std::min<uint64_t>(n_loci, uint64_t(std::max(1, ctx->cuCount * wavesPerCu))));
     grid                  = rt::roundGrid(int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(grid), wsBudget / stride))));
