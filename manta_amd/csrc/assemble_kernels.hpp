@@ -108,7 +108,7 @@ struct AsmParams {
 // per-workgroup workspace carve (host and device agree through asmWorkspaceLayout)
 // --------------------------------------------------------------------------------------------------
 struct AsmWsLayout {
-  uint64_t codes, nmask, rd_cw, rd_mw, rd_len, rd_hasn, slots, slot_id, inst_slot, node_key, node_cnt, node_flag, node_aux, rec, links,
+  uint64_t codes, nmask, rd_cw, rd_mw, rd_len, rd_hasn, slots, node_key, node_cnt, node_flag, node_aux, rec, links,
       frontier, cand_seq, cand_bits, cand_meta, walk_left, walk_right, pseudo_seq, pseudo_len, exact, node_k32, tent, lane_seq,
       lane_bits, lane_meta, lane_vis, total;
 };
@@ -152,9 +152,7 @@ WV_HD AsmWsLayout asmWorkspaceLayout(
   L.rd_mw      = asmPut(o, 4ull * (cap_reads + 1));
   L.rd_len     = asmPut(o, 4ull * (cap_reads + 1));
   L.rd_hasn    = asmPut(o, 4ull * (cap_reads + 1));
-  L.slots      = asmPut(o, 4ull * cap_slots);
-  L.slot_id    = asmPut(o, 4ull * cap_slots);
-  L.inst_slot  = asmPut(o, 4ull * 16 * (cap_words + 2));
+  L.slots      = asmPut(o, 8ull * cap_slots);  // {packed base index of the word's first occurrence, node id} per slot
   L.node_key   = asmPut(o, 4ull * cap_nodes);
   L.node_cnt   = asmPut(o, 4ull * cap_nodes);
   L.node_flag  = asmPut(o, 4ull * cap_nodes);
@@ -213,7 +211,7 @@ struct Assembler {
   uint8_t*         ws;
   AsmWsLayout      L;
   // workspace views
-  uint32_t *codes, *nmask, *rd_cw, *rd_mw, *rd_len, *rd_hasn, *slots, *slot_id, *inst_slot, *node_key, *node_cnt, *node_flag, *node_aux;
+  uint32_t *codes, *nmask, *rd_cw, *rd_mw, *rd_len, *rd_hasn, *slots, *node_key, *node_cnt, *node_flag, *node_aux;
   uint8_t*  rec;        // node records (see asmRecStride)
   unsigned  recStride;
   uint32_t* links;      // succ[4] | pred[4] per node, plain 32-bit ids (cycle test, exact repeat search, wide-set walk)
@@ -245,8 +243,6 @@ struct Assembler {
     rd_len     = reinterpret_cast<uint32_t*>(ws + L.rd_len);
     rd_hasn    = reinterpret_cast<uint32_t*>(ws + L.rd_hasn);
     slots      = reinterpret_cast<uint32_t*>(ws + L.slots);
-    slot_id    = reinterpret_cast<uint32_t*>(ws + L.slot_id);
-    inst_slot  = reinterpret_cast<uint32_t*>(ws + L.inst_slot);
     node_key   = reinterpret_cast<uint32_t*>(ws + L.node_key);
     node_cnt   = reinterpret_cast<uint32_t*>(ws + L.node_cnt);
     node_flag  = reinterpret_cast<uint32_t*>(ws + L.node_flag);
@@ -455,6 +451,9 @@ struct Assembler {
     return false;
   }
 
+  /// one table slot = 8 bytes {pb, node id}: a lookup touches one line
+  WV_DEV uint64_t slotPair(const unsigned sidx) const { return *reinterpret_cast<const uint64_t*>(&slots[2 * size_t(sidx)]); }
+
   /// node id of the k-mer `key`, or ASM_NONE
   template <int KW>
   WV_DEV unsigned lookup(const Key<KW>& key) const
@@ -462,12 +461,42 @@ struct Assembler {
     const unsigned mask = slotMask;
     unsigned       s    = keyHash(key) & mask;
     for (unsigned probe = 0; probe <= mask; ++probe) {
-      const uint32_t cur = slots[s];
+      const uint64_t pr  = slotPair(s);
+      const uint32_t cur = uint32_t(pr);
       if (cur == ASM_NONE) return ASM_NONE;
-      if (keyEq(keyAt<KW>(cur), key)) return slot_id[s];
+      if (keyEq(keyAt<KW>(cur), key)) return uint32_t(pr >> 32);
       s = (s + 1) & mask;
     }
     return ASM_NONE;
+  }
+
+  /// four lookups with their memory round trips overlapped: all slot loads first, then all key fetches; only a
+  /// collision (first probed slot holds another word) falls back to the serial probe loop
+  template <int KW>
+  WV_DEV void lookup4(const Key<KW> (&keys)[4], unsigned (&out)[4]) const
+  {
+    const unsigned mask = slotMask;
+    uint64_t       pr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pr[i] = slotPair(keyHash(keys[i]) & mask);
+    Key<KW> got[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (uint32_t(pr[i]) != ASM_NONE) {
+        got[i] = keyAt<KW>(uint32_t(pr[i]));
+      } else {
+        for (int w = 0; w < KW; ++w) got[i].w[w] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (uint32_t(pr[i]) == ASM_NONE)
+        out[i] = ASM_NONE;
+      else if (keyEq(got[i], keys[i]))
+        out[i] = uint32_t(pr[i] >> 32);
+      else
+        out[i] = lookup<KW>(keys[i]);
+    }
   }
 
   // ------------------------------------------------------------------------------------------------
@@ -568,80 +597,94 @@ struct Assembler {
       inst += (len >= k) ? (len - k + 1) : 0u;
     }
     inst = waveSum(inst);
+    // The table is sized for the DISTINCT words, which is usually a small fraction of the instances (reads overlap):
+    // start at half the instance count and double on overflow (load factor > 0.7), which re-runs the pass.
     unsigned tableSlots = 64;
-    while (tableSlots < ((2 * inst) >> ((P.flags >> 8) & 7u)) && tableSlots < P.cap_slots) tableSlots <<= 1;
-    slotMask = tableSlots - 1;
-    for (unsigned s = lane; s < tableSlots; s += 64) slots[s] = ASM_NONE;
-    wv::sync();
+    while (tableSlots < (inst >> 1) && tableSlots < P.cap_slots) tableSlots <<= 1;
+    bool full = false;
+    while (true) {
+      slotMask = tableSlots - 1;
+      for (unsigned s = lane; s < tableSlots; s += 64) *reinterpret_cast<uint64_t*>(&slots[2 * size_t(s)]) = uint64_t(ASM_NONE);
+      wv::sync();
 
-    // one fused pass over the k-mer instances (assembly/IterativeAssembler.cpp:516-548):
-    //   claim-or-find the word's slot with one atomicCAS; the claimers of this step get dense node ids from a
-    //   ballot prefix and initialise their node; after a wave-local fence every instance ORs its read into the
-    //   word's support set.  Per-read de-dup is implicit (sets).
-    bool           full = false;
-    const unsigned mask = slotMask;
-    nNodes              = 0;
-    for (unsigned rBase = 0; rBase < nReads; rBase += 64) {
-      // read descriptors of up to 64 reads live in lane registers; v_readlane hands them out per read
-      const unsigned rMine = rBase + lane;
-      const unsigned lenV  = (rMine < nReads) ? rd_len[rMine] : 0u;
-      const unsigned cwoV  = (rMine < nReads) ? rd_cw[rMine] : 0u;
-      const unsigned mwoV  = (rMine < nReads) ? rd_mw[rMine] : 0u;
-      const unsigned hasnV = (rMine < nReads) ? rd_hasn[rMine] : 0u;
-      const unsigned rEnd  = (nReads - rBase < 64) ? (nReads - rBase) : 64u;
-      for (unsigned ri = 0; ri < rEnd; ++ri) {
-        const unsigned r   = rBase + ri;
-        const unsigned len = wv::readlane(lenV, int(ri));
-        if (len < k) continue;  // :522
-        const unsigned cwo = wv::readlane(cwoV, int(ri)), mwo = wv::readlane(mwoV, int(ri));
-        const bool     rdHasN = wv::readlane(hasnV, int(ri)) != 0;  // most reads have no 'N': skip the bitmap test
-        const uint64_t bit = uint64_t(1) << (r & 63);
-        for (unsigned j0 = 0; j0 + k <= len; j0 += 64) {
-          const unsigned j    = j0 + lane;
-          const unsigned pb   = cwo * 16 + j;
-          unsigned       slot = ASM_NONE;
-          bool           won  = false;
-          if (j + k <= len && !(rdHasN && windowHasN(mwo, j))) {  // :531
-            const Key<KW> key = keyAt<KW>(pb);
-            unsigned      s   = keyHash(key) & mask;
-            for (unsigned probe = 0; probe <= mask; ++probe) {
-              uint32_t cur = wv::atomic_load(&slots[s]);
-              if (cur == ASM_NONE) {
-                cur = wv::atomic_cas(&slots[s], ASM_NONE, pb);
+      // one fused pass over the k-mer instances (assembly/IterativeAssembler.cpp:516-548):
+      //   claim-or-find the word's slot with one atomicCAS; the claimers of this step get dense node ids from a
+      //   ballot prefix and initialise their node; after a wave-local fence every instance ORs its read into the
+      //   word's support set.  Per-read de-dup is implicit (sets).
+      const unsigned mask     = slotMask;
+      const unsigned maxNodes = (tableSlots < P.cap_slots) ? unsigned((uint64_t(tableSlots) * 7) / 10) : tableSlots;
+      bool           overflow = false;
+      full                    = false;  // a lane can run out of slots while the table overflows; only the final pass counts
+      nNodes                  = 0;
+      for (unsigned rBase = 0; rBase < nReads && !overflow; rBase += 64) {
+        // read descriptors of up to 64 reads live in lane registers; v_readlane hands them out per read
+        const unsigned rMine = rBase + lane;
+        const unsigned lenV  = (rMine < nReads) ? rd_len[rMine] : 0u;
+        const unsigned cwoV  = (rMine < nReads) ? rd_cw[rMine] : 0u;
+        const unsigned mwoV  = (rMine < nReads) ? rd_mw[rMine] : 0u;
+        const unsigned hasnV = (rMine < nReads) ? rd_hasn[rMine] : 0u;
+        const unsigned rEnd  = (nReads - rBase < 64) ? (nReads - rBase) : 64u;
+        for (unsigned ri = 0; ri < rEnd && !overflow; ++ri) {
+          const unsigned r   = rBase + ri;
+          const unsigned len = wv::readlane(lenV, int(ri));
+          if (len < k) continue;  // :522
+          const unsigned cwo = wv::readlane(cwoV, int(ri)), mwo = wv::readlane(mwoV, int(ri));
+          const bool     rdHasN = wv::readlane(hasnV, int(ri)) != 0;  // most reads have no 'N': skip the bitmap test
+          const uint64_t bit = uint64_t(1) << (r & 63);
+          for (unsigned j0 = 0; j0 + k <= len && !overflow; j0 += 64) {
+            const unsigned j    = j0 + lane;
+            const unsigned pb   = cwo * 16 + j;
+            unsigned       slot = ASM_NONE;
+            bool           won  = false;
+            unsigned       foundId = ASM_NONE;
+            if (j + k <= len && !(rdHasN && windowHasN(mwo, j))) {  // :531
+              const Key<KW> key = keyAt<KW>(pb);
+              unsigned      s   = keyHash(key) & mask;
+              for (unsigned probe = 0; probe <= mask; ++probe) {
+                uint32_t cur = wv::atomic_load(&slots[2 * size_t(s)]);
                 if (cur == ASM_NONE) {
+                  cur = wv::atomic_cas(&slots[2 * size_t(s)], ASM_NONE, pb);
+                  if (cur == ASM_NONE) {
+                    slot = s;
+                    won  = true;
+                    break;
+                  }
+                }
+                if (keyEq(keyAt<KW>(cur), key)) {
                   slot = s;
-                  won  = true;
                   break;
                 }
+                s = (s + 1) & mask;
               }
-              if (keyEq(keyAt<KW>(cur), key)) {
-                slot = s;
-                break;
-              }
-              s = (s + 1) & mask;
+              if (slot == ASM_NONE) full = true;
             }
-            if (slot == ASM_NONE) full = true;
+            const uint64_t m  = wv::ballot(won);
+            const unsigned id = nNodes + unsigned(wv::popc(m & ((uint64_t(1) << lane) - 1)));
+            nNodes += unsigned(wv::popc(m));
+            if (nNodes > P.cap_nodes) {
+              status = ASM_E_TABLE_FULL;
+              return;
+            }
+            if (nNodes > maxNodes) {  // uniform: the table is too small for this locus, start over with twice the slots
+              overflow = true;
+              break;
+            }
+            if (won) {
+              slots[2 * size_t(slot) + 1] = id;
+              node_key[id]                = pb;
+              for (unsigned w = 0; w < W; ++w) recSup(id)[w] = 0;
+            }
+            wv::sync();
+            if (slot != ASM_NONE)
+              wv::atomic_or(reinterpret_cast<unsigned long long*>(&recSup(wv::atomic_load(&slots[2 * size_t(slot) + 1]))[r >> 6]), bit);
           }
-          const uint64_t m  = wv::ballot(won);
-          const unsigned id = nNodes + unsigned(wv::popc(m & ((uint64_t(1) << lane) - 1)));
-          nNodes += unsigned(wv::popc(m));
-          if (nNodes > P.cap_nodes) {
-            status = ASM_E_TABLE_FULL;
-            return;
-          }
-          if (won) {
-            slot_id[slot] = id;
-            node_key[id]  = pb;
-            for (unsigned w = 0; w < W; ++w) recSup(id)[w] = 0;
-          }
-          wv::sync();
-          if (slot != ASM_NONE)
-            wv::atomic_or(reinterpret_cast<unsigned long long*>(&recSup(wv::atomic_load(&slot_id[slot]))[r >> 6]), bit);
         }
       }
+      wv::sync();
+      wv::fence_acquire();  // slots / supports were filled by L2 atomics: drop stale L1 lines before plain re-reads
+      if (!overflow) break;
+      tableSlots <<= 1;
     }
-    wv::sync();
-    wv::fence_acquire();  // slots / supports were filled by L2 atomics: drop stale L1 lines before plain re-reads
     if (wv::any(full)) {
       status = ASM_E_TABLE_FULL;
       return;
@@ -661,11 +704,17 @@ struct Assembler {
       bool          selfLoop = false;
       unsigned      indeg    = 0;
       unsigned      sIds[4], pIds[4];
+      {
+        Key<KW> ks[4], kp[4];
+        for (unsigned c = 0; c < 4; ++c) {
+          ks[c] = keyShiftAppend<KW>(key, c);
+          kp[c] = keyShiftPrepend<KW>(key, c);
+        }
+        lookup4<KW>(ks, sIds);
+        lookup4<KW>(kp, pIds);
+      }
       for (unsigned c = 0; c < 4; ++c) {
-        const unsigned s = lookup<KW>(keyShiftAppend<KW>(key, c));
-        const unsigned p = lookup<KW>(keyShiftPrepend<KW>(key, c));
-        sIds[c]          = s;
-        pIds[c]          = p;
+        const unsigned s = sIds[c], p = pIds[c];
         recSucc(nd)[c]   = s;
         recPred(nd)[c]   = p;
         if (s == nd) selfLoop = true;  // homopolymer (:574-577)
