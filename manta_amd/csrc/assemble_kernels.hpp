@@ -42,7 +42,10 @@ static const int      ASM_MAX_KW   = 8;    // k <= 128
 static const unsigned ASM_MAX_W    = 16;   // <= 1024 reads incl. pseudo reads
 static const unsigned ASM_MAX_CAND = 64;   // 2*maxAssemblyCount must not exceed this
 static const unsigned TENT_CAP     = 256;  // tentative-seed list capacity of one speculative round
-static const unsigned ASM_LDS_BYTES = 10240;  // dynamic LDS per wavefront (visited bitmaps of a speculative round)
+#ifndef MANTA_ASM_LDS
+#define MANTA_ASM_LDS 10240
+#endif
+static const unsigned ASM_LDS_BYTES = MANTA_ASM_LDS;  // dynamic LDS per wavefront (visited bitmaps of a speculative round)
 static const unsigned WQ_MAX       = 4;    // lane-private walks hold read sets of up to 4 qwords (<= 256 reads) in registers
 
 struct AsmOptsDev {
@@ -1319,7 +1322,10 @@ struct Assembler {
 
 namespace manta_dev {
 
-WV_KERNEL_OCC(4) void assemble_kernel(const AsmParams P)
+#ifndef MANTA_ASM_OCC
+#define MANTA_ASM_OCC 4
+#endif
+WV_KERNEL_OCC(MANTA_ASM_OCC) void assemble_kernel(const AsmParams P)
 {
   uint8_t* wsBase = P.ws + uint64_t(wv::block()) * P.ws_stride;
   while (true) {
