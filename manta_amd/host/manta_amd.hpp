@@ -17,6 +17,7 @@
 // re-entrant per thread: each host thread owns one lazily created context (GenerateSVCandidates.cpp:232-250).
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <iterator>
 #include <set>
@@ -67,6 +68,7 @@ struct known_pos_range2 {  // blt_util/known_pos_range2.hpp:33-135 (the members 
   pos_t    begin_pos() const { return _begin; }
   pos_t    end_pos() const { return _end; }
   unsigned size() const { return unsigned(_end > _begin ? _end - _begin : 0); }
+  pos_t    center_pos() const { return _begin + pos_t((std::max(size(), 1u) - 1) / 2); }
   bool     is_range_intersect(const known_pos_range2& pr) const { return (pr._end > _begin) && (pr._begin < _end); }
   void     merge_range(const known_pos_range2& kpr)
   {

@@ -43,9 +43,17 @@ inline bool isInnies(const bool isIdx1First, const index_t idx1, const index_t i
 inline bool isOutties(const bool isIdx1First, const index_t idx1, const index_t idx2) { return isInnies(!isIdx1First, idx1, idx2); }
 }  // namespace SVBreakendState
 
-struct SVBreakend {  // manta/SVBreakend.hpp:210-290
+struct SVBreakend {  // manta/SVBreakend.hpp:210-295
+  /// low-resolution evidence counts that the candidate VCF reports (lowresEvidence PAIR / LOCAL_PAIR, :248-250); they are
+  /// produced upstream of the refiner and only carried through it
+  unsigned getPairCount() const { return pairCount; }
+  unsigned getLocalPairCount() const { return localPairCount; }
+  /// :280-291
+  pos_t getLeftSideOfBkptAdjustment() const { return (state == SVBreakendState::LEFT_OPEN) ? -1 : 0; }
+
   SVBreakendState::index_t state = SVBreakendState::UNKNOWN;
   GenomeInterval           interval;
+  unsigned                 pairCount = 0, localPairCount = 0;
 };
 
 /// manta/SVCandidate.hpp:33-190
@@ -53,6 +61,7 @@ struct SVCandidate {
   bool isImprecise() const { return _isImprecise; }
   void setPrecise() { _isImprecise = false; }
   bool isForward() const { return forwardTranscriptStrandReadCount > reverseTranscriptStrandReadCount; }
+  bool isBreakendRangeSameShift() const { return bp1.state != bp2.state; }  // manta/SVCandidate.hpp:124
 
   SVBreakend        bp1, bp2;
   std::string       insertSeq;
@@ -87,6 +96,21 @@ inline SV_TYPE::index_t getSVType(const SVCandidate& sv)  // SVCandidateUtil.cpp
 }
 namespace EXTENDED_SV_TYPE {
 enum index_t { UNKNOWN, INTERTRANSLOC, INTRATRANSLOC, INVERSION, INSERT, DELETE, TANDUP };
+inline bool        isSVTransloc(const index_t idx) { return idx == INTERTRANSLOC || idx == INTRATRANSLOC; }
+inline bool        isSVIndel(const index_t idx) { return idx == INSERT || idx == DELETE; }
+inline bool        isSVInv(const index_t idx) { return idx == INVERSION; }
+inline const char* label(const index_t idx)  // SVCandidateUtil.hpp:109-128
+{
+  switch (idx) {
+  case INTERTRANSLOC:
+  case INTRATRANSLOC:
+  case INVERSION: return "BND";
+  case INSERT: return "INS";
+  case DELETE: return "DEL";
+  case TANDUP: return "DUP:TANDEM";
+  default: return "UNKNOWN";
+  }
+}
 }
 inline EXTENDED_SV_TYPE::index_t getExtendedSVType(const SVCandidate& sv, const bool isForceIntraChromBnd = false)  // :96-136
 {

@@ -334,3 +334,86 @@ REF_EXPORT int ref_get_candidate_assembly_data(const ref_refine_input_t* in, cha
     return emit(std::string("EXCEPTION ") + e.what(), out, cap);
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// candidateSV.vcf records of the refined candidates: the reference's own VcfWriterCandidateSV / VcfWriterSV /
+// JunctionIdGenerator (format/VcfWriter{,Candidate}SV.cpp, manta/JunctionIdGenerator.cpp, unmodified), fed with the
+// SVCandidate objects the refiner above produced.  REF / HOMSEQ come through the same in-memory
+// get_standardized_region_seq double.  The writer insists on a file: records go to a scratch file and are read back.
+// ------------------------------------------------------------------------------------------------------------------
+#include "format/VcfWriterCandidateSV.hpp"
+#include "manta/JunctionIdGenerator.hpp"
+
+#include <cstdio>
+#include <fstream>
+#include <unistd.h>
+
+REF_EXPORT int ref_candidate_vcf_records(const ref_refine_input_t* in, char* out, int cap)
+{
+  try {
+    RefinerLocusInputs locus;
+    for (int i = 0; i < in->n_chrom; ++i) locus.chroms.emplace_back(in->chrom_seq[i]);
+    for (int i = 0; i < in->n_reads; ++i) locus.complexReads.emplace_back(in->reads[i]);
+    locus.spanningReads = locus.complexReads;
+    g_locus             = &locus;
+
+    bam_header_info header;
+    for (int i = 0; i < in->n_chrom; ++i) header.chrom_data.emplace_back(std::to_string(i).c_str(), unsigned(locus.chroms[i].size()));
+    GSCOptions options;
+    auto setWords = [](IterativeAssemblerOptions& o, const int32_t* w) {
+      if (w[0] > 0) o.minWordLength = w[0];
+      if (w[1] > 0) o.maxWordLength = w[1];
+      if (w[2] > 0) o.wordStepSize = w[2];
+    };
+    setWords(options.refineOpt.smallSVAssembleOpt, in->small_word);
+    setWords(options.refineOpt.spanningAssembleOpt, in->spanning_word);
+    AllSampleReadCounts counts;
+    auto                edgeTrackerPtr(std::make_shared<EdgeRuntimeTracker>(std::string("/dev/null")));
+    const SVCandidateAssemblyRefiner refiner(options, header, counts, edgeTrackerPtr);
+
+    SVCandidate sv;
+    sv.bp1.state    = static_cast<SVBreakendState::index_t>(in->bp_state[0]);
+    sv.bp1.interval = GenomeInterval(in->bp_tid[0], in->bp_begin[0], in->bp_end[0]);
+    sv.bp2.state    = static_cast<SVBreakendState::index_t>(in->bp_state[1]);
+    sv.bp2.interval = GenomeInterval(in->bp_tid[1], in->bp_begin[1], in->bp_end[1]);
+    // low-resolution evidence travels through the refiner into the PAIR_COUNT tags of the candidate records
+    sv.bp1.lowresEvidence.add(SVEvidenceType::PAIR, 7);
+    sv.bp1.lowresEvidence.add(SVEvidenceType::LOCAL_PAIR, 3);
+    sv.bp2.lowresEvidence.add(SVEvidenceType::PAIR, 7);
+    sv.bp2.lowresEvidence.add(SVEvidenceType::LOCAL_PAIR, 5);
+    sv.candidateIndex = 4;
+
+    SVCandidateAssemblyData data;
+    refiner.getCandidateAssemblyData(sv, in->is_find_large_insertions != 0, data);
+
+    char tmpl[] = "/tmp/manta_ref_vcf_XXXXXX";
+    const int fd = mkstemp(tmpl);
+    if (fd >= 0) close(fd);
+    const std::string vcfName(tmpl);
+    {
+      const bool                 isOutputContig(false);
+      const std::string          refName("in-memory");
+      const VcfWriterCandidateSV writer(refName, header, vcfName, isOutputContig);
+      JunctionIdGenerator        idgen;
+      SVCandidateSetData         svData;
+      EdgeInfo                   edge;
+      edge.locusIndex = 11;
+      edge.nodeIndex1 = 2;
+      edge.nodeIndex2 = 3;
+      for (const SVCandidate& refined : data.svs) {
+        SVId svId;
+        idgen.getId(edge, refined, false, svId);
+        writer.writeSV(svData, data, refined, svId);
+      }
+    }
+    std::ifstream      ifs(vcfName);
+    std::ostringstream text;
+    text << ifs.rdbuf();
+    std::remove(vcfName.c_str());
+    g_locus = nullptr;
+    return emit(text.str(), out, cap);
+  } catch (const std::exception& e) {
+    g_locus = nullptr;
+    return emit(std::string("EXCEPTION ") + e.what(), out, cap);
+  }
+}

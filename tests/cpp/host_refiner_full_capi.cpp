@@ -5,7 +5,7 @@
 #include <cstring>
 #include <sstream>
 
-#include "refiner.hpp"
+#include "vcf_candidate.hpp"
 
 using namespace manta_amd;
 #define MINE_EXPORT extern "C" __attribute__((visibility("default")))
@@ -188,6 +188,50 @@ MINE_EXPORT void mine_last_stats(uint64_t* out)
   out[2] = g_stats.contigAlignments;
   out[3] = g_stats.realignedContigs;
   out[4] = g_stats.largeInsertionAlignments;
+}
+
+/// candidateSV.vcf records of the refined candidates of one call (same fixed evidence counts / edge ids as the reference driver)
+MINE_EXPORT int mine_candidate_vcf_records(const ref_refine_input_t* in, char* out, int cap)
+{
+  try {
+    MemorySource    source;
+    bam_header_info header;
+    for (int i = 0; i < in->n_chrom; ++i) {
+      source.chroms.emplace_back(in->chrom_seq[i]);
+      header.chrom_data.emplace_back(std::to_string(i).c_str(), unsigned(source.chroms.back().size()));
+    }
+    GSCOptions options;
+    setOptions(*in, options);
+    MemorySource::Pile pile;
+    pile.tid = in->bp_tid[0];
+    pile.pos = in->bp_begin[0];
+    for (int i = 0; i < in->n_reads; ++i) pile.reads.emplace_back(in->reads[i]);
+    source.piles.push_back(pile);
+    SVCandidate sv(makeSV(*in));
+    sv.bp1.pairCount      = 7;
+    sv.bp1.localPairCount = 3;
+    sv.bp2.pairCount      = 7;
+    sv.bp2.localPairCount = 5;
+    sv.candidateIndex     = 4;
+    const SVCandidateAssemblyRefiner refiner(options, header, source);
+    SVCandidateAssemblyData          data;
+    refiner.getCandidateAssemblyData(sv, in->is_find_large_insertions != 0, data);
+    std::ostringstream         vcf;
+    const VcfWriterCandidateSV writer(source, header, vcf);
+    const JunctionIdGenerator  idgen;
+    EdgeInfo                   edge;
+    edge.locusIndex = 11;
+    edge.nodeIndex1 = 2;
+    edge.nodeIndex2 = 3;
+    for (const SVCandidate& refined : data.svs) {
+      SVId svId;
+      idgen.getId(edge, refined, false, svId);
+      writer.writeSV(refined, svId);
+    }
+    return emit(vcf.str(), out, cap);
+  } catch (const std::exception& e) {
+    return emit(std::string("EXCEPTION ") + e.what(), out, cap);
+  }
 }
 
 MINE_EXPORT int mine_get_candidate_assembly_data(const ref_refine_input_t* in, char* out, int cap)

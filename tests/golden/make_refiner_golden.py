@@ -29,3 +29,12 @@ json.dump({"seed": 4242, "names": [n for n, _ in cases], "source": "reference SV
            "(unmodified) via oracle/ref_refiner_driver.cpp", "texts": [rl.run(c) for _, c in cases]},
           open(os.path.join(ROOT, "tests", "golden", "refiner_calls.json"), "w"), indent=0)
 print("wrote", len(cases), "refiner calls")
+
+# ---- candidateSV.vcf records (tests/test_vcf_candidate.py) ----
+from test_vcf_candidate import vcf_cases  # noqa: E402
+
+vc = vcf_cases(4242)
+json.dump({"seed": 4242, "names": [n for n, _ in vc], "source": "reference VcfWriterCandidateSV/VcfWriterSV/JunctionIdGenerator (unmodified) over the "
+           "reference refiner's output, oracle/ref_refiner_driver.cpp: ref_candidate_vcf_records", "records": [rl.vcf(c) for _, c in vc]},
+          open(os.path.join(ROOT, "tests", "golden", "candidate_vcf_records.json"), "w"), indent=0)
+print("wrote", sum(r.count("\n") for r in [rl.vcf(c) for _, c in vc]), "vcf records")

@@ -38,6 +38,7 @@ def fill(inp, case, keep):
 class RefinerLib:
     def __init__(self, path, prefix):
         self.lib = ctypes.CDLL(path)
+        self.prefix = prefix
         self.single = getattr(self.lib, prefix + "_get_candidate_assembly_data")
         self.single.restype = ctypes.c_int
         self.multi = getattr(self.lib, prefix + "_get_candidate_assembly_data_multi", None)
@@ -52,6 +53,14 @@ class RefinerLib:
         fill(inp, case, keep)
         buf = ctypes.create_string_buffer(1 << 22)
         self.single(ctypes.byref(inp), buf, len(buf))
+        return buf.value.decode()
+
+    def vcf(self, case):
+        """candidateSV.vcf records of the refined candidates of one call"""
+        keep, inp = [], RefineInput()
+        fill(inp, case, keep)
+        buf = ctypes.create_string_buffer(1 << 22)
+        getattr(self.lib, self.prefix + "_candidate_vcf_records")(ctypes.byref(inp), buf, len(buf))
         return buf.value.decode()
 
     def run_multi(self, cases, batched):

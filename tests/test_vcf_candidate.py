@@ -1,0 +1,57 @@
+"""candidateSV.vcf records: manta_amd/host/vcf_candidate.hpp (record formation over the refiner's output) against the
+reference's own VcfWriterCandidateSV + VcfWriterSV + JunctionIdGenerator, compiled unmodified and fed by the reference's own
+refiner run in memory (oracle/ref_refiner_driver.cpp: ref_candidate_vcf_records).  Byte comparison of whole records:
+CHROM POS ID REF ALT QUAL FILTER INFO (END/SVTYPE/SVLEN/CIGAR/CIPOS/CIEND/HOMLEN/HOMSEQ/SVINSLEN/SVINSSEQ/LEFT_SVINSSEQ/...)."""
+import json
+import os
+import random
+
+import pytest
+
+from refiner_loci import spanning_case
+from test_refiner import GOLDEN, mine_emu, mine_gpu, ref, scenario_cases  # noqa: F401  (fixtures)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN_VCF = os.path.join(ROOT, "tests", "golden", "candidate_vcf_records.json")
+
+
+def vcf_cases(seed):
+    rng = random.Random(seed + 5)
+    extra = [("tandem-dup", spanning_case(rng, "LR", same_chrom=True)),          # outward-facing breakends on one chromosome
+             ("tandem-dup-ins", spanning_case(rng, "LR", same_chrom=True, ins_len=7)),
+             ("large-del", spanning_case(rng, "RL", same_chrom=True)),            # > 1000 bp: symbolic <DEL> with CIEND
+             ("large-del-ins", spanning_case(rng, "RL", same_chrom=True, ins_len=9, homology=0)),
+             ("inversion-hom", spanning_case(rng, "RR", same_chrom=True, homology=3)),
+             ("inversion-ins-LL", spanning_case(rng, "LL", same_chrom=True, ins_len=6))]
+    return scenario_cases(seed) + extra
+
+
+def test_golden_records(mine_emu):
+    g = json.load(open(GOLDEN_VCF))
+    cases = vcf_cases(g["seed"])
+    assert [n for n, _ in cases] == g["names"]
+    n_records = 0
+    for (name, c), want in zip(cases, g["records"]):
+        assert mine_emu.vcf(c) == want, name
+        n_records += want.count("\n")
+    assert n_records > 40
+
+
+def test_records_against_reference_writer(mine_emu, ref):
+    kinds = set()
+    for seed in (31, 32):
+        for name, c in vcf_cases(seed):
+            want = ref.vcf(c)
+            assert not want.startswith("EXCEPTION"), (name, want)
+            assert mine_emu.vcf(c) == want, name
+            for line in want.splitlines():
+                kinds.add(line.split("\t")[2].split(":")[0] + ("sym" if "<" in line.split("\t")[4] else ""))
+    # small and symbolic deletions / insertions, breakends, tandem duplications all occur
+    assert {"MantaDEL", "MantaINS", "MantaBND", "MantaDELsym", "MantaINSsym", "MantaDUPsym"} <= kinds, kinds
+
+
+@pytest.mark.gpu
+def test_records_on_gpu(mine_gpu):
+    g = json.load(open(GOLDEN_VCF))
+    for (name, c), want in zip(vcf_cases(g["seed"]), g["records"]):
+        assert mine_gpu.vcf(c) == want, name
