@@ -316,7 +316,6 @@ struct AsmStage {
     P.growth_buckets = dGrowth + ctx->growthSize.size();
     P.n_growth       = uint32_t(ctx->growthSize.size());
     P.flags          = std::getenv("MANTA_AMD_SERIAL_WALK") ? ASM_FLAG_SERIAL_WALK : 0u;
-    if (std::getenv("MANTA_AMD_TABLE_SHIFT")) P.flags |= (unsigned(std::atoi(std::getenv("MANTA_AMD_TABLE_SHIFT"))) & 7u) << 8;  // experiment
     rt::launch(assemble_kernel, grid, ASM_LDS_BYTES, P);
   }
 

@@ -10,10 +10,11 @@
 //                                                             -> one lane per node
 //   3. libstdc++ node order after those insertions (front-of-bucket insertion, whole-list re-insertion on
 //      every rehash, bucket growth schedule recorded by the host from the live library), applied twice
-//      because `wordIndices` is filled by iterating `wordCount` (:631-633)      -> lane 0, serial
-//   4. the DFS itself (:555-625), recursion unrolled, successors in alphabet order -> lane 0, serial
-// Steps 3-4 are inherently sequential in the reference as well; they only run for loci whose k-mer graph has
-// a cycle (tandem repeats), which the wave-parallel Kahn peel in assemble_kernels.hpp detects.
+//      because `wordIndices` is filled by iterating `wordCount` (:631-633)      -> a sort per rehash stage, wave-parallel
+//   4. the DFS itself (:555-625), successors in alphabet order -> runs of single-successor nodes are discovered and
+//      unwound by the whole wave, lane 0 keeps the Tarjan bookkeeping of the junction nodes
+// This only runs for loci whose k-mer graph has a cycle (tandem repeats), which the wave-parallel Kahn peel in
+// assemble_kernels.hpp detects.
 // The same construction is restated on the CPU in oracle/manta_oracle.cpp (unorderedMapOrder / repeatNodes)
 // and checked there against the real std::unordered_map.
 #pragma once
@@ -58,68 +59,7 @@ WV_DEV uint64_t libstdcxxStringHash(const uint32_t* codes, const unsigned pb, co
   return hash;
 }
 
-/// serial (one lane) emulation of libstdc++'s node order: seqIn[0..n) = keys (node ids) in insertion order,
-/// seqOut[0..n) = the same ids in iteration order
-WV_DEV void unorderedOrderSerial(
-    const AsmParams& P, const uint64_t* h, const uint32_t* seqIn, uint32_t* seqOut, uint32_t* next, uint32_t* before,
-    uint32_t* tmp, const unsigned n)
-{
-  const uint32_t NIL = 0xffffffffu, EMPTY = 0xfffffffeu, HEAD = 0xfffffffdu;
-  unsigned       nb = 1;
-  before[0]         = EMPTY;
-  uint32_t head     = NIL;
-  unsigned schedPos = 0;
-  for (unsigned i = 0; i < n; ++i) {
-    if (schedPos < P.n_growth && P.growth_size[schedPos] == i) {
-      // rehash: re-insert every node in current list order (bits/hashtable.h _M_rehash_aux)
-      nb = P.growth_buckets[schedPos];
-      ++schedPos;
-      unsigned m = 0;
-      for (uint32_t p = head; p != NIL; p = next[p]) tmp[m++] = p;
-      for (unsigned b = 0; b < nb; ++b) before[b] = EMPTY;
-      head = NIL;
-      for (unsigned j = 0; j < m; ++j) {
-        const uint32_t node = tmp[j];
-        const unsigned b    = unsigned(h[node] % nb);
-        if (before[b] != EMPTY) {
-          if (before[b] == HEAD) {
-            next[node] = head;
-            head       = node;
-          } else {
-            next[node]       = next[before[b]];
-            next[before[b]] = node;
-          }
-        } else {
-          next[node] = head;
-          head       = node;
-          if (next[node] != NIL) before[unsigned(h[next[node]] % nb)] = node;
-          before[b] = HEAD;
-        }
-      }
-    }
-    const uint32_t node = seqIn[i];
-    const unsigned b    = unsigned(h[node] % nb);
-    if (before[b] != EMPTY) {  // bits/hashtable.h _M_insert_bucket_begin
-      if (before[b] == HEAD) {
-        next[node] = head;
-        head       = node;
-      } else {
-        next[node]       = next[before[b]];
-        next[before[b]] = node;
-      }
-    } else {
-      next[node] = head;
-      head       = node;
-      if (next[node] != NIL) before[unsigned(h[next[node]] % nb)] = node;
-      before[b] = HEAD;
-    }
-  }
-  unsigned m = 0;
-  for (uint32_t p = head; p != NIL; p = next[p]) seqOut[m++] = p;
-}
-
-
-/// Wave-parallel form of the same order.  libstdc++'s insertion rule (front of the bucket's run if the bucket is
+/// libstdc++'s node order after inserting `ins` (iteration order of the unordered_map).  The insertion rule (front of the bucket's run if the bucket is
 /// non-empty, else front of the whole list) makes the iteration order after inserting a sequence S into `nb` buckets a
 /// pure sort: buckets by the time of their FIRST element, latest first; inside a bucket by time, latest first.  A rehash
 /// (bits/hashtable.h _M_rehash_aux, unique keys) re-inserts the current list in list order under the new bucket count,
