@@ -607,7 +607,7 @@ struct Assembler {
     bool full = false;
     while (true) {
       slotMask = tableSlots - 1;
-      for (unsigned s = lane; s < tableSlots; s += 64) *reinterpret_cast<uint64_t*>(&slots[2 * size_t(s)]) = uint64_t(ASM_NONE);
+      for (unsigned s = lane; s < tableSlots; s += 64) *reinterpret_cast<uint64_t*>(&slots[2 * size_t(s)]) = ~uint64_t(0);  // {no word, no id}
       wv::sync();
 
       // one fused pass over the k-mer instances (assembly/IterativeAssembler.cpp:516-548):
@@ -644,9 +644,13 @@ struct Assembler {
               const Key<KW> key = keyAt<KW>(pb);
               unsigned      s   = keyHash(key) & mask;
               for (unsigned probe = 0; probe <= mask; ++probe) {
-                uint32_t cur = wv::atomic_load(&slots[2 * size_t(s)]);
+                // one 8-byte load brings the word AND (for words claimed in an earlier step) its node id
+                const uint64_t pr  = wv::atomic_load(reinterpret_cast<const unsigned long long*>(&slots[2 * size_t(s)]));
+                uint32_t       cur = uint32_t(pr);
+                foundId            = uint32_t(pr >> 32);
                 if (cur == ASM_NONE) {
-                  cur = wv::atomic_cas(&slots[2 * size_t(s)], ASM_NONE, pb);
+                  cur     = wv::atomic_cas(&slots[2 * size_t(s)], ASM_NONE, pb);
+                  foundId = ASM_NONE;  // claimed just now (by this lane or a neighbour): the id is not written yet
                   if (cur == ASM_NONE) {
                     slot = s;
                     won  = true;
@@ -672,14 +676,17 @@ struct Assembler {
               overflow = true;
               break;
             }
-            if (won) {
-              slots[2 * size_t(slot) + 1] = id;
-              node_key[id]                = pb;
-              for (unsigned w = 0; w < W; ++w) recSup(id)[w] = 0;
+            unsigned myId = won ? id : foundId;
+            if (m) {  // some lane created a word in this step: publish the new nodes before anybody ORs into them
+              if (won) {
+                slots[2 * size_t(slot) + 1] = id;
+                node_key[id]                = pb;
+                for (unsigned w = 0; w < W; ++w) recSup(id)[w] = 0;
+              }
+              wv::sync();
+              if (slot != ASM_NONE && myId == ASM_NONE) myId = wv::atomic_load(&slots[2 * size_t(slot) + 1]);
             }
-            wv::sync();
-            if (slot != ASM_NONE)
-              wv::atomic_or(reinterpret_cast<unsigned long long*>(&recSup(wv::atomic_load(&slots[2 * size_t(slot) + 1]))[r >> 6]), bit);
+            if (slot != ASM_NONE) wv::atomic_or(reinterpret_cast<unsigned long long*>(&recSup(myId)[r >> 6]), bit);
           }
         }
       }

@@ -80,6 +80,7 @@ WV_DEV unsigned long long atomic_or(unsigned long long* p, unsigned long long v)
 WV_DEV unsigned long long atomic_add(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 /// L1-bypassing load of a word other lanes update with atomics
 WV_DEV unsigned atomic_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WV_DEV unsigned long long atomic_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 /// drop this CU's (possibly stale) L1 lines: needed before plain re-reads of memory that was updated by L2 atomics
 WV_DEV void fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
