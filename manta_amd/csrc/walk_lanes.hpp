@@ -55,32 +55,100 @@ WV_DEV unsigned Assembler::selectTentative(const unsigned T)
   if (U == 0) return 0;
   unsigned cStar = 1, pStar = 0xffffffffu;
   if (U > T) {
+    // Both thresholds come from histograms in LDS (one pass over the compacted arrays each) instead of binary searches
+    // that re-read the arrays once per probe.
+    uint32_t*      hist = reinterpret_cast<uint32_t*>(wv::lds(ASM_LDS_BYTES));
     const unsigned cmax = waveMax(myMax);
-    unsigned       lo = 1, hi = cmax;  // largest c with #{cnt >= c} >= T
-    while (lo < hi) {
-      const unsigned mid = lo + (hi - lo + 1) / 2;
-      unsigned       n   = 0;
-      for (unsigned i = lane; i < U; i += 64) n += (uCnt[i] >= mid) ? 1u : 0u;
-      if (waveSum(n) >= T)
-        lo = mid;
-      else
-        hi = mid - 1;
+    // ---- count level: largest c with #{cnt >= c} >= T.  Counts above HBINS-1 share the top bin (they are all taken
+    // when the cut falls below it; if the cut falls inside the top bin the binary search below resolves it). ----
+    static const unsigned HBINS = 1024;
+    const unsigned        nb    = (cmax + 1 < HBINS) ? (cmax + 1) : HBINS;
+    for (unsigned i = lane; i < nb; i += 64) hist[i] = 0;
+    wv::sync();
+    for (unsigned i = lane; i < U; i += 64) {
+      const unsigned c = uCnt[i];
+      wv::atomic_add(&hist[(c < nb) ? c : (nb - 1)], 1u);
     }
-    cStar = lo;
+    wv::sync();
+    {
+      // walk the bins from the top in chunks of 64, lane 0 = highest bin of the chunk
+      unsigned carry = 0, found = 0;
+      for (unsigned top = ((nb + 63) / 64) * 64; top > 0 && !found; top -= 64) {
+        const unsigned bin = top - 1 - lane;
+        const unsigned h   = (bin < nb) ? hist[bin] : 0u;
+        unsigned       inc = h;
+        for (int off = 1; off < 64; off <<= 1) {
+          const unsigned o = wv::shfl(inc, int(lane) - off);
+          if (int(lane) >= off) inc += o;
+        }
+        const uint64_t reach = wv::ballot(carry + inc >= T && bin < nb);
+        if (reach) {
+          cStar = top - 1 - unsigned(wv::ctz(reach));
+          found = 1;
+        }
+        carry += wv::shfl(inc, 63);
+      }
+      if (!found) cStar = 1;
+    }
+    wv::sync();
+    if (cStar >= nb - 1 && cmax + 1 > HBINS) {  // the cut lies among the very large counts: exact search there (rare)
+      unsigned lo = nb - 1, hi = cmax;
+      while (lo < hi) {
+        const unsigned mid = lo + (hi - lo + 1) / 2;
+        unsigned       n   = 0;
+        for (unsigned i = lane; i < U; i += 64) n += (uCnt[i] >= mid) ? 1u : 0u;
+        if (waveSum(n) >= T)
+          lo = mid;
+        else
+          hi = mid - 1;
+      }
+      cStar = lo;
+    }
     unsigned above = 0;
     for (unsigned i = lane; i < U; i += 64) above += (uCnt[i] > cStar) ? 1u : 0u;
-    const unsigned need = T - waveSum(above);  // >= 1 words wanted from the tie level
-    unsigned       plo = 0, phi = 0xffffffffu;  // smallest prefix p with #{cnt == cStar, k32 <= p} >= need
-    while (plo < phi) {
-      const unsigned mid = plo + (phi - plo) / 2;
-      unsigned       n   = 0;
-      for (unsigned i = lane; i < U; i += 64) n += (uCnt[i] == cStar && uK32[i] <= mid) ? 1u : 0u;
-      if (waveSum(n) >= need)
-        phi = mid;
-      else
-        plo = mid + 1;
+    unsigned need = T - waveSum(above);  // >= 1 words wanted from the tie level
+    // ---- tie level: smallest prefix p with #{cnt == cStar, k32 <= p} >= need, by radix select (8 bits per pass) ----
+    unsigned prefix = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      for (unsigned i = lane; i < 256; i += 64) hist[i] = 0;
+      wv::sync();
+      for (unsigned i = lane; i < U; i += 64) {
+        if (uCnt[i] != cStar) continue;
+        const unsigned p = uK32[i];
+        if (shift < 24 && (p >> (shift + 8)) != (prefix >> (shift + 8))) continue;
+        wv::atomic_add(&hist[(p >> shift) & 255u], 1u);
+      }
+      wv::sync();
+      // lane l owns bins 4l .. 4l+3
+      const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+      const unsigned mine = h0 + h1 + h2 + h3;
+      unsigned       inc  = mine;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = wv::shfl(inc, int(lane) - off);
+        if (int(lane) >= off) inc += o;
+      }
+      const uint64_t reach = wv::ballot(inc >= need);
+      const int      ln    = wv::ctz(reach);  // never empty: the level holds at least `need` words
+      const unsigned before = wv::shfl(inc - mine, ln);
+      const unsigned q0 = wv::shfl(h0, ln), q1 = wv::shfl(h1, ln), q2 = wv::shfl(h2, ln);
+      unsigned       digit = 4u * unsigned(ln), acc = before;
+      if (acc + q0 < need) {
+        acc += q0;
+        digit++;
+        if (acc + q1 < need) {
+          acc += q1;
+          digit++;
+          if (acc + q2 < need) {
+            acc += q2;
+            digit++;
+          }
+        }
+      }
+      prefix |= digit << shift;
+      need -= acc;
+      wv::sync();
     }
-    pStar = plo;
+    pStar = prefix;
   }
   // gather (every word outside this list sorts after every word inside it)
   unsigned total = 0;
