@@ -770,14 +770,20 @@ struct Assembler {
       for (unsigned h = 0; h < 2; ++h) {
         const unsigned nd = w * 2 + h;
         if (nd >= nNodes) continue;
-        unsigned od = 0;
+        unsigned od = 0, only = ASM_NONE;
         for (unsigned c = 0; c < 4; ++c) {
           const unsigned s = recSucc(nd)[c];
-          if (s != ASM_NONE && s != nd) od++;
+          if (s != ASM_NONE && s != nd) {
+            od++;
+            only = s;
+          }
         }
         const unsigned id  = node_aux[nd];
         const bool     src = (id == 0 || od == 0);
-        v |= (id | (od << 4) | (src ? 0x100u : 0u)) << (16 * h);
+        // "simple edge" nd -> nd+1: the only way out of nd and the only way into nd+1 (node ids follow read order, so
+        // the unbranched stretches of the graph are mostly runs of consecutive ids)
+        const bool simple = (od == 1 && only == nd + 1 && nd + 1 < nNodes && node_aux[nd + 1] == 1);
+        v |= (id | (od << 4) | (src ? 0x100u : 0u) | (simple ? 0x200u : 0u)) << (16 * h);
         if (src) cur[wv::atomic_add(&cnt[0], 1u)] = nd;
       }
       st[w] = v;
@@ -810,6 +816,53 @@ struct Assembler {
         }
       }
       wv::sync();
+      // Stretch peel: a new source (sink) at the head (tail) of a run of simple edges drags the whole run with it, one
+      // node per round.  When the next frontier is small -- the steady state: the two ends of the main path -- take such
+      // runs 64 nodes at a time: everything strictly inside the run has no other neighbour, so it leaves silently; the
+      // node at the far end is marked and queued, and the regular round updates ITS neighbours.
+      {
+        const unsigned nNext = wv::first(wv::atomic_load(&cnt[which ^ 1]));
+        if (nNext > 0 && nNext <= 8) {
+          auto stateOf = [&](const unsigned n) { return (wv::atomic_load(&st[n >> 1]) >> (16 * (n & 1))) & 0xffffu; };
+          for (unsigned qi = 0; qi < nNext; ++qi) {
+            const unsigned f  = wv::first(nxt[qi]);
+            const unsigned sf = wv::first(stateOf(f));
+            for (int dir = 0; dir < 2; ++dir) {
+              if (dir == 0 ? ((sf & 0xfu) != 0) : ((sf & 0xf0u) != 0)) continue;  // forward from a source, backward from a sink
+              unsigned c = f, total = 0;
+              while (true) {
+                // lane l looks at the edge between c+-l and c+-(l+1) and at the far node of that edge
+                bool ok = false;
+                if (dir == 0) {
+                  const unsigned a = c + lane;
+                  if (a + 1 < nNodes) ok = (stateOf(a) & 0x200u) && !(stateOf(a + 1) & 0x100u);
+                } else {
+                  if (c >= lane + 1) {
+                    const unsigned b = c - lane - 1;
+                    ok               = (stateOf(b) & 0x200u) && !(stateOf(b) & 0x100u);
+                  }
+                }
+                const uint64_t good = wv::ballot(ok);
+                const unsigned take = (~good == 0) ? 64u : unsigned(wv::ctz(~good));
+                if (take == 0) break;
+                if (lane < take) {
+                  const unsigned n = (dir == 0) ? (c + lane + 1) : (c - lane - 1);
+                  wv::atomic_or(&st[n >> 1], 0x100u << (16 * (n & 1)));
+                }
+                total += take;
+                c = (dir == 0) ? (c + take) : (c - take);
+                wv::sync();
+                if (take < 64) break;
+              }
+              if (total > 0) {
+                if (lane == 0) nxt[wv::atomic_add(&cnt[which ^ 1], 1u)] = c;  // far end: counted and expanded next round
+                removed += total - 1;
+                wv::sync();
+              }
+            }
+          }
+        }
+      }
       if (lane == 0) cnt[which] = 0;
       wv::sync();
       which ^= 1;
