@@ -45,7 +45,11 @@ static const unsigned TENT_CAP     = 256;  // tentative-seed list capacity of on
 #ifndef MANTA_ASM_LDS
 #define MANTA_ASM_LDS 10240
 #endif
-static const unsigned ASM_LDS_BYTES = MANTA_ASM_LDS;  // dynamic LDS per wavefront (visited bitmaps of a speculative round)
+static const unsigned ASM_LDS_BYTES = MANTA_ASM_LDS;
+#ifndef MANTA_ASM_STRETCH
+#define MANTA_ASM_STRETCH 96
+#endif
+static const unsigned ASM_STRETCH_MAX = MANTA_ASM_STRETCH;  // frontier size up to which the cycle check tries stretch peels  // dynamic LDS per wavefront (visited bitmaps of a speculative round)
 static const unsigned WQ_MAX       = 4;    // lane-private walks hold read sets of up to 4 qwords (<= 256 reads) in registers
 
 struct AsmOptsDev {
@@ -822,7 +826,7 @@ struct Assembler {
       // node at the far end is marked and queued, and the regular round updates ITS neighbours.
       {
         const unsigned nNext = wv::first(wv::atomic_load(&cnt[which ^ 1]));
-        if (nNext > 0 && nNext <= 8) {
+        if (nNext > 0 && nNext <= ASM_STRETCH_MAX) {
           auto stateOf = [&](const unsigned n) { return (wv::atomic_load(&st[n >> 1]) >> (16 * (n & 1))) & 0xffffu; };
           for (unsigned qi = 0; qi < nNext; ++qi) {
             const unsigned f  = wv::first(nxt[qi]);
