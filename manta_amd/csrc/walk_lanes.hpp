@@ -525,8 +525,14 @@ WV_DEV bool Assembler::contigRounds()
   nCand                   = 0;
   while (nCand < capCand) {
     // first round: the top seed alone (its walk consumes the main path, which would invalidate most of a wide
-    // first round); later rounds: what is still needed plus a margin for invalidated tentative seeds
-    unsigned T = (nCand == 0) ? 1u : (capCand - nCand) + (capCand - nCand) / 4 + 2;
+    // first round -- measured: a 32-wide first round is 3 % slower)
+    // later rounds: as many tentative seeds as keep the lane-private visited bitmaps in LDS (idle lanes cost nothing: a
+    // gather is priced per instruction, not per live lane), and at least what is still needed
+    unsigned T = 1;
+    if (nCand != 0) {
+      const unsigned fit = ASM_LDS_BYTES / (useWords * 4 + 4);
+      T                  = (fit > (capCand - nCand) + 2) ? fit : (capCand - nCand) + 2;
+    }
     if (T > 64) T = 64;
     const unsigned nT = selectTentative(T);
     tick(5);
