@@ -117,7 +117,7 @@ struct AsmParams {
 struct AsmWsLayout {
   uint64_t codes, nmask, rd_cw, rd_mw, rd_len, rd_hasn, slots, node_key, node_cnt, node_flag, node_aux, rec, links,
       frontier, cand_seq, cand_bits, cand_meta, walk_left, walk_right, pseudo_seq, pseudo_len, exact, node_k32, tent, lane_seq,
-      lane_bits, lane_meta, lane_vis, total;
+      lane_bits, lane_meta, lane_vis, unused, total;
 };
 
 WV_HD uint64_t asmAlign16(uint64_t v)
@@ -181,12 +181,12 @@ WV_HD AsmWsLayout asmWorkspaceLayout(
   L.lane_bits  = asmPut(o, 64ull * 2 * WQ_MAX * 8);
   L.lane_meta  = asmPut(o, 64ull * 8 * 4);
   L.lane_vis   = asmPut(o, 64ull * 4 * ((cap_nodes + 31) / 32));
+  L.unused     = asmPut(o, 4ull * ((cap_nodes + 31) / 32 + 2));  // "unusedWords" (:678-682) as a bitmap over node ids
   L.total      = asmAlign16(o);
   return L;
 }
 
 // node_flag bits
-static const unsigned NF_UNUSED = 1u;   // still eligible as a seed ("unusedWords", :678-682)
 static const unsigned NF_REPEAT = 2u;   // member of repeatWords
 // bits 8.. : serial of the last contig that used the word ("wordsInContig", :182)
 
@@ -228,7 +228,7 @@ struct Assembler {
   int32_t*  cand_meta;  // per candidate: len, consBegin, consEnd, pad
   uint32_t* pseudo_len;
   uint32_t* exact_ws;
-  uint32_t *node_k32, *tent_raw, *tent_sorted, *lane_vis;
+  uint32_t *node_k32, *tent_raw, *tent_sorted, *lane_vis, *unused_bits;
   uint8_t*  lane_seq;
   uint64_t* lane_bits;
   int32_t*  lane_meta;
@@ -273,6 +273,7 @@ struct Assembler {
     lane_bits  = reinterpret_cast<uint64_t*>(ws + L.lane_bits);
     lane_meta  = reinterpret_cast<int32_t*>(ws + L.lane_meta);
     lane_vis   = reinterpret_cast<uint32_t*>(ws + L.lane_vis);
+    unused_bits = reinterpret_cast<uint32_t*>(ws + L.unused);
   }
 
   /// optional per-phase shader-clock profile (compiled in with -DMANTA_ASM_PROFILE; costs registers)
@@ -745,12 +746,21 @@ struct Assembler {
       }
       packLinks(sIds, cnt, recPacked(nd, 0)[0], recPacked(nd, 0)[1]);
       packLinks(pIds, cnt, recPacked(nd, 16)[0], recPacked(nd, 16)[1]);
-      node_flag[nd] = ((cnt >= P.opt.minCoverage) ? NF_UNUSED : 0u) | (selfLoop ? NF_REPEAT : 0u);
+      node_flag[nd] = selfLoop ? NF_REPEAT : 0u;
       node_aux[nd]  = indeg;
+    }
+    wv::sync();
+    // seed eligibility (:679-682) as a bitmap over node ids: one ballot per 64 nodes
+    for (unsigned base = 0; base < nNodes; base += 64) {
+      const unsigned nd = base + lane;
+      const uint64_t m  = wv::ballot(nd < nNodes && node_cnt[nd] >= P.opt.minCoverage);
+      if (lane < 2) unused_bits[(base >> 5) + lane] = uint32_t(m >> (32 * lane));
     }
     wv::sync();
     tick(2);
   }
+
+  WV_DEV bool isUnused(const unsigned nd) const { return (unused_bits[nd >> 5] >> (nd & 31)) & 1u; }
 
   WV_DEV uint64_t normalMask(const unsigned w) const
   {
@@ -895,7 +905,7 @@ struct Assembler {
     const unsigned lane = unsigned(wv::lane());
     unsigned       best = 0;
     for (unsigned nd = lane; nd < nNodes; nd += 64) {
-      if (node_flag[nd] & NF_UNUSED) {
+      if (isUnused(nd)) {
         const unsigned c = node_cnt[nd];
         best             = (c > best) ? c : best;
       }
@@ -905,13 +915,13 @@ struct Assembler {
     // smallest 16-base prefix among the best-count words, then the full k-mer only among prefix ties
     unsigned minPre = 0xffffffffu;
     for (unsigned nd = lane; nd < nNodes; nd += 64)
-      if ((node_flag[nd] & NF_UNUSED) && node_cnt[nd] == best) minPre = (node_k32[nd] < minPre) ? node_k32[nd] : minPre;
+      if (isUnused(nd) && node_cnt[nd] == best) minPre = (node_k32[nd] < minPre) ? node_k32[nd] : minPre;
     minPre = ~waveMax(~minPre);
     unsigned mine = ASM_NONE;
     GKey     mineKey;
     for (int i = 0; i < ASM_MAX_KW; ++i) mineKey.w[i] = 0xffffffffu;
     for (unsigned nd = lane; nd < nNodes; nd += 64) {
-      if ((node_flag[nd] & NF_UNUSED) && node_cnt[nd] == best && node_k32[nd] == minPre) {
+      if (isUnused(nd) && node_cnt[nd] == best && node_k32[nd] == minPre) {
         const GKey key = keyAt<ASM_MAX_KW>(node_key[nd]);
         if (mine == ASM_NONE || keyLess(key, mineKey)) {
           mine    = nd;
@@ -964,7 +974,10 @@ struct Assembler {
     if (lane == 0) seedFlag = node_flag[seed];
     seedFlag                = wv::readlane(seedFlag, 0);
     const bool seedIsRepeat = (seedFlag & NF_REPEAT) != 0;
-    if (lane == 0) node_flag[seed] = (seedFlag & NF_REPEAT) | (serial << 8);  // unused.erase(seed), wordsInContig
+    if (lane == 0) {
+      node_flag[seed] = (seedFlag & NF_REPEAT) | (serial << 8);  // wordsInContig
+      unused_bits[seed >> 5] &= ~(1u << (seed & 31));          // unused.erase(seed)
+    }
 
     // seed k-mer text
     const unsigned seedPb = node_key[seed];
@@ -1083,7 +1096,10 @@ struct Assembler {
         Rj |= add;            // :440-442
         S |= maxWR & ~Rj;     // :458-464
         S &= ~rm;             // :471-473
-        if (lane == 0) node_flag[maxNode] = (maxFlag & NF_REPEAT) | (serial << 8);  // :482-484
+        if (lane == 0) {  // :482-484
+          node_flag[maxNode] = (maxFlag & NF_REPEAT) | (serial << 8);
+          unused_bits[maxNode >> 5] &= ~(1u << (maxNode & 31));
+        }
         cur = maxNode;
       }
       if (isEnd)

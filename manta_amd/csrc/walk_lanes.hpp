@@ -39,7 +39,7 @@ WV_DEV unsigned Assembler::selectTentative(const unsigned T)
   unsigned  U = 0, myMax = 0;
   for (unsigned base = 0; base < nNodes; base += 64) {
     const unsigned nd  = base + lane;
-    const bool     sel = (nd < nNodes) && (node_flag[nd] & NF_UNUSED);
+    const bool     sel = (nd < nNodes) && isUnused(nd);
     const uint64_t m   = wv::ballot(sel);
     if (sel) {
       const unsigned pos = U + unsigned(wv::popc(m & ((uint64_t(1) << lane) - 1)));
@@ -506,9 +506,7 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
     m[4]       = rep ? 1 : 0;
     m[5]       = tooLong ? 1 : 0;
     m[6]       = seedRepeat ? 1 : 0;
-    // the visited set must be readable by every lane during acceptance
-    if (visInLds)
-      for (unsigned w = 0; w < useWords; ++w) lane_vis[size_t(lane) * visWords + w] = vis[w];
+    // (the visited bitmaps stay where they are -- LDS or lane_vis -- and are read there during acceptance)
   }
   wv::sync();
 }
@@ -541,10 +539,10 @@ WV_DEV bool Assembler::contigRounds()
     tick(6);
     for (unsigned t = 0; t < nT && nCand < capCand; ++t) {
       const unsigned seed = tent_sorted[t];
-      unsigned seedFlag = 0;  // read by ONE lane before this iteration's flag updates, then broadcast
-      if (lane == 0) seedFlag = node_flag[seed];
-      seedFlag = wv::readlane(seedFlag, 0);
-      if (!(seedFlag & NF_UNUSED)) continue;  // consumed by an accepted walk: not a seed for the reference either
+      unsigned seedFree = 0;  // read by ONE lane before this iteration's updates, then broadcast
+      if (lane == 0) seedFree = isUnused(seed) ? 1u : 0u;
+      seedFree = wv::readlane(seedFree, 0);
+      if (!seedFree) continue;  // consumed by an accepted walk: not a seed for the reference either
       const int32_t* m = lane_meta + t * 8;
       if (m[5]) {
         status = ASM_E_CONTIG_TOO_LONG;
@@ -587,15 +585,11 @@ WV_DEV bool Assembler::contigRounds()
         }
       }
       // unusedWords.erase for every word of the accepted walk (:170,482)
-      const uint32_t* vis = lane_vis + size_t(t) * visWords;
-      for (unsigned w = lane; w < useWords; w += 64) {
-        uint32_t bits = vis[w];
-        while (bits) {
-          const unsigned b = unsigned(wv::ctz(uint64_t(bits)));
-          bits &= bits - 1;
-          node_flag[w * 32 + b] &= ~NF_UNUSED;
-        }
-      }
+      // the walks' visited bitmaps are still where walkLanes kept them (LDS if they fitted)
+      const bool      visInLds = (nT * useWords * 4 <= ASM_LDS_BYTES);
+      const uint32_t* vis      = visInLds ? (reinterpret_cast<const uint32_t*>(wv::lds(ASM_LDS_BYTES)) + size_t(t) * useWords)
+                                          : (lane_vis + size_t(t) * visWords);
+      for (unsigned w = lane; w < useWords; w += 64) unused_bits[w] &= ~vis[w];
       wv::sync();
       if (m[4]) success = false;
       nCand++;
