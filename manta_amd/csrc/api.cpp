@@ -740,7 +740,7 @@ int manta_smallsv_run(manta_smallsv_t* b)
     const uint64_t   cigarCap = nSlots * (4ull * std::min<uint64_t>(as.maxContigLen, 4096) + 16);
     uint32_t*        dCigar   = b->dCigar.as<uint32_t>(cigarCap + 16);
     const uint32_t   tableCap = nextPow2(2ull * as.maxContigLen);
-    const int        schedGrid = rt::roundGrid(int(std::min<uint64_t>(nSlots, uint64_t(std::max(1, ctx->cuCount * 16)))));
+    const int        schedGrid = rt::roundGrid(int(std::min<uint64_t>(nLoci, uint64_t(std::max(1, ctx->cuCount * 32)))));
     uint32_t*        dTable   = b->dTable.as<uint32_t>(uint64_t(tableCap) * schedGrid);
     rt::dzero(dSmall, sizeof(uint32_t) * 64);
     rt::dzero(dResults, sizeof(AlignResultDev) * nSlots);

@@ -10,7 +10,7 @@
 namespace manta_dev {
 
 static const int      SMALLSV_MER       = 10;    // SVCandidateAssemblyRefiner.cpp:1986
-static const unsigned SCHED_LDS_BYTES   = 8192;  // per wavefront: 10-mer table of contigs up to 1024 bp lives in LDS
+static const unsigned SCHED_LDS_BYTES   = 4096;  // per wavefront: 10-mer table of contigs up to 512 bp lives in LDS (32 waves/CU fit)
 
 struct SmallSvCuts {
   int32_t leadingCut, trailingCut, maxLeadingCut, maxTrailingCut;  // :1912-1915
@@ -67,12 +67,16 @@ WV_DEV unsigned merCode(const uint8_t* p, bool& valid)
 /// code of the 10-mer starting at p0+l; `valid` is false if the 10-mer leaves [0,len) or holds a non-ACGT base.
 /// All 64 lanes must call.
 static const int MER_BATCH = 55;
-WV_DEV unsigned merCodes55(const uint8_t* seq, const int len, const int p0, bool& valid)
+/// the lane's base code (0..3, 4 = not ACGT / outside the sequence) for batch start p0: the only memory access of a batch
+WV_DEV unsigned merLoadBase(const uint8_t* seq, const int len, const int p0)
+{
+  const int pos = p0 + wv::lane();
+  return (pos >= 0 && pos < len) ? baseCode(seq[pos]) : 4u;
+}
+/// 10-mer codes of the batch from the per-lane base codes
+WV_DEV unsigned merCodesFromBase(const unsigned c, bool& valid)
 {
   const int      l   = wv::lane();
-  const int      pos = p0 + l;
-  unsigned       c   = 4;
-  if (pos >= 0 && pos < len) c = baseCode(seq[pos]);
   unsigned bad = (c > 3) ? 1u : 0u;
   unsigned w1  = c & 3u;
   const unsigned w2 = (w1 << 2) | wv::shfl(w1, (l + 1) & 63);
@@ -85,6 +89,10 @@ WV_DEV unsigned merCodes55(const uint8_t* seq, const int len, const int p0, bool
   const unsigned b10 = b8 | wv::shfl(b2, (l + 8) & 63);
   valid = (l < MER_BATCH) && (b10 == 0);
   return w10;
+}
+WV_DEV unsigned merCodes55(const uint8_t* seq, const int len, const int p0, bool& valid)
+{
+  return merCodesFromBase(merLoadBase(seq, len, p0), valid);
 }
 
 WV_DEV bool merLookup(const uint32_t* table, const unsigned mask, const unsigned code)
@@ -150,31 +158,42 @@ WV_DEV SmallSvTaskInfo scheduleSlot(const ScheduleParams& P, const unsigned slot
   // first hit scanning forward (:1997-2001)
   int adjLead = maxFwdRefIndex + 1;
   if (adjLead < minRefIndex) adjLead = minRefIndex;  // empty scan range: the loop variable keeps its initial value
-  for (int base = minRefIndex; base <= maxFwdRefIndex; base += MER_BATCH) {
-    bool           valid;
-    const unsigned code = merCodes55(ref, refSize, base, valid);
-    const int      i    = base + int(lane);
-    const bool     hit  = valid && i <= maxFwdRefIndex && merLookup(table, mask, code);
-    const uint64_t m    = wv::ballot(hit);
-    if (m) {
-      adjLead = base + wv::ctz(m);
-      break;
+  {
+    // the next batch's bases are requested before this batch is looked up (one memory round trip per batch otherwise)
+    unsigned cNext = merLoadBase(ref, refSize, minRefIndex);
+    for (int base = minRefIndex; base <= maxFwdRefIndex; base += MER_BATCH) {
+      const unsigned c = cNext;
+      cNext            = merLoadBase(ref, refSize, base + MER_BATCH);
+      bool           valid;
+      const unsigned code = merCodesFromBase(c, valid);
+      const int      i    = base + int(lane);
+      const bool     hit  = valid && i <= maxFwdRefIndex && merLookup(table, mask, code);
+      const uint64_t m    = wv::ballot(hit);
+      if (m) {
+        adjLead = base + wv::ctz(m);
+        break;
+      }
     }
   }
   // last hit scanning backward (:2004-2008): windows of 55 start positions, highest window first
   const int minRevRefIndex = (minRefIndex > refSize - cuts.maxTrailingCut) ? minRefIndex : (refSize - cuts.maxTrailingCut);
   int       revIndex       = minRevRefIndex - 1;
   if (revIndex > maxRefIndex) revIndex = maxRefIndex;  // empty scan range
-  for (int top = maxRefIndex; top >= minRevRefIndex; top -= MER_BATCH) {
-    const int      base = top - (MER_BATCH - 1);
-    bool           valid;
-    const unsigned code = merCodes55(ref, refSize, base, valid);
-    const int      i    = base + int(lane);
-    const bool     hit  = valid && i >= minRevRefIndex && i <= top && merLookup(table, mask, code);
-    const uint64_t m    = wv::ballot(hit);
-    if (m) {
-      revIndex = base + (63 - wv::clz(m));
-      break;
+  {
+    unsigned cNext = merLoadBase(ref, refSize, maxRefIndex - (MER_BATCH - 1));
+    for (int top = maxRefIndex; top >= minRevRefIndex; top -= MER_BATCH) {
+      const int      base = top - (MER_BATCH - 1);
+      const unsigned c    = cNext;
+      cNext               = merLoadBase(ref, refSize, base - MER_BATCH);
+      bool           valid;
+      const unsigned code = merCodesFromBase(c, valid);
+      const int      i    = base + int(lane);
+      const bool     hit  = valid && i >= minRevRefIndex && i <= top && merLookup(table, mask, code);
+      const uint64_t m    = wv::ballot(hit);
+      if (m) {
+        revIndex = base + (63 - wv::clz(m));
+        break;
+      }
     }
   }
   const int adjTrail = refSize - (revIndex + SMALLSV_MER);
@@ -236,15 +255,26 @@ WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
   uint32_t*      gtable = P.table_ws + size_t(wv::block()) * P.table_cap;
   uint32_t*      ltable = reinterpret_cast<uint32_t*>(wv::lds(SCHED_LDS_BYTES));
   const unsigned total  = P.n_loci * P.max_assembly_count;
+  // the work unit is a LOCUS (most contig slots are empty; one queue pop per slot made the queue head the bottleneck)
   while (true) {
-    unsigned slot = 0;
-    if (lane == 0) slot = wv::atomic_add(P.counter, 1u);
-    slot = wv::first(slot);
-    if (slot >= total) break;
-    const SmallSvTaskInfo info = scheduleSlot(P, slot, total, ltable, gtable);
-    wv::sync();  // single reconvergence point of every exit of scheduleSlot
-    if (lane == 0) P.info[slot] = info;
-    wv::sync();
+    unsigned locus = 0;
+    if (lane == 0) locus = wv::atomic_add(P.counter, 1u);
+    locus = wv::first(locus);
+    if (locus >= P.n_loci) break;
+    const AsmLocusOut lo       = P.loci[locus];
+    const unsigned    nContigs = (lo.status == ASM_OK) ? lo.n_contigs : 0u;
+    // slots without a contig: one lane each
+    if (lane >= nContigs && lane < P.max_assembly_count) {
+      SmallSvTaskInfo none = {(lo.status != ASM_OK) ? 1 : 0, 0, 0, -1};
+      P.info[locus * P.max_assembly_count + lane] = none;
+    }
+    for (unsigned ci = 0; ci < nContigs; ++ci) {
+      const unsigned        slot = locus * P.max_assembly_count + ci;
+      const SmallSvTaskInfo info = scheduleSlot(P, slot, total, ltable, gtable);
+      wv::sync();  // single reconvergence point of every exit of scheduleSlot
+      if (lane == 0) P.info[slot] = info;
+      wv::sync();
+    }
   }
 }
 
