@@ -164,3 +164,19 @@ def test_refiner_on_gpu(mine_gpu):
     for (name, c), want in zip(cases, g["texts"]):
         assert mine_gpu.run(c) == want, name
     assert mine_gpu.run_multi([c for _, c in cases[:3]], batched=True).startswith(g["texts"][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_refiner_gpu_equals_emulator_on_fresh_cases(mine_gpu, mine_emu):
+    """fresh random scenarios (no golden text exists for them, and the reference is not on the GPU box): the device build
+    and the wave-emulator build of the same sources must agree call for call -- this is the tier that exposes
+    hardware-only behaviour (it is how the schedule-kernel hang on contig-less loci was found)"""
+    n = 0
+    for seed in (900, 901):
+        for name, c in scenario_cases(seed):
+            assert mine_gpu.run(c) == mine_emu.run(c), (seed, name)
+            n += 1
+    cases = [c for _, c in scenario_cases(902)][:12]
+    assert mine_gpu.run_multi(cases[:1], batched=True) == mine_emu.run_multi(cases[:1], batched=True)
+    assert n >= 50
