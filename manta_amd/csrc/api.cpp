@@ -422,6 +422,8 @@ struct manta_smallsv {
   bool                  uploaded = false, ran = false;
   DevBuf                dRefs, dRefOff, dCuts, dTasks, dInfo, dResults, dBucketIds, dSmall, dCigar, dTable, dPtrWs;
   rt::Event             evStart, evAsm, evSched, evAlign;
+  rt::Stream            side[3];
+  rt::Event             sideDone[3];
   manta_smallsv_stats_t stats{};
   explicit manta_smallsv(manta_ctx_t* c) : ctx(c), asmStage(c) {}
 };
@@ -791,35 +793,57 @@ int manta_smallsv_run(manta_smallsv_t* b)
     b->stats.ptr_matrix_bytes = 0;
     const int    maxWaves = std::max(1, ctx->cuCount * alignWavesPerCu());
     const size_t wsBudget = std::min<size_t>(rt::freeBytes() / 2, size_t(48) << 30);
-    for (int k = 0; k < kNumESet; ++k) {
-      const uint32_t cnt = hSmall[k];
-      if (cnt == 0) continue;
-      const uint64_t stride = (alignPtrSlabBytes(MANTA_ALIGNER_LARGE_INDEL, kESet[k], hSmall[16 + k]) + 255) & ~uint64_t(255);
-      int            grid   = int(std::min<size_t>(cnt, size_t(maxWaves)));
-      grid                  = int(std::max<size_t>(1, std::min<size_t>(size_t(grid), wsBudget / stride)));
-      grid                  = rt::roundGrid(grid);
-      uint8_t* dWs          = b->dPtrWs.as<uint8_t>(stride * grid);
-      AlignParams P;
-      P.tasks          = dTasks;
-      P.results        = dResults;
-      P.cigar          = dCigar;
-      P.task_ids       = dBuckets + uint64_t(k) * nSlots;
-      P.n_tasks        = cnt;
-      P.n_tasks_dev    = nullptr;
-      P.counter        = dSmall + 40 + k;
-      P.ptr_ws         = dWs;
-      P.ptr_ws_stride  = stride;
-      P.match          = b->scores.match;
-      P.mismatch       = b->scores.mismatch;
-      P.open           = b->scores.open;
-      P.extend         = b->scores.extend;
-      P.off_edge       = b->scores.off_edge;
-      P.allow_edge_ins = b->scores.is_allow_edge_insertion ? 1 : 0;
-      P.extra          = b->largeIndel;
-      launchAlignKind(MANTA_ALIGNER_LARGE_INDEL, k, grid, P);
-      b->stats.n_align_launches++;
-      b->stats.n_alignments += cnt;
-      if (k + 1 < kNumESet) rt::sync();  // the slab buffer may be re-sized for the next bucket
+    // The E buckets are independent launches: they run on side streams so that the tail of one overlaps the others
+    // (a launch's last alignments leave most of the device idle otherwise).  Each bucket gets its own slab region.
+    {
+      struct Launch {
+        int      k, grid;
+        uint64_t stride, slabOff;
+      };
+      std::vector<Launch> launches;
+      uint64_t            slabBytes = 0;
+      for (int k = kNumESet - 1; k >= 0; --k) {  // widest (longest-running) buckets first
+        const uint32_t cnt = hSmall[k];
+        if (cnt == 0) continue;
+        const uint64_t stride = (alignPtrSlabBytes(MANTA_ALIGNER_LARGE_INDEL, kESet[k], hSmall[16 + k]) + 255) & ~uint64_t(255);
+        int            grid   = int(std::min<size_t>(cnt, size_t(maxWaves)));
+        grid                  = int(std::max<size_t>(1, std::min<size_t>(size_t(grid), (wsBudget / 3) / stride)));
+        grid                  = rt::roundGrid(grid);
+        launches.push_back(Launch{k, grid, stride, slabBytes});
+        slabBytes += stride * uint64_t(grid);
+      }
+      uint8_t* dWsAll = b->dPtrWs.as<uint8_t>(slabBytes + 256);
+      for (size_t i = 0; i < launches.size(); ++i) {
+        const Launch& l(launches[i]);
+        AlignParams   P;
+        P.tasks          = dTasks;
+        P.results        = dResults;
+        P.cigar          = dCigar;
+        P.task_ids       = dBuckets + uint64_t(l.k) * nSlots;
+        P.n_tasks        = hSmall[l.k];
+        P.n_tasks_dev    = nullptr;
+        P.counter        = dSmall + 40 + l.k;
+        P.ptr_ws         = dWsAll + l.slabOff;
+        P.ptr_ws_stride  = l.stride;
+        P.match          = b->scores.match;
+        P.mismatch       = b->scores.mismatch;
+        P.open           = b->scores.open;
+        P.extend         = b->scores.extend;
+        P.off_edge       = b->scores.off_edge;
+        P.allow_edge_ins = b->scores.is_allow_edge_insertion ? 1 : 0;
+        P.extra          = b->largeIndel;
+        rt::Stream& st(b->side[i % 3]);
+        rt::useStream(&st);
+        launchAlignKind(MANTA_ALIGNER_LARGE_INDEL, l.k, l.grid, P);
+        rt::useStream(nullptr);
+        b->stats.n_align_launches++;
+        b->stats.n_alignments += hSmall[l.k];
+      }
+      // the null stream (events, later copies) continues after every side stream has drained
+      for (size_t i = 0; i < std::min<size_t>(launches.size(), 3); ++i) {
+        b->sideDone[i].recordOn(b->side[i]);
+        rt::nullStreamWaits(b->sideDone[i]);
+      }
     }
     b->evAlign.record();
     rt::sync();

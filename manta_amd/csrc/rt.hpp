@@ -28,7 +28,10 @@ inline void  sync() {}
 template <typename K, typename P>
 inline void launch(K kernel, int grid, size_t ldsBytes, const P& params) { wv_emu::launch(grid, ldsBytes, [&]() { kernel(params); }); }
 inline int roundGrid(int waves) { return waves; }
-struct Event { void record() {} };
+struct Stream {};
+inline void useStream(Stream*) {}
+struct Event { void record() {} void recordOn(Stream&) {} };
+inline void nullStreamWaits(Event&) {}
 inline float elapsedMs(const Event&, const Event&) { return 0.f; }
 }  // namespace rt
 #else
@@ -79,11 +82,25 @@ inline void d2h(void* h, const void* d, size_t n) { if (n) check(hipMemcpy(h, d,
 inline void dzero(void* d, size_t n) { if (n) check(hipMemsetAsync(d, 0, n, 0), "hipMemset"); }
 inline void dfill(void* d, int byte, size_t n) { if (n) check(hipMemsetAsync(d, byte, n, 0), "hipMemset"); }
 inline void sync() { check(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
+/// a non-blocking side stream: independent kernels (the aligner's E buckets) overlap their tails on these
+struct Stream {
+  hipStream_t s = nullptr;
+  Stream() { check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"); }
+  ~Stream() { if (s) (void)hipStreamDestroy(s); }
+  Stream(const Stream&) = delete;
+  Stream& operator=(const Stream&) = delete;
+};
+inline hipStream_t& launchStream()
+{
+  static thread_local hipStream_t cur = nullptr;  // null stream unless useStream() says otherwise
+  return cur;
+}
+inline void useStream(Stream* st) { launchStream() = st ? st->s : nullptr; }
 template <typename K, typename P>
 inline void launch(K kernel, int grid, size_t ldsBytes, const P& params)
 {
   // `grid` counts WAVEFRONTS and must be a multiple of WV_WAVES_PER_WG (see roundGrid); ldsBytes is per wave
-  hipLaunchKernelGGL(kernel, dim3(grid / WV_WAVES_PER_WG), dim3(64 * WV_WAVES_PER_WG), ldsBytes * WV_WAVES_PER_WG, 0, params);
+  hipLaunchKernelGGL(kernel, dim3(grid / WV_WAVES_PER_WG), dim3(64 * WV_WAVES_PER_WG), ldsBytes * WV_WAVES_PER_WG, launchStream(), params);
   check(hipGetLastError(), "kernel launch");
 }
 inline int roundGrid(int waves) { return ((waves + WV_WAVES_PER_WG - 1) / WV_WAVES_PER_WG) * WV_WAVES_PER_WG; }
@@ -95,7 +112,9 @@ struct Event {
   Event(const Event&) = delete;
   Event& operator=(const Event&) = delete;
   void record() { check(hipEventRecord(e, 0), "hipEventRecord"); }
+  void recordOn(Stream& st) { check(hipEventRecord(e, st.s), "hipEventRecord"); }
 };
+inline void nullStreamWaits(Event& ev) { check(hipStreamWaitEvent(nullptr, ev.e, 0), "hipStreamWaitEvent"); }
 inline float elapsedMs(const Event& a, const Event& b)
 {
   float ms = 0.f;
