@@ -441,6 +441,8 @@ struct manta_spanning {
   DevBuf                dRefs1, dRef1Off, dRefs2, dRef2Off, dCuts, dTasks, dTasks2, dInfo, dResults, dResults2, dBucketIds, dBucketIds2, dSmall,
       dCigar, dPtrWs;
   rt::Event             evStart, evAsm, evSched, evAlign;
+  rt::Stream            side[3];
+  rt::Event             sideDone[3];
   manta_smallsv_stats_t stats{};
   explicit manta_spanning(manta_ctx_t* c) : ctx(c), asmStage(c) {}
 };
@@ -1088,24 +1090,37 @@ int manta_spanning_run(manta_spanning_t* b)
     const size_t wsBudget = std::min<size_t>(rt::freeBytes() / 2, size_t(48) << 30);
     auto alignRound = [&](const uint32_t* hCounts, const uint32_t* hMaxref, const AlignTaskDev* tasks, AlignResultDev* results,
                           const uint32_t* bucketIds, uint32_t* counters) {
-      for (int k = 0; k < kNumESet; ++k) {
+      // buckets on side streams, one slab region each (see manta_smallsv_run)
+      struct Launch {
+        int      k, grid;
+        uint64_t stride, slabOff;
+      };
+      std::vector<Launch> launches;
+      uint64_t            slabBytes = 0;
+      for (int k = kNumESet - 1; k >= 0; --k) {
         const uint32_t cnt = hCounts[k];
         if (cnt == 0) continue;
         const uint64_t stride = (alignPtrSlabBytes(MANTA_ALIGNER_JUMP, kESet[k], hMaxref[k]) + 255) & ~uint64_t(255);
         int            grid   = int(std::min<size_t>(cnt, size_t(maxWaves)));
-        grid                  = int(std::max<size_t>(1, std::min<size_t>(size_t(grid), wsBudget / stride)));
+        grid                  = int(std::max<size_t>(1, std::min<size_t>(size_t(grid), (wsBudget / 3) / stride)));
         grid                  = rt::roundGrid(grid);
-        uint8_t* dWs          = b->dPtrWs.as<uint8_t>(stride * grid);
-        AlignParams P;
+        launches.push_back(Launch{k, grid, stride, slabBytes});
+        slabBytes += stride * uint64_t(grid);
+      }
+      if (launches.empty()) return;
+      uint8_t* dWsAll = b->dPtrWs.as<uint8_t>(slabBytes + 256);
+      for (size_t i = 0; i < launches.size(); ++i) {
+        const Launch& l(launches[i]);
+        AlignParams   P;
         P.tasks          = tasks;
         P.results        = results;
         P.cigar          = dCigar;
-        P.task_ids       = bucketIds + uint64_t(k) * nSlots;
-        P.n_tasks        = cnt;
+        P.task_ids       = bucketIds + uint64_t(l.k) * nSlots;
+        P.n_tasks        = hCounts[l.k];
         P.n_tasks_dev    = nullptr;
-        P.counter        = counters + k;
-        P.ptr_ws         = dWs;
-        P.ptr_ws_stride  = stride;
+        P.counter        = counters + l.k;
+        P.ptr_ws         = dWsAll + l.slabOff;
+        P.ptr_ws_stride  = l.stride;
         P.match          = b->scores.match;
         P.mismatch       = b->scores.mismatch;
         P.open           = b->scores.open;
@@ -1113,11 +1128,17 @@ int manta_spanning_run(manta_spanning_t* b)
         P.off_edge       = b->scores.off_edge;
         P.allow_edge_ins = 0;
         P.extra          = b->jumpScore;
-        launchAlignKind(MANTA_ALIGNER_JUMP, k, grid, P);
+        rt::useStream(&b->side[i % 3]);
+        launchAlignKind(MANTA_ALIGNER_JUMP, l.k, l.grid, P);
+        rt::useStream(nullptr);
         b->stats.n_align_launches++;
-        b->stats.n_alignments += cnt;
-        rt::sync();  // the slab buffer may be re-sized for the next bucket
+        b->stats.n_alignments += hCounts[l.k];
       }
+      for (size_t i = 0; i < std::min<size_t>(launches.size(), 3); ++i) {
+        b->sideDone[i].recordOn(b->side[i]);
+        rt::nullStreamWaits(b->sideDone[i]);
+      }
+      rt::sync();  // the next stage reads the results and may re-size the slab buffer
     };
     uint32_t hSmall[64];
     rt::d2h(hSmall, dSmall, sizeof(hSmall));
