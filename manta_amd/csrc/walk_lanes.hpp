@@ -200,15 +200,21 @@ WV_DEV unsigned Assembler::selectTentative(const unsigned T)
 /// The (<= 4) existing candidate words of a walk step, compacted in alphabet order, with everything the step needs:
 /// per candidate three 16-byte blocks of its 64-byte record (links in walking direction + count, links against it,
 /// read support) and the lane's visited-bitmap word.
-static const unsigned WALK_NPRE = 2;  // candidate slots fetched ahead; a 3rd/4th candidate (rare) is fetched on demand
+/// candidate slots fetched ahead (further candidates, rare, are fetched on demand).  Wide read sets keep one slot: the
+/// second one's support words pushed the step loop into scratch (63 spill accesses per step at WQ = 4).
+template <int WQ>
+struct WalkPre {
+  static const unsigned N = (WQ <= 2) ? 2 : 1;
+};
 template <int WQ>
 struct StepData {
   unsigned m;        // number of candidates
   unsigned node[4];  // compacted, alphabet order
   unsigned syms;     // their symbols, 2 bits each
-  uint64_t flo[WALK_NPRE], fhi[WALK_NPRE], blo[WALK_NPRE], bhi[WALK_NPRE];
-  uint64_t sup[WALK_NPRE][WQ];
-  unsigned visWord[WALK_NPRE];
+  static const unsigned NPRE = WalkPre<WQ>::N;
+  uint64_t flo[NPRE], fhi[NPRE], blo[NPRE], bhi[NPRE];
+  uint64_t sup[NPRE][WQ];
+  unsigned visWord[NPRE];
 };
 
 /// One round: lane t < nT walks tent_sorted[t] with private state (assembly/IterativeAssembler.cpp:149-501).
@@ -292,7 +298,7 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
         d.m++;
       }
     }
-    for (unsigned i = 0; i < WALK_NPRE; ++i) {
+    for (unsigned i = 0; i < WalkPre<WQ>::N; ++i) {
       d.flo[i] = d.fhi[i] = d.blo[i] = d.bhi[i] = 0;
       d.visWord[i] = 0;
       for (int w = 0; w < WQ; ++w) d.sup[i][w] = 0;
@@ -335,7 +341,7 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
       const bool live = active && i < D.m;
       uint64_t   cflo, cfhi, cblo, cbhi, csup[WQ];
       unsigned   cvis;
-      if (i < WALK_NPRE) {
+      if (i < WalkPre<WQ>::N) {
         cflo = D.flo[i];
         cfhi = D.fhi[i];
         cblo = D.blo[i];
