@@ -696,6 +696,7 @@ struct Assembler {
                 slots[2 * size_t(slot) + 1] = id;
                 node_key[id]                = pb;
                 for (unsigned w = 0; w < W; ++w) recSup(id)[w] = 0;
+                for (unsigned c = 0; c < 4; ++c) recPred(id)[c] = ASM_NONE;  // filled by the successors' scatter
               }
               wv::sync();
               if (slot != ASM_NONE && myId == ASM_NONE) myId = wv::atomic_load(&slots[2 * size_t(slot) + 1]);
@@ -726,28 +727,35 @@ struct Assembler {
       const Key<KW> key = keyAt<KW>(node_key[nd]);
       node_k32[nd]  = key.w[0];
       bool          selfLoop = false;
-      unsigned      indeg    = 0;
-      unsigned      sIds[4], pIds[4];
+      unsigned      sIds[4];
       {
-        Key<KW> ks[4], kp[4];
-        for (unsigned c = 0; c < 4; ++c) {
-          ks[c] = keyShiftAppend<KW>(key, c);
-          kp[c] = keyShiftPrepend<KW>(key, c);
-        }
+        Key<KW> ks[4];
+        for (unsigned c = 0; c < 4; ++c) ks[c] = keyShiftAppend<KW>(key, c);
         lookup4<KW>(ks, sIds);
-        lookup4<KW>(kp, pIds);
       }
+      // Predecessor links are not looked up: nd is the predecessor of each of its successors through nd's own first
+      // base, so the successor lookups scatter them (every (word, symbol) slot has exactly one writer).
+      const unsigned firstBase = key.w[0] >> 30;
       for (unsigned c = 0; c < 4; ++c) {
-        const unsigned s = sIds[c], p = pIds[c];
+        const unsigned s = sIds[c];
         recSucc(nd)[c]   = s;
-        recPred(nd)[c]   = p;
+        if (s != ASM_NONE) recPred(s)[firstBase] = nd;
         if (s == nd) selfLoop = true;  // homopolymer (:574-577)
-        if (p != ASM_NONE && p != nd) indeg++;
       }
       packLinks(sIds, cnt, recPacked(nd, 0)[0], recPacked(nd, 0)[1]);
-      packLinks(pIds, cnt, recPacked(nd, 16)[0], recPacked(nd, 16)[1]);
       node_flag[nd] = selfLoop ? NF_REPEAT : 0u;
-      node_aux[nd]  = indeg;
+    }
+    wv::sync();
+    wv::fence_acquire();
+    for (unsigned nd = lane; nd < nNodes; nd += 64) {
+      unsigned pIds[4], indeg = 0;
+      for (unsigned c = 0; c < 4; ++c) {
+        const unsigned p = recPred(nd)[c];
+        pIds[c]          = p;
+        if (p != ASM_NONE && p != nd) indeg++;
+      }
+      packLinks(pIds, node_cnt[nd], recPacked(nd, 16)[0], recPacked(nd, 16)[1]);
+      node_aux[nd] = indeg;
     }
     wv::sync();
     // seed eligibility (:679-682) as a bitmap over node ids: one ballot per 64 nodes
