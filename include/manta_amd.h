@@ -11,7 +11,7 @@
  *   - every function returns MANTA_OK (0) or a negative MANTA_E_* code; manta_last_error() gives the message
  *     (the reference reports errors as C++ exceptions, common/Exceptions.hpp:54-85; the C++ adapter re-throws).
  *   - sequences are raw bytes exactly as the reference's std::string holds them (1 byte per base).
- *   - all batch calls are synchronous; a context is bound to one GPU and is NOT re-entrant (the reference's
+ *   - all calls are synchronous; a context is bound to one GPU and is NOT re-entrant (the reference's
  *     aligner/refiner objects are not either: alignment/GlobalJumpAligner.hpp:117-124) -- use one context per
  *     host worker thread (GenerateSVCandidates.cpp:232-250).
  *   - there is no CPU fallback: if no gfx950 device / HIP runtime is usable, manta_ctx_create fails.
@@ -232,6 +232,67 @@ int  manta_spanning_download(manta_spanning_t* b, manta_asm_locus_result_t* loci
                              uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
                              uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
                              uint64_t* cigar_arena_used);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Mixed word lengths in one batch (minWordLength drawn per locus).  Overrides
+ * IterativeAssemblerOptions::minWordLength / maxWordLength (options/IterativeAssemblerOptions.hpp:38-40) per locus for
+ * the NEXT upload of the pipeline; pass NULL, NULL to go back to the option block.
+ * ---------------------------------------------------------------------------------------------------- */
+int manta_smallsv_set_word_lengths(manta_smallsv_t* b, uint32_t n_loci, const uint32_t* min_word_length,
+                                   const uint32_t* max_word_length);
+int manta_spanning_set_word_lengths(manta_spanning_t* b, uint32_t n_loci, const uint32_t* min_word_length,
+                                    const uint32_t* max_word_length);
+
+/* page-locked host memory: input/output buffers allocated here are copied by DMA without a staging pass */
+int  manta_host_alloc(uint64_t bytes, void** out);
+void manta_host_free(void* p);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Whole-batch calls: what a GenerateSVCandidates worker pool does with its edges
+ * (GenerateSVCandidates.cpp:232-266 hands EdgeRetriever ranges to --threads workers, each with a private refiner;
+ * EdgeRetrieverBin.cpp:38-57 splits the edge list into contiguous bins), here for one GPU: the batch is cut into
+ * contiguous blocks of block_loci loci, the blocks go into a queue ordered by decreasing cost (reads x bases), and
+ * n_workers host threads -- each with a private pipeline on its own HIP stream -- pull blocks:
+ * upload -> kernels -> download.  The copies of one block overlap the kernels of the others, and the VALU-bound
+ * aligner of one block runs beside the assembler of the next.  Synchronous: on return every result is in the caller's
+ * records and arenas (same layout as manta_*_download; offsets are relative to the arena starts; loci[i] belongs to
+ * input locus i, contig records of different blocks are not in locus order -- use first_contig).
+ * Per-item failures (MANTA_E_UNSUPPORTED / MANTA_E_DEVICE_FAULT in a locus or alignment status) do not stop the batch:
+ * the call returns the code, every other item is valid.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct {
+  uint32_t block_loci; /* 0 = 2048 */
+  uint32_t n_workers;  /* 0 = 4 */
+} manta_batch_plan_t;
+
+typedef struct {
+  double   wall_ms;                    /* call entry -> all results host-visible */
+  double   h2d_ms, kernel_ms, d2h_ms;  /* host wall time per phase, summed over blocks (blocks overlap) */
+  float    assemble_ms, schedule_ms, align_ms; /* HIP-event times, summed over blocks */
+  uint32_t n_blocks, n_workers;
+  uint64_t n_alignments, dp_cells, ptr_matrix_bytes;
+  uint64_t h2d_bytes, d2h_bytes;       /* PCIe traffic of the call */
+} manta_batch_stats_t;
+
+int manta_smallsv_batch(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t large_indel_score,
+    uint32_t n_loci, const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const uint8_t* refs,
+    const uint64_t* ref_off, const manta_ref_cuts_t* cuts, const uint32_t* locus_min_word_length /* nullable */,
+    const uint32_t* locus_max_word_length /* nullable */, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs,
+    manta_smallsv_alignment_t* alignments, uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap,
+    uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used, uint32_t* cigar_arena,
+    uint64_t cigar_arena_cap, uint64_t* cigar_arena_used, const manta_batch_plan_t* plan /* nullable */,
+    manta_batch_stats_t* stats /* nullable */);
+
+int manta_spanning_batch(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t jump_score, uint32_t n_loci,
+    const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const uint8_t* refs1,
+    const uint64_t* ref1_off, const uint8_t* refs2, const uint64_t* ref2_off, const manta_jump_cuts_t* cuts,
+    const uint32_t* locus_min_word_length /* nullable */, const uint32_t* locus_max_word_length /* nullable */,
+    manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_spanning_alignment_t* alignments, uint64_t contigs_cap,
+    uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
+    uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap, uint64_t* cigar_arena_used,
+    const manta_batch_plan_t* plan /* nullable */, manta_batch_stats_t* stats /* nullable */);
 
 #ifdef __cplusplus
 }

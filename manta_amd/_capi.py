@@ -222,6 +222,40 @@ def _assemble_batch(self, opts, loci_reads, strict=True):
 Lib.assemble_batch = _assemble_batch
 
 
+def _decode_loci(kind, n_reads, res, contigs, aligns, seq, bits, cig):
+    """raw result records/arenas -> one dict per locus (kind: "smallsv" | "spanning")"""
+    out = []
+    for l in range(len(n_reads)):
+        r = res[l]
+        d = dict(status=r.status, n_reads=int(n_reads[l]), n_words=r.n_words, final_word_length=r.final_word_length,
+                 n_iterations=r.n_iterations, cyclic_iterations=r.cyclic_iterations, contigs=[], pseudo=[], aligns=[])
+        if r.status == 0:
+            for c in range(r.n_contigs):
+                cc = contigs[r.first_contig + c]
+                d["contigs"].append(dict(seq=seq[cc.seq_off:cc.seq_off + cc.seq_len].tobytes().decode("latin-1"),
+                                         seed=cc.seed_read_count, cons=(cc.conservative_begin, cc.conservative_end),
+                                         support=_bits_members(bits[cc.support_off:cc.support_off + r.n_words]),
+                                         reject=_bits_members(bits[cc.reject_off:cc.reject_off + r.n_words])))
+                a = aligns[r.first_contig + c]
+                if kind == "smallsv":
+                    d["aligns"].append(dict(status=a.align.status, lead=a.adjusted_leading_cut, trail=a.adjusted_trailing_cut,
+                                            score=a.align.score, is_jumped=a.align.is_jumped, begin1=a.align.begin_pos1,
+                                            cigar1=cigar_string(cig[a.align.cigar1_off:a.align.cigar1_off + a.align.cigar1_len])))
+                else:
+                    d["aligns"].append(dict(status=a.align.status, is_uncut=a.is_uncut, score=a.align.score, begin1=a.align.begin_pos1,
+                                            begin2=a.align.begin_pos2, jump_insert_size=a.align.jump_insert_size,
+                                            jump_range=a.align.jump_range,
+                                            cigar1=cigar_string(cig[a.align.cigar1_off:a.align.cigar1_off + a.align.cigar1_len]),
+                                            cigar2=cigar_string(cig[a.align.cigar2_off:a.align.cigar2_off + a.align.cigar2_len])))
+            off = int(r.pseudo_seq_off)
+            for p in range(r.n_pseudo):
+                ln = int(bits[r.pseudo_len_off + p])
+                d["pseudo"].append(seq[off:off + ln].tobytes().decode("latin-1"))
+                off += ln
+        out.append(d)
+    return out
+
+
 class SmallSvBatch:
     """Staged fused pipeline (manta_smallsv_*): upload once, run many times (bench), download."""
 
@@ -294,29 +328,7 @@ class SmallSvBatch:
             ctypes.byref(su), bits.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(bits_cap), ctypes.byref(bu),
             cig.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(cig_cap), ctypes.byref(cu))
         self.lib._check(rc, allow=() if strict else (-5, -6, -7))
-        out = []
-        for l in range(n):
-            r = res[l]
-            d = dict(status=r.status, n_reads=int(self.n_reads[l]), n_words=r.n_words, final_word_length=r.final_word_length,
-                     n_iterations=r.n_iterations, cyclic_iterations=r.cyclic_iterations, contigs=[], pseudo=[], aligns=[])
-            if r.status == 0:
-                for c in range(r.n_contigs):
-                    cc = contigs[r.first_contig + c]
-                    d["contigs"].append(dict(seq=seq[cc.seq_off:cc.seq_off + cc.seq_len].tobytes().decode("latin-1"),
-                                             seed=cc.seed_read_count, cons=(cc.conservative_begin, cc.conservative_end),
-                                             support=_bits_members(bits[cc.support_off:cc.support_off + r.n_words]),
-                                             reject=_bits_members(bits[cc.reject_off:cc.reject_off + r.n_words])))
-                    a = aligns[r.first_contig + c]
-                    d["aligns"].append(dict(status=a.align.status, lead=a.adjusted_leading_cut, trail=a.adjusted_trailing_cut,
-                                            score=a.align.score, is_jumped=a.align.is_jumped, begin1=a.align.begin_pos1,
-                                            cigar1=cigar_string(cig[a.align.cigar1_off:a.align.cigar1_off + a.align.cigar1_len])))
-                off = int(r.pseudo_seq_off)
-                for p in range(r.n_pseudo):
-                    ln = int(bits[r.pseudo_len_off + p])
-                    d["pseudo"].append(seq[off:off + ln].tobytes().decode("latin-1"))
-                    off += ln
-            out.append(d)
-        return out
+        return _decode_loci("smallsv", self.n_reads, res, contigs, aligns, seq, bits, cig)
 
 
 def small_sv_text(d):
@@ -429,28 +441,127 @@ class SpanningBatch:
             ctypes.byref(su), bits.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(bits_cap), ctypes.byref(bu),
             cig.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(cig_cap), ctypes.byref(cu))
         self.lib._check(rc, allow=() if strict else (-4, -5, -6, -7))
-        out = []
-        for l in range(n):
-            r = res[l]
-            d = dict(status=r.status, n_reads=int(self.n_reads[l]), n_words=r.n_words, final_word_length=r.final_word_length,
-                     n_iterations=r.n_iterations, cyclic_iterations=r.cyclic_iterations, contigs=[], pseudo=[], aligns=[])
-            if r.status == 0:
-                for c in range(r.n_contigs):
-                    cc = contigs[r.first_contig + c]
-                    d["contigs"].append(dict(seq=seq[cc.seq_off:cc.seq_off + cc.seq_len].tobytes().decode("latin-1"),
-                                             seed=cc.seed_read_count, cons=(cc.conservative_begin, cc.conservative_end),
-                                             support=_bits_members(bits[cc.support_off:cc.support_off + r.n_words]),
-                                             reject=_bits_members(bits[cc.reject_off:cc.reject_off + r.n_words])))
-                    a = aligns[r.first_contig + c]
-                    d["aligns"].append(dict(status=a.align.status, is_uncut=a.is_uncut, score=a.align.score, begin1=a.align.begin_pos1,
-                                            begin2=a.align.begin_pos2, jump_insert_size=a.align.jump_insert_size,
-                                            jump_range=a.align.jump_range,
-                                            cigar1=cigar_string(cig[a.align.cigar1_off:a.align.cigar1_off + a.align.cigar1_len]),
-                                            cigar2=cigar_string(cig[a.align.cigar2_off:a.align.cigar2_off + a.align.cigar2_len])))
-                off = int(r.pseudo_seq_off)
-                for p in range(r.n_pseudo):
-                    ln = int(bits[r.pseudo_len_off + p])
-                    d["pseudo"].append(seq[off:off + ln].tobytes().decode("latin-1"))
-                    off += ln
-            out.append(d)
-        return out
+        return _decode_loci("spanning", self.n_reads, res, contigs, aligns, seq, bits, cig)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# whole-batch calls (manta_smallsv_batch / manta_spanning_batch) and pinned host memory
+# ---------------------------------------------------------------------------------------------------------------
+class BatchPlan(ctypes.Structure):
+    _fields_ = [("block_loci", ctypes.c_uint32), ("n_workers", ctypes.c_uint32)]
+
+
+class BatchStats(ctypes.Structure):
+    _fields_ = [("wall_ms", ctypes.c_double), ("h2d_ms", ctypes.c_double), ("kernel_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double),
+                ("assemble_ms", ctypes.c_float), ("schedule_ms", ctypes.c_float), ("align_ms", ctypes.c_float),
+                ("n_blocks", ctypes.c_uint32), ("n_workers", ctypes.c_uint32), ("n_alignments", ctypes.c_uint64),
+                ("dp_cells", ctypes.c_uint64), ("ptr_matrix_bytes", ctypes.c_uint64), ("h2d_bytes", ctypes.c_uint64),
+                ("d2h_bytes", ctypes.c_uint64)]
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def pinned_empty(lib, shape, dtype):
+    """numpy array over page-locked host memory (manta_host_alloc).  The memory lives until pinned_free(array) or
+    process exit (bench/test processes allocate a handful of these once)."""
+    dtype = np.dtype(dtype)
+    count = int(np.prod(shape))
+    n = max(count * dtype.itemsize, 1)
+    ptr = ctypes.c_void_p()
+    lib.lib.manta_host_alloc.argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
+    lib.lib.manta_host_free.argtypes = [ctypes.c_void_p]
+    rc = lib.lib.manta_host_alloc(n, ctypes.byref(ptr))
+    if rc != 0:
+        raise MantaError(rc, "manta_host_alloc failed")
+    buf = (ctypes.c_uint8 * n).from_address(ptr.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+    _PINNED[arr.ctypes.data] = (lib, ptr)
+    return arr
+
+
+_PINNED = {}
+
+
+def pinned_free(arr):
+    lib, ptr = _PINNED.pop(arr.ctypes.data)
+    lib.lib.manta_host_free(ptr)
+
+
+def pinned_copy(lib, a):
+    out = pinned_empty(lib, a.shape, a.dtype)
+    out[...] = a
+    return out
+
+
+class BatchOutput:
+    """caller-side result records and arenas of a whole-batch call (allocated once, reusable across calls)"""
+
+    def __init__(self, lib, kind, n_loci, max_asm, seq_cap, bits_cap, cig_cap, pinned=False):
+        self.kind, self.n_loci = kind, n_loci
+        self.ccap = n_loci * max_asm + 1
+        self.res = (AsmLocusResult * n_loci)()
+        self.contigs = (AsmContig * self.ccap)()
+        self.aligns = ((SmallSvAlignment if kind == "smallsv" else SpanningAlignment) * self.ccap)()
+        mk = (lambda n, dt: pinned_empty(lib, (n,), dt)) if pinned else (lambda n, dt: np.zeros(n, dtype=dt))
+        self.seq, self.bits, self.cig = mk(seq_cap, np.uint8), mk(bits_cap, np.uint64), mk(cig_cap, np.uint32)
+        self.used = [ctypes.c_uint64(0) for _ in range(3)]
+        self.stats = BatchStats()
+
+    def decode(self, n_reads):
+        return _decode_loci(self.kind, n_reads, self.res, self.contigs, self.aligns, self.seq, self.bits, self.cig)
+
+    def stats_dict(self):
+        return {f[0]: getattr(self.stats, f[0]) for f in BatchStats._fields_}
+
+
+def _smallsv_batch(self, opts, scores, large_indel_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True):
+    """batch = (bases, read_off, begin, refs, ref_off, cuts) numpy arrays as synth.config2_batch returns them"""
+    bases, read_off, begin, refs, ref_off, cuts = batch
+    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers)
+    n = len(begin) - 1
+    f = self.lib.manta_smallsv_batch
+    f.restype = ctypes.c_int
+    rc = f(self.ctx, ctypes.byref(o), ctypes.byref(sc), ctypes.c_int32(large_indel_score), ctypes.c_uint32(n), _p(bases), _p(read_off),
+           _p(begin), _p(refs), _p(ref_off), _p(cuts), _p(min_wl), _p(max_wl), out.res, out.contigs, out.aligns, ctypes.c_uint64(out.ccap),
+           _p(out.seq), ctypes.c_uint64(len(out.seq)), ctypes.byref(out.used[0]), _p(out.bits), ctypes.c_uint64(len(out.bits)),
+           ctypes.byref(out.used[1]), _p(out.cig), ctypes.c_uint64(len(out.cig)), ctypes.byref(out.used[2]), ctypes.byref(plan),
+           ctypes.byref(out.stats))
+    self._check(rc, allow=() if strict else (-4, -5, -7))
+    return rc
+
+
+def _spanning_batch(self, opts, scores, jump_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True):
+    """batch = (bases, read_off, begin, refs1, ref1_off, refs2, ref2_off, cuts)"""
+    bases, read_off, begin, r1, o1, r2, o2, cuts = batch
+    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers)
+    n = len(begin) - 1
+    f = self.lib.manta_spanning_batch
+    f.restype = ctypes.c_int
+    rc = f(self.ctx, ctypes.byref(o), ctypes.byref(sc), ctypes.c_int32(jump_score), ctypes.c_uint32(n), _p(bases), _p(read_off), _p(begin),
+           _p(r1), _p(o1), _p(r2), _p(o2), _p(cuts), _p(min_wl), _p(max_wl), out.res, out.contigs, out.aligns, ctypes.c_uint64(out.ccap),
+           _p(out.seq), ctypes.c_uint64(len(out.seq)), ctypes.byref(out.used[0]), _p(out.bits), ctypes.c_uint64(len(out.bits)),
+           ctypes.byref(out.used[1]), _p(out.cig), ctypes.c_uint64(len(out.cig)), ctypes.byref(out.used[2]), ctypes.byref(plan),
+           ctypes.byref(out.stats))
+    self._check(rc, allow=() if strict else (-4, -5, -7))
+    return rc
+
+
+Lib.smallsv_batch = _smallsv_batch
+Lib.spanning_batch = _spanning_batch
+
+
+def pack_spanning(loci_reads, refs1, refs2, cuts):
+    """python lists -> the packed arrays manta_spanning_upload / manta_spanning_batch take"""
+    bases, read_off, begin = pack_loci(loci_reads)
+
+    def pack(refs):
+        rb = [_b(r) for r in refs]
+        off = np.zeros(len(rb) + 1, dtype=np.uint64)
+        np.cumsum([len(r) for r in rb], out=off[1:])
+        return np.frombuffer(b"".join(rb) + b"\0", dtype=np.uint8), off
+    r1, o1 = pack(refs1)
+    r2, o2 = pack(refs2)
+    c = np.ascontiguousarray(np.array(cuts, dtype=np.int32).reshape(len(begin) - 1, 4))
+    return bases, read_off, begin, r1, o1, r2, o2, c

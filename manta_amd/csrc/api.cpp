@@ -4,10 +4,15 @@
 #include "../../include/manta_amd.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "align_kernels.hpp"
@@ -50,14 +55,54 @@ struct DevBuf {
   }
 };
 
+/// grow-only page-locked host buffer: device -> host staging of the pipelines (DMA needs pinned memory to run
+/// asynchronously on the pipeline's stream)
+struct PinnedBuf {
+  void*  p   = nullptr;
+  size_t cap = 0;
+  ~PinnedBuf()
+  {
+    if (p) rt::hostFree(p);
+  }
+  template <typename T>
+  T* as(size_t count)
+  {
+    const size_t n = count * sizeof(T);
+    if (n > cap) {
+      if (p) rt::hostFree(p);
+      cap = n + n / 4 + 256;
+      p   = rt::hostAlloc(cap);
+    }
+    return static_cast<T*>(p);
+  }
+};
+
+double nowMs()
+{
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+/// live contexts/pipelines of this process share the device's free memory (per-wave workspaces are sized from it)
+std::atomic<int> g_liveWorkspaces{0};
+
 }  // namespace
 
+struct manta_smallsv;
+struct manta_spanning;
+
 struct manta_ctx {
+  std::mutex  errMu;  // the workers of a whole-batch call report through the same context
   std::string lastError;
   std::string deviceName;
   int         cuCount = 0;
   // align scratch
   DevBuf dSeq, dTasks, dResults, dCigar, dTaskIds, dCounter, dPtrWs;
+  rt::Stream stream;  // the context's own stream (manta_align_batch / manta_assemble_batch run on it)
+  int        deviceId = 0;
+  // worker pipelines of the whole-batch calls (manta_smallsv_batch / manta_spanning_batch), kept across calls
+  std::vector<manta_smallsv*>  smallPool;
+  std::vector<manta_spanning*> spanPool;
+  ~manta_ctx();
   std::vector<uint32_t> growthSize, growthBuckets;  // libstdc++ bucket growth schedule (see repeat_exact.hpp)
 };
 
@@ -65,8 +110,17 @@ namespace {
 
 int fail(manta_ctx_t* ctx, int code, const std::string& msg)
 {
-  if (ctx) ctx->lastError = msg;
+  if (ctx) {
+    std::lock_guard<std::mutex> g(ctx->errMu);
+    ctx->lastError = msg;
+  }
   return code;
+}
+
+std::string lastErrorOf(manta_ctx_t* ctx)
+{
+  std::lock_guard<std::mutex> g(ctx->errMu);
+  return ctx->lastError;
 }
 
 const int kESet[]  = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32};
@@ -168,6 +222,13 @@ bool stringHashMatchesLibstdcxx()
   return true;
 }
 
+/// device memory one pipeline may take for its per-wave workspaces: an equal share of half the free memory, capped
+size_t workspaceBudget(const size_t capBytes)
+{
+  const int live = std::max(1, g_liveWorkspaces.load());
+  return std::min<size_t>(rt::freeBytes() / 2 / size_t(live), capBytes);
+}
+
 uint32_t nextPow2(uint64_t v)
 {
   uint64_t p = 1;
@@ -182,7 +243,7 @@ int asmStatusToAbi(int st)
   case ASM_E_ALPHABET:
   case ASM_E_WORD_TOO_LONG:
   case ASM_E_TOO_MANY_READS: return MANTA_E_UNSUPPORTED;
-  case ASM_E_OUT_CAPACITY: return MANTA_E_CAPACITY;
+  // (ASM_E_OUT_CAPACITY = the library's own device arena ran out: not something the caller's arenas can fix)
   default: return MANTA_E_DEVICE_FAULT;
   }
 }
@@ -191,13 +252,32 @@ int asmStatusToAbi(int st)
 /// One batch of loci through assemble_kernel: sizing, staging, launch, fetch.
 struct AsmStage {
   manta_ctx_t* ctx;
-  explicit AsmStage(manta_ctx_t* c) : ctx(c) {}
+  explicit AsmStage(manta_ctx_t* c) : ctx(c) { g_liveWorkspaces++; }
+  ~AsmStage() { g_liveWorkspaces--; }
+  AsmStage(const AsmStage&) = delete;
+  AsmStage& operator=(const AsmStage&) = delete;
+  // device -> host staging (pinned), filled by stageOut()
+  PinnedBuf     pLoci, pCont, pSeq, pBits, pCnt;
+  AsmLocusOut*  hLoci = nullptr;
+  AsmContigOut* hCont = nullptr;
+  uint8_t*      hSeq  = nullptr;
+  uint64_t*     hBits = nullptr;
+  uint64_t*     hCnt  = nullptr;
+  uint64_t      seqUsedDev = 0, bitsUsedDev = 0, nContigsOut = 0, pseudoBytesOut = 0, pseudoCountOut = 0;
+  bool          staged = false;
 
   manta_asm_options_t opt{};
   uint32_t            nLoci = 0, nReadsTotal = 0, maxContigLen = 0, wMax = 0, capWords = 0, capReads = 0, capNodes = 0, capSlots = 0;
   uint64_t            nBases = 0, stride = 0, devSeqCap = 0, devBitsCap = 0;
   int                 grid = 1;
-  DevBuf              bBases, bReadOff, bLocusBegin, bLoci, bContigs, bSeqArena, bBitsArena, bCounters, bWs, bGrowth;
+  DevBuf              bBases, bReadOff, bLocusBegin, bLoci, bContigs, bSeqArena, bBitsArena, bCounters, bWs, bGrowth, bWl, bOrder;
+  // optional per-locus word lengths of the NEXT batch (manta_*_set_word_lengths); empty = the option block's values
+  std::vector<uint32_t> locusMinWl, locusMaxWl;
+  std::vector<uint32_t> order;  // loci by decreasing estimated cost: the work queue hands out the long ones first
+  uint32_t              maxWordLen = 0;
+  uint32_t*             dMinWl = nullptr;
+  uint32_t*             dMaxWl = nullptr;
+  uint32_t*             dOrder = nullptr;
   uint8_t*            dBases = nullptr;
   uint64_t*           dOff   = nullptr;
   uint32_t*           dBegin = nullptr;
@@ -217,10 +297,22 @@ struct AsmStage {
     if (2 * o.max_assembly_count > ASM_MAX_CAND) return fail(ctx, MANTA_E_UNSUPPORTED, "maxAssemblyCount above 32 is not supported");
     opt         = o;
     nLoci       = n_loci;
+    for (uint32_t l = 0; l < n_loci; ++l)  // validate before the last elements are trusted as totals
+      if (locus_read_begin[l + 1] < locus_read_begin[l]) return fail(ctx, MANTA_E_INVALID_ARG, "locus_read_begin not monotone");
     nReadsTotal = locus_read_begin[n_loci];
+    maxWordLen  = o.max_word_length;
+    if (!locusMinWl.empty()) {
+      if (locusMinWl.size() != n_loci || locusMaxWl.size() != n_loci)
+        return fail(ctx, MANTA_E_INVALID_ARG, "per-locus word lengths were set for a different number of loci");
+      for (uint32_t l = 0; l < n_loci; ++l) {
+        if (locusMinWl[l] == 0 || locusMaxWl[l] > 16u * ASM_MAX_KW) return fail(ctx, MANTA_E_UNSUPPORTED, "per-locus word length outside 1..128");
+        maxWordLen = std::max(maxWordLen, locusMaxWl[l]);
+      }
+    }
     nBases      = read_off[nReadsTotal];
     uint64_t maxLocusBases = 0, maxLocusWords = 0, bitsBound = 0;
     uint32_t maxLocusReads = 0, maxReadLen = 0;
+    std::vector<uint64_t> cost(n_loci);
     for (uint32_t l = 0; l < n_loci; ++l) {
       const uint32_t rb = locus_read_begin[l], re = locus_read_begin[l + 1];
       if (re < rb || re > nReadsTotal) return fail(ctx, MANTA_E_INVALID_ARG, "locus_read_begin not monotone");
@@ -232,17 +324,23 @@ struct AsmStage {
         w += (len + 15) / 16 + 1;
         maxReadLen = std::max<uint32_t>(maxReadLen, uint32_t(len));
       }
+      cost[l]       = b * uint64_t(re - rb);
       maxLocusBases = std::max(maxLocusBases, b);
       maxLocusWords = std::max(maxLocusWords, w);
       maxLocusReads = std::max(maxLocusReads, re - rb);
       const uint64_t W = ((re - rb) + 2 * opt.max_assembly_count + 63) / 64;
       bitsBound += uint64_t(opt.max_assembly_count) * 2 * W + 2 * opt.max_assembly_count;
     }
+    // work-queue order: most expensive loci first (reads x bases is what the table pass and the walks scale with), so
+    // that the long ones are not the last to start
+    order.resize(n_loci);
+    for (uint32_t l = 0; l < n_loci; ++l) order[l] = l;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
     const uint32_t nCandMax = 2 * opt.max_assembly_count;
     wMax                    = uint32_t((maxLocusReads + nCandMax + 63) / 64);
     if (wMax > ASM_MAX_W) return fail(ctx, MANTA_E_UNSUPPORTED, "more than ~1000 reads in one locus");
-    maxContigLen               = uint32_t(std::min<uint64_t>(maxLocusBases, 32768) + opt.max_word_length + 16);
-    const uint64_t pseudoLen   = std::min<uint64_t>(maxContigLen, 3ull * maxReadLen + opt.max_word_length);
+    maxContigLen               = uint32_t(std::min<uint64_t>(maxLocusBases, 32768) + maxWordLen + 16);
+    const uint64_t pseudoLen   = std::min<uint64_t>(maxContigLen, 3ull * maxReadLen + maxWordLen);
     const uint64_t pseudoBases = uint64_t(nCandMax) * pseudoLen;
     capWords                   = uint32_t(maxLocusWords + pseudoBases / 16 + 2 * nCandMax + 8);
     capReads                   = maxLocusReads + nCandMax + 1;
@@ -254,11 +352,14 @@ struct AsmStage {
     // per-wave workspaces: at most half of the free HBM, 64 GiB by default (MANTA_AMD_WS_BUDGET_GB lowers it for callers
     // that keep several batches resident at once)
     const size_t wsCapGb  = std::getenv("MANTA_AMD_WS_BUDGET_GB") ? size_t(std::max(1, std::atoi(std::getenv("MANTA_AMD_WS_BUDGET_GB")))) : size_t(64);
-    const size_t wsBudget = std::min<size_t>(rt::freeBytes() / 2, wsCapGb << 30);
+    const size_t wsBudget = workspaceBudget(wsCapGb << 30);
     const int wavesPerCu  = std::getenv("MANTA_AMD_ASM_WAVES_PER_CU") ? std::atoi(std::getenv("MANTA_AMD_ASM_WAVES_PER_CU")) : 16;
     grid                  = int(std::min<uint64_t>(n_loci, uint64_t(std::max(1, ctx->cuCount * wavesPerCu))));
     grid                  = rt::roundGrid(int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(grid), wsBudget / stride))));
-    devSeqCap  = uint64_t(n_loci) * std::min<uint64_t>(3ull * opt.max_assembly_count * pseudoLen, 65536) + 4096;
+    // contig + pseudo-read text one locus can emit at worst; the arena holds the typical case for every locus plus one
+    // worst case, so a single-locus call (the runIterativeAssembler adapter) can never exhaust it
+    const uint64_t worstLocusSeq = uint64_t(opt.max_assembly_count) * maxContigLen + uint64_t(nCandMax) * pseudoLen;
+    devSeqCap  = uint64_t(n_loci) * std::min<uint64_t>(worstLocusSeq, 65536) + worstLocusSeq + 4096;
     devBitsCap = bitsBound + 64;
     if (ctx->growthSize.empty()) recordGrowthSchedule(ctx->growthSize, ctx->growthBuckets, 4u << 20);
     return MANTA_OK;
@@ -276,6 +377,15 @@ struct AsmStage {
     dCnt    = bCounters.as<uint64_t>(16);
     dWs     = bWs.as<uint8_t>(stride * grid);
     dGrowth = bGrowth.as<uint32_t>(2 * ctx->growthSize.size() + 2);
+    dOrder  = bOrder.as<uint32_t>(nLoci);
+    rt::h2d(dOrder, order.data(), sizeof(uint32_t) * nLoci);
+    dMinWl = dMaxWl = nullptr;
+    if (!locusMinWl.empty()) {
+      dMinWl = bWl.as<uint32_t>(2ull * nLoci);
+      dMaxWl = dMinWl + nLoci;
+      rt::h2d(dMinWl, locusMinWl.data(), sizeof(uint32_t) * nLoci);
+      rt::h2d(dMaxWl, locusMaxWl.data(), sizeof(uint32_t) * nLoci);
+    }
     rt::h2d(dBases, bases, nBases);
     rt::h2d(dOff, read_off, sizeof(uint64_t) * (nReadsTotal + 1));
     rt::h2d(dBegin, locus_read_begin, sizeof(uint32_t) * (nLoci + 1));
@@ -316,27 +426,42 @@ struct AsmStage {
     P.growth_buckets = dGrowth + ctx->growthSize.size();
     P.n_growth       = uint32_t(ctx->growthSize.size());
     P.flags          = std::getenv("MANTA_AMD_SERIAL_WALK") ? ASM_FLAG_SERIAL_WALK : 0u;
+    P.locus_min_wl   = dMinWl;
+    P.locus_max_wl   = dMaxWl;
+    P.locus_ids      = dOrder;
     rt::launch(assemble_kernel, grid, ASM_LDS_BYTES, P);
   }
 
-  /// upper bounds of what fetch() writes into the caller's arenas
-  void outputSizes(uint64_t& nContigs, uint64_t& seqBytes, uint64_t& bitsWords) const
+  /// Device -> pinned host staging of everything the assembler produced, with EXACT sizes: the fixed records and the
+  /// arena counters first (one round trip), then exactly the used part of the text / bitset arenas.
+  /// `moreCopies` lets a pipeline queue its own copies behind the second round so that one sync covers them.
+  template <typename F>
+  void stageOut(F moreCopies)
   {
-    uint64_t hCnt[3];
-    rt::d2h(hCnt, dCnt, sizeof(hCnt));
-    nContigs  = uint64_t(nLoci) * opt.max_assembly_count + 1;
-    seqBytes  = std::min<uint64_t>(hCnt[1], devSeqCap) + 64;
-    bitsWords = std::min<uint64_t>(hCnt[2], devBitsCap) + 64;
-  }
-
-  int fetch(
-      manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, uint64_t contigs_cap, uint8_t* seq_arena,
-      uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used)
-  {
-    std::vector<AsmLocusOut>  hLoci(nLoci);
-    std::vector<AsmContigOut> hCont(uint64_t(nLoci) * opt.max_assembly_count);
-    uint64_t                  hCnt[16];
-    rt::d2h(hCnt, dCnt, sizeof(hCnt));
+    hCnt  = pCnt.as<uint64_t>(16);
+    hLoci = pLoci.as<AsmLocusOut>(nLoci);
+    hCont = pCont.as<AsmContigOut>(uint64_t(nLoci) * opt.max_assembly_count);
+    rt::d2hAsync(hCnt, dCnt, sizeof(uint64_t) * 16);
+    rt::d2hAsync(hLoci, dLoci, sizeof(AsmLocusOut) * nLoci);
+    rt::d2hAsync(hCont, dCont, sizeof(AsmContigOut) * uint64_t(nLoci) * opt.max_assembly_count);
+    rt::sync();
+    seqUsedDev  = std::min<uint64_t>(hCnt[1], devSeqCap);
+    bitsUsedDev = std::min<uint64_t>(hCnt[2], devBitsCap);
+    hSeq        = pSeq.as<uint8_t>(seqUsedDev + 1);
+    hBits       = pBits.as<uint64_t>(bitsUsedDev + 1);
+    rt::d2hAsync(hSeq, dSeq, seqUsedDev);
+    rt::d2hAsync(hBits, dBits, sizeof(uint64_t) * bitsUsedDev);
+    moreCopies();
+    rt::sync();
+    nContigsOut = pseudoBytesOut = pseudoCountOut = 0;
+    for (uint32_t l = 0; l < nLoci; ++l) {
+      const AsmLocusOut& h(hLoci[l]);
+      if (h.status != ASM_OK) continue;
+      nContigsOut += h.n_contigs;
+      pseudoCountOut += h.n_pseudo;
+      for (uint32_t q = 0; q < h.n_pseudo; ++q) pseudoBytesOut += hBits[h.pseudo_len_off + q];
+    }
+    staged = true;
     if (std::getenv("MANTA_AMD_PROFILE")) {
       static const char* names[8] = {"pack", "table", "links", "cycle-check", "exact", "seed", "walk", "select+emit"};
       uint64_t           tot = 0;
@@ -345,14 +470,44 @@ struct AsmStage {
       for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s=%.1f%%", names[i], tot ? 100.0 * double(hCnt[4 + i]) / double(tot) : 0.0);
       std::fprintf(stderr, " | avg clocks/locus=%.0f\n", double(tot) / nLoci);
     }
-    rt::d2h(hLoci.data(), dLoci, sizeof(AsmLocusOut) * nLoci);
-    rt::d2h(hCont.data(), dCont, sizeof(AsmContigOut) * hCont.size());
-    const uint64_t seqUsedDev = std::min<uint64_t>(hCnt[1], devSeqCap), bitsUsedDev = std::min<uint64_t>(hCnt[2], devBitsCap);
-    std::vector<uint8_t>  hSeq(seqUsedDev + 1);
-    std::vector<uint64_t> hBits(bitsUsedDev + 1);
-    rt::d2h(hSeq.data(), dSeq, seqUsedDev);
-    rt::d2h(hBits.data(), dBits, sizeof(uint64_t) * bitsUsedDev);
+  }
+  void stageOut()
+  {
+    stageOut([] {});
+  }
 
+  /// exact sizes compact() will write (valid after stageOut): contig records, text bytes, bitset qwords
+  void exactSizes(uint64_t& nContigs, uint64_t& seqBytes, uint64_t& bitsWords) const
+  {
+    nContigs = nContigsOut;
+    seqBytes = pseudoBytesOut;
+    bitsWords = pseudoCountOut;
+    for (uint32_t l = 0; l < nLoci; ++l) {
+      const AsmLocusOut& h(hLoci[l]);
+      if (h.status != ASM_OK) continue;
+      for (uint32_t c = 0; c < h.n_contigs; ++c) seqBytes += hCont[uint64_t(l) * opt.max_assembly_count + c].seq_len;
+      bitsWords += 2ull * h.n_words * h.n_contigs;
+    }
+  }
+
+  /// upper bounds of what compact() writes into the caller's arenas (cheap: counters only)
+  void outputSizes(uint64_t& nContigs, uint64_t& seqBytes, uint64_t& bitsWords) const
+  {
+    uint64_t c[3];
+    rt::d2h(c, dCnt, sizeof(c));
+    nContigs  = uint64_t(nLoci) * opt.max_assembly_count + 1;
+    seqBytes  = std::min<uint64_t>(c[1], devSeqCap) + 64;
+    bitsWords = std::min<uint64_t>(c[2], devBitsCap) + 64;
+  }
+
+  /// staging -> the caller's records and arenas.  Offsets written into the records are relative to the arena pointers
+  /// passed here plus `seqBase` / `bitsBase` / `contigBase` (a whole-batch call hands every block its own region of the
+  /// caller's arenas).
+  int compact(
+      manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, uint64_t contigs_cap, uint8_t* seq_arena,
+      uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used,
+      uint64_t contigBase = 0, uint64_t seqBase = 0, uint64_t bitsBase = 0)
+  {
     uint64_t seqUsed = 0, bitsUsed = 0, nContigs = 0;
     int      worst = MANTA_OK;
     for (uint32_t l = 0; l < nLoci; ++l) {
@@ -360,7 +515,7 @@ struct AsmStage {
       manta_asm_locus_result_t& o(loci[l]);
       std::memset(&o, 0, sizeof(o));
       o.status       = asmStatusToAbi(h.status);
-      o.first_contig = uint32_t(nContigs);
+      o.first_contig = uint32_t(contigBase + nContigs);
       if (o.status != MANTA_OK) {
         worst = o.status;
         if (std::getenv("MANTA_AMD_DEBUG"))
@@ -379,12 +534,12 @@ struct AsmStage {
         manta_asm_contig_t& oc(contigs[nContigs++]);
         if (seqUsed + hc.seq_len > seq_arena_cap || bitsUsed + 2ull * h.n_words > bits_arena_cap)
           return fail(ctx, MANTA_E_CAPACITY, "output arena too small");
-        std::memcpy(seq_arena + seqUsed, hSeq.data() + hc.seq_off, hc.seq_len);
-        std::memcpy(bits_arena + bitsUsed, hBits.data() + hc.bits_off, sizeof(uint64_t) * 2 * h.n_words);
-        oc.seq_off            = seqUsed;
+        std::memcpy(seq_arena + seqUsed, hSeq + hc.seq_off, hc.seq_len);
+        std::memcpy(bits_arena + bitsUsed, hBits + hc.bits_off, sizeof(uint64_t) * 2 * h.n_words);
+        oc.seq_off            = seqBase + seqUsed;
         oc.seq_len            = hc.seq_len;
-        oc.support_off        = bitsUsed;
-        oc.reject_off         = bitsUsed + h.n_words;
+        oc.support_off        = bitsBase + bitsUsed;
+        oc.reject_off         = bitsBase + bitsUsed + h.n_words;
         oc.seed_read_count    = 0;
         oc.conservative_begin = hc.cons_begin;
         oc.conservative_end   = hc.cons_end;
@@ -392,13 +547,13 @@ struct AsmStage {
         bitsUsed += 2ull * h.n_words;
       }
       uint64_t pBytes = 0;
-      for (uint32_t p = 0; p < h.n_pseudo; ++p) pBytes += hBits[h.pseudo_len_off + p];
+      for (uint32_t q = 0; q < h.n_pseudo; ++q) pBytes += hBits[h.pseudo_len_off + q];
       if (seqUsed + pBytes > seq_arena_cap || bitsUsed + h.n_pseudo > bits_arena_cap)
         return fail(ctx, MANTA_E_CAPACITY, "output arena too small");
-      std::memcpy(seq_arena + seqUsed, hSeq.data() + h.pseudo_off, pBytes);
-      std::memcpy(bits_arena + bitsUsed, hBits.data() + h.pseudo_len_off, sizeof(uint64_t) * h.n_pseudo);
-      o.pseudo_seq_off = seqUsed;
-      o.pseudo_len_off = bitsUsed;
+      std::memcpy(seq_arena + seqUsed, hSeq + h.pseudo_off, pBytes);
+      std::memcpy(bits_arena + bitsUsed, hBits + h.pseudo_len_off, sizeof(uint64_t) * h.n_pseudo);
+      o.pseudo_seq_off = seqBase + seqUsed;
+      o.pseudo_len_off = bitsBase + bitsUsed;
       seqUsed += pBytes;
       bitsUsed += h.n_pseudo;
     }
@@ -406,6 +561,14 @@ struct AsmStage {
     if (bits_arena_used) *bits_arena_used = bitsUsed;
     if (worst != MANTA_OK) return fail(ctx, worst, "one or more loci failed; see per-locus status");
     return MANTA_OK;
+  }
+
+  int fetch(
+      manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, uint64_t contigs_cap, uint8_t* seq_arena,
+      uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used)
+  {
+    stageOut();
+    return compact(loci, contigs, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used);
   }
 };
 
@@ -422,9 +585,18 @@ struct manta_smallsv {
   bool                  uploaded = false, ran = false;
   DevBuf                dRefs, dRefOff, dCuts, dTasks, dInfo, dResults, dBucketIds, dSmall, dCigar, dTable, dPtrWs;
   rt::Event             evStart, evAsm, evSched, evAlign;
+  rt::Stream            main;  // everything of this pipeline except the aligner buckets
   rt::Stream            side[3];
   rt::Event             sideDone[3];
   manta_smallsv_stats_t stats{};
+  // device -> host staging (pinned)
+  PinnedBuf             pRes, pInfo, pTasks, pCig;
+  AlignResultDev*       hRes   = nullptr;
+  SmallSvTaskInfo*      hInfo  = nullptr;
+  AlignTaskDev*         hTasks = nullptr;
+  uint32_t*             hCig   = nullptr;
+  uint64_t              cigDev = 0;  // cigar words the schedule kernel handed out (known after run)
+  bool                  staged = false;
   explicit manta_smallsv(manta_ctx_t* c) : ctx(c), asmStage(c) {}
 };
 
@@ -441,9 +613,18 @@ struct manta_spanning {
   DevBuf                dRefs1, dRef1Off, dRefs2, dRef2Off, dCuts, dTasks, dTasks2, dInfo, dResults, dResults2, dBucketIds, dBucketIds2, dSmall,
       dCigar, dPtrWs;
   rt::Event             evStart, evAsm, evSched, evAlign;
+  rt::Stream            main;
   rt::Stream            side[3];
   rt::Event             sideDone[3];
   manta_smallsv_stats_t stats{};
+  PinnedBuf             pRes, pRes2, pInfo, pTasks, pTasks2, pCuts, pCig;
+  AlignResultDev *      hRes = nullptr, *hRes2 = nullptr;
+  SpanTaskInfo*         hInfo = nullptr;
+  AlignTaskDev *        hTasks = nullptr, *hTasks2 = nullptr;
+  JumpCuts*             hCuts = nullptr;
+  uint32_t*             hCig  = nullptr;
+  uint64_t              cigDev = 0;
+  bool                  staged = false;
   explicit manta_spanning(manta_ctx_t* c) : ctx(c), asmStage(c) {}
 };
 
@@ -465,6 +646,7 @@ int manta_ctx_create(int device_id, manta_ctx_t** out)
     manta_ctx_t* ctx = new manta_ctx();
     ctx->deviceName  = rt::deviceName();
     ctx->cuCount     = rt::cuCount();
+    ctx->deviceId    = rt::currentDevice();
     *out             = ctx;
     return MANTA_OK;
   } catch (const std::exception& e) {
@@ -503,6 +685,7 @@ int manta_align_batch(
   if (n_tasks == 0) return MANTA_OK;
 
   try {
+    rt::ScopedStream onStream(ctx->stream);
     // ---- validate + bucket by columns-per-lane (E) ----
     std::vector<AlignTaskDev>          dev(n_tasks);
     std::vector<std::vector<uint32_t>> buckets(kNumESet);
@@ -514,8 +697,8 @@ int manta_align_batch(
       manta_align_result_t&     r(results[i]);
       std::memset(&r, 0, sizeof(r));
       const bool jump = (kind == MANTA_ALIGNER_JUMP);
-      if (t.query_off + t.query_len > seq_arena_bytes || t.ref1_off + t.ref1_len > seq_arena_bytes ||
-          (jump && t.ref2_off + t.ref2_len > seq_arena_bytes))
+      auto outside = [&](uint64_t off, uint64_t len) { return off > seq_arena_bytes || len > seq_arena_bytes - off; };
+      if (outside(t.query_off, t.query_len) || outside(t.ref1_off, t.ref1_len) || (jump && outside(t.ref2_off, t.ref2_len)))
         return fail(ctx, MANTA_E_INVALID_ARG, "manta_align_batch: task " + std::to_string(i) + " outside the sequence arena");
       if (t.query_len == 0 || t.ref1_len == 0 || (jump && t.ref2_len == 0)) {
         r.status = MANTA_E_EMPTY_SEQ;  // GlobalJumpAlignerImpl.hpp:50-58, GlobalAlignerImpl.hpp:44-49
@@ -560,7 +743,7 @@ int manta_align_batch(
     rt::dzero(dResults, sizeof(AlignResultDev) * n_tasks);
 
     const int    maxWaves  = std::max(1, ctx->cuCount * alignWavesPerCu());
-    const size_t wsBudget  = std::min<size_t>(rt::freeBytes() / 2, size_t(24) << 30);
+    const size_t wsBudget  = workspaceBudget(size_t(24) << 30);
     size_t       idsCursor = 0;
     for (int b = 0; b < kNumESet; ++b) {
       if (buckets[b].empty()) continue;
@@ -649,6 +832,7 @@ int manta_assemble_batch(
   if (bits_arena_used) *bits_arena_used = 0;
   if (n_loci == 0) return MANTA_OK;
   try {
+    rt::ScopedStream onStream(ctx->stream);
     AsmStage st(ctx);
     int      rc = st.plan(*opt, n_loci, read_off, locus_read_begin);
     if (rc != MANTA_OK) return rc;
@@ -697,6 +881,7 @@ int manta_smallsv_upload(
   if (n_loci == 0 || !bases || !read_off || !locus_read_begin || !refs || !ref_off || !cuts)
     return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_upload: null argument or empty batch");
   try {
+    rt::ScopedStream onStream(b->main);
     b->uploaded = false;
     int rc      = b->asmStage.plan(b->opt, n_loci, read_off, locus_read_begin);
     if (rc != MANTA_OK) return rc;
@@ -731,6 +916,7 @@ int manta_smallsv_run(manta_smallsv_t* b)
   manta_ctx_t* ctx = b->ctx;
   if (!b->uploaded) return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_run: nothing uploaded");
   try {
+    rt::ScopedStream onStream(b->main);
     const uint32_t nLoci   = b->nLoci;
     const uint32_t maxAsm  = b->opt.max_assembly_count;
     const uint64_t nSlots  = uint64_t(nLoci) * maxAsm;
@@ -794,7 +980,7 @@ int manta_smallsv_run(manta_smallsv_t* b)
     b->stats.n_alignments     = 0;
     b->stats.ptr_matrix_bytes = 0;
     const int    maxWaves = std::max(1, ctx->cuCount * alignWavesPerCu());
-    const size_t wsBudget = std::min<size_t>(rt::freeBytes() / 2, size_t(48) << 30);
+    const size_t wsBudget = workspaceBudget(size_t(48) << 30);
     // The E buckets are independent launches: they run on side streams so that the tail of one overlaps the others
     // (a launch's last alignments leave most of the device idle otherwise).  Each bucket gets its own slab region.
     {
@@ -844,7 +1030,7 @@ int manta_smallsv_run(manta_smallsv_t* b)
       // the null stream (events, later copies) continues after every side stream has drained
       for (size_t i = 0; i < std::min<size_t>(launches.size(), 3); ++i) {
         b->sideDone[i].recordOn(b->side[i]);
-        rt::nullStreamWaits(b->sideDone[i]);
+        rt::curStreamWaits(b->sideDone[i]);
       }
     }
     b->evAlign.record();
@@ -873,6 +1059,7 @@ int manta_smallsv_output_sizes(const manta_smallsv_t* b, uint64_t* contigs, uint
   if (!b || !contigs || !seq_bytes || !bits_words || !cigar_words) return MANTA_E_INVALID_ARG;
   if (!b->ran) return fail(b->ctx, MANTA_E_INVALID_ARG, "manta_smallsv_output_sizes: run first");
   try {
+    rt::ScopedStream onStream(const_cast<manta_smallsv_t*>(b)->main);
     b->asmStage.outputSizes(*contigs, *seq_bytes, *bits_words);
     uint32_t hSmall[40];
     rt::d2h(hSmall, b->dSmall.p, sizeof(hSmall));
@@ -884,6 +1071,111 @@ int manta_smallsv_output_sizes(const manta_smallsv_t* b, uint64_t* contigs, uint
     return fail(b->ctx, MANTA_E_HIP, e.what());
   }
 }
+
+}  // extern "C"
+
+namespace {
+
+/// device -> pinned staging of one finished small-SV run
+void smallsvStage(manta_smallsv* b)
+{
+  const uint64_t nSlots = uint64_t(b->nLoci) * b->opt.max_assembly_count;
+  uint32_t       hSmall[40];
+  rt::d2h(hSmall, b->dSmall.p, sizeof(hSmall));
+  std::memcpy(&b->cigDev, hSmall + 34, sizeof(uint64_t));
+  b->hRes   = b->pRes.as<AlignResultDev>(nSlots);
+  b->hInfo  = b->pInfo.as<SmallSvTaskInfo>(nSlots);
+  b->hTasks = b->pTasks.as<AlignTaskDev>(nSlots);
+  b->hCig   = b->pCig.as<uint32_t>(b->cigDev + 1);
+  b->asmStage.stageOut([&] {
+    rt::d2hAsync(b->hRes, b->dResults.p, sizeof(AlignResultDev) * nSlots);
+    rt::d2hAsync(b->hInfo, b->dInfo.p, sizeof(SmallSvTaskInfo) * nSlots);
+    rt::d2hAsync(b->hTasks, b->dTasks.p, sizeof(AlignTaskDev) * nSlots);
+    rt::d2hAsync(b->hCig, b->dCigar.p, sizeof(uint32_t) * b->cigDev);
+  });
+  b->staged = true;
+}
+
+/// bytes a stageOut moved over PCIe (for the batch statistics)
+uint64_t smallsvStagedBytes(const manta_smallsv* b)
+{
+  const uint64_t nSlots = uint64_t(b->nLoci) * b->opt.max_assembly_count;
+  return b->asmStage.seqUsedDev + 8 * b->asmStage.bitsUsedDev + sizeof(AsmLocusOut) * uint64_t(b->nLoci) + sizeof(AsmContigOut) * nSlots +
+         (sizeof(AlignResultDev) + sizeof(SmallSvTaskInfo) + sizeof(AlignTaskDev)) * nSlots + 4 * b->cigDev + 128 + 160;
+}
+
+/// exact number of cigar words smallsvCompact will write
+uint64_t smallsvCigarWords(const manta_smallsv* b)
+{
+  const uint32_t maxAsm = b->opt.max_assembly_count;
+  uint64_t       n      = 0;
+  for (uint32_t l = 0; l < b->nLoci; ++l) {
+    const AsmLocusOut& h(b->asmStage.hLoci[l]);
+    if (h.status != ASM_OK) continue;
+    for (uint32_t c = 0; c < h.n_contigs; ++c) {
+      const uint64_t slot = uint64_t(l) * maxAsm + c;
+      if (b->hInfo[slot].status == 0 && b->hInfo[slot].bucket >= 0 && b->hRes[slot].status == 0) n += b->hRes[slot].cigar1_len;
+    }
+  }
+  return n;
+}
+
+/// staging -> caller records/arenas.  `loci` is this block's slice; `contigs` / `alignments` are the caller's whole arrays
+/// and this block writes [contigBase, contigBase + contigs_cap); the three arenas are this block's regions, offsets in the
+/// records are made relative to the caller's arena starts by adding the *Base values.
+int smallsvCompact(
+    manta_smallsv* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_smallsv_alignment_t* alignments,
+    uint64_t contigBase, uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t seqBase, uint64_t* seq_arena_used,
+    uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t bitsBase, uint64_t* bits_arena_used, uint32_t* cigar_arena,
+    uint64_t cigar_arena_cap, uint64_t cigarBase, uint64_t* cigar_arena_used)
+{
+  manta_ctx_t* ctx = b->ctx;
+  int rc = b->asmStage.compact(loci, contigs + contigBase, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap,
+                               bits_arena_used, contigBase, seqBase, bitsBase);
+  if (rc != MANTA_OK && rc != MANTA_E_UNSUPPORTED && rc != MANTA_E_DEVICE_FAULT) return rc;
+  const uint32_t nLoci  = b->nLoci;
+  const uint32_t maxAsm = b->opt.max_assembly_count;
+  uint64_t       used = 0, cells = 0, ptrBytes = 0;
+  int            worst = rc;
+  for (uint32_t l = 0; l < nLoci; ++l) {
+    if (loci[l].status != MANTA_OK) continue;
+    for (uint32_t c = 0; c < loci[l].n_contigs; ++c) {
+      const uint64_t             slot = uint64_t(l) * maxAsm + c;
+      manta_smallsv_alignment_t& a(alignments[loci[l].first_contig + c]);
+      std::memset(&a, 0, sizeof(a));
+      const SmallSvTaskInfo& inf(b->hInfo[slot]);
+      a.adjusted_leading_cut  = inf.adj_leading_cut;
+      a.adjusted_trailing_cut = inf.adj_trailing_cut;
+      if (inf.status != 0 || inf.bucket < 0 || b->hRes[slot].status != 0) {
+        a.align.status = (inf.status == 5) ? MANTA_E_DEVICE_FAULT : MANTA_E_UNSUPPORTED;
+        worst          = a.align.status;
+        continue;
+      }
+      const AlignResultDev& h(b->hRes[slot]);
+      const uint64_t        n = h.cigar1_len;
+      if (used + n > cigar_arena_cap) return fail(ctx, MANTA_E_CAPACITY, "manta_smallsv_download: cigar arena too small");
+      std::memcpy(cigar_arena + used, b->hCig + b->hTasks[slot].cigar_off, sizeof(uint32_t) * n);
+      a.align.score      = h.score;
+      a.align.is_jumped  = h.is_jumped;
+      a.align.begin_pos1 = h.begin1 + inf.adj_leading_cut;  // SVCandidateAssemblyRefiner.cpp:2039
+      a.align.cigar1_len = h.cigar1_len;
+      a.align.cigar1_off = cigarBase + used;
+      a.align.cigar2_off = cigarBase + used + n;
+      used += n;
+      cells += uint64_t(b->hTasks[slot].query_len) * b->hTasks[slot].ref1_len;
+      ptrBytes += 2ull * (uint64_t(b->hTasks[slot].query_len) + 1) * (uint64_t(b->hTasks[slot].ref1_len) + 1);
+    }
+  }
+  b->stats.dp_cells         = cells;
+  b->stats.ptr_matrix_bytes = ptrBytes;
+  if (cigar_arena_used) *cigar_arena_used = used;
+  if (worst != MANTA_OK) return fail(ctx, worst, "manta_smallsv_download: one or more loci/contigs failed; see per-item status");
+  return MANTA_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 int manta_smallsv_download(
     manta_smallsv_t* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_smallsv_alignment_t* alignments,
@@ -897,60 +1189,10 @@ int manta_smallsv_download(
   if (!loci || !contigs || !alignments || !seq_arena || !bits_arena || !cigar_arena)
     return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_download: null argument");
   try {
-    int rc = b->asmStage.fetch(loci, contigs, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap,
-                               bits_arena_used);
-    if (rc != MANTA_OK && rc != MANTA_E_UNSUPPORTED && rc != MANTA_E_DEVICE_FAULT) return rc;
-    const uint32_t nLoci  = b->nLoci;
-    const uint32_t maxAsm = b->opt.max_assembly_count;
-    const uint64_t nSlots = uint64_t(nLoci) * maxAsm;
-    std::vector<AlignResultDev>  hRes(nSlots);
-    std::vector<SmallSvTaskInfo> hInfo(nSlots);
-    std::vector<AlignTaskDev>    hTasks(nSlots);
-    uint32_t                     hSmall[40];
-    rt::d2h(hRes.data(), b->dResults.p, sizeof(AlignResultDev) * nSlots);
-    rt::d2h(hInfo.data(), b->dInfo.p, sizeof(SmallSvTaskInfo) * nSlots);
-    rt::d2h(hTasks.data(), b->dTasks.p, sizeof(AlignTaskDev) * nSlots);
-    rt::d2h(hSmall, b->dSmall.p, sizeof(hSmall));
-    uint64_t cigDev = 0;
-    std::memcpy(&cigDev, hSmall + 34, sizeof(uint64_t));
-    std::vector<uint32_t> hCig(cigDev + 1);
-    rt::d2h(hCig.data(), b->dCigar.p, sizeof(uint32_t) * cigDev);
-    uint64_t used = 0, cells = 0, ptrBytes = 0;
-    int      worst = rc;
-    for (uint32_t l = 0; l < nLoci; ++l) {
-      if (loci[l].status != MANTA_OK) continue;
-      for (uint32_t c = 0; c < loci[l].n_contigs; ++c) {
-        const uint64_t             slot = uint64_t(l) * maxAsm + c;
-        manta_smallsv_alignment_t& a(alignments[loci[l].first_contig + c]);
-        std::memset(&a, 0, sizeof(a));
-        const SmallSvTaskInfo& inf(hInfo[slot]);
-        a.adjusted_leading_cut  = inf.adj_leading_cut;
-        a.adjusted_trailing_cut = inf.adj_trailing_cut;
-        if (inf.status != 0 || inf.bucket < 0 || hRes[slot].status != 0) {
-          a.align.status = (inf.status == 5) ? MANTA_E_CAPACITY : MANTA_E_UNSUPPORTED;
-          worst          = a.align.status;
-          continue;
-        }
-        const AlignResultDev& h(hRes[slot]);
-        const uint64_t        n = h.cigar1_len;
-        if (used + n > cigar_arena_cap) return fail(ctx, MANTA_E_CAPACITY, "manta_smallsv_download: cigar arena too small");
-        std::memcpy(cigar_arena + used, hCig.data() + hTasks[slot].cigar_off, sizeof(uint32_t) * n);
-        a.align.score      = h.score;
-        a.align.is_jumped  = h.is_jumped;
-        a.align.begin_pos1 = h.begin1 + inf.adj_leading_cut;  // SVCandidateAssemblyRefiner.cpp:2039
-        a.align.cigar1_len = h.cigar1_len;
-        a.align.cigar1_off = used;
-        a.align.cigar2_off = used + n;
-        used += n;
-        cells += uint64_t(hTasks[slot].query_len) * hTasks[slot].ref1_len;
-        ptrBytes += 2ull * (uint64_t(hTasks[slot].query_len) + 1) * (uint64_t(hTasks[slot].ref1_len) + 1);
-      }
-    }
-    b->stats.dp_cells         = cells;
-    b->stats.ptr_matrix_bytes = ptrBytes;
-    if (cigar_arena_used) *cigar_arena_used = used;
-    if (worst != MANTA_OK) return fail(ctx, worst, "manta_smallsv_download: one or more loci/contigs failed; see per-item status");
-    return MANTA_OK;
+    rt::ScopedStream onStream(b->main);
+    smallsvStage(b);
+    return smallsvCompact(b, loci, contigs, alignments, 0, contigs_cap, seq_arena, seq_arena_cap, 0, seq_arena_used, bits_arena,
+                          bits_arena_cap, 0, bits_arena_used, cigar_arena, cigar_arena_cap, 0, cigar_arena_used);
   } catch (const std::exception& e) {
     return fail(ctx, MANTA_E_HIP, e.what());
   }
@@ -988,6 +1230,7 @@ int manta_spanning_upload(
   if (n_loci == 0 || !bases || !read_off || !locus_read_begin || !refs1 || !ref1_off || !refs2 || !ref2_off || !cuts)
     return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_upload: null argument or empty batch");
   try {
+    rt::ScopedStream onStream(b->main);
     b->uploaded = false;
     int rc      = b->asmStage.plan(b->opt, n_loci, read_off, locus_read_begin);
     if (rc != MANTA_OK) return rc;
@@ -1022,6 +1265,7 @@ int manta_spanning_run(manta_spanning_t* b)
   manta_ctx_t* ctx = b->ctx;
   if (!b->uploaded) return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_run: nothing uploaded");
   try {
+    rt::ScopedStream onStream(b->main);
     const uint32_t nLoci  = b->nLoci;
     const uint32_t maxAsm = b->opt.max_assembly_count;
     const uint64_t nSlots = uint64_t(nLoci) * maxAsm;
@@ -1087,7 +1331,7 @@ int manta_spanning_run(manta_spanning_t* b)
     b->stats.n_align_launches = 0;
     b->stats.n_alignments     = 0;
     const int    maxWaves = std::max(1, ctx->cuCount * alignWavesPerCu());
-    const size_t wsBudget = std::min<size_t>(rt::freeBytes() / 2, size_t(48) << 30);
+    const size_t wsBudget = workspaceBudget(size_t(48) << 30);
     auto alignRound = [&](const uint32_t* hCounts, const uint32_t* hMaxref, const AlignTaskDev* tasks, AlignResultDev* results,
                           const uint32_t* bucketIds, uint32_t* counters) {
       // buckets on side streams, one slab region each (see manta_smallsv_run)
@@ -1136,7 +1380,7 @@ int manta_spanning_run(manta_spanning_t* b)
       }
       for (size_t i = 0; i < std::min<size_t>(launches.size(), 3); ++i) {
         b->sideDone[i].recordOn(b->side[i]);
-        rt::nullStreamWaits(b->sideDone[i]);
+        rt::curStreamWaits(b->sideDone[i]);
       }
       rt::sync();  // the next stage reads the results and may re-size the slab buffer
     };
@@ -1173,6 +1417,7 @@ int manta_spanning_output_sizes(const manta_spanning_t* b, uint64_t* contigs, ui
   if (!b || !contigs || !seq_bytes || !bits_words || !cigar_words) return MANTA_E_INVALID_ARG;
   if (!b->ran) return fail(b->ctx, MANTA_E_INVALID_ARG, "manta_spanning_output_sizes: run first");
   try {
+    rt::ScopedStream onStream(const_cast<manta_spanning_t*>(b)->main);
     b->asmStage.outputSizes(*contigs, *seq_bytes, *bits_words);
     uint32_t hSmall[72];
     rt::d2h(hSmall, b->dSmall.p, sizeof(hSmall));
@@ -1184,6 +1429,123 @@ int manta_spanning_output_sizes(const manta_spanning_t* b, uint64_t* contigs, ui
     return fail(b->ctx, MANTA_E_HIP, e.what());
   }
 }
+
+}  // extern "C"
+
+namespace {
+
+void spanningStage(manta_spanning* b)
+{
+  const uint32_t nLoci  = b->nLoci;
+  const uint64_t nSlots = uint64_t(nLoci) * b->opt.max_assembly_count;
+  uint32_t       hSmall[72];
+  rt::d2h(hSmall, b->dSmall.p, sizeof(hSmall));
+  std::memcpy(&b->cigDev, hSmall + 64, sizeof(uint64_t));
+  b->hRes    = b->pRes.as<AlignResultDev>(nSlots);
+  b->hRes2   = b->pRes2.as<AlignResultDev>(nSlots);
+  b->hInfo   = b->pInfo.as<SpanTaskInfo>(nSlots);
+  b->hTasks  = b->pTasks.as<AlignTaskDev>(nSlots);
+  b->hTasks2 = b->pTasks2.as<AlignTaskDev>(nSlots);
+  b->hCuts   = b->pCuts.as<JumpCuts>(nLoci);
+  b->hCig    = b->pCig.as<uint32_t>(b->cigDev + 1);
+  b->asmStage.stageOut([&] {
+    rt::d2hAsync(b->hRes, b->dResults.p, sizeof(AlignResultDev) * nSlots);
+    rt::d2hAsync(b->hRes2, b->dResults2.p, sizeof(AlignResultDev) * nSlots);
+    rt::d2hAsync(b->hInfo, b->dInfo.p, sizeof(SpanTaskInfo) * nSlots);
+    rt::d2hAsync(b->hTasks, b->dTasks.p, sizeof(AlignTaskDev) * nSlots);
+    rt::d2hAsync(b->hTasks2, b->dTasks2.p, sizeof(AlignTaskDev) * nSlots);
+    rt::d2hAsync(b->hCuts, b->dCuts.p, sizeof(JumpCuts) * nLoci);
+    rt::d2hAsync(b->hCig, b->dCigar.p, sizeof(uint32_t) * b->cigDev);
+  });
+  b->staged = true;
+}
+
+uint64_t spanningStagedBytes(const manta_spanning* b)
+{
+  const uint64_t nSlots = uint64_t(b->nLoci) * b->opt.max_assembly_count;
+  return b->asmStage.seqUsedDev + 8 * b->asmStage.bitsUsedDev + sizeof(AsmLocusOut) * uint64_t(b->nLoci) + sizeof(AsmContigOut) * nSlots +
+         (2 * sizeof(AlignResultDev) + sizeof(SpanTaskInfo) + 2 * sizeof(AlignTaskDev)) * nSlots + sizeof(JumpCuts) * uint64_t(b->nLoci) +
+         4 * b->cigDev + 128 + 288;
+}
+
+uint64_t spanningCigarWords(const manta_spanning* b)
+{
+  const uint32_t maxAsm = b->opt.max_assembly_count;
+  uint64_t       n      = 0;
+  for (uint32_t l = 0; l < b->nLoci; ++l) {
+    const AsmLocusOut& lo(b->asmStage.hLoci[l]);
+    if (lo.status != ASM_OK) continue;
+    for (uint32_t c = 0; c < lo.n_contigs; ++c) {
+      const uint64_t        slot = uint64_t(l) * maxAsm + c;
+      const SpanTaskInfo&   inf(b->hInfo[slot]);
+      const bool            uncut = inf.is_uncut != 0;
+      const AlignResultDev& h(uncut ? b->hRes2[slot] : b->hRes[slot]);
+      if (inf.status != 0 || h.status != 0 || (uncut ? inf.bucket2 : inf.bucket) < 0) continue;
+      n += uint64_t(h.cigar1_len) + h.cigar2_len;
+    }
+  }
+  return n;
+}
+
+int spanningCompact(
+    manta_spanning* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_spanning_alignment_t* alignments,
+    uint64_t contigBase, uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t seqBase, uint64_t* seq_arena_used,
+    uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t bitsBase, uint64_t* bits_arena_used, uint32_t* cigar_arena,
+    uint64_t cigar_arena_cap, uint64_t cigarBase, uint64_t* cigar_arena_used)
+{
+  manta_ctx_t* ctx = b->ctx;
+  int rc = b->asmStage.compact(loci, contigs + contigBase, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap,
+                               bits_arena_used, contigBase, seqBase, bitsBase);
+  if (rc != MANTA_OK && rc != MANTA_E_UNSUPPORTED && rc != MANTA_E_DEVICE_FAULT) return rc;
+  const uint32_t nLoci  = b->nLoci;
+  const uint32_t maxAsm = b->opt.max_assembly_count;
+  uint64_t       used = 0, cells = 0, ptrBytes = 0;
+  int            worst = rc;
+  for (uint32_t l = 0; l < nLoci; ++l) {
+    if (loci[l].status != MANTA_OK) continue;
+    for (uint32_t c = 0; c < loci[l].n_contigs; ++c) {
+      const uint64_t              slot = uint64_t(l) * maxAsm + c;
+      manta_spanning_alignment_t& a(alignments[loci[l].first_contig + c]);
+      std::memset(&a, 0, sizeof(a));
+      const SpanTaskInfo&   inf(b->hInfo[slot]);
+      const bool            uncut = inf.is_uncut != 0;
+      const AlignResultDev& h(uncut ? b->hRes2[slot] : b->hRes[slot]);
+      const AlignTaskDev&   t(uncut ? b->hTasks2[slot] : b->hTasks[slot]);
+      a.is_uncut = uncut ? 1 : 0;
+      if (inf.status != 0 || h.status != 0 || (uncut ? inf.bucket2 : inf.bucket) < 0) {
+        a.align.status = (inf.status == 5) ? MANTA_E_DEVICE_FAULT : (inf.status == 6) ? MANTA_E_EMPTY_SEQ : MANTA_E_UNSUPPORTED;
+        worst          = a.align.status;
+        continue;
+      }
+      const uint64_t n = uint64_t(h.cigar1_len) + h.cigar2_len;
+      if (used + n > cigar_arena_cap) return fail(ctx, MANTA_E_CAPACITY, "manta_spanning_download: cigar arena too small");
+      std::memcpy(cigar_arena + used, b->hCig + t.cigar_off, sizeof(uint32_t) * n);
+      a.align.score            = h.score;
+      a.align.is_jumped        = h.is_jumped;
+      a.align.begin_pos1       = h.begin1 + (uncut ? 0 : b->hCuts[l].a1Lead);  // SVCandidateAssemblyRefiner.cpp:1716-1717
+      a.align.begin_pos2       = h.begin2 + (uncut ? 0 : b->hCuts[l].a2Lead);
+      a.align.jump_insert_size = h.jump_insert_size;
+      a.align.jump_range       = h.jump_range;
+      a.align.cigar1_len       = h.cigar1_len;
+      a.align.cigar2_len       = h.cigar2_len;
+      a.align.cigar1_off       = cigarBase + used;
+      a.align.cigar2_off       = cigarBase + used + h.cigar1_len;
+      used += n;
+      const uint64_t refLen = uint64_t(t.ref1_len) + t.ref2_len;
+      cells += uint64_t(t.query_len) * refLen;
+      ptrBytes += (uint64_t(t.query_len) + 1) * (refLen + 2);
+    }
+  }
+  b->stats.dp_cells         = cells;
+  b->stats.ptr_matrix_bytes = ptrBytes;
+  if (cigar_arena_used) *cigar_arena_used = used;
+  if (worst != MANTA_OK) return fail(ctx, worst, "manta_spanning_download: one or more loci/contigs failed; see per-item status");
+  return MANTA_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 int manta_spanning_download(
     manta_spanning_t* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_spanning_alignment_t* alignments,
@@ -1197,73 +1559,386 @@ int manta_spanning_download(
   if (!loci || !contigs || !alignments || !seq_arena || !bits_arena || !cigar_arena)
     return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_download: null argument");
   try {
-    int rc = b->asmStage.fetch(loci, contigs, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap,
-                               bits_arena_used);
-    if (rc != MANTA_OK && rc != MANTA_E_UNSUPPORTED && rc != MANTA_E_DEVICE_FAULT) return rc;
-    const uint32_t nLoci  = b->nLoci;
-    const uint32_t maxAsm = b->opt.max_assembly_count;
-    const uint64_t nSlots = uint64_t(nLoci) * maxAsm;
-    std::vector<AlignResultDev> hRes(nSlots), hRes2(nSlots);
-    std::vector<SpanTaskInfo>   hInfo(nSlots);
-    std::vector<AlignTaskDev>   hTasks(nSlots), hTasks2(nSlots);
-    std::vector<JumpCuts>       hCuts(nLoci);
-    uint32_t                    hSmall[72];
-    rt::d2h(hRes.data(), b->dResults.p, sizeof(AlignResultDev) * nSlots);
-    rt::d2h(hRes2.data(), b->dResults2.p, sizeof(AlignResultDev) * nSlots);
-    rt::d2h(hInfo.data(), b->dInfo.p, sizeof(SpanTaskInfo) * nSlots);
-    rt::d2h(hTasks.data(), b->dTasks.p, sizeof(AlignTaskDev) * nSlots);
-    rt::d2h(hTasks2.data(), b->dTasks2.p, sizeof(AlignTaskDev) * nSlots);
-    rt::d2h(hCuts.data(), b->dCuts.p, sizeof(JumpCuts) * nLoci);
-    rt::d2h(hSmall, b->dSmall.p, sizeof(hSmall));
-    uint64_t cigDev = 0;
-    std::memcpy(&cigDev, hSmall + 64, sizeof(uint64_t));
-    std::vector<uint32_t> hCig(cigDev + 1);
-    rt::d2h(hCig.data(), b->dCigar.p, sizeof(uint32_t) * cigDev);
-    uint64_t used = 0, cells = 0, ptrBytes = 0;
-    int      worst = rc;
-    for (uint32_t l = 0; l < nLoci; ++l) {
-      if (loci[l].status != MANTA_OK) continue;
-      for (uint32_t c = 0; c < loci[l].n_contigs; ++c) {
-        const uint64_t              slot = uint64_t(l) * maxAsm + c;
-        manta_spanning_alignment_t& a(alignments[loci[l].first_contig + c]);
-        std::memset(&a, 0, sizeof(a));
-        const SpanTaskInfo&   inf(hInfo[slot]);
-        const bool            uncut = inf.is_uncut != 0;
-        const AlignResultDev& h(uncut ? hRes2[slot] : hRes[slot]);
-        const AlignTaskDev&   t(uncut ? hTasks2[slot] : hTasks[slot]);
-        a.is_uncut = uncut ? 1 : 0;
-        if (inf.status != 0 || h.status != 0 || (uncut ? inf.bucket2 : inf.bucket) < 0) {
-          a.align.status = (inf.status == 5) ? MANTA_E_CAPACITY : (inf.status == 6) ? MANTA_E_EMPTY_SEQ : MANTA_E_UNSUPPORTED;
-          worst          = a.align.status;
-          continue;
-        }
-        const uint64_t n = uint64_t(h.cigar1_len) + h.cigar2_len;
-        if (used + n > cigar_arena_cap) return fail(ctx, MANTA_E_CAPACITY, "manta_spanning_download: cigar arena too small");
-        std::memcpy(cigar_arena + used, hCig.data() + t.cigar_off, sizeof(uint32_t) * n);
-        a.align.score            = h.score;
-        a.align.is_jumped        = h.is_jumped;
-        a.align.begin_pos1       = h.begin1 + (uncut ? 0 : hCuts[l].a1Lead);  // SVCandidateAssemblyRefiner.cpp:1716-1717
-        a.align.begin_pos2       = h.begin2 + (uncut ? 0 : hCuts[l].a2Lead);
-        a.align.jump_insert_size = h.jump_insert_size;
-        a.align.jump_range       = h.jump_range;
-        a.align.cigar1_len       = h.cigar1_len;
-        a.align.cigar2_len       = h.cigar2_len;
-        a.align.cigar1_off       = used;
-        a.align.cigar2_off       = used + h.cigar1_len;
-        used += n;
-        const uint64_t refLen = uint64_t(t.ref1_len) + t.ref2_len;
-        cells += uint64_t(t.query_len) * refLen;
-        ptrBytes += (uint64_t(t.query_len) + 1) * (refLen + 2);
-      }
-    }
-    b->stats.dp_cells         = cells;
-    b->stats.ptr_matrix_bytes = ptrBytes;
-    if (cigar_arena_used) *cigar_arena_used = used;
-    if (worst != MANTA_OK) return fail(ctx, worst, "manta_spanning_download: one or more loci/contigs failed; see per-item status");
-    return MANTA_OK;
+    rt::ScopedStream onStream(b->main);
+    spanningStage(b);
+    return spanningCompact(b, loci, contigs, alignments, 0, contigs_cap, seq_arena, seq_arena_cap, 0, seq_arena_used, bits_arena,
+                           bits_arena_cap, 0, bits_arena_used, cigar_arena, cigar_arena_cap, 0, cigar_arena_used);
   } catch (const std::exception& e) {
     return fail(ctx, MANTA_E_HIP, e.what());
   }
+}
+
+}  // extern "C"
+
+
+
+// ------------------------------------------------------------------------------------------------------
+// per-locus word lengths, pinned host memory, whole-batch calls
+// ------------------------------------------------------------------------------------------------------
+manta_ctx::~manta_ctx()
+{
+  for (manta_smallsv* p : smallPool) delete p;
+  for (manta_spanning* p : spanPool) delete p;
+}
+
+namespace {
+
+int setWordLengths(manta_ctx_t* ctx, AsmStage& as, uint32_t n_loci, const uint32_t* minWl, const uint32_t* maxWl)
+{
+  as.locusMinWl.clear();
+  as.locusMaxWl.clear();
+  if (!minWl && !maxWl) return MANTA_OK;
+  if (!minWl || !maxWl || n_loci == 0) return fail(ctx, MANTA_E_INVALID_ARG, "set_word_lengths: both arrays (or neither) must be given");
+  as.locusMinWl.assign(minWl, minWl + n_loci);
+  as.locusMaxWl.assign(maxWl, maxWl + n_loci);
+  return MANTA_OK;
+}
+
+/// what the workers of one whole-batch call share: the block queue, the bump allocators over the caller's arenas, the
+/// first fatal error and the statistics
+struct BatchShared {
+  std::vector<uint32_t> blockOrder;  // block indices, most expensive first
+  std::atomic<uint32_t> next{0};
+  std::atomic<uint64_t> contigsUsed{0}, seqUsed{0}, bitsUsed{0}, cigarUsed{0};
+  std::mutex            mu;
+  int                   fatal = MANTA_OK, worst = MANTA_OK;
+  std::string           msg;
+  manta_batch_stats_t   st{};
+  void                  error(int code, const std::string& m, bool isFatal)
+  {
+    std::lock_guard<std::mutex> g(mu);
+    if (isFatal) {
+      if (fatal == MANTA_OK) {
+        fatal = code;
+        msg   = m;
+      }
+    } else if (worst == MANTA_OK) {
+      worst = code;
+      msg   = m;
+    }
+  }
+  bool stop()
+  {
+    std::lock_guard<std::mutex> g(mu);
+    return fatal != MANTA_OK;
+  }
+};
+
+bool perItemCode(int rc)
+{
+  return rc == MANTA_E_UNSUPPORTED || rc == MANTA_E_DEVICE_FAULT || rc == MANTA_E_EMPTY_SEQ;
+}
+
+/// contiguous blocks of `blockLoci` loci, ordered by decreasing cost (reads x bases, the same estimate the kernels'
+/// work queue uses): EdgeRetrieverBin.cpp:38-57 hands out contiguous edge ranges too, but statically
+void planBlocks(BatchShared& sh, uint32_t n_loci, uint32_t blockLoci, const uint64_t* read_off, const uint32_t* locus_read_begin)
+{
+  const uint32_t        nBlocks = (n_loci + blockLoci - 1) / blockLoci;
+  std::vector<uint64_t> cost(nBlocks, 0);
+  for (uint32_t b = 0; b < nBlocks; ++b) {
+    const uint32_t l0 = b * blockLoci, l1 = std::min(n_loci, l0 + blockLoci);
+    for (uint32_t l = l0; l < l1; ++l) {
+      const uint32_t rb = locus_read_begin[l], re = locus_read_begin[l + 1];
+      cost[b] += (read_off[re] - read_off[rb]) * uint64_t(re - rb);
+    }
+  }
+  sh.blockOrder.resize(nBlocks);
+  for (uint32_t b = 0; b < nBlocks; ++b) sh.blockOrder[b] = b;
+  std::stable_sort(sh.blockOrder.begin(), sh.blockOrder.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+}
+
+template <typename T>
+void rebase(std::vector<T>& out, const T* src, size_t first, size_t count)
+{
+  out.resize(count);
+  const T base = src[first];
+  for (size_t i = 0; i < count; ++i) out[i] = src[first + i] - base;
+}
+
+}  // namespace
+
+extern "C" {
+
+int manta_host_alloc(uint64_t bytes, void** out)
+{
+  if (!out) return MANTA_E_INVALID_ARG;
+  try {
+    *out = rt::hostAlloc(size_t(bytes));
+    return MANTA_OK;
+  } catch (const std::exception& e) {
+    g_createError = e.what();
+    *out          = nullptr;
+    return MANTA_E_HIP;
+  }
+}
+
+void manta_host_free(void* p)
+{
+  if (p) rt::hostFree(p);
+}
+
+int manta_smallsv_set_word_lengths(manta_smallsv_t* b, uint32_t n_loci, const uint32_t* min_word_length, const uint32_t* max_word_length)
+{
+  if (!b) return MANTA_E_INVALID_ARG;
+  return setWordLengths(b->ctx, b->asmStage, n_loci, min_word_length, max_word_length);
+}
+
+int manta_spanning_set_word_lengths(manta_spanning_t* b, uint32_t n_loci, const uint32_t* min_word_length, const uint32_t* max_word_length)
+{
+  if (!b) return MANTA_E_INVALID_ARG;
+  return setWordLengths(b->ctx, b->asmStage, n_loci, min_word_length, max_word_length);
+}
+
+int manta_smallsv_batch(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t large_indel_score, uint32_t n_loci,
+    const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const uint8_t* refs, const uint64_t* ref_off,
+    const manta_ref_cuts_t* cuts, const uint32_t* locus_min_word_length, const uint32_t* locus_max_word_length,
+    manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_smallsv_alignment_t* alignments, uint64_t contigs_cap,
+    uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
+    uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap, uint64_t* cigar_arena_used,
+    const manta_batch_plan_t* plan, manta_batch_stats_t* stats)
+{
+  if (!ctx) return MANTA_E_INVALID_ARG;
+  if (!opt || !scores || n_loci == 0 || !bases || !read_off || !locus_read_begin || !refs || !ref_off || !cuts || !loci || !contigs ||
+      !alignments || !seq_arena || !bits_arena || !cigar_arena)
+    return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_batch: null argument or empty batch");
+  if ((locus_min_word_length == nullptr) != (locus_max_word_length == nullptr))
+    return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_batch: per-locus word lengths need both arrays");
+  for (uint32_t l = 0; l < n_loci; ++l)
+    if (locus_read_begin[l + 1] < locus_read_begin[l] || ref_off[l + 1] < ref_off[l])
+      return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_batch: offsets not monotone");
+  const uint32_t blockLoci = (plan && plan->block_loci) ? plan->block_loci : 2048u;
+  BatchShared    sh;
+  planBlocks(sh, n_loci, blockLoci, read_off, locus_read_begin);
+  const uint32_t nBlocks  = uint32_t(sh.blockOrder.size());
+  const uint32_t nWorkers = std::max(1u, std::min(nBlocks, (plan && plan->n_workers) ? plan->n_workers : 4u));
+  try {
+    rt::setDevice(ctx->deviceId);
+    while (ctx->smallPool.size() < nWorkers) ctx->smallPool.push_back(new manta_smallsv(ctx));
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
+  const double tStart = nowMs();
+  auto         worker = [&](const uint32_t w) {
+    manta_smallsv* b = ctx->smallPool[w];
+    try {
+      rt::setDevice(ctx->deviceId);
+      b->opt        = *opt;
+      b->scores     = *scores;
+      b->largeIndel = large_indel_score;
+      std::vector<uint64_t> rOff, fOff;
+      std::vector<uint32_t> lBeg;
+      while (!sh.stop()) {
+        const uint32_t qi = sh.next.fetch_add(1);
+        if (qi >= nBlocks) break;
+        const uint32_t blk = sh.blockOrder[qi];
+        const uint32_t l0 = blk * blockLoci, l1 = std::min(n_loci, l0 + blockLoci), n = l1 - l0;
+        const uint32_t r0 = locus_read_begin[l0], r1 = locus_read_begin[l1];
+        rebase(rOff, read_off, r0, size_t(r1 - r0) + 1);
+        rebase(lBeg, locus_read_begin, l0, size_t(n) + 1);
+        rebase(fOff, ref_off, l0, size_t(n) + 1);
+        setWordLengths(ctx, b->asmStage, n, locus_min_word_length ? locus_min_word_length + l0 : nullptr,
+                       locus_max_word_length ? locus_max_word_length + l0 : nullptr);
+        const double t0 = nowMs();
+        int          rc = manta_smallsv_upload(b, n, bases + read_off[r0], rOff.data(), lBeg.data(), refs + ref_off[l0], fOff.data(), cuts + l0);
+        if (perItemCode(rc)) {  // a locus outside the supported envelope: this block's loci carry the code, the batch goes on
+          for (uint32_t l = l0; l < l1; ++l) {
+            std::memset(&loci[l], 0, sizeof(loci[l]));
+            loci[l].status = rc;
+          }
+          sh.error(rc, lastErrorOf(ctx), false);
+          continue;
+        }
+        if (rc != MANTA_OK) {
+          sh.error(rc, lastErrorOf(ctx), true);
+          break;
+        }
+        const double t1 = nowMs();
+        rc              = manta_smallsv_run(b);
+        if (rc != MANTA_OK) {
+          sh.error(rc, lastErrorOf(ctx), true);
+          break;
+        }
+        const double t2 = nowMs();
+        uint64_t     nC = 0, nS = 0, nB = 0, nG = 0;
+        {
+          rt::ScopedStream onStream(b->main);
+          smallsvStage(b);
+        }
+        b->asmStage.exactSizes(nC, nS, nB);
+        nG = smallsvCigarWords(b);
+        const uint64_t cBase = sh.contigsUsed.fetch_add(nC), sBase = sh.seqUsed.fetch_add(nS), bBase = sh.bitsUsed.fetch_add(nB),
+                       gBase = sh.cigarUsed.fetch_add(nG);
+        if (cBase + nC > contigs_cap || sBase + nS > seq_arena_cap || bBase + nB > bits_arena_cap || gBase + nG > cigar_arena_cap) {
+          sh.error(MANTA_E_CAPACITY, "manta_smallsv_batch: caller arenas too small", true);
+          break;
+        }
+        rc = smallsvCompact(b, loci + l0, contigs, alignments, cBase, nC, seq_arena + sBase, nS, sBase, nullptr, bits_arena + bBase, nB, bBase,
+                            nullptr, cigar_arena + gBase, nG, gBase, nullptr);
+        const double t3 = nowMs();
+        if (rc != MANTA_OK) {
+          sh.error(rc, lastErrorOf(ctx), !perItemCode(rc));
+          if (!perItemCode(rc)) break;
+        }
+        std::lock_guard<std::mutex> g(sh.mu);
+        sh.st.h2d_ms += t1 - t0;
+        sh.st.kernel_ms += t2 - t1;
+        sh.st.d2h_ms += t3 - t2;
+        sh.st.assemble_ms += b->stats.assemble_ms;
+        sh.st.schedule_ms += b->stats.schedule_ms;
+        sh.st.align_ms += b->stats.align_ms;
+        sh.st.n_alignments += b->stats.n_alignments;
+        sh.st.dp_cells += b->stats.dp_cells;
+        sh.st.ptr_matrix_bytes += b->stats.ptr_matrix_bytes;
+        sh.st.h2d_bytes += (read_off[r1] - read_off[r0]) + (ref_off[l1] - ref_off[l0]) + 8ull * (r1 - r0 + 1) + 12ull * (n + 1) + 16ull * n;
+        sh.st.d2h_bytes += smallsvStagedBytes(b);
+      }
+    } catch (const std::exception& e) {
+      sh.error(MANTA_E_HIP, e.what(), true);
+    }
+  };
+  std::vector<std::thread> threads;
+  for (uint32_t w = 1; w < nWorkers; ++w) threads.emplace_back(worker, w);
+  worker(0);
+  for (std::thread& t : threads) t.join();
+  sh.st.wall_ms   = nowMs() - tStart;
+  sh.st.n_blocks  = nBlocks;
+  sh.st.n_workers = nWorkers;
+  if (stats) *stats = sh.st;
+  if (seq_arena_used) *seq_arena_used = sh.seqUsed.load();
+  if (bits_arena_used) *bits_arena_used = sh.bitsUsed.load();
+  if (cigar_arena_used) *cigar_arena_used = sh.cigarUsed.load();
+  if (sh.fatal != MANTA_OK) return fail(ctx, sh.fatal, sh.msg);
+  if (sh.worst != MANTA_OK) return fail(ctx, sh.worst, sh.msg);
+  return MANTA_OK;
+}
+
+int manta_spanning_batch(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t jump_score, uint32_t n_loci,
+    const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const uint8_t* refs1, const uint64_t* ref1_off,
+    const uint8_t* refs2, const uint64_t* ref2_off, const manta_jump_cuts_t* cuts, const uint32_t* locus_min_word_length,
+    const uint32_t* locus_max_word_length, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs,
+    manta_spanning_alignment_t* alignments, uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used,
+    uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
+    uint64_t* cigar_arena_used, const manta_batch_plan_t* plan, manta_batch_stats_t* stats)
+{
+  if (!ctx) return MANTA_E_INVALID_ARG;
+  if (!opt || !scores || n_loci == 0 || !bases || !read_off || !locus_read_begin || !refs1 || !ref1_off || !refs2 || !ref2_off || !cuts ||
+      !loci || !contigs || !alignments || !seq_arena || !bits_arena || !cigar_arena)
+    return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_batch: null argument or empty batch");
+  if (scores->is_allow_edge_insertion) return fail(ctx, MANTA_E_INVALID_ARG, "GlobalJumpAligner does not support isAllowEdgeInsertion");
+  if ((locus_min_word_length == nullptr) != (locus_max_word_length == nullptr))
+    return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_batch: per-locus word lengths need both arrays");
+  for (uint32_t l = 0; l < n_loci; ++l)
+    if (locus_read_begin[l + 1] < locus_read_begin[l] || ref1_off[l + 1] < ref1_off[l] || ref2_off[l + 1] < ref2_off[l])
+      return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_batch: offsets not monotone");
+  const uint32_t blockLoci = (plan && plan->block_loci) ? plan->block_loci : 2048u;
+  BatchShared    sh;
+  planBlocks(sh, n_loci, blockLoci, read_off, locus_read_begin);
+  const uint32_t nBlocks  = uint32_t(sh.blockOrder.size());
+  const uint32_t nWorkers = std::max(1u, std::min(nBlocks, (plan && plan->n_workers) ? plan->n_workers : 4u));
+  try {
+    rt::setDevice(ctx->deviceId);
+    while (ctx->spanPool.size() < nWorkers) ctx->spanPool.push_back(new manta_spanning(ctx));
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
+  const double tStart = nowMs();
+  auto         worker = [&](const uint32_t w) {
+    manta_spanning* b = ctx->spanPool[w];
+    try {
+      rt::setDevice(ctx->deviceId);
+      b->opt       = *opt;
+      b->scores    = *scores;
+      b->jumpScore = jump_score;
+      std::vector<uint64_t> rOff, f1Off, f2Off;
+      std::vector<uint32_t> lBeg;
+      while (!sh.stop()) {
+        const uint32_t qi = sh.next.fetch_add(1);
+        if (qi >= nBlocks) break;
+        const uint32_t blk = sh.blockOrder[qi];
+        const uint32_t l0 = blk * blockLoci, l1 = std::min(n_loci, l0 + blockLoci), n = l1 - l0;
+        const uint32_t r0 = locus_read_begin[l0], r1 = locus_read_begin[l1];
+        rebase(rOff, read_off, r0, size_t(r1 - r0) + 1);
+        rebase(lBeg, locus_read_begin, l0, size_t(n) + 1);
+        rebase(f1Off, ref1_off, l0, size_t(n) + 1);
+        rebase(f2Off, ref2_off, l0, size_t(n) + 1);
+        setWordLengths(ctx, b->asmStage, n, locus_min_word_length ? locus_min_word_length + l0 : nullptr,
+                       locus_max_word_length ? locus_max_word_length + l0 : nullptr);
+        const double t0 = nowMs();
+        int          rc = manta_spanning_upload(b, n, bases + read_off[r0], rOff.data(), lBeg.data(), refs1 + ref1_off[l0], f1Off.data(),
+                                                refs2 + ref2_off[l0], f2Off.data(), cuts + l0);
+        if (perItemCode(rc)) {  // a locus outside the supported envelope: this block's loci carry the code, the batch goes on
+          for (uint32_t l = l0; l < l1; ++l) {
+            std::memset(&loci[l], 0, sizeof(loci[l]));
+            loci[l].status = rc;
+          }
+          sh.error(rc, lastErrorOf(ctx), false);
+          continue;
+        }
+        if (rc != MANTA_OK) {
+          sh.error(rc, lastErrorOf(ctx), true);
+          break;
+        }
+        const double t1 = nowMs();
+        rc              = manta_spanning_run(b);
+        if (rc != MANTA_OK) {
+          sh.error(rc, lastErrorOf(ctx), true);
+          break;
+        }
+        const double t2 = nowMs();
+        uint64_t     nC = 0, nS = 0, nB = 0, nG = 0;
+        {
+          rt::ScopedStream onStream(b->main);
+          spanningStage(b);
+        }
+        b->asmStage.exactSizes(nC, nS, nB);
+        nG = spanningCigarWords(b);
+        const uint64_t cBase = sh.contigsUsed.fetch_add(nC), sBase = sh.seqUsed.fetch_add(nS), bBase = sh.bitsUsed.fetch_add(nB),
+                       gBase = sh.cigarUsed.fetch_add(nG);
+        if (cBase + nC > contigs_cap || sBase + nS > seq_arena_cap || bBase + nB > bits_arena_cap || gBase + nG > cigar_arena_cap) {
+          sh.error(MANTA_E_CAPACITY, "manta_spanning_batch: caller arenas too small", true);
+          break;
+        }
+        rc = spanningCompact(b, loci + l0, contigs, alignments, cBase, nC, seq_arena + sBase, nS, sBase, nullptr, bits_arena + bBase, nB, bBase,
+                             nullptr, cigar_arena + gBase, nG, gBase, nullptr);
+        const double t3 = nowMs();
+        if (rc != MANTA_OK) {
+          sh.error(rc, lastErrorOf(ctx), !perItemCode(rc));
+          if (!perItemCode(rc)) break;
+        }
+        std::lock_guard<std::mutex> g(sh.mu);
+        sh.st.h2d_ms += t1 - t0;
+        sh.st.kernel_ms += t2 - t1;
+        sh.st.d2h_ms += t3 - t2;
+        sh.st.assemble_ms += b->stats.assemble_ms;
+        sh.st.schedule_ms += b->stats.schedule_ms;
+        sh.st.align_ms += b->stats.align_ms;
+        sh.st.n_alignments += b->stats.n_alignments;
+        sh.st.dp_cells += b->stats.dp_cells;
+        sh.st.ptr_matrix_bytes += b->stats.ptr_matrix_bytes;
+        sh.st.h2d_bytes += (read_off[r1] - read_off[r0]) + (ref1_off[l1] - ref1_off[l0]) + (ref2_off[l1] - ref2_off[l0]) + 8ull * (r1 - r0 + 1) +
+                           20ull * (n + 1) + 16ull * n;
+        sh.st.d2h_bytes += spanningStagedBytes(b);
+      }
+    } catch (const std::exception& e) {
+      sh.error(MANTA_E_HIP, e.what(), true);
+    }
+  };
+  std::vector<std::thread> threads;
+  for (uint32_t w = 1; w < nWorkers; ++w) threads.emplace_back(worker, w);
+  worker(0);
+  for (std::thread& t : threads) t.join();
+  sh.st.wall_ms   = nowMs() - tStart;
+  sh.st.n_blocks  = nBlocks;
+  sh.st.n_workers = nWorkers;
+  if (stats) *stats = sh.st;
+  if (seq_arena_used) *seq_arena_used = sh.seqUsed.load();
+  if (bits_arena_used) *bits_arena_used = sh.bitsUsed.load();
+  if (cigar_arena_used) *cigar_arena_used = sh.cigarUsed.load();
+  if (sh.fatal != MANTA_OK) return fail(ctx, sh.fatal, sh.msg);
+  if (sh.worst != MANTA_OK) return fail(ctx, sh.worst, sh.msg);
+  return MANTA_OK;
 }
 
 }  // extern "C"

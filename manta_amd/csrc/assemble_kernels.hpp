@@ -109,6 +109,11 @@ struct AsmParams {
   const uint32_t* growth_buckets;  ///< bucket count after it
   uint32_t        n_growth;
   uint32_t        flags;  ///< ASM_FLAG_*
+  // optional per-locus word lengths (mixed-k batches); nullptr = opt.minWordLength / maxWordLength
+  const uint32_t* locus_min_wl;
+  const uint32_t* locus_max_wl;
+  // optional locus list of this launch (the kernel then works on loci[locus_ids[i]], i < n_loci); nullptr = identity
+  const uint32_t* locus_ids;
 };
 
 // --------------------------------------------------------------------------------------------------
@@ -1371,7 +1376,9 @@ struct Assembler {
     tMark               = wv::clock();
     cyclicIters         = 0;
     nCand               = 0;
-    k                   = P.opt.minWordLength;
+    const unsigned minWL = P.locus_min_wl ? P.locus_min_wl[locus] : P.opt.minWordLength;
+    const unsigned maxWL = P.locus_max_wl ? P.locus_max_wl[locus] : P.opt.maxWordLength;
+    k                   = minWL;
     // zero the N bitmap region (filled with atomic_or)
     for (unsigned i = lane; i < maskWordCap() + 2; i += 64) nmask[i] = 0;
     wv::sync();
@@ -1382,14 +1389,14 @@ struct Assembler {
     W = (nNormal + 2 * P.opt.maxAssemblyCount + 63) / 64;
     if (W == 0) W = 1;
     recStride = asmRecStride(W);
-    if (status == ASM_OK && (P.opt.maxWordLength > 16u * ASM_MAX_KW || P.opt.minWordLength == 0)) status = ASM_E_WORD_TOO_LONG;
+    if (status == ASM_OK && (maxWL > 16u * ASM_MAX_KW || minWL == 0)) status = ASM_E_WORD_TOO_LONG;
     if (status == ASM_OK && 2 * P.opt.maxAssemblyCount > ASM_MAX_CAND) status = ASM_E_INTERNAL;
 
     nReads            = nNormal;
     unsigned nPseudo  = 0;
     unsigned nIter    = 0;
     if (status == ASM_OK) {
-      for (unsigned wl = P.opt.minWordLength; wl <= P.opt.maxWordLength; wl += P.opt.wordStepSize) {
+      for (unsigned wl = minWL; wl <= maxWL; wl += P.opt.wordStepSize) {
         k = wl;
         nIter++;
         const bool ok = buildContigsForK();
@@ -1431,7 +1438,7 @@ WV_KERNEL_OCC(MANTA_ASM_OCC) void assemble_kernel(const AsmParams P)
     slot = wv::first(slot);
     if (slot >= P.n_loci) break;
     Assembler a(P, wsBase);
-    a.run(slot);
+    a.run(P.locus_ids ? P.locus_ids[slot] : slot);
     wv::sync();
   }
 }

@@ -22,6 +22,9 @@ inline void* dmalloc(size_t n) { void* p = std::malloc(n ? n : 1); if (!p) throw
 inline void  dfree(void* p) { std::free(p); }
 inline void  h2d(void* d, const void* h, size_t n) { if (n) std::memcpy(d, h, n); }
 inline void  d2h(void* h, const void* d, size_t n) { if (n) std::memcpy(h, d, n); }
+inline void  d2hAsync(void* h, const void* d, size_t n) { if (n) std::memcpy(h, d, n); }
+inline void  setDevice(int) {}
+inline int   currentDevice() { return 0; }
 inline void  dzero(void* d, size_t n) { if (n) std::memset(d, 0, n); }
 inline void  dfill(void* d, int byte, size_t n) { if (n) std::memset(d, byte, n); }
 inline void  sync() {}
@@ -30,9 +33,13 @@ inline void launch(K kernel, int grid, size_t ldsBytes, const P& params) { wv_em
 inline int roundGrid(int waves) { return waves; }
 struct Stream {};
 inline void useStream(Stream*) {}
+struct ScopedStream { explicit ScopedStream(Stream&) {} };
 struct Event { void record() {} void recordOn(Stream&) {} };
-inline void nullStreamWaits(Event&) {}
+inline void curStreamWaits(Event&) {}
+inline void streamWaits(Stream&, Event&) {}
 inline float elapsedMs(const Event&, const Event&) { return 0.f; }
+inline void* hostAlloc(size_t n) { void* p = std::malloc(n ? n : 1); if (!p) throw Error("emu malloc failed"); return p; }
+inline void  hostFree(void* p) { std::free(p); }
 }  // namespace rt
 #else
 #include <hip/hip_runtime.h>
@@ -47,6 +54,13 @@ inline void init(int dev)
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw Error("no HIP device available (this library has no CPU path)");
   if (dev >= 0) check(hipSetDevice(dev), "hipSetDevice");
+}
+inline void setDevice(int dev) { check(hipSetDevice(dev), "hipSetDevice"); }
+inline int  currentDevice()
+{
+  int dev = 0;
+  check(hipGetDevice(&dev), "hipGetDevice");
+  return dev;
 }
 inline std::string deviceName()
 {
@@ -77,12 +91,10 @@ inline void* dmalloc(size_t n)
   return p;
 }
 inline void dfree(void* p) { (void)hipFree(p); }
-inline void h2d(void* d, const void* h, size_t n) { if (n) check(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D"); }
-inline void d2h(void* h, const void* d, size_t n) { if (n) check(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
-inline void dzero(void* d, size_t n) { if (n) check(hipMemsetAsync(d, 0, n, 0), "hipMemset"); }
-inline void dfill(void* d, int byte, size_t n) { if (n) check(hipMemsetAsync(d, byte, n, 0), "hipMemset"); }
-inline void sync() { check(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
-/// a non-blocking side stream: independent kernels (the aligner's E buckets) overlap their tails on these
+/// a non-blocking stream.  Every pipeline object / context owns one and makes it the calling thread's CURRENT stream for
+/// the duration of an API call (ScopedStream): copies, memsets, launches and events below all go to the current stream, so
+/// pipelines driven by different host threads overlap on the device (nothing here touches the null stream or
+/// hipDeviceSynchronize).
 struct Stream {
   hipStream_t s = nullptr;
   Stream() { check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"); }
@@ -92,10 +104,40 @@ struct Stream {
 };
 inline hipStream_t& launchStream()
 {
-  static thread_local hipStream_t cur = nullptr;  // null stream unless useStream() says otherwise
+  static thread_local hipStream_t cur = nullptr;  // null stream unless a ScopedStream / useStream() says otherwise
   return cur;
 }
 inline void useStream(Stream* st) { launchStream() = st ? st->s : nullptr; }
+struct ScopedStream {
+  hipStream_t prev;
+  explicit ScopedStream(Stream& st) : prev(launchStream()) { launchStream() = st.s; }
+  ~ScopedStream() { launchStream() = prev; }
+  ScopedStream(const ScopedStream&) = delete;
+  ScopedStream& operator=(const ScopedStream&) = delete;
+};
+inline void sync() { check(hipStreamSynchronize(launchStream()), "hipStreamSynchronize"); }
+/// host -> device on the current stream.  Pageable sources are staged by the runtime before the call returns; pinned
+/// sources (hostAlloc) are DMA'd asynchronously -- callers sync() before they let the source go.
+inline void h2d(void* d, const void* h, size_t n) { if (n) check(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, launchStream()), "hipMemcpy H2D"); }
+/// device -> host on the current stream; returns when the bytes are on the host
+inline void d2h(void* h, const void* d, size_t n)
+{
+  if (!n) return;
+  check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, launchStream()), "hipMemcpy D2H");
+  sync();
+}
+/// same without the wait: several copies, then one sync()
+inline void d2hAsync(void* h, const void* d, size_t n) { if (n) check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, launchStream()), "hipMemcpy D2H"); }
+inline void dzero(void* d, size_t n) { if (n) check(hipMemsetAsync(d, 0, n, launchStream()), "hipMemset"); }
+inline void dfill(void* d, int byte, size_t n) { if (n) check(hipMemsetAsync(d, byte, n, launchStream()), "hipMemset"); }
+/// page-locked host memory (staging buffers of the pipelines; manta_host_alloc)
+inline void* hostAlloc(size_t n)
+{
+  void* p = nullptr;
+  check(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault), "hipHostMalloc");
+  return p;
+}
+inline void hostFree(void* p) { (void)hipHostFree(p); }
 template <typename K, typename P>
 inline void launch(K kernel, int grid, size_t ldsBytes, const P& params)
 {
@@ -104,17 +146,18 @@ inline void launch(K kernel, int grid, size_t ldsBytes, const P& params)
   check(hipGetLastError(), "kernel launch");
 }
 inline int roundGrid(int waves) { return ((waves + WV_WAVES_PER_WG - 1) / WV_WAVES_PER_WG) * WV_WAVES_PER_WG; }
-/// HIP event on the (null) stream the kernels are launched on
+/// HIP event, recorded on the current stream
 struct Event {
   hipEvent_t e = nullptr;
   Event() { check(hipEventCreate(&e), "hipEventCreate"); }
   ~Event() { if (e) (void)hipEventDestroy(e); }
   Event(const Event&) = delete;
   Event& operator=(const Event&) = delete;
-  void record() { check(hipEventRecord(e, 0), "hipEventRecord"); }
+  void record() { check(hipEventRecord(e, launchStream()), "hipEventRecord"); }
   void recordOn(Stream& st) { check(hipEventRecord(e, st.s), "hipEventRecord"); }
 };
-inline void nullStreamWaits(Event& ev) { check(hipStreamWaitEvent(nullptr, ev.e, 0), "hipStreamWaitEvent"); }
+inline void curStreamWaits(Event& ev) { check(hipStreamWaitEvent(launchStream(), ev.e, 0), "hipStreamWaitEvent"); }
+inline void streamWaits(Stream& st, Event& ev) { check(hipStreamWaitEvent(st.s, ev.e, 0), "hipStreamWaitEvent"); }
 inline float elapsedMs(const Event& a, const Event& b)
 {
   float ms = 0.f;

@@ -1,0 +1,87 @@
+"""Whole-batch calls (manta_smallsv_batch / manta_spanning_batch): blocks pulled from a cost-ordered queue by several host
+workers, results compacted into the caller's arenas.  Every locus must equal the oracle and the staged API; mixed word
+lengths per locus go through the same launch."""
+import numpy as np
+import pytest
+
+from manta_amd._capi import BatchOutput, SmallSvBatch, SpanningBatch, pack_spanning, small_sv_text
+from oracle_lib import asm_opts
+from synth import breakend_locus, config2_batch, unpack_locus
+from test_spanning_pipeline import SC as SPAN_SC, oracle_locus
+
+SCORES = [2, -8, -24, -1, -1, 0]
+
+
+def small_batch(n, seed):
+    return config2_batch(n, seed=seed, n_reads=20, read_len=80, ref_len=500)
+
+
+def check_smallsv(lib, oracle, n, block, workers, mixed):
+    batch = small_batch(n, 4242)
+    batch = batch[:5] + (np.tile(np.array([40, 40, 200, 200], dtype=np.int32), (n, 1)),)
+    opts = asm_opts(minWordLength=25, maxWordLength=45)
+    min_wl = max_wl = None
+    if mixed:
+        min_wl = np.array([21 + 4 * (l % 4) for l in range(n)], dtype=np.uint32)
+        max_wl = np.maximum(min_wl + 10, 41).astype(np.uint32)
+    out = BatchOutput(lib, "smallsv", n, 10, 1 << 20, 1 << 16, 1 << 18)
+    lib.smallsv_batch(opts, SCORES, -100, batch, out, min_wl=min_wl, max_wl=max_wl, block_loci=block, n_workers=workers)
+    st = out.stats_dict()
+    assert st["n_blocks"] == (n + block - 1) // block and st["n_workers"] == min(workers, st["n_blocks"])
+    res = out.decode(np.diff(batch[2]))
+    for l, r in enumerate(res):
+        reads, ref, cuts = unpack_locus(batch, l)
+        o = opts if not mixed else asm_opts(minWordLength=int(min_wl[l]), maxWordLength=int(max_wl[l]))
+        assert small_sv_text(r) == oracle.small_sv_locus(o, SCORES, -100, reads, ref, cuts), l
+    return res
+
+
+def test_emulated_smallsv_batch_blocks_and_workers(emu, oracle):
+    res = check_smallsv(emu, oracle, 11, block=4, workers=3, mixed=False)
+    # the staged API gives the same thing
+    batch = small_batch(11, 4242)
+    batch = batch[:5] + (np.tile(np.array([40, 40, 200, 200], dtype=np.int32), (11, 1)),)
+    p = SmallSvBatch(emu, asm_opts(minWordLength=25, maxWordLength=45), SCORES, -100)
+    p.upload_packed(*batch)
+    p.run()
+    assert [small_sv_text(r) for r in p.download()] == [small_sv_text(r) for r in res]
+
+
+def test_emulated_smallsv_batch_mixed_word_lengths(emu, oracle):
+    check_smallsv(emu, oracle, 8, block=8, workers=1, mixed=True)
+
+
+def spanning_case(n):
+    loci = [breakend_locus(300 + s, n_reads=24, read_len=70, ref_len=320) for s in range(n)]
+    cuts = [(30, 30, 30, 30)] * n
+    return loci, cuts, pack_spanning([l[0] for l in loci], [l[1] for l in loci], [l[2] for l in loci], cuts)
+
+
+def check_spanning(lib, oracle, n, block, workers):
+    loci, cuts, batch = spanning_case(n)
+    ks = [25, 30, 35]
+    min_wl = np.array([ks[l % 3] for l in range(n)], dtype=np.uint32)
+    max_wl = np.full(n, 45, dtype=np.uint32)
+    opts = asm_opts(minWordLength=25, maxWordLength=45, minContigLength=40)
+    out = BatchOutput(lib, "spanning", n, 10, 1 << 20, 1 << 16, 1 << 18)
+    lib.spanning_batch(opts, SPAN_SC, -100, batch, out, min_wl=min_wl, max_wl=max_wl, block_loci=block, n_workers=workers)
+    res = out.decode(np.diff(batch[2]))
+    for l, r in enumerate(res):
+        o = asm_opts(minWordLength=int(min_wl[l]), maxWordLength=45, minContigLength=40)
+        text, want = oracle_locus(oracle, o, loci[l][0], loci[l][1], loci[l][2], cuts[l])
+        got = [(a["score"], a["jump_insert_size"], a["jump_range"], a["begin1"], a["cigar1"], a["begin2"], a["cigar2"], a["is_uncut"])
+               for a in r["aligns"]]
+        assert got == want, l
+        assert r["final_word_length"] >= int(min_wl[l])
+
+
+def test_emulated_spanning_batch_mixed_word_lengths(emu, oracle):
+    check_spanning(emu, oracle, 7, block=3, workers=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_gpu_batch_calls(gpu, oracle):
+    check_smallsv(gpu, oracle, 300, block=64, workers=4, mixed=False)
+    check_smallsv(gpu, oracle, 96, block=32, workers=3, mixed=True)
+    check_spanning(gpu, oracle, 60, block=16, workers=4)
