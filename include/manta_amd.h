@@ -260,9 +260,12 @@ void manta_host_free(void* p);
  * Per-item failures (MANTA_E_UNSUPPORTED / MANTA_E_DEVICE_FAULT in a locus or alignment status) do not stop the batch:
  * the call returns the code, every other item is valid.
  * ---------------------------------------------------------------------------------------------------- */
+#define MANTA_BATCH_SERIAL_KERNELS 1u /* one block's kernels at a time; uploads / downloads of the others still overlap them */
 typedef struct {
   uint32_t block_loci; /* 0 = 2048 */
   uint32_t n_workers;  /* 0 = 4 */
+  uint32_t flags;      /* MANTA_BATCH_* */
+  uint32_t reserved;
 } manta_batch_plan_t;
 
 typedef struct {
@@ -270,7 +273,7 @@ typedef struct {
   double   h2d_ms, kernel_ms, d2h_ms;  /* host wall time per phase, summed over blocks (blocks overlap) */
   float    assemble_ms, schedule_ms, align_ms; /* HIP-event times, summed over blocks */
   uint32_t n_blocks, n_workers;
-  uint64_t n_alignments, dp_cells, ptr_matrix_bytes;
+  uint64_t n_alignments, n_align_launches, dp_cells, ptr_matrix_bytes;
   uint64_t h2d_bytes, d2h_bytes;       /* PCIe traffic of the call */
 } manta_batch_stats_t;
 

@@ -448,14 +448,14 @@ class SpanningBatch:
 # whole-batch calls (manta_smallsv_batch / manta_spanning_batch) and pinned host memory
 # ---------------------------------------------------------------------------------------------------------------
 class BatchPlan(ctypes.Structure):
-    _fields_ = [("block_loci", ctypes.c_uint32), ("n_workers", ctypes.c_uint32)]
+    _fields_ = [("block_loci", ctypes.c_uint32), ("n_workers", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class BatchStats(ctypes.Structure):
     _fields_ = [("wall_ms", ctypes.c_double), ("h2d_ms", ctypes.c_double), ("kernel_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double),
                 ("assemble_ms", ctypes.c_float), ("schedule_ms", ctypes.c_float), ("align_ms", ctypes.c_float),
                 ("n_blocks", ctypes.c_uint32), ("n_workers", ctypes.c_uint32), ("n_alignments", ctypes.c_uint64),
-                ("dp_cells", ctypes.c_uint64), ("ptr_matrix_bytes", ctypes.c_uint64), ("h2d_bytes", ctypes.c_uint64),
+                ("n_align_launches", ctypes.c_uint64), ("dp_cells", ctypes.c_uint64), ("ptr_matrix_bytes", ctypes.c_uint64), ("h2d_bytes", ctypes.c_uint64),
                 ("d2h_bytes", ctypes.c_uint64)]
 
 
@@ -516,10 +516,10 @@ class BatchOutput:
         return {f[0]: getattr(self.stats, f[0]) for f in BatchStats._fields_}
 
 
-def _smallsv_batch(self, opts, scores, large_indel_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True):
+def _smallsv_batch(self, opts, scores, large_indel_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True, serial_kernels=False):
     """batch = (bases, read_off, begin, refs, ref_off, cuts) numpy arrays as synth.config2_batch returns them"""
     bases, read_off, begin, refs, ref_off, cuts = batch
-    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers)
+    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, 1 if serial_kernels else 0, 0)
     n = len(begin) - 1
     f = self.lib.manta_smallsv_batch
     f.restype = ctypes.c_int
@@ -532,10 +532,10 @@ def _smallsv_batch(self, opts, scores, large_indel_score, batch, out, min_wl=Non
     return rc
 
 
-def _spanning_batch(self, opts, scores, jump_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True):
+def _spanning_batch(self, opts, scores, jump_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True, serial_kernels=False):
     """batch = (bases, read_off, begin, refs1, ref1_off, refs2, ref2_off, cuts)"""
     bases, read_off, begin, r1, o1, r2, o2, cuts = batch
-    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers)
+    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, 1 if serial_kernels else 0, 0)
     n = len(begin) - 1
     f = self.lib.manta_spanning_batch
     f.restype = ctypes.c_int

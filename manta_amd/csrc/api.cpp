@@ -17,6 +17,7 @@
 
 #include "align_kernels.hpp"
 #include "assemble_kernels.hpp"
+#include "asm_lds.hpp"
 #include "pipeline_kernels.hpp"
 #include <unordered_map>
 #include "rt.hpp"
@@ -115,6 +116,12 @@ int fail(manta_ctx_t* ctx, int code, const std::string& msg)
     ctx->lastError = msg;
   }
   return code;
+}
+
+/// failures of single loci / alignments: reported in the per-item status, never fatal for the batch
+bool perItemCode(int rc)
+{
+  return rc == MANTA_E_UNSUPPORTED || rc == MANTA_E_DEVICE_FAULT || rc == MANTA_E_EMPTY_SEQ;
 }
 
 std::string lastErrorOf(manta_ctx_t* ctx)
@@ -265,6 +272,7 @@ struct AsmStage {
   uint64_t*     hCnt  = nullptr;
   uint64_t      seqUsedDev = 0, bitsUsedDev = 0, nContigsOut = 0, pseudoBytesOut = 0, pseudoCountOut = 0;
   bool          staged = false;
+  uint32_t      ldsFallbacks = 0;  // loci assemble_lds_kernel handed to the general path (valid after stageOut)
 
   manta_asm_options_t opt{};
   uint32_t            nLoci = 0, nReadsTotal = 0, maxContigLen = 0, wMax = 0, capWords = 0, capReads = 0, capNodes = 0, capSlots = 0;
@@ -275,6 +283,8 @@ struct AsmStage {
   std::vector<uint32_t> locusMinWl, locusMaxWl;
   std::vector<uint32_t> order;  // loci by decreasing estimated cost: the work queue hands out the long ones first
   uint32_t              maxWordLen = 0;
+  bool                  useLds = false;  // assemble_lds_kernel (LDS-resident graph, general path as in-kernel fallback)
+  int                   gridLds = 1;
   uint32_t*             dMinWl = nullptr;
   uint32_t*             dMaxWl = nullptr;
   uint32_t*             dOrder = nullptr;
@@ -313,6 +323,7 @@ struct AsmStage {
     uint64_t maxLocusBases = 0, maxLocusWords = 0, bitsBound = 0;
     uint32_t maxLocusReads = 0, maxReadLen = 0;
     std::vector<uint64_t> cost(n_loci);
+    uint32_t              ldsFit = 0;  // loci small enough for the LDS-resident fast path
     for (uint32_t l = 0; l < n_loci; ++l) {
       const uint32_t rb = locus_read_begin[l], re = locus_read_begin[l + 1];
       if (re < rb || re > nReadsTotal) return fail(ctx, MANTA_E_INVALID_ARG, "locus_read_begin not monotone");
@@ -325,6 +336,7 @@ struct AsmStage {
         maxReadLen = std::max<uint32_t>(maxReadLen, uint32_t(len));
       }
       cost[l]       = b * uint64_t(re - rb);
+      if ((re - rb) + 2 * opt.max_assembly_count <= LN_MAX_READS && w + 2 <= LN_MAX_PILE) ldsFit++;
       maxLocusBases = std::max(maxLocusBases, b);
       maxLocusWords = std::max(maxLocusWords, w);
       maxLocusReads = std::max(maxLocusReads, re - rb);
@@ -356,6 +368,15 @@ struct AsmStage {
     const int wavesPerCu  = std::getenv("MANTA_AMD_ASM_WAVES_PER_CU") ? std::atoi(std::getenv("MANTA_AMD_ASM_WAVES_PER_CU")) : 16;
     grid                  = int(std::min<uint64_t>(n_loci, uint64_t(std::max(1, ctx->cuCount * wavesPerCu))));
     grid                  = rt::roundGrid(int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(grid), wsBudget / stride))));
+    // The LDS-resident fast path (asm_lds.hpp) is opt-in: MANTA_AMD_ASM_PATH=lds.  Measured on MI355X: it cuts
+    // the HBM traffic of the stage to about the algorithmic bytes, but only 3 loci per CU fit the LDS and one wave per
+    // SIMD cannot hide the ALU/LDS latency of the ~900 dependent walk steps of a locus -- 22.7 ms per 10 k config-2 loci
+    // against 12.3 ms for the HBM-slab kernel at 16 waves per CU.
+    const char* pathEnv = std::getenv("MANTA_AMD_ASM_PATH");
+    useLds              = pathEnv && std::string(pathEnv) == "lds" && ldsFit > 0;
+    const int ldsPerCu = int(163840 / LN_BUDGET);
+    gridLds            = int(std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n_loci, uint64_t(ctx->cuCount) * ldsPerCu), wsBudget / stride)));
+    if (useLds) grid = std::max(grid, gridLds);  // one workspace slab per workgroup of either kernel
     // contig + pseudo-read text one locus can emit at worst; the arena holds the typical case for every locus plus one
     // worst case, so a single-locus call (the runIterativeAssembler adapter) can never exhaust it
     const uint64_t worstLocusSeq = uint64_t(opt.max_assembly_count) * maxContigLen + uint64_t(nCandMax) * pseudoLen;
@@ -429,21 +450,31 @@ struct AsmStage {
     P.locus_min_wl   = dMinWl;
     P.locus_max_wl   = dMaxWl;
     P.locus_ids      = dOrder;
-    rt::launch(assemble_kernel, grid, ASM_LDS_BYTES, P);
+    if (useLds) {
+      if (std::getenv("MANTA_AMD_LDS_OFF")) P.flags |= ASM_FLAG_NO_LDS_PATH;  // A/B: same kernel, every locus through the general path
+      rt::launchSingle(assemble_lds_kernel, gridLds, LN_BUDGET, P);
+    } else {
+      rt::launch(assemble_kernel, grid, ASM_LDS_BYTES, P);
+    }
   }
 
   /// Device -> pinned host staging of everything the assembler produced, with EXACT sizes: the fixed records and the
   /// arena counters first (one round trip), then exactly the used part of the text / bitset arenas.
   /// `moreCopies` lets a pipeline queue its own copies behind the second round so that one sync covers them.
-  template <typename F>
-  void stageOut(F moreCopies)
+  /// `firstCopies` / `moreCopies` let a pipeline queue its own copies in the first / second round trip; with
+  /// `sparseContigs` false the (mostly empty) per-slot contig records stay on the device (the pipeline brings packed ones)
+  template <typename F0, typename F>
+  void stageOut(F0 firstCopies, F moreCopies, bool sparseContigs = true)
   {
     hCnt  = pCnt.as<uint64_t>(16);
     hLoci = pLoci.as<AsmLocusOut>(nLoci);
-    hCont = pCont.as<AsmContigOut>(uint64_t(nLoci) * opt.max_assembly_count);
     rt::d2hAsync(hCnt, dCnt, sizeof(uint64_t) * 16);
     rt::d2hAsync(hLoci, dLoci, sizeof(AsmLocusOut) * nLoci);
-    rt::d2hAsync(hCont, dCont, sizeof(AsmContigOut) * uint64_t(nLoci) * opt.max_assembly_count);
+    if (sparseContigs) {
+      hCont = pCont.as<AsmContigOut>(uint64_t(nLoci) * opt.max_assembly_count);
+      rt::d2hAsync(hCont, dCont, sizeof(AsmContigOut) * uint64_t(nLoci) * opt.max_assembly_count);
+    }
+    firstCopies();
     rt::sync();
     seqUsedDev  = std::min<uint64_t>(hCnt[1], devSeqCap);
     bitsUsedDev = std::min<uint64_t>(hCnt[2], devBitsCap);
@@ -462,6 +493,9 @@ struct AsmStage {
       for (uint32_t q = 0; q < h.n_pseudo; ++q) pseudoBytesOut += hBits[h.pseudo_len_off + q];
     }
     staged = true;
+    ldsFallbacks = useLds ? uint32_t(hCnt[0] >> 32) : 0u;
+    if (std::getenv("MANTA_AMD_DEBUG") && useLds)
+      std::fprintf(stderr, "manta_amd: assemble_lds_kernel: %u of %u loci went through the general path\n", ldsFallbacks, nLoci);
     if (std::getenv("MANTA_AMD_PROFILE")) {
       static const char* names[8] = {"pack", "table", "links", "cycle-check", "exact", "seed", "walk", "select+emit"};
       uint64_t           tot = 0;
@@ -473,11 +507,17 @@ struct AsmStage {
   }
   void stageOut()
   {
-    stageOut([] {});
+    stageOut([] {}, [] {});
   }
 
   /// exact sizes compact() will write (valid after stageOut): contig records, text bytes, bitset qwords
-  void exactSizes(uint64_t& nContigs, uint64_t& seqBytes, uint64_t& bitsWords) const
+  struct SparseContigs {
+    const AsmStage* st;
+    const AsmContigOut& operator()(uint32_t l, uint32_t c) const { return st->hCont[uint64_t(l) * st->opt.max_assembly_count + c]; }
+  };
+  void exactSizes(uint64_t& nContigs, uint64_t& seqBytes, uint64_t& bitsWords) const { exactSizes(SparseContigs{this}, nContigs, seqBytes, bitsWords); }
+  template <typename ContigAt>
+  void exactSizes(ContigAt contigAt, uint64_t& nContigs, uint64_t& seqBytes, uint64_t& bitsWords) const
   {
     nContigs = nContigsOut;
     seqBytes = pseudoBytesOut;
@@ -485,7 +525,7 @@ struct AsmStage {
     for (uint32_t l = 0; l < nLoci; ++l) {
       const AsmLocusOut& h(hLoci[l]);
       if (h.status != ASM_OK) continue;
-      for (uint32_t c = 0; c < h.n_contigs; ++c) seqBytes += hCont[uint64_t(l) * opt.max_assembly_count + c].seq_len;
+      for (uint32_t c = 0; c < h.n_contigs; ++c) seqBytes += contigAt(l, c).seq_len;
       bitsWords += 2ull * h.n_words * h.n_contigs;
     }
   }
@@ -507,6 +547,15 @@ struct AsmStage {
       manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, uint64_t contigs_cap, uint8_t* seq_arena,
       uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used,
       uint64_t contigBase = 0, uint64_t seqBase = 0, uint64_t bitsBase = 0)
+  {
+    return compact(SparseContigs{this}, loci, contigs, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap,
+                   bits_arena_used, contigBase, seqBase, bitsBase);
+  }
+  template <typename ContigAt>
+  int compact(
+      ContigAt contigAt, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, uint64_t contigs_cap, uint8_t* seq_arena,
+      uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used,
+      uint64_t contigBase, uint64_t seqBase, uint64_t bitsBase)
   {
     uint64_t seqUsed = 0, bitsUsed = 0, nContigs = 0;
     int      worst = MANTA_OK;
@@ -530,7 +579,7 @@ struct AsmStage {
       o.cyclic_iterations = h.cyclic_iterations;
       if (nContigs + h.n_contigs > contigs_cap) return fail(ctx, MANTA_E_CAPACITY, "contig array too small");
       for (uint32_t c = 0; c < h.n_contigs; ++c) {
-        const AsmContigOut& hc(hCont[uint64_t(l) * opt.max_assembly_count + c]);
+        const AsmContigOut& hc(contigAt(l, c));
         manta_asm_contig_t& oc(contigs[nContigs++]);
         if (seqUsed + hc.seq_len > seq_arena_cap || bitsUsed + 2ull * h.n_words > bits_arena_cap)
           return fail(ctx, MANTA_E_CAPACITY, "output arena too small");
@@ -590,12 +639,12 @@ struct manta_smallsv {
   rt::Event             sideDone[3];
   manta_smallsv_stats_t stats{};
   // device -> host staging (pinned)
-  PinnedBuf             pRes, pInfo, pTasks, pCig;
-  AlignResultDev*       hRes   = nullptr;
-  SmallSvTaskInfo*      hInfo  = nullptr;
-  AlignTaskDev*         hTasks = nullptr;
-  uint32_t*             hCig   = nullptr;
-  uint64_t              cigDev = 0;  // cigar words the schedule kernel handed out (known after run)
+  DevBuf                dFirst, dPacked, dCigPacked, dPackCnt;
+  PinnedBuf             pFirst, pPacked, pCig, pPackCnt;
+  uint32_t*             hFirst  = nullptr;
+  PackedContigOut*      hPacked = nullptr;
+  uint32_t*             hCig    = nullptr;
+  uint32_t*             hPackCnt = nullptr;  // [0] packed contigs, [1] packed cigar words
   bool                  staged = false;
   explicit manta_smallsv(manta_ctx_t* c) : ctx(c), asmStage(c) {}
 };
@@ -617,16 +666,47 @@ struct manta_spanning {
   rt::Stream            side[3];
   rt::Event             sideDone[3];
   manta_smallsv_stats_t stats{};
-  PinnedBuf             pRes, pRes2, pInfo, pTasks, pTasks2, pCuts, pCig;
-  AlignResultDev *      hRes = nullptr, *hRes2 = nullptr;
-  SpanTaskInfo*         hInfo = nullptr;
-  AlignTaskDev *        hTasks = nullptr, *hTasks2 = nullptr;
-  JumpCuts*             hCuts = nullptr;
-  uint32_t*             hCig  = nullptr;
-  uint64_t              cigDev = 0;
+  DevBuf                dFirst, dPacked, dCigPacked, dPackCnt;
+  PinnedBuf             pFirst, pPacked, pCig, pPackCnt;
+  std::vector<JumpCuts> hostCuts;  // the caller's cuts of the uploaded batch
+  uint32_t*             hFirst  = nullptr;
+  PackedContigOut*      hPacked = nullptr;
+  uint32_t*             hCig    = nullptr;
+  uint32_t*             hPackCnt = nullptr;
   bool                  staged = false;
   explicit manta_spanning(manta_ctx_t* c) : ctx(c), asmStage(c) {}
 };
+
+namespace {
+
+/// the last kernel of a pipeline run: dense per-contig records + back-to-back CIGARs (pack_results_kernel)
+template <typename Pipe>
+void launchPack(Pipe* b, const AlignTaskDev* tasks, const AlignTaskDev* tasks2, const AlignResultDev* res, const AlignResultDev* res2,
+                const SmallSvTaskInfo* infoSmall, const SpanTaskInfo* infoSpan, const uint32_t* cigar, uint64_t cigarCap)
+{
+  const uint32_t nLoci  = b->nLoci;
+  const uint64_t nSlots = uint64_t(nLoci) * b->opt.max_assembly_count;
+  PackParams     K;
+  K.loci               = b->asmStage.dLoci;
+  K.contigs            = b->asmStage.dCont;
+  K.n_loci             = nLoci;
+  K.max_assembly_count = b->opt.max_assembly_count;
+  K.tasks              = tasks;
+  K.tasks2             = tasks2;
+  K.results            = res;
+  K.results2           = res2;
+  K.info_small         = infoSmall;
+  K.info_span          = infoSpan;
+  K.cigar              = cigar;
+  K.first              = b->dFirst.template as<uint32_t>(nLoci);
+  K.packed             = b->dPacked.template as<PackedContigOut>(nSlots);
+  K.cigar_packed       = b->dCigPacked.template as<uint32_t>(cigarCap + 16);
+  K.counters           = b->dPackCnt.template as<uint32_t>(4);
+  rt::dzero(K.counters, 16);
+  rt::launch(pack_results_kernel, rt::roundGrid(int(std::min<uint64_t>((nLoci + 63) / 64, uint64_t(std::max(1, b->ctx->cuCount * 8))))), 0, K);
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -1033,6 +1113,7 @@ int manta_smallsv_run(manta_smallsv_t* b)
         rt::curStreamWaits(b->sideDone[i]);
       }
     }
+    launchPack(b, dTasks, nullptr, dResults, nullptr, dInfo, nullptr, dCigar, cigarCap);
     b->evAlign.record();
     rt::sync();
     stage("aligned");
@@ -1076,48 +1157,41 @@ int manta_smallsv_output_sizes(const manta_smallsv_t* b, uint64_t* contigs, uint
 
 namespace {
 
-/// device -> pinned staging of one finished small-SV run
-void smallsvStage(manta_smallsv* b)
+/// device -> pinned staging of one finished pipeline run (both pipelines): counters + locus records + first-contig
+/// index in the first round trip, then exactly the used part of every arena
+template <typename Pipe>
+void pipeStage(Pipe* b)
 {
-  const uint64_t nSlots = uint64_t(b->nLoci) * b->opt.max_assembly_count;
-  uint32_t       hSmall[40];
-  rt::d2h(hSmall, b->dSmall.p, sizeof(hSmall));
-  std::memcpy(&b->cigDev, hSmall + 34, sizeof(uint64_t));
-  b->hRes   = b->pRes.as<AlignResultDev>(nSlots);
-  b->hInfo  = b->pInfo.as<SmallSvTaskInfo>(nSlots);
-  b->hTasks = b->pTasks.as<AlignTaskDev>(nSlots);
-  b->hCig   = b->pCig.as<uint32_t>(b->cigDev + 1);
-  b->asmStage.stageOut([&] {
-    rt::d2hAsync(b->hRes, b->dResults.p, sizeof(AlignResultDev) * nSlots);
-    rt::d2hAsync(b->hInfo, b->dInfo.p, sizeof(SmallSvTaskInfo) * nSlots);
-    rt::d2hAsync(b->hTasks, b->dTasks.p, sizeof(AlignTaskDev) * nSlots);
-    rt::d2hAsync(b->hCig, b->dCigar.p, sizeof(uint32_t) * b->cigDev);
-  });
+  const uint32_t nLoci = b->nLoci;
+  b->hPackCnt          = b->pPackCnt.template as<uint32_t>(4);
+  b->hFirst            = b->pFirst.template as<uint32_t>(nLoci);
+  b->asmStage.stageOut(
+      [&] {
+        rt::d2hAsync(b->hPackCnt, b->dPackCnt.p, 16);
+        rt::d2hAsync(b->hFirst, b->dFirst.p, sizeof(uint32_t) * nLoci);
+      },
+      [&] {
+        b->hPacked = b->pPacked.template as<PackedContigOut>(uint64_t(b->hPackCnt[0]) + 1);
+        b->hCig    = b->pCig.template as<uint32_t>(uint64_t(b->hPackCnt[1]) + 1);
+        rt::d2hAsync(b->hPacked, b->dPacked.p, sizeof(PackedContigOut) * uint64_t(b->hPackCnt[0]));
+        rt::d2hAsync(b->hCig, b->dCigPacked.p, sizeof(uint32_t) * uint64_t(b->hPackCnt[1]));
+      },
+      false);
   b->staged = true;
 }
 
-/// bytes a stageOut moved over PCIe (for the batch statistics)
-uint64_t smallsvStagedBytes(const manta_smallsv* b)
-{
-  const uint64_t nSlots = uint64_t(b->nLoci) * b->opt.max_assembly_count;
-  return b->asmStage.seqUsedDev + 8 * b->asmStage.bitsUsedDev + sizeof(AsmLocusOut) * uint64_t(b->nLoci) + sizeof(AsmContigOut) * nSlots +
-         (sizeof(AlignResultDev) + sizeof(SmallSvTaskInfo) + sizeof(AlignTaskDev)) * nSlots + 4 * b->cigDev + 128 + 160;
-}
+template <typename Pipe>
+struct PackedContigs {
+  const Pipe* b;
+  const AsmContigOut& operator()(uint32_t l, uint32_t c) const { return b->hPacked[b->hFirst[l] + c].contig; }
+};
 
-/// exact number of cigar words smallsvCompact will write
-uint64_t smallsvCigarWords(const manta_smallsv* b)
+/// bytes a pipeStage moved over PCIe (for the batch statistics)
+template <typename Pipe>
+uint64_t pipeStagedBytes(const Pipe* b)
 {
-  const uint32_t maxAsm = b->opt.max_assembly_count;
-  uint64_t       n      = 0;
-  for (uint32_t l = 0; l < b->nLoci; ++l) {
-    const AsmLocusOut& h(b->asmStage.hLoci[l]);
-    if (h.status != ASM_OK) continue;
-    for (uint32_t c = 0; c < h.n_contigs; ++c) {
-      const uint64_t slot = uint64_t(l) * maxAsm + c;
-      if (b->hInfo[slot].status == 0 && b->hInfo[slot].bucket >= 0 && b->hRes[slot].status == 0) n += b->hRes[slot].cigar1_len;
-    }
-  }
-  return n;
+  return b->asmStage.seqUsedDev + 8 * b->asmStage.bitsUsedDev + (sizeof(AsmLocusOut) + 4) * uint64_t(b->nLoci) +
+         sizeof(PackedContigOut) * uint64_t(b->hPackCnt[0]) + 4ull * b->hPackCnt[1] + 128 + 16;
 }
 
 /// staging -> caller records/arenas.  `loci` is this block's slice; `contigs` / `alignments` are the caller's whole arrays
@@ -1130,40 +1204,37 @@ int smallsvCompact(
     uint64_t cigar_arena_cap, uint64_t cigarBase, uint64_t* cigar_arena_used)
 {
   manta_ctx_t* ctx = b->ctx;
-  int rc = b->asmStage.compact(loci, contigs + contigBase, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap,
-                               bits_arena_used, contigBase, seqBase, bitsBase);
-  if (rc != MANTA_OK && rc != MANTA_E_UNSUPPORTED && rc != MANTA_E_DEVICE_FAULT) return rc;
-  const uint32_t nLoci  = b->nLoci;
-  const uint32_t maxAsm = b->opt.max_assembly_count;
+  int rc = b->asmStage.compact(PackedContigs<manta_smallsv>{b}, loci, contigs + contigBase, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used,
+                               bits_arena, bits_arena_cap, bits_arena_used, contigBase, seqBase, bitsBase);
+  if (rc != MANTA_OK && !perItemCode(rc)) return rc;
+  const uint32_t nLoci = b->nLoci;
   uint64_t       used = 0, cells = 0, ptrBytes = 0;
   int            worst = rc;
   for (uint32_t l = 0; l < nLoci; ++l) {
     if (loci[l].status != MANTA_OK) continue;
     for (uint32_t c = 0; c < loci[l].n_contigs; ++c) {
-      const uint64_t             slot = uint64_t(l) * maxAsm + c;
       manta_smallsv_alignment_t& a(alignments[loci[l].first_contig + c]);
       std::memset(&a, 0, sizeof(a));
-      const SmallSvTaskInfo& inf(b->hInfo[slot]);
-      a.adjusted_leading_cut  = inf.adj_leading_cut;
-      a.adjusted_trailing_cut = inf.adj_trailing_cut;
-      if (inf.status != 0 || inf.bucket < 0 || b->hRes[slot].status != 0) {
-        a.align.status = (inf.status == 5) ? MANTA_E_DEVICE_FAULT : MANTA_E_UNSUPPORTED;
+      const PackedContigOut& h(b->hPacked[b->hFirst[l] + c]);
+      a.adjusted_leading_cut  = h.a;
+      a.adjusted_trailing_cut = h.b;
+      if (h.info_status != 0 || h.bucket < 0 || h.res_status != 0) {
+        a.align.status = (h.info_status == 5) ? MANTA_E_DEVICE_FAULT : MANTA_E_UNSUPPORTED;
         worst          = a.align.status;
         continue;
       }
-      const AlignResultDev& h(b->hRes[slot]);
-      const uint64_t        n = h.cigar1_len;
+      const uint64_t n = h.cigar1_len;
       if (used + n > cigar_arena_cap) return fail(ctx, MANTA_E_CAPACITY, "manta_smallsv_download: cigar arena too small");
-      std::memcpy(cigar_arena + used, b->hCig + b->hTasks[slot].cigar_off, sizeof(uint32_t) * n);
+      std::memcpy(cigar_arena + used, b->hCig + h.cigar_off, sizeof(uint32_t) * n);
       a.align.score      = h.score;
       a.align.is_jumped  = h.is_jumped;
-      a.align.begin_pos1 = h.begin1 + inf.adj_leading_cut;  // SVCandidateAssemblyRefiner.cpp:2039
+      a.align.begin_pos1 = h.begin1 + h.a;  // SVCandidateAssemblyRefiner.cpp:2039
       a.align.cigar1_len = h.cigar1_len;
       a.align.cigar1_off = cigarBase + used;
       a.align.cigar2_off = cigarBase + used + n;
       used += n;
-      cells += uint64_t(b->hTasks[slot].query_len) * b->hTasks[slot].ref1_len;
-      ptrBytes += 2ull * (uint64_t(b->hTasks[slot].query_len) + 1) * (uint64_t(b->hTasks[slot].ref1_len) + 1);
+      cells += uint64_t(h.query_len) * h.ref_len;
+      ptrBytes += 2ull * (uint64_t(h.query_len) + 1) * (uint64_t(h.ref_len) + 1);
     }
   }
   b->stats.dp_cells         = cells;
@@ -1190,7 +1261,7 @@ int manta_smallsv_download(
     return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_download: null argument");
   try {
     rt::ScopedStream onStream(b->main);
-    smallsvStage(b);
+    pipeStage(b);
     return smallsvCompact(b, loci, contigs, alignments, 0, contigs_cap, seq_arena, seq_arena_cap, 0, seq_arena_used, bits_arena,
                           bits_arena_cap, 0, bits_arena_used, cigar_arena, cigar_arena_cap, 0, cigar_arena_used);
   } catch (const std::exception& e) {
@@ -1251,6 +1322,7 @@ int manta_spanning_upload(
     rt::h2d(b->dRefs2.as<uint8_t>(b->ref2Bytes + 16), refs2, b->ref2Bytes);
     rt::h2d(b->dRef2Off.as<uint64_t>(n_loci + 1), ref2_off, sizeof(uint64_t) * (n_loci + 1));
     rt::h2d(b->dCuts.as<JumpCuts>(n_loci), cuts, sizeof(JumpCuts) * n_loci);
+    b->hostCuts.assign(reinterpret_cast<const JumpCuts*>(cuts), reinterpret_cast<const JumpCuts*>(cuts) + n_loci);
     rt::sync();
     b->uploaded = true;
     return MANTA_OK;
@@ -1391,6 +1463,7 @@ int manta_spanning_run(manta_spanning_t* b)
     rt::launch(spanning_realign_kernel, rt::roundGrid(int(std::min<uint64_t>((nLoci + 63) / 64, uint64_t(std::max(1, ctx->cuCount * 8))))), 0, S);
     rt::d2h(hSmall, dSmall, sizeof(hSmall));
     alignRound(hSmall + 32, hSmall + 48, dTasks2, dResults2, dBuckets2, dSmall + 88);
+    launchPack(b, dTasks, dTasks2, dResults, dResults2, nullptr, dInfo, dCigar, cigarCap);
     b->evAlign.record();
     rt::sync();
     stage("aligned round 2");
@@ -1434,59 +1507,6 @@ int manta_spanning_output_sizes(const manta_spanning_t* b, uint64_t* contigs, ui
 
 namespace {
 
-void spanningStage(manta_spanning* b)
-{
-  const uint32_t nLoci  = b->nLoci;
-  const uint64_t nSlots = uint64_t(nLoci) * b->opt.max_assembly_count;
-  uint32_t       hSmall[72];
-  rt::d2h(hSmall, b->dSmall.p, sizeof(hSmall));
-  std::memcpy(&b->cigDev, hSmall + 64, sizeof(uint64_t));
-  b->hRes    = b->pRes.as<AlignResultDev>(nSlots);
-  b->hRes2   = b->pRes2.as<AlignResultDev>(nSlots);
-  b->hInfo   = b->pInfo.as<SpanTaskInfo>(nSlots);
-  b->hTasks  = b->pTasks.as<AlignTaskDev>(nSlots);
-  b->hTasks2 = b->pTasks2.as<AlignTaskDev>(nSlots);
-  b->hCuts   = b->pCuts.as<JumpCuts>(nLoci);
-  b->hCig    = b->pCig.as<uint32_t>(b->cigDev + 1);
-  b->asmStage.stageOut([&] {
-    rt::d2hAsync(b->hRes, b->dResults.p, sizeof(AlignResultDev) * nSlots);
-    rt::d2hAsync(b->hRes2, b->dResults2.p, sizeof(AlignResultDev) * nSlots);
-    rt::d2hAsync(b->hInfo, b->dInfo.p, sizeof(SpanTaskInfo) * nSlots);
-    rt::d2hAsync(b->hTasks, b->dTasks.p, sizeof(AlignTaskDev) * nSlots);
-    rt::d2hAsync(b->hTasks2, b->dTasks2.p, sizeof(AlignTaskDev) * nSlots);
-    rt::d2hAsync(b->hCuts, b->dCuts.p, sizeof(JumpCuts) * nLoci);
-    rt::d2hAsync(b->hCig, b->dCigar.p, sizeof(uint32_t) * b->cigDev);
-  });
-  b->staged = true;
-}
-
-uint64_t spanningStagedBytes(const manta_spanning* b)
-{
-  const uint64_t nSlots = uint64_t(b->nLoci) * b->opt.max_assembly_count;
-  return b->asmStage.seqUsedDev + 8 * b->asmStage.bitsUsedDev + sizeof(AsmLocusOut) * uint64_t(b->nLoci) + sizeof(AsmContigOut) * nSlots +
-         (2 * sizeof(AlignResultDev) + sizeof(SpanTaskInfo) + 2 * sizeof(AlignTaskDev)) * nSlots + sizeof(JumpCuts) * uint64_t(b->nLoci) +
-         4 * b->cigDev + 128 + 288;
-}
-
-uint64_t spanningCigarWords(const manta_spanning* b)
-{
-  const uint32_t maxAsm = b->opt.max_assembly_count;
-  uint64_t       n      = 0;
-  for (uint32_t l = 0; l < b->nLoci; ++l) {
-    const AsmLocusOut& lo(b->asmStage.hLoci[l]);
-    if (lo.status != ASM_OK) continue;
-    for (uint32_t c = 0; c < lo.n_contigs; ++c) {
-      const uint64_t        slot = uint64_t(l) * maxAsm + c;
-      const SpanTaskInfo&   inf(b->hInfo[slot]);
-      const bool            uncut = inf.is_uncut != 0;
-      const AlignResultDev& h(uncut ? b->hRes2[slot] : b->hRes[slot]);
-      if (inf.status != 0 || h.status != 0 || (uncut ? inf.bucket2 : inf.bucket) < 0) continue;
-      n += uint64_t(h.cigar1_len) + h.cigar2_len;
-    }
-  }
-  return n;
-}
-
 int spanningCompact(
     manta_spanning* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_spanning_alignment_t* alignments,
     uint64_t contigBase, uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t seqBase, uint64_t* seq_arena_used,
@@ -1494,36 +1514,32 @@ int spanningCompact(
     uint64_t cigar_arena_cap, uint64_t cigarBase, uint64_t* cigar_arena_used)
 {
   manta_ctx_t* ctx = b->ctx;
-  int rc = b->asmStage.compact(loci, contigs + contigBase, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap,
-                               bits_arena_used, contigBase, seqBase, bitsBase);
-  if (rc != MANTA_OK && rc != MANTA_E_UNSUPPORTED && rc != MANTA_E_DEVICE_FAULT) return rc;
-  const uint32_t nLoci  = b->nLoci;
-  const uint32_t maxAsm = b->opt.max_assembly_count;
+  int rc = b->asmStage.compact(PackedContigs<manta_spanning>{b}, loci, contigs + contigBase, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used,
+                               bits_arena, bits_arena_cap, bits_arena_used, contigBase, seqBase, bitsBase);
+  if (rc != MANTA_OK && !perItemCode(rc)) return rc;
+  const uint32_t nLoci = b->nLoci;
   uint64_t       used = 0, cells = 0, ptrBytes = 0;
   int            worst = rc;
   for (uint32_t l = 0; l < nLoci; ++l) {
     if (loci[l].status != MANTA_OK) continue;
     for (uint32_t c = 0; c < loci[l].n_contigs; ++c) {
-      const uint64_t              slot = uint64_t(l) * maxAsm + c;
       manta_spanning_alignment_t& a(alignments[loci[l].first_contig + c]);
       std::memset(&a, 0, sizeof(a));
-      const SpanTaskInfo&   inf(b->hInfo[slot]);
-      const bool            uncut = inf.is_uncut != 0;
-      const AlignResultDev& h(uncut ? b->hRes2[slot] : b->hRes[slot]);
-      const AlignTaskDev&   t(uncut ? b->hTasks2[slot] : b->hTasks[slot]);
-      a.is_uncut = uncut ? 1 : 0;
-      if (inf.status != 0 || h.status != 0 || (uncut ? inf.bucket2 : inf.bucket) < 0) {
-        a.align.status = (inf.status == 5) ? MANTA_E_DEVICE_FAULT : (inf.status == 6) ? MANTA_E_EMPTY_SEQ : MANTA_E_UNSUPPORTED;
+      const PackedContigOut& h(b->hPacked[b->hFirst[l] + c]);
+      const bool             uncut = h.a != 0;
+      a.is_uncut                   = uncut ? 1 : 0;
+      if (h.info_status != 0 || h.res_status != 0 || h.bucket < 0) {
+        a.align.status = (h.info_status == 5) ? MANTA_E_DEVICE_FAULT : (h.info_status == 6) ? MANTA_E_EMPTY_SEQ : MANTA_E_UNSUPPORTED;
         worst          = a.align.status;
         continue;
       }
       const uint64_t n = uint64_t(h.cigar1_len) + h.cigar2_len;
       if (used + n > cigar_arena_cap) return fail(ctx, MANTA_E_CAPACITY, "manta_spanning_download: cigar arena too small");
-      std::memcpy(cigar_arena + used, b->hCig + t.cigar_off, sizeof(uint32_t) * n);
+      std::memcpy(cigar_arena + used, b->hCig + h.cigar_off, sizeof(uint32_t) * n);
       a.align.score            = h.score;
       a.align.is_jumped        = h.is_jumped;
-      a.align.begin_pos1       = h.begin1 + (uncut ? 0 : b->hCuts[l].a1Lead);  // SVCandidateAssemblyRefiner.cpp:1716-1717
-      a.align.begin_pos2       = h.begin2 + (uncut ? 0 : b->hCuts[l].a2Lead);
+      a.align.begin_pos1       = h.begin1 + (uncut ? 0 : b->hostCuts[l].a1Lead);  // SVCandidateAssemblyRefiner.cpp:1716-1717
+      a.align.begin_pos2       = h.begin2 + (uncut ? 0 : b->hostCuts[l].a2Lead);
       a.align.jump_insert_size = h.jump_insert_size;
       a.align.jump_range       = h.jump_range;
       a.align.cigar1_len       = h.cigar1_len;
@@ -1531,9 +1547,8 @@ int spanningCompact(
       a.align.cigar1_off       = cigarBase + used;
       a.align.cigar2_off       = cigarBase + used + h.cigar1_len;
       used += n;
-      const uint64_t refLen = uint64_t(t.ref1_len) + t.ref2_len;
-      cells += uint64_t(t.query_len) * refLen;
-      ptrBytes += (uint64_t(t.query_len) + 1) * (refLen + 2);
+      cells += uint64_t(h.query_len) * h.ref_len;
+      ptrBytes += (uint64_t(h.query_len) + 1) * (uint64_t(h.ref_len) + 2);
     }
   }
   b->stats.dp_cells         = cells;
@@ -1560,7 +1575,7 @@ int manta_spanning_download(
     return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_download: null argument");
   try {
     rt::ScopedStream onStream(b->main);
-    spanningStage(b);
+    pipeStage(b);
     return spanningCompact(b, loci, contigs, alignments, 0, contigs_cap, seq_arena, seq_arena_cap, 0, seq_arena_used, bits_arena,
                            bits_arena_cap, 0, bits_arena_used, cigar_arena, cigar_arena_cap, 0, cigar_arena_used);
   } catch (const std::exception& e) {
@@ -1601,6 +1616,8 @@ struct BatchShared {
   std::atomic<uint32_t> next{0};
   std::atomic<uint64_t> contigsUsed{0}, seqUsed{0}, bitsUsed{0}, cigarUsed{0};
   std::mutex            mu;
+  std::mutex            kernelMu;  // MANTA_BATCH_SERIAL_KERNELS
+  bool                  serialKernels = false;
   int                   fatal = MANTA_OK, worst = MANTA_OK;
   std::string           msg;
   manta_batch_stats_t   st{};
@@ -1623,11 +1640,6 @@ struct BatchShared {
     return fatal != MANTA_OK;
   }
 };
-
-bool perItemCode(int rc)
-{
-  return rc == MANTA_E_UNSUPPORTED || rc == MANTA_E_DEVICE_FAULT || rc == MANTA_E_EMPTY_SEQ;
-}
 
 /// contiguous blocks of `blockLoci` loci, ordered by decreasing cost (reads x bases, the same estimate the kernels'
 /// work queue uses): EdgeRetrieverBin.cpp:38-57 hands out contiguous edge ranges too, but statically
@@ -1709,6 +1721,7 @@ int manta_smallsv_batch(
       return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_batch: offsets not monotone");
   const uint32_t blockLoci = (plan && plan->block_loci) ? plan->block_loci : 2048u;
   BatchShared    sh;
+  sh.serialKernels = plan && (plan->flags & MANTA_BATCH_SERIAL_KERNELS);
   planBlocks(sh, n_loci, blockLoci, read_off, locus_read_begin);
   const uint32_t nBlocks  = uint32_t(sh.blockOrder.size());
   const uint32_t nWorkers = std::max(1u, std::min(nBlocks, (plan && plan->n_workers) ? plan->n_workers : 4u));
@@ -1754,7 +1767,11 @@ int manta_smallsv_batch(
           break;
         }
         const double t1 = nowMs();
-        rc              = manta_smallsv_run(b);
+        {
+          std::unique_lock<std::mutex> only(sh.kernelMu, std::defer_lock);
+          if (sh.serialKernels) only.lock();
+          rc = manta_smallsv_run(b);
+        }
         if (rc != MANTA_OK) {
           sh.error(rc, lastErrorOf(ctx), true);
           break;
@@ -1763,10 +1780,10 @@ int manta_smallsv_batch(
         uint64_t     nC = 0, nS = 0, nB = 0, nG = 0;
         {
           rt::ScopedStream onStream(b->main);
-          smallsvStage(b);
+          pipeStage(b);
         }
-        b->asmStage.exactSizes(nC, nS, nB);
-        nG = smallsvCigarWords(b);
+        b->asmStage.exactSizes(PackedContigs<manta_smallsv>{b}, nC, nS, nB);
+        nG = b->hPackCnt[1];
         const uint64_t cBase = sh.contigsUsed.fetch_add(nC), sBase = sh.seqUsed.fetch_add(nS), bBase = sh.bitsUsed.fetch_add(nB),
                        gBase = sh.cigarUsed.fetch_add(nG);
         if (cBase + nC > contigs_cap || sBase + nS > seq_arena_cap || bBase + nB > bits_arena_cap || gBase + nG > cigar_arena_cap) {
@@ -1788,10 +1805,11 @@ int manta_smallsv_batch(
         sh.st.schedule_ms += b->stats.schedule_ms;
         sh.st.align_ms += b->stats.align_ms;
         sh.st.n_alignments += b->stats.n_alignments;
+        sh.st.n_align_launches += b->stats.n_align_launches;
         sh.st.dp_cells += b->stats.dp_cells;
         sh.st.ptr_matrix_bytes += b->stats.ptr_matrix_bytes;
         sh.st.h2d_bytes += (read_off[r1] - read_off[r0]) + (ref_off[l1] - ref_off[l0]) + 8ull * (r1 - r0 + 1) + 12ull * (n + 1) + 16ull * n;
-        sh.st.d2h_bytes += smallsvStagedBytes(b);
+        sh.st.d2h_bytes += pipeStagedBytes(b);
       }
     } catch (const std::exception& e) {
       sh.error(MANTA_E_HIP, e.what(), true);
@@ -1834,6 +1852,7 @@ int manta_spanning_batch(
       return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_batch: offsets not monotone");
   const uint32_t blockLoci = (plan && plan->block_loci) ? plan->block_loci : 2048u;
   BatchShared    sh;
+  sh.serialKernels = plan && (plan->flags & MANTA_BATCH_SERIAL_KERNELS);
   planBlocks(sh, n_loci, blockLoci, read_off, locus_read_begin);
   const uint32_t nBlocks  = uint32_t(sh.blockOrder.size());
   const uint32_t nWorkers = std::max(1u, std::min(nBlocks, (plan && plan->n_workers) ? plan->n_workers : 4u));
@@ -1881,7 +1900,11 @@ int manta_spanning_batch(
           break;
         }
         const double t1 = nowMs();
-        rc              = manta_spanning_run(b);
+        {
+          std::unique_lock<std::mutex> only(sh.kernelMu, std::defer_lock);
+          if (sh.serialKernels) only.lock();
+          rc = manta_spanning_run(b);
+        }
         if (rc != MANTA_OK) {
           sh.error(rc, lastErrorOf(ctx), true);
           break;
@@ -1890,10 +1913,10 @@ int manta_spanning_batch(
         uint64_t     nC = 0, nS = 0, nB = 0, nG = 0;
         {
           rt::ScopedStream onStream(b->main);
-          spanningStage(b);
+          pipeStage(b);
         }
-        b->asmStage.exactSizes(nC, nS, nB);
-        nG = spanningCigarWords(b);
+        b->asmStage.exactSizes(PackedContigs<manta_spanning>{b}, nC, nS, nB);
+        nG = b->hPackCnt[1];
         const uint64_t cBase = sh.contigsUsed.fetch_add(nC), sBase = sh.seqUsed.fetch_add(nS), bBase = sh.bitsUsed.fetch_add(nB),
                        gBase = sh.cigarUsed.fetch_add(nG);
         if (cBase + nC > contigs_cap || sBase + nS > seq_arena_cap || bBase + nB > bits_arena_cap || gBase + nG > cigar_arena_cap) {
@@ -1915,11 +1938,12 @@ int manta_spanning_batch(
         sh.st.schedule_ms += b->stats.schedule_ms;
         sh.st.align_ms += b->stats.align_ms;
         sh.st.n_alignments += b->stats.n_alignments;
+        sh.st.n_align_launches += b->stats.n_align_launches;
         sh.st.dp_cells += b->stats.dp_cells;
         sh.st.ptr_matrix_bytes += b->stats.ptr_matrix_bytes;
         sh.st.h2d_bytes += (read_off[r1] - read_off[r0]) + (ref1_off[l1] - ref1_off[l0]) + (ref2_off[l1] - ref2_off[l0]) + 8ull * (r1 - r0 + 1) +
                            20ull * (n + 1) + 16ull * n;
-        sh.st.d2h_bytes += spanningStagedBytes(b);
+        sh.st.d2h_bytes += pipeStagedBytes(b);
       }
     } catch (const std::exception& e) {
       sh.error(MANTA_E_HIP, e.what(), true);

@@ -36,6 +36,7 @@ enum {
   ASM_E_INTERNAL       = 7
 };
 
+static const unsigned ASM_FLAG_NO_LDS_PATH = 2u;  // A/B knob of assemble_lds_kernel: every locus through the general path
 static const unsigned ASM_FLAG_SERIAL_WALK = 1u;  // debug/A-B knob: build contigs one at a time even for small read sets
 static const unsigned ASM_NONE     = 0xffffffffu;
 static const int      ASM_MAX_KW   = 8;    // k <= 128

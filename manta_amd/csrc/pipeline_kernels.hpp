@@ -439,4 +439,92 @@ WV_KERNEL void spanning_realign_kernel(const SpanParams P)
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Result packing: the last kernel of both pipelines.  The stages above keep one record per (locus, contig slot) --
+// mostly empty -- and a CIGAR region of 4*Q+16 words per task; a result download of those would move ~10x the payload
+// over PCIe.  One lane per locus gathers what the host needs into dense arrays: one PackedContigOut per contig and
+// the CIGAR words back to back.
+// ------------------------------------------------------------------------------------------------------
+struct PackedContigOut {
+  AsmContigOut contig;
+  int32_t      info_status;  ///< the schedule kernel's per-slot status
+  int32_t      bucket;       ///< E bucket of the alignment that counts (-1: none)
+  int32_t      res_status;   ///< AlignResultDev::status of that alignment
+  int32_t      score, is_jumped, begin1, begin2;
+  uint32_t     jump_insert_size, jump_range, cigar1_len, cigar2_len;
+  uint32_t     cigar_off;  ///< first word in the packed CIGAR arena
+  int32_t      a, b;       ///< small SV: adjusted leading / trailing cut; spanning: is_uncut, 0
+  uint32_t     query_len, ref_len;
+};
+
+struct PackParams {
+  const AsmLocusOut*     loci;
+  const AsmContigOut*    contigs;
+  uint32_t               n_loci, max_assembly_count;
+  const AlignTaskDev*    tasks;
+  const AlignTaskDev*    tasks2;  ///< spanning round 2 (nullptr for small SV)
+  const AlignResultDev*  results;
+  const AlignResultDev*  results2;
+  const SmallSvTaskInfo* info_small;  ///< exactly one of info_small / info_span is set
+  const SpanTaskInfo*    info_span;
+  const uint32_t*        cigar;
+  uint32_t*              first;         ///< out: n_loci, index of the locus' first packed contig
+  PackedContigOut*       packed;        ///< out
+  uint32_t*              cigar_packed;  ///< out
+  uint32_t*              counters;      ///< [0] packed contigs, [1] packed cigar words (zeroed before launch)
+};
+
+WV_KERNEL void pack_results_kernel(const PackParams P)
+{
+  for (unsigned locus = unsigned(wv::block()) * 64 + unsigned(wv::lane()); locus < P.n_loci; locus += unsigned(wv::nblocks()) * 64) {
+    const AsmLocusOut lo = P.loci[locus];
+    const unsigned    n  = (lo.status == ASM_OK) ? lo.n_contigs : 0u;
+    const unsigned    base = n ? wv::atomic_add(&P.counters[0], n) : 0u;
+    P.first[locus]         = base;
+    for (unsigned c = 0; c < n; ++c) {
+      const unsigned  slot = locus * P.max_assembly_count + c;
+      PackedContigOut o;
+      o.contig = P.contigs[slot];
+      const AlignResultDev* res  = &P.results[slot];
+      const AlignTaskDev*   task = &P.tasks[slot];
+      if (P.info_small) {
+        const SmallSvTaskInfo inf = P.info_small[slot];
+        o.info_status             = inf.status;
+        o.bucket                  = inf.bucket;
+        o.a                       = inf.adj_leading_cut;
+        o.b                       = inf.adj_trailing_cut;
+      } else {
+        const SpanTaskInfo inf = P.info_span[slot];
+        const bool         uncut = inf.is_uncut != 0;
+        o.info_status            = inf.status;
+        o.bucket                 = uncut ? inf.bucket2 : inf.bucket;
+        o.a                      = uncut ? 1 : 0;
+        o.b                      = 0;
+        if (uncut) {
+          res  = &P.results2[slot];
+          task = &P.tasks2[slot];
+        }
+      }
+      const bool           ok = (o.info_status == 0 && o.bucket >= 0);
+      const AlignResultDev r  = *res;
+      o.res_status            = ok ? r.status : -1;
+      o.score                 = r.score;
+      o.is_jumped             = r.is_jumped;
+      o.begin1                = r.begin1;
+      o.begin2                = r.begin2;
+      o.jump_insert_size      = r.jump_insert_size;
+      o.jump_range            = r.jump_range;
+      o.cigar1_len            = (ok && r.status == 0) ? r.cigar1_len : 0u;
+      o.cigar2_len            = (ok && r.status == 0) ? r.cigar2_len : 0u;
+      o.query_len             = ok ? task->query_len : 0u;
+      o.ref_len               = ok ? (task->ref1_len + task->ref2_len) : 0u;
+      const unsigned words    = o.cigar1_len + o.cigar2_len;
+      o.cigar_off             = words ? wv::atomic_add(&P.counters[1], words) : 0u;
+      const uint32_t* src     = P.cigar + task->cigar_off;
+      for (unsigned i = 0; i < words; ++i) P.cigar_packed[o.cigar_off + i] = src[i];
+      P.packed[base + c] = o;
+    }
+  }
+}
+
 }  // namespace manta_dev

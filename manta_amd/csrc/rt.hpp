@@ -30,6 +30,8 @@ inline void  dfill(void* d, int byte, size_t n) { if (n) std::memset(d, byte, n)
 inline void  sync() {}
 template <typename K, typename P>
 inline void launch(K kernel, int grid, size_t ldsBytes, const P& params) { wv_emu::launch(grid, ldsBytes, [&]() { kernel(params); }); }
+template <typename K, typename P>
+inline void launchSingle(K kernel, int grid, size_t ldsBytes, const P& params) { wv_emu::launch(grid, ldsBytes, [&]() { kernel(params); }); }
 inline int roundGrid(int waves) { return waves; }
 struct Stream {};
 inline void useStream(Stream*) {}
@@ -143,6 +145,19 @@ inline void launch(K kernel, int grid, size_t ldsBytes, const P& params)
 {
   // `grid` counts WAVEFRONTS and must be a multiple of WV_WAVES_PER_WG (see roundGrid); ldsBytes is per wave
   hipLaunchKernelGGL(kernel, dim3(grid / WV_WAVES_PER_WG), dim3(64 * WV_WAVES_PER_WG), ldsBytes * WV_WAVES_PER_WG, launchStream(), params);
+  check(hipGetLastError(), "kernel launch");
+}
+/// `grid` single-wave workgroups with `ldsBytes` of dynamic LDS each (may exceed the 64 KB default limit)
+template <typename K, typename P>
+inline void launchSingle(K kernel, int grid, size_t ldsBytes, const P& params)
+{
+  static thread_local const void* prepared = nullptr;
+  if (prepared != reinterpret_cast<const void*>(kernel)) {
+    check(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)),
+          "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    prepared = reinterpret_cast<const void*>(kernel);
+  }
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), ldsBytes, launchStream(), params);
   check(hipGetLastError(), "kernel launch");
 }
 inline int roundGrid(int waves) { return ((waves + WV_WAVES_PER_WG - 1) / WV_WAVES_PER_WG) * WV_WAVES_PER_WG; }

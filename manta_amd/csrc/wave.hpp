@@ -20,6 +20,8 @@
 #define WV_KERNEL __global__ __launch_bounds__(64 * WV_WAVES_PER_WG)
 // same, additionally asking the register allocator for at least `w` resident waves per SIMD
 #define WV_KERNEL_OCC(w) __global__ __launch_bounds__(64 * WV_WAVES_PER_WG, w)
+// single-wave workgroups (the LDS-resident assembler: one locus per workgroup, the workgroup's LDS is the wave's)
+#define WV_KERNEL_SINGLE __global__ __launch_bounds__(64)
 #define WV_HD __host__ __device__ inline
 // cold paths (measured: real out-of-line calls cost more than they save on gfx950, so this is still inline)
 #define WV_DEV_COLD __device__ __forceinline__
@@ -34,6 +36,10 @@ WV_DEV int block() { return int(blockIdx.x) * WV_WAVES_PER_WG + __builtin_amdgcn
 WV_DEV int nblocks() { return int(gridDim.x) * WV_WAVES_PER_WG; }
 /// this wavefront's share of the dynamic LDS (ldsBytes passed to rt::launch is PER WAVE)
 WV_DEV char* lds(const unsigned bytesPerWave) { return wv_dyn_lds + size_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))) * bytesPerWave; }
+
+/// single-wave workgroups: workgroup index and the whole dynamic LDS
+WV_DEV int   block_single() { return int(blockIdx.x); }
+WV_DEV char* lds_single() { return wv_dyn_lds; }
 
 /// lane l receives lane (l-1)'s value; lane 0 receives `fill`   (v_mov_b32_dpp wave_shr:1)
 WV_DEV int shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }

@@ -37,14 +37,23 @@ struct GeneralException : public std::logic_error {
   int errorCode;
 };
 
-/// one ABI context per host thread
+namespace detail {
+struct ThreadContextHolder {
+  manta_ctx_t* ctx = nullptr;
+  ~ThreadContextHolder() { manta_ctx_destroy(ctx); }
+};
+// internal linkage on purpose: a function-local static of an inline function would be ONE object per process
+// (STB_GNU_UNIQUE), shared even between two differently built copies of this library loaded side by side (the test
+// suite loads the device build and the wave-emulator build into one process)
+namespace {
+thread_local ThreadContextHolder g_threadContext;
+}
+}  // namespace detail
+
+/// one ABI context per host thread (and per translation unit that includes this header)
 inline manta_ctx_t* threadContext()
 {
-  struct Holder {
-    manta_ctx_t* ctx = nullptr;
-    ~Holder() { manta_ctx_destroy(ctx); }
-  };
-  static thread_local Holder h;
+  detail::ThreadContextHolder& h(detail::g_threadContext);
   if (!h.ctx) {
     const int rc = manta_ctx_create(-1, &h.ctx);
     if (rc != MANTA_OK) throw GeneralException(std::string("manta_amd: no usable GPU context: ") + manta_last_error(nullptr), rc);

@@ -409,6 +409,15 @@ struct AsmOutput {
   }
 };
 
+/// the kernels read input arenas in aligned dwords: one pad byte behind the last base, taken back on every exit path
+struct SentinelByte {
+  std::vector<uint8_t>& v;
+  explicit SentinelByte(std::vector<uint8_t>& vec) : v(vec) { v.push_back(0); }
+  ~SentinelByte() { v.pop_back(); }
+  SentinelByte(const SentinelByte&) = delete;
+  SentinelByte& operator=(const SentinelByte&) = delete;
+};
+
 struct SmallSvOutput : AsmOutput {
   std::vector<manta_smallsv_alignment_t> aligns;
   std::vector<uint32_t>                  cigar;
@@ -416,11 +425,10 @@ struct SmallSvOutput : AsmOutput {
 
 /// the fused device pipeline for a batch of complex loci
 inline void smallSvBatch(
-    manta_smallsv_t*& b, const IterativeAssemblerOptions& opt, const AlignmentScores<int>& scores, const int largeIndelScore,
+    manta_ctx_t* ctx, manta_smallsv_t*& b, const IterativeAssemblerOptions& opt, const AlignmentScores<int>& scores, const int largeIndelScore,
     PackedReads& in, const std::vector<const std::string*>& refs, const std::vector<manta_ref_cuts_t>& cuts, SmallSvOutput& out)
 {
   if (in.nLoci() == 0) return;
-  manta_ctx_t*               ctx = threadContext();
   const manta_asm_options_t  o   = toAbi(opt);
   const manta_align_scores_t sc  = toAbi(scores);
   std::vector<uint8_t>       refBytes;
@@ -430,7 +438,7 @@ inline void smallSvBatch(
     refOff.push_back(refBytes.size());
   }
   refBytes.push_back(0);
-  in.bases.push_back(0);
+  SentinelByte guard(in.bases);
   auto check = [&](const int rc) {
     if (rc == MANTA_OK) return;
     throw GeneralException("manta_amd small-SV pipeline: " + std::string(manta_last_error(ctx)), rc);
@@ -439,15 +447,17 @@ inline void smallSvBatch(
   check(manta_smallsv_upload(b, in.nLoci(), in.bases.data(), in.readOff.data(), in.locusBegin.data(), refBytes.data(), refOff.data(),
                              cuts.data()));
   check(manta_smallsv_run(b));
-  in.bases.pop_back();
   uint64_t nc = 0, sb = 0, bw = 0, cw = 0;
   check(manta_smallsv_output_sizes(b, &nc, &sb, &bw, &cw));
   out.sizeTo(in.nLoci(), nc, sb, bw);
   out.aligns.resize(nc);
   out.cigar.resize(cw);
-  uint64_t su = 0, bu = 0, cu = 0;
-  check(manta_smallsv_download(b, out.loci.data(), out.contigs.data(), out.aligns.data(), out.contigs.size(), out.seq.data(), out.seq.size(),
-                               &su, out.bits.data(), out.bits.size(), &bu, out.cigar.data(), out.cigar.size(), &cu));
+  uint64_t  su = 0, bu = 0, cu = 0;
+  const int rc = manta_smallsv_download(b, out.loci.data(), out.contigs.data(), out.aligns.data(), out.contigs.size(), out.seq.data(),
+                                        out.seq.size(), &su, out.bits.data(), out.bits.size(), &bu, out.cigar.data(), out.cigar.size(), &cu);
+  // per-item failures (a contig outside the aligner's envelope, ...) are in the per-locus / per-contig status and become
+  // that candidate's exception; only a failure of the call itself is fatal here
+  if (rc != MANTA_E_UNSUPPORTED && rc != MANTA_E_DEVICE_FAULT && rc != MANTA_E_EMPTY_SEQ) check(rc);
 }
 
 struct SpanningOutput : AsmOutput {
@@ -457,12 +467,11 @@ struct SpanningOutput : AsmOutput {
 
 /// the fused device pipeline for a batch of spanning loci (references already oriented, in alignment order)
 inline void spanningBatch(
-    manta_spanning_t*& b, const IterativeAssemblerOptions& opt, const AlignmentScores<int>& scores, const int jumpScore, PackedReads& in,
+    manta_ctx_t* ctx, manta_spanning_t*& b, const IterativeAssemblerOptions& opt, const AlignmentScores<int>& scores, const int jumpScore, PackedReads& in,
     const std::vector<const std::string*>& refs1, const std::vector<const std::string*>& refs2, const std::vector<manta_jump_cuts_t>& cuts,
     SpanningOutput& out)
 {
   if (in.nLoci() == 0) return;
-  manta_ctx_t*               ctx = threadContext();
   const manta_asm_options_t  o   = toAbi(opt);
   const manta_align_scores_t sc  = toAbi(scores);
   std::vector<uint8_t>       ref1Bytes, ref2Bytes;
@@ -475,7 +484,7 @@ inline void spanningBatch(
   }
   ref1Bytes.push_back(0);
   ref2Bytes.push_back(0);
-  in.bases.push_back(0);
+  SentinelByte guard(in.bases);
   auto check = [&](const int rc) {
     if (rc == MANTA_OK) return;
     throw GeneralException("manta_amd spanning pipeline: " + std::string(manta_last_error(ctx)), rc);
@@ -484,7 +493,6 @@ inline void spanningBatch(
   check(manta_spanning_upload(b, in.nLoci(), in.bases.data(), in.readOff.data(), in.locusBegin.data(), ref1Bytes.data(), ref1Off.data(),
                               ref2Bytes.data(), ref2Off.data(), cuts.data()));
   check(manta_spanning_run(b));
-  in.bases.pop_back();
   uint64_t nc = 0, sb = 0, bw = 0, cw = 0;
   check(manta_spanning_output_sizes(b, &nc, &sb, &bw, &cw));
   out.sizeTo(in.nLoci(), nc, sb, bw);
@@ -493,9 +501,7 @@ inline void spanningBatch(
   uint64_t  su = 0, bu = 0, cu = 0;
   const int rc = manta_spanning_download(b, out.loci.data(), out.contigs.data(), out.aligns.data(), out.contigs.size(), out.seq.data(),
                                          out.seq.size(), &su, out.bits.data(), out.bits.size(), &bu, out.cigar.data(), out.cigar.size(), &cu);
-  if (rc == MANTA_E_EMPTY_SEQ)  // the reference throws from GlobalJumpAligner::align (GlobalJumpAlignerImpl.hpp:50-58)
-    throw GeneralException("Unexpected empty reference sequence");
-  check(rc);
+  if (rc != MANTA_E_UNSUPPORTED && rc != MANTA_E_DEVICE_FAULT && rc != MANTA_E_EMPTY_SEQ) check(rc);  // per-item codes: see smallSvBatch
 }
 
 }  // namespace detail
@@ -511,6 +517,7 @@ struct SVCandidateAssemblyRefiner {
   {
     if (_smallPipe) manta_smallsv_destroy(_smallPipe);
     if (_spanPipe) manta_spanning_destroy(_spanPipe);
+    if (_ctx) manta_ctx_destroy(_ctx);
   }
   SVCandidateAssemblyRefiner(const SVCandidateAssemblyRefiner&) = delete;
   SVCandidateAssemblyRefiner& operator=(const SVCandidateAssemblyRefiner&) = delete;
@@ -538,21 +545,55 @@ struct SVCandidateAssemblyRefiner {
   /// The same call for a whole list of candidates (one edge's worth, or many edges' worth: the only cross-candidate
   /// state is the geometric _spanToComplexAssmRegions filter, applied here in list order exactly as consecutive
   /// single calls would).  Every device stage runs once over the whole list.
+  /// `errors` (optional): one slot per candidate; a candidate whose processing throws (as the reference's single call
+  /// would: off-chromosome regions, empty sequences, an input outside the device path's envelope) gets its exception
+  /// there and an empty result, every other candidate is computed.  Without it the first such exception is re-thrown
+  /// after the whole batch has been processed.
   void getCandidateAssemblyDataBatch(
-      const std::vector<SVCandidate>& svs, const bool isFindLargeInsertions, std::vector<SVCandidateAssemblyData>& out) const
+      const std::vector<SVCandidate>& svs, const bool isFindLargeInsertions, std::vector<SVCandidateAssemblyData>& out,
+      std::vector<std::exception_ptr>* errors = nullptr) const
   {
     const size_t n = svs.size();
     out.assign(n, SVCandidateAssemblyData());
     std::vector<Plan> plans(n);
     _times = RefinerTimes();
+    _errors.assign(n, std::exception_ptr());
     const double t0 = now();
-    for (size_t i = 0; i < n; ++i) plan(svs[i], plans[i], out[i]);
+    for (size_t i = 0; i < n; ++i) {
+      try {
+        plan(svs[i], plans[i], out[i]);
+      } catch (...) {
+        plans[i].kind = Plan::NONE;
+        recordError(i, out);
+      }
+    }
     _times.plan = now() - t0;
     runSmall(plans, isFindLargeInsertions, out);
     runSpanning(plans, out);
+    if (errors) {
+      *errors = _errors;
+      return;
+    }
+    for (const std::exception_ptr& e : _errors)
+      if (e) std::rethrow_exception(e);
   }
 
 private:
+  /// the refiner's own ABI context: its pipelines live and report errors through it, whichever host thread calls
+  manta_ctx_t* deviceContext() const
+  {
+    if (!_ctx) {
+      const int rc = manta_ctx_create(-1, &_ctx);
+      if (rc != MANTA_OK) throw GeneralException(std::string("manta_amd: no usable GPU context: ") + manta_last_error(nullptr), rc);
+    }
+    return _ctx;
+  }
+  void recordError(const size_t candidate, std::vector<SVCandidateAssemblyData>& out) const
+  {
+    std::lock_guard<std::mutex> g(_errorLock);
+    if (!_errors[candidate]) _errors[candidate] = std::current_exception();
+    out[candidate] = SVCandidateAssemblyData();
+  }
   static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
   struct Plan {
@@ -688,14 +729,14 @@ private:
     const double          tPacked = now();
     _times.pack += tPacked - tStart;
     detail::SmallSvOutput dev;
-    detail::smallSvBatch(_smallPipe, _opt.refineOpt.smallSVAssembleOpt, _opt.refineOpt.largeSVAlignScores, _opt.refineOpt.largeGapOpenScore, packed,
+    detail::smallSvBatch(deviceContext(), _smallPipe, _opt.refineOpt.smallSVAssembleOpt, _opt.refineOpt.largeSVAlignScores, _opt.refineOpt.largeGapOpenScore, packed,
                          refs, cuts, dev);
     const double tDevice = now();
     _times.device += tDevice - tPacked;
 
     std::vector<std::unique_ptr<LargeInsertionWork>> liWorkByLocus(which.size());
     std::atomic<uint64_t>                            nContigs(0);
-    detail::parallelFor(which.size(), _hostThreads, [&](const size_t w) {
+    auto smallLocus = [&](const size_t w) {
       const Plan&              p(plans[which[w]]);
       SVCandidateAssemblyData& data(out[which[w]]);
       dev.toContigs(unsigned(w), data.contigs);
@@ -802,6 +843,14 @@ private:
           work->insPos    = insPos;
           liWorkByLocus[w] = std::move(work);
         }
+      }
+    };
+    // a candidate's failure (the reference would throw from its getCandidateAssemblyData call) stays that candidate's
+    detail::parallelFor(which.size(), _hostThreads, [&](const size_t w) {
+      try {
+        smallLocus(w);
+      } catch (...) {
+        recordError(which[w], out);
       }
     });
     _stats.contigAlignments += nContigs;
@@ -960,13 +1009,13 @@ private:
     const double           tPacked = now();
     _times.pack += tPacked - tStart;
     detail::SpanningOutput dev;
-    detail::spanningBatch(_spanPipe, _opt.refineOpt.spanningAssembleOpt, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, packed, refs1,
+    detail::spanningBatch(deviceContext(), _spanPipe, _opt.refineOpt.spanningAssembleOpt, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, packed, refs1,
                           refs2, cuts, dev);
     const double tDevice = now();
     _times.device += tDevice - tPacked;
 
     std::atomic<uint64_t> nContigs(0), nRealigned(0);
-    detail::parallelFor(loci.size(), _hostThreads, [&](const size_t l) {
+    auto spanningLocus = [&](const size_t l) {
       const SpanningLocus&     sl(loci[l]);
       const Plan&              p(plans[sl.planIndex]);
       SVCandidateAssemblyData& data(out[sl.planIndex]);
@@ -977,6 +1026,8 @@ private:
       for (unsigned c = 0; c < contigCount; ++c) {
         JumpAlignmentResult<int>&         alignment(data.spanningAlignments[c]);
         const manta_spanning_alignment_t& da(dev.aligns[dev.loci[l].first_contig + c]);
+        if (da.align.status == MANTA_E_EMPTY_SEQ)  // the reference throws from GlobalJumpAligner::align (GlobalJumpAlignerImpl.hpp:50-58)
+          throw GeneralException("Unexpected empty reference sequence");
         if (da.align.status != MANTA_OK) throw GeneralException("manta_amd spanning pipeline: contig alignment failed on the device", da.align.status);
         nRealigned += da.is_uncut ? 1 : 0;
         alignment.clear();
@@ -1012,6 +1063,13 @@ private:
         getFwdStrandInsertSegment(align, data.contigs[data.bestAlignmentIndex].seq, data.bporient.isBp1Reversed, sv.insertSeq);
       if (_opt.isOutputContig) sv.contigSeq = data.contigs[data.bestAlignmentIndex].seq;
       detail::addCigarToSpanningAlignment(sv);
+    };
+    detail::parallelFor(loci.size(), _hostThreads, [&](const size_t l) {
+      try {
+        spanningLocus(l);
+      } catch (...) {
+        recordError(loci[l].planIndex, out);
+      }
     });
     _stats.contigAlignments += nContigs;
     _stats.realignedContigs += nRealigned;
@@ -1024,6 +1082,9 @@ private:
   mutable GenomeIntervalTracker _spanToComplexAssmRegions;
   mutable Stats                 _stats;
   mutable RefinerTimes          _times;
+  mutable std::vector<std::exception_ptr> _errors;  ///< per candidate of the running batch call
+  mutable std::mutex                      _errorLock;
+  mutable manta_ctx_t*          _ctx       = nullptr;
   mutable manta_smallsv_t*      _smallPipe = nullptr;  ///< device pipelines of this refiner (and of the thread that
   mutable manta_spanning_t*     _spanPipe  = nullptr;  ///< first used it: one ABI context per host thread)
   unsigned                      _hostThreads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));

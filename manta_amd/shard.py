@@ -4,7 +4,7 @@ Loci are independent units, so the multi-GPU path has no data-path collective: e
 takes a contiguous slice of the locus list -- the same partition the reference's `--bin-index/--bin-count` makes
 (contiguous ranges balanced by cumulative cost, EdgeRetrieverBin.cpp:38-57) -- and the only communication is the
 final gather of the (small, variable-length) candidate records to rank 0 over torch.distributed (RCCL on GPUs,
-gloo in the CPU tests).  Output order is irrelevant downstream (sortVcf.py sorts), rank order is kept anyway.
+gloo in the CPU tests): sizes by all_gather, payload by one padded gather that only rank 0 receives.  Output order is irrelevant downstream (sortVcf.py sorts), rank order is kept anyway.
 """
 import numpy as np
 import torch
@@ -26,36 +26,45 @@ def shard_bounds(costs, world, rank):
     return edges[rank], edges[rank + 1]
 
 
-def gather_records(local_blobs, device="cpu"):
-    """local_blobs: list of bytes (one per local locus, in order).  Returns on rank 0 the concatenated list over ranks
-    (rank order), elsewhere None.  Two collectives: all_gather of sizes, then one padded all_gather of the payload."""
+def gather_bytes(local, device="cpu"):
+    """one uint8 array per rank -> list of arrays on rank 0 (rank order), None elsewhere.  Only rank 0 receives the payload:
+    an all_gather of the 8-byte sizes, then ONE padded gather to rank 0."""
+    local = np.ascontiguousarray(local, dtype=np.uint8)
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return list(local_blobs)
+        return [local]
     world, rank = dist.get_world_size(), dist.get_rank()
-    lens = np.array([len(b) for b in local_blobs], dtype=np.int64)
-    payload = np.frombuffer(b"".join(local_blobs), dtype=np.uint8) if len(local_blobs) else np.zeros(0, dtype=np.uint8)
-    meta = torch.tensor([len(lens), len(payload)], dtype=torch.int64, device=device)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    max_items = int(max(m[0].item() for m in metas))
-    max_bytes = int(max(m[1].item() for m in metas))
-    lens_t = torch.zeros(max(1, max_items), dtype=torch.int64, device=device)
-    lens_t[:len(lens)] = torch.from_numpy(lens).to(device)
-    pay_t = torch.zeros(max(1, max_bytes), dtype=torch.uint8, device=device)
-    pay_t[:len(payload)] = torch.from_numpy(payload.copy()).to(device)
-    all_lens = [torch.zeros_like(lens_t) for _ in range(world)]
-    all_pay = [torch.zeros_like(pay_t) for _ in range(world)]
-    dist.all_gather(all_lens, lens_t)
-    dist.all_gather(all_pay, pay_t)
+    size = torch.tensor([len(local)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    max_bytes = max(1, int(max(s.item() for s in sizes)))
+    pay = torch.zeros(max_bytes, dtype=torch.uint8, device=device)
+    if len(local):
+        pay[:len(local)] = torch.from_numpy(local).to(device, non_blocking=True)
+    recv = [torch.zeros_like(pay) for _ in range(world)] if rank == 0 else None
+    dist.gather(pay, recv, dst=0)
     if rank != 0:
         return None
+    return [recv[r][:int(sizes[r].item())].cpu().numpy() for r in range(world)]
+
+
+def gather_records(local_blobs, device="cpu"):
+    """local_blobs: list of bytes (one per local locus, in order).  Returns on rank 0 the concatenated list over ranks
+    (rank order), elsewhere None.  The record lengths travel in front of the payload in the same gather."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return list(local_blobs)
+    lens = np.array([len(b) for b in local_blobs], dtype=np.int64)
+    head = np.array([len(lens)], dtype=np.int64)
+    blob = np.frombuffer(head.tobytes() + lens.tobytes() + b"".join(local_blobs), dtype=np.uint8)
+    got = gather_bytes(blob, device)
+    if got is None:
+        return None
     out = []
-    for r in range(world):
-        n_items = int(metas[r][0].item())
-        ls = all_lens[r][:n_items].cpu().numpy()
-        buf = all_pay[r].cpu().numpy().tobytes()
+    for buf in got:
+        n = int(np.frombuffer(buf[:8].tobytes(), dtype=np.int64)[0])
+        ls = np.frombuffer(buf[8:8 + 8 * n].tobytes(), dtype=np.int64)
+        raw = buf[8 + 8 * n:].tobytes()
         off = 0
         for ln in ls:
-            out.append(buf[off:off + int(ln)])
+            out.append(raw[off:off + int(ln)])
             off += int(ln)
     return out

@@ -18,6 +18,7 @@
 #define WV_DEV inline
 #define WV_KERNEL
 #define WV_KERNEL_OCC(w)
+#define WV_KERNEL_SINGLE
 #define WV_WAVES_PER_WG 1
 #define WV_HD inline
 #define WV_DEV_COLD inline
@@ -139,6 +140,9 @@ inline char* lds(const unsigned)
   char* p = wv_emu::W()->ldsMem.data();
   return p + ((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15);
 }
+
+inline int   block_single() { return block(); }
+inline char* lds_single() { return lds(0); }
 
 inline int shr1(int v, int fill)
 {

@@ -131,3 +131,13 @@ def unpack_locus(batch, l):
     bases, read_off, begin, refs, ref_off, cuts = batch
     reads = [bases[int(read_off[r]):int(read_off[r + 1])].tobytes() for r in range(int(begin[l]), int(begin[l + 1]))]
     return reads, refs[int(ref_off[l]):int(ref_off[l + 1])].tobytes(), tuple(int(x) for x in cuts[l])
+
+
+C5_WORD_LENGTHS = tuple(range(25, 80, 5))  # minWordLength drawn per locus from {25,30,...,75}
+
+
+def config5_locus(i, seed0=555000):
+    """Config-5 shape locus i: (reads, ref1, ref2, minWordLength, maxWordLength); k from a per-locus hash of the seed"""
+    reads, ref1, ref2 = breakend_locus(seed0 + i)
+    k = C5_WORD_LENGTHS[int(np.random.default_rng(seed0 + i + 7919).integers(0, len(C5_WORD_LENGTHS)))]
+    return reads, ref1, ref2, k, max(76, k)

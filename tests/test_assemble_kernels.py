@@ -48,6 +48,21 @@ def test_emulated_assembler_reference_golden(emu):
         assert assembly_text(r) == c["ref_text"], c["name"]
 
 
+@pytest.mark.gpu
+def test_gpu_assembler_reference_golden(gpu):
+    """the reference's own assembler unit-test vectors (assembly/test/IterativeAssemblerTest.cpp:30-205) on the device"""
+    n = 0
+    for c in ASM:
+        if any(set(r) - set("ACGTN") for r in c["reads"]):
+            r = gpu.assemble_batch(asm_opts(**c["opts"]), [c["reads"]], strict=False)[0]
+            assert r["status"] == -5, c["name"]  # reported, never guessed
+            continue
+        r = gpu.assemble_batch(asm_opts(**c["opts"]), [c["reads"]])[0]
+        assert assembly_text(r) == c["ref_text"], c["name"]
+        n += 1
+    assert n >= 2
+
+
 def test_junk_alphabet_is_reported_not_guessed(emu):
     c = ASM[0]
     r = emu.assemble_batch(asm_opts(**c["opts"]), [c["reads"]], strict=False)[0]
@@ -129,3 +144,53 @@ def test_emulated_serial_and_speculative_walks_agree(emu, oracle, monkeypatch):
     assert _check(emu, oracle, cases) == len(cases)
     monkeypatch.setenv("MANTA_AMD_SERIAL_WALK", "1")
     assert _check(emu, oracle, cases) == len(cases)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LDS-resident fast path (assemble_lds_kernel, asm_lds.hpp): same results as the oracle, and everything it cannot hold
+# (cycles, next word length, N-masked piles are fine, wide read sets) falls back to the general path inside the kernel
+# ---------------------------------------------------------------------------------------------------------------
+def _lds_cases():
+    cases = [(asm_opts(minWordLength=31), small_indel_locus(s)[0]) for s in range(3)]
+    cases += [(asm_opts(minWordLength=31), small_indel_locus(50 + s, n_rate=0.01)[0]) for s in range(2)]   # 'N' windows are skipped
+    cases += [(asm_opts(minWordLength=25, maxWordLength=45), small_indel_locus(60 + s, tandem=True)[0]) for s in range(3)]  # cycles -> fallback
+    cases += _mid_cases(range(30))
+    for seed in range(30):
+        rng = random.Random(seed)
+        k0 = rng.choice([4, 5, 6, 8, 10])
+        cases.append((asm_opts(minWordLength=k0, maxWordLength=k0 + rng.choice([0, 4, 9, 15]), wordStepSize=rng.choice([1, 2, 3, 5]),
+                               minCoverage=rng.choice([1, 1, 2]), minSupportReads=rng.choice([1, 2]), minUnusedReads=rng.choice([1, 3]),
+                               maxAssemblyCount=rng.choice([2, 10])), repeat_rich_pile(seed)))
+    cases.append((asm_opts(minWordLength=15, maxWordLength=25), small_indel_locus(11, n_reads=140, read_len=40, ref_len=300, sub_rate=0.01)[0]))  # W > 2
+    cases.append((asm_opts(minWordLength=15), []))
+    cases.append((asm_opts(minWordLength=15), [b"ACGT", b"AC"]))
+    return cases
+
+
+def test_emulated_lds_fast_path_matches_oracle(emu, oracle, monkeypatch):
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "lds")
+    cases = _lds_cases()
+    assert _check(emu, oracle, cases) == len(cases)
+
+
+def test_emulated_lds_path_batch_with_mixed_loci(emu, oracle, monkeypatch):
+    """one launch: fast-path loci, fallback loci (tandem repeats, > 108 reads) and an empty pile side by side"""
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "lds")
+    o = asm_opts(minWordLength=21, maxWordLength=41)
+    loci = [small_indel_locus(1, n_reads=30, read_len=60, ref_len=300)[0], [],
+            small_indel_locus(2, n_reads=30, read_len=60, ref_len=300, tandem=True)[0],
+            small_indel_locus(3, n_reads=150, read_len=50, ref_len=300)[0],
+            small_indel_locus(4, n_reads=40, read_len=70, ref_len=300, n_rate=0.02)[0]]
+    for reads, r in zip(loci, emu.assemble_batch(o, loci)):
+        assert assembly_text(r) == oracle.assemble(o, reads)
+
+
+@pytest.mark.gpu
+def test_gpu_lds_fast_path_matches_oracle(gpu, oracle, monkeypatch):
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "lds")
+    cases = _lds_cases() + [(asm_opts(minWordLength=31), small_indel_locus(100 + s)[0]) for s in range(64)]
+    assert _check(gpu, oracle, cases) == len(cases)
+    o = asm_opts(minWordLength=31)
+    loci = [small_indel_locus(s, tandem=(s % 4 == 0), n_rate=(0.01 if s % 5 == 0 else 0.0))[0] for s in range(200)]
+    for reads, r in zip(loci, gpu.assemble_batch(o, loci)):
+        assert assembly_text(r) == oracle.assemble(o, reads)

@@ -52,7 +52,7 @@ def test_emulated_smallsv_batch_mixed_word_lengths(emu, oracle):
 
 
 def spanning_case(n):
-    loci = [breakend_locus(300 + s, n_reads=24, read_len=70, ref_len=320) for s in range(n)]
+    loci = [breakend_locus(300 + s, n_reads=24, read_len=70, ref_len=320, tandem_frac=0.0) for s in range(n)]
     cuts = [(30, 30, 30, 30)] * n
     return loci, cuts, pack_spanning([l[0] for l in loci], [l[1] for l in loci], [l[2] for l in loci], cuts)
 

@@ -1,0 +1,81 @@
+"""Full-size reference parity on the GPU through digests.
+
+tests/golden/make_digests.py ran the UNMODIFIED reference sources (oracle/_ref) over every locus of the metric's workload
+(config 2, 10 000 loci, seed 12345) and over 2 048 config-5 shaped loci (mixed word lengths) and stored the SHA-256 of the
+canonical text per locus.  Here the device results are rendered to the same text and every locus is compared.
+The CPU tier pins the digest files themselves: the CPU restatement (oracle/) must reproduce a sample of them."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from manta_amd._capi import BatchOutput, assembly_text, pack_spanning, small_sv_text
+from oracle_lib import asm_opts
+from synth import config2_batch, config5_locus, unpack_locus
+from test_spanning_pipeline import SC as SPAN_SC, oracle_locus
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+C2_OPTS = asm_opts(minWordLength=31, maxWordLength=76, wordStepSize=5)
+C2_SCORES = [2, -8, -24, -1, -1, 0]
+C5_CUTS = (100, 100, 100, 100)
+
+
+def digests(name):
+    raw = open(os.path.join(GOLD, name), "rb").read()
+    return [raw[i:i + 32] for i in range(0, len(raw), 32)]
+
+
+def c5_text(asm_text, aligns):
+    return asm_text + "".join("span %d score=%d ins=%d range=%d begin1=%d cigar1=%s begin2=%d cigar2=%s uncut=%d\n" % ((i,) + tuple(a))
+                              for i, a in enumerate(aligns))
+
+
+def test_digest_files_match_the_restatement_on_a_sample(oracle):
+    d2 = digests("config2_digests.bin")
+    assert len(d2) == 10000
+    batch = config2_batch(10000, seed=12345)
+    for l in (0, 1, 4999, 9999):
+        reads, ref, cuts = unpack_locus(batch, l)
+        assert hashlib.sha256(oracle.small_sv_locus(C2_OPTS, C2_SCORES, -100, reads, ref, cuts).encode("latin-1")).digest() == d2[l]
+    d5 = digests("config5_digests.bin")
+    assert len(d5) == 2048
+    for i in (0, 2047):
+        reads, ref1, ref2, k, kmax = config5_locus(i)
+        o = asm_opts(minWordLength=k, maxWordLength=kmax, minContigLength=75)
+        text, aligns = oracle_locus(oracle, o, reads, ref1, ref2, C5_CUTS)
+        assert hashlib.sha256(c5_text(text, aligns).encode("latin-1")).digest() == d5[i]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpu_config2_all_10000_loci_match_reference_digests(gpu):
+    want = digests("config2_digests.bin")
+    batch = config2_batch(10000, seed=12345)
+    out = BatchOutput(gpu, "smallsv", 10000, 10, 64 << 20, 8 << 20, 16 << 20)
+    gpu.smallsv_batch(C2_OPTS, C2_SCORES, -100, batch, out, block_loci=2500, n_workers=4)
+    res = out.decode(np.diff(batch[2]))
+    bad = [l for l, r in enumerate(res) if hashlib.sha256(small_sv_text(r).encode("latin-1")).digest() != want[l]]
+    assert not bad, "%d of 10000 loci differ from the reference, first: %s" % (len(bad), bad[:10])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpu_config5_2048_loci_match_reference_digests(gpu):
+    want = digests("config5_digests.bin")
+    n = len(want)
+    loci = [config5_locus(i) for i in range(n)]
+    batch = pack_spanning([l[0] for l in loci], [l[1] for l in loci], [l[2] for l in loci], [C5_CUTS] * n)
+    min_wl = np.array([l[3] for l in loci], dtype=np.uint32)
+    max_wl = np.array([l[4] for l in loci], dtype=np.uint32)
+    out = BatchOutput(gpu, "spanning", n, 10, 64 << 20, 8 << 20, 16 << 20)
+    gpu.spanning_batch(asm_opts(minWordLength=41, minContigLength=75), SPAN_SC, -100, batch, out, min_wl=min_wl, max_wl=max_wl,
+                       block_loci=512, n_workers=4)
+    res = out.decode(np.diff(batch[2]))
+    bad = []
+    for i, r in enumerate(res):
+        got = [(a["score"], a["jump_insert_size"], a["jump_range"], a["begin1"], a["cigar1"], a["begin2"], a["cigar2"], a["is_uncut"])
+               for a in r["aligns"]]
+        if hashlib.sha256(c5_text(assembly_text(r), got).encode("latin-1")).digest() != want[i]:
+            bad.append(i)
+    assert not bad, "%d of %d loci differ from the reference, first: %s" % (len(bad), n, bad[:10])

@@ -1,6 +1,9 @@
 """Pins the CPU restatement (oracle/manta_oracle.cpp) against the UNMODIFIED reference sources compiled into
 oracle/_ref (skipped where the reference build is unavailable)."""
+import os
 import random
+
+import pytest
 
 from oracle_lib import asm_opts
 from synth import repeat_rich_pile, small_indel_locus, breakend_locus
@@ -93,3 +96,16 @@ def test_aligners_random(oracle, reflib):
         extra = rng.choice([-100, -3, -20, -50])
         q, r1, r2 = _rand_align_case(rng, kind, 120)
         assert reflib.align(kind, sc, extra, q, r1, r2) == oracle.align(kind, sc, extra, q, r1, r2)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference sources only exist in the authoring container")
+def test_oracle_recipe_builds_from_clean(tmp_path):
+    """`make -C oracle clean all` in a scratch copy: the committed recipe alone must produce both _ref libraries"""
+    import shutil
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    dst = tmp_path / "oracle"
+    shutil.copytree(src, dst, ignore=shutil.ignore_patterns("_ref", "*.so"))
+    subprocess.check_call(["make", "-s", "-C", str(dst), "-j4", "all"])
+    for f in ("libmanta_oracle.so", "_ref/libmanta_ref.so", "_ref/libmanta_ref_refiner.so"):
+        assert (dst / f).exists(), f
