@@ -33,6 +33,8 @@ extern "C" {
 #define MANTA_E_UNSUPPORTED (-5)  /* input outside the supported envelope (see DESIGN.md limits) */
 #define MANTA_E_CAPACITY (-6)     /* caller-provided output arena too small */
 #define MANTA_E_DEVICE_FAULT (-7) /* kernel reported an internal overflow for some locus/task */
+#define MANTA_E_SPLIT_QUERY_NOT_SHORTER (-8) /* splitReadAligner: querySize >= targetSize (SplitReadAlignment.cpp:237-247) */
+#define MANTA_E_SPLIT_EMPTY_SCAN (-9)        /* splitReadAligner: scanEnd < scanStart (SplitReadAlignment.cpp:265-273) */
 
 typedef struct manta_ctx manta_ctx_t;
 
@@ -232,6 +234,41 @@ int  manta_spanning_download(manta_spanning_t* b, manta_asm_locus_result_t* loci
                              uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
                              uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
                              uint64_t* cigar_arena_used);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Split-read scoring.  Replaces
+ *   void splitReadAligner(flankScoreSize, querySeq, qualConvert, queryQual, targetSeq, targetBpOffsetRange, alignment)
+ *                               applications/GenerateSVCandidates/SplitReadAlignment.hpp:57-64 (.cpp:223-350)
+ * called per read and per allele from SVScorerSplit.cpp (scoreSplitReads), for a whole batch of (read, target) pairs.
+ * The two tables are the caller's own qscore_snp (blt_util/qscore_snp.hpp:33-55: qphred_to_ln_comp_error_prob and
+ * qphred_to_ln_error_prob for q = 0..MAX_QSCORE), ln_one_third = std::log(1/3.f) and ln_random_base = -std::log(4.f) as the
+ * reference computes them (:50, :76): passed in, so the sums are formed from the caller's exact values.
+ * Float policy: best_ln_lhood is BIT-IDENTICAL to the reference's alignLnLhood (same operations in the same order: a float
+ * accumulator, each term added in double and rounded back, N terms added in float); best_pos follows the reference's
+ * strict-'>' scan.  The remaining SRAlignmentInfo fields (alignScore, isEvidence, evidence: three float ratio tests) are
+ * scalar glue on the sizes and mismatch counts returned here; manta_amd/host/split_read.hpp forms them with the
+ * reference's expressions.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct {
+  uint64_t query_off, qual_off, target_off; /* into the caller's arena; qual = query_len basecall qualities */
+  uint32_t query_len, target_len;
+  int32_t  bp_begin, bp_end;  /* targetBpOffsetRange */
+  uint32_t flank_score_size;
+  uint32_t reserved;
+} manta_split_task_t;
+
+typedef struct {
+  int32_t  status;        /* MANTA_OK, MANTA_E_SPLIT_* (the reference throws), MANTA_E_UNSUPPORTED (quality above the table) */
+  uint32_t best_pos;      /* SRAlignmentInfo::alignPos */
+  float    best_ln_lhood; /* SRAlignmentInfo::alignLnLhood */
+  uint32_t left_size, hom_size, right_size; /* :309-337; left_size > query_len is the reference's "unexpected outcome" throw */
+  uint32_t left_mismatches, hom_mismatches, right_mismatches; /* calculateAlignScore :95-121 */
+} manta_split_result_t;
+
+int manta_split_read_batch(
+    manta_ctx_t* ctx, const double* ln_comp_error_prob, const double* ln_error_prob, uint32_t n_qscores, float ln_one_third,
+    float ln_random_base, uint32_t n_tasks, const manta_split_task_t* tasks, const uint8_t* arena, uint64_t arena_bytes,
+    manta_split_result_t* results);
 
 /* ------------------------------------------------------------------------------------------------------
  * Mixed word lengths in one batch (minWordLength drawn per locus).  Overrides

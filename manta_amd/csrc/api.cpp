@@ -19,6 +19,7 @@
 #include "assemble_kernels.hpp"
 #include "asm_lds.hpp"
 #include "pipeline_kernels.hpp"
+#include "split_kernels.hpp"
 #include <unordered_map>
 #include "rt.hpp"
 
@@ -98,6 +99,7 @@ struct manta_ctx {
   int         cuCount = 0;
   // align scratch
   DevBuf dSeq, dTasks, dResults, dCigar, dTaskIds, dCounter, dPtrWs;
+  DevBuf dSplitTasks, dSplitResults, dSplitTables;
   rt::Stream stream;  // the context's own stream (manta_align_batch / manta_assemble_batch run on it)
   int        deviceId = 0;
   // worker pipelines of the whole-batch calls (manta_smallsv_batch / manta_spanning_batch), kept across calls
@@ -1966,3 +1968,88 @@ int manta_spanning_batch(
 }
 
 }  // extern "C"
+
+
+// ------------------------------------------------------------------------------------------------------
+// split-read scoring
+// ------------------------------------------------------------------------------------------------------
+extern "C" int manta_split_read_batch(
+    manta_ctx_t* ctx, const double* ln_comp_error_prob, const double* ln_error_prob, uint32_t n_qscores, float ln_one_third,
+    float ln_random_base, uint32_t n_tasks, const manta_split_task_t* tasks, const uint8_t* arena, uint64_t arena_bytes,
+    manta_split_result_t* results)
+{
+  if (!ctx) return MANTA_E_INVALID_ARG;
+  if (!ln_comp_error_prob || !ln_error_prob || n_qscores == 0 || (n_tasks && (!tasks || !arena || !results)))
+    return fail(ctx, MANTA_E_INVALID_ARG, "manta_split_read_batch: null argument");
+  if (n_tasks == 0) return MANTA_OK;
+  try {
+    rt::setDevice(ctx->deviceId);
+    rt::ScopedStream onStream(ctx->stream);
+    std::vector<SplitTaskDev> dev(n_tasks);
+    uint8_t*                  dArena = ctx->dSeq.as<uint8_t>(arena_bytes + 16);
+    auto outside = [&](uint64_t off, uint64_t len) { return off > arena_bytes || len > arena_bytes - off; };
+    for (uint32_t i = 0; i < n_tasks; ++i) {
+      const manta_split_task_t& t(tasks[i]);
+      if (outside(t.query_off, t.query_len) || outside(t.qual_off, t.query_len) || outside(t.target_off, t.target_len))
+        return fail(ctx, MANTA_E_INVALID_ARG, "manta_split_read_batch: task " + std::to_string(i) + " outside the arena");
+      SplitTaskDev& d(dev[i]);
+      d.query            = dArena + t.query_off;
+      d.qual             = dArena + t.qual_off;
+      d.target           = dArena + t.target_off;
+      d.query_len        = t.query_len;
+      d.target_len       = t.target_len;
+      d.bp_begin         = t.bp_begin;
+      d.bp_end           = t.bp_end;
+      d.flank_score_size = t.flank_score_size;
+      d.reserved         = 0;
+    }
+    SplitTaskDev*   dTasks = ctx->dSplitTasks.as<SplitTaskDev>(n_tasks);
+    SplitResultDev* dRes   = ctx->dSplitResults.as<SplitResultDev>(n_tasks);
+    double*         dTab   = ctx->dSplitTables.as<double>(2ull * n_qscores + 2);
+    uint32_t*       dCount = ctx->dCounter.as<uint32_t>(kNumESet);
+    rt::h2d(dArena, arena, arena_bytes);
+    rt::h2d(dTasks, dev.data(), sizeof(SplitTaskDev) * n_tasks);
+    rt::h2d(dTab, ln_comp_error_prob, sizeof(double) * n_qscores);
+    rt::h2d(dTab + n_qscores, ln_error_prob, sizeof(double) * n_qscores);
+    rt::dzero(dCount, sizeof(uint32_t));
+    SplitParams P;
+    P.tasks          = dTasks;
+    P.results        = dRes;
+    P.n_tasks        = n_tasks;
+    P.n_q            = n_qscores;
+    P.ln_comp_error  = dTab;
+    P.ln_error       = dTab + n_qscores;
+    P.ln_one_third   = ln_one_third;
+    P.ln_random_base = ln_random_base;
+    P.counter        = dCount;
+    const int grid = rt::roundGrid(int(std::min<uint64_t>(n_tasks, uint64_t(std::max(1, ctx->cuCount * 32)))));
+    rt::launch(split_read_kernel, grid, 0, P);
+    std::vector<SplitResultDev> h(n_tasks);
+    rt::d2h(h.data(), dRes, sizeof(SplitResultDev) * n_tasks);
+    int worst = MANTA_OK;
+    for (uint32_t i = 0; i < n_tasks; ++i) {
+      manta_split_result_t& r(results[i]);
+      std::memset(&r, 0, sizeof(r));
+      const SplitResultDev& d(h[i]);
+      r.status = (d.status == 0) ? MANTA_OK : (d.status == 3) ? MANTA_E_UNSUPPORTED : MANTA_E_INVALID_ARG;
+      if (d.status == 1) r.status = MANTA_E_SPLIT_QUERY_NOT_SHORTER;
+      if (d.status == 2) r.status = MANTA_E_SPLIT_EMPTY_SCAN;
+      if (r.status != MANTA_OK) {
+        worst = r.status;
+        continue;
+      }
+      r.best_pos         = d.best_pos;
+      r.best_ln_lhood    = d.best_ln_lhood;
+      r.left_size        = d.left_size;
+      r.hom_size         = d.hom_size;
+      r.right_size       = d.right_size;
+      r.left_mismatches  = d.left_mismatches;
+      r.hom_mismatches   = d.hom_mismatches;
+      r.right_mismatches = d.right_mismatches;
+    }
+    if (worst != MANTA_OK) return fail(ctx, worst, "manta_split_read_batch: one or more tasks failed; see per-task status");
+    return MANTA_OK;
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
+}
