@@ -88,3 +88,58 @@ MINE_EXPORT int mine_split_read_aligner_batch(
     return emitText(std::string("FATAL ") + e.what() + "\n", out, cap);
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// shadow-read aligner call site (same signature and text as ref_shadow_realign in oracle/ref_scoring_driver.cpp)
+// ---------------------------------------------------------------------------------------------------------------
+#include "shadow_align.hpp"
+
+MINE_EXPORT int mine_shadow_realign(
+    const char* extendedContig, int bp1Begin, int bp1End, int bp2Begin, int bp2End, const char* insertSeq, int isUnknownSizeInsertion,
+    const char* unknownLeft, const char* unknownRight, int align1BeginPos, const char* align1Cigar, unsigned nReads, const char* const* reads,
+    const int* isLeftOfInsert, const int* anchorPos, char* out, int cap)
+{
+  std::string text;
+  try {
+    SVCandidate sv;
+    sv.bp1.interval = GenomeInterval(0, bp1Begin, bp1End);
+    sv.bp2.interval = GenomeInterval(0, bp2Begin, bp2End);
+    sv.bp1.state    = SVBreakendState::RIGHT_OPEN;
+    sv.bp2.state    = SVBreakendState::LEFT_OPEN;
+    sv.insertSeq    = insertSeq;
+    sv.isUnknownSizeInsertion       = isUnknownSizeInsertion != 0;
+    sv.unknownSizeInsertionLeftSeq  = unknownLeft;
+    sv.unknownSizeInsertionRightSeq = unknownRight;
+    sv.setPrecise();
+    sv.assemblyAlignIndex = 0;
+    SVCandidateAssemblyData data;
+    data.isSpanning         = true;
+    data.bestAlignmentIndex = 0;
+    SVCandidateAssemblyData::JumpAlignmentResultType ja;
+    ja.align1.beginPos = align1BeginPos;
+    ja.align1.apath    = ALIGNPATH::cigar_to_apath(align1Cigar);
+    data.spanningAlignments.push_back(ja);
+    data.extendedContigs.push_back(extendedContig);
+    const AlignmentScores<int> spanningAlignScores(2, -8, -12, -1, -1);  // SVRefinerOptions.hpp:43
+    const ShadowRealigner      sh(spanningAlignScores, 50, data, sv);    // PairOptions::minFragSupport = 50
+    std::vector<std::string>   rs(nReads);
+    std::vector<ShadowRead>    in(nReads);
+    for (unsigned i = 0; i < nReads; ++i) {
+      rs[i]                = reads[i];
+      in[i].isLeftOfInsert = isLeftOfInsert[i] != 0;
+      in[i].floatRead      = &rs[i];
+      in[i].anchorPos      = anchorPos[i];
+    }
+    std::vector<ShadowResult> res;
+    sh.realignPairedReads(in, res);
+    for (unsigned i = 0; i < nReads; ++i) {
+      if (!res[i].error.empty())
+        text += "EXCEPTION\n";
+      else
+        text += "pass=" + std::to_string(res[i].isUsable ? 1 : 0) + " altTemplateSize=" + std::to_string(res[i].isUsable ? res[i].altTemplateSize : 0) + "\n";
+    }
+  } catch (const std::exception& e) {
+    text = std::string("FATAL ") + e.what() + "\n";
+  }
+  return emitText(text, out, cap);
+}
