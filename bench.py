@@ -319,6 +319,32 @@ def main():
                                 "ms_per_step": round(dt / nrun * 1e3, 3),
                                 "kernels_ms": {k: round(v / nrun, 3) for k, v in ks.items()}}
             pipe.close()
+        # ---- the same batch delivered as packed piles (what the read-pile builder emits from BAM records) ----
+        if not spanning and world == 1:
+            from manta_amd._capi import pack_piles
+            piles = pack_piles(batch[0], batch[1], batch[2])
+            pin = piles if args.pageable else piles.pinned(lib)
+            refs_p, roff_p, cuts_p = dev_batch[3], dev_batch[4], dev_batch[5]
+            out2 = BatchOutput(lib, "smallsv", n_loci, 10, len(out.seq), len(out.bits), len(out.cig), pinned=not args.pageable)
+
+            def step_piles():
+                lib.smallsv_batch_piles(opts, SCORES, LARGE_INDEL, pin, refs_p, roff_p, cuts_p, out2, block_loci=block, n_workers=workers,
+                                        serial_kernels=args.serial_kernels)
+            step_piles()
+            nrun = max(2, steps)
+            t2 = time.perf_counter()
+            h2d = 0
+            for _ in range(nrun):
+                step_piles()
+                h2d += out2.stats_dict()["h2d_bytes"]
+            dt2 = time.perf_counter() - t2
+            same = [small_sv_text(r) for r in out2.decode(n_reads)] == [small_sv_text(r) for r in results]
+            if not same:
+                raise SystemExit("PARITY FAILURE: packed-pile input and 1-byte-per-base input disagree")
+            o["packed_input"] = {"value": round(n_loci * nrun / dt2, 1), "unit": "loci/s", "ms_per_step": round(dt2 / nrun * 1e3, 3),
+                                 "h2d_MB_per_step": round(h2d / nrun / 1e6, 2),
+                                 "note": "read piles as 2-bit codes + N bitmap (manta_packed_piles_t, 0.375 B/base) instead of 1 B/base; "
+                                         "same timed region; results identical to the default run"}
         # ---- CPU baseline: the reference's own sources (oracle/_ref) on this box's host cores ----
         if world == 1 and not args.no_cpu_baseline:
             cores = cores_available()

@@ -280,6 +280,31 @@ int manta_smallsv_set_word_lengths(manta_smallsv_t* b, uint32_t n_loci, const ui
 int manta_spanning_set_word_lengths(manta_spanning_t* b, uint32_t n_loci, const uint32_t* min_word_length,
                                     const uint32_t* max_word_length);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Packed read piles.  The read-pile builder (manta_amd/host/read_pile.hpp) turns what
+ * SVCandidateAssembler::getBreakendReads keeps of every BAM record -- insertAssemblyRead, manta/SVCandidateAssembler.cpp:
+ * 102-136: the 4-bit BAM sequence (htsapi/bam_seq.hpp:41-59) with Q < minQval masked to N, reverse-complemented where the
+ * breakend is reversed -- directly into the layout the kernels pack into, instead of the reference's std::string per read:
+ *   codes  2 bits per base (A,C,G,T = 0..3; 0 under an N), 16 bases per dword, first base in the top bits
+ *   nmask  1 bit per base (1 = 'N'), 32 bases per dword, first base in bit 0
+ * 0.375 byte per base over PCIe instead of 1, and the device's stage 0 becomes a copy.  Unused bits of a read's last
+ * dwords must be zero.  Offsets are in dwords; read r of the batch owns ceil(len/16) code and ceil(len/32) mask dwords.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct {
+  const uint32_t* codes;
+  const uint32_t* nmask;
+  const uint32_t* read_len;         /* [R] bases per read */
+  const uint64_t* read_code_off;    /* [R+1] */
+  const uint64_t* read_mask_off;    /* [R+1] */
+  const uint32_t* locus_read_begin; /* [n_loci+1] read-index range of every locus */
+} manta_packed_piles_t;
+
+int manta_smallsv_upload_piles(manta_smallsv_t* b, uint32_t n_loci, const manta_packed_piles_t* piles, const uint8_t* refs,
+                               const uint64_t* ref_off, const manta_ref_cuts_t* cuts);
+int manta_spanning_upload_piles(manta_spanning_t* b, uint32_t n_loci, const manta_packed_piles_t* piles, const uint8_t* refs1,
+                                const uint64_t* ref1_off, const uint8_t* refs2, const uint64_t* ref2_off,
+                                const manta_jump_cuts_t* cuts);
+
 /* page-locked host memory: input/output buffers allocated here are copied by DMA without a staging pass */
 int  manta_host_alloc(uint64_t bytes, void** out);
 void manta_host_free(void* p);
@@ -323,6 +348,16 @@ int manta_smallsv_batch(
     uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used, uint32_t* cigar_arena,
     uint64_t cigar_arena_cap, uint64_t* cigar_arena_used, const manta_batch_plan_t* plan /* nullable */,
     manta_batch_stats_t* stats /* nullable */);
+
+/* the same with the read piles in packed form */
+int manta_smallsv_batch_piles(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t large_indel_score,
+    uint32_t n_loci, const manta_packed_piles_t* piles, const uint8_t* refs, const uint64_t* ref_off, const manta_ref_cuts_t* cuts,
+    const uint32_t* locus_min_word_length /* nullable */, const uint32_t* locus_max_word_length /* nullable */,
+    manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_smallsv_alignment_t* alignments, uint64_t contigs_cap,
+    uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
+    uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap, uint64_t* cigar_arena_used,
+    const manta_batch_plan_t* plan /* nullable */, manta_batch_stats_t* stats /* nullable */);
 
 int manta_spanning_batch(
     manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t jump_score, uint32_t n_loci,

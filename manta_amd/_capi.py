@@ -565,3 +565,100 @@ def pack_spanning(loci_reads, refs1, refs2, cuts):
     r2, o2 = pack(refs2)
     c = np.ascontiguousarray(np.array(cuts, dtype=np.int32).reshape(len(begin) - 1, 4))
     return bases, read_off, begin, r1, o1, r2, o2, c
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# packed read piles (manta_packed_piles_t)
+# ---------------------------------------------------------------------------------------------------------------
+class PackedPilesStruct(ctypes.Structure):
+    _fields_ = [("codes", ctypes.c_void_p), ("nmask", ctypes.c_void_p), ("read_len", ctypes.c_void_p), ("read_code_off", ctypes.c_void_p),
+                ("read_mask_off", ctypes.c_void_p), ("locus_read_begin", ctypes.c_void_p)]
+
+
+class PackedPiles:
+    """numpy arrays in the layout of manta_packed_piles_t"""
+
+    def __init__(self, codes, nmask, read_len, code_off, mask_off, begin):
+        self.codes, self.nmask, self.read_len, self.code_off, self.mask_off, self.begin = codes, nmask, read_len, code_off, mask_off, begin
+
+    def struct(self):
+        return PackedPilesStruct(*[a.ctypes.data for a in (self.codes, self.nmask, self.read_len, self.code_off, self.mask_off, self.begin)])
+
+    def nbytes(self):
+        return sum(a.nbytes for a in (self.codes, self.nmask, self.read_len, self.code_off, self.mask_off, self.begin))
+
+    def pinned(self, lib):
+        return PackedPiles(*[pinned_copy(lib, a) for a in (self.codes, self.nmask, self.read_len, self.code_off, self.mask_off, self.begin)])
+
+
+def pack_piles(bases, read_off, begin):
+    """1-byte-per-base piles (bases uint8 over {A,C,G,T,N}, read_off uint64, locus_read_begin uint32) -> PackedPiles.
+    numpy restatement of manta_amd/host/read_pile.hpp::ReadPileBuilder::addRead for tests and bench.py."""
+    read_off = np.asarray(read_off, dtype=np.uint64)
+    lens = np.diff(read_off).astype(np.int64)
+    n_reads = len(lens)
+    cw, mw = (lens + 15) // 16, (lens + 31) // 32
+    code_off = np.zeros(n_reads + 1, dtype=np.uint64)
+    mask_off = np.zeros(n_reads + 1, dtype=np.uint64)
+    np.cumsum(cw, out=code_off[1:])
+    np.cumsum(mw, out=mask_off[1:])
+    total = int(read_off[-1])
+    b = np.asarray(bases[:total], dtype=np.uint8)
+    lut = np.full(256, 255, dtype=np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        lut[ch] = i
+    lut[ord("N")] = 4
+    c = lut[b]
+    if (c == 255).any():
+        raise ValueError("pack_piles: byte outside {A,C,G,T,N}")
+    read_of_base = np.repeat(np.arange(n_reads), lens)
+    pos = np.arange(total, dtype=np.int64) - np.repeat(read_off[:-1].astype(np.int64), lens)
+    codes = np.zeros(int(code_off[-1]), dtype=np.uint32)
+    nmask = np.zeros(int(mask_off[-1]), dtype=np.uint32)
+    is_n = c == 4
+    cidx = code_off[:-1].astype(np.int64)[read_of_base] + pos // 16
+    val = (np.where(is_n, 0, c).astype(np.uint32)) << (30 - 2 * (pos % 16)).astype(np.uint32)
+    np.bitwise_or.at(codes, cidx, val)
+    if is_n.any():
+        midx = mask_off[:-1].astype(np.int64)[read_of_base[is_n]] + pos[is_n] // 32
+        np.bitwise_or.at(nmask, midx, (np.uint32(1) << (pos[is_n] % 32).astype(np.uint32)))
+    return PackedPiles(codes, nmask, lens.astype(np.uint32), code_off, mask_off, np.ascontiguousarray(begin, dtype=np.uint32))
+
+
+def _smallsv_upload_piles(self, piles, refs, ref_off, cuts):
+    self.n_loci = len(piles.begin) - 1
+    self.n_reads = np.diff(piles.begin)
+    self._keep = (piles, refs, ref_off, cuts)
+    st = piles.struct()
+    self.lib._check(self.lib.lib.manta_smallsv_upload_piles(self.h, ctypes.c_uint32(self.n_loci), ctypes.byref(st), _p(refs), _p(ref_off), _p(cuts)))
+
+
+def _spanning_upload_piles(self, piles, r1, o1, r2, o2, cuts):
+    self.n_loci = len(piles.begin) - 1
+    self.n_reads = np.diff(piles.begin)
+    self._keep = (piles, r1, o1, r2, o2, cuts)
+    st = piles.struct()
+    self.lib._check(self.lib.lib.manta_spanning_upload_piles(self.h, ctypes.c_uint32(self.n_loci), ctypes.byref(st), _p(r1), _p(o1), _p(r2),
+                                                             _p(o2), _p(cuts)))
+
+
+SmallSvBatch.upload_piles = _smallsv_upload_piles
+SpanningBatch.upload_piles = _spanning_upload_piles
+
+
+def _smallsv_batch_piles(self, opts, scores, large_indel_score, piles, refs, ref_off, cuts, out, min_wl=None, max_wl=None, block_loci=0,
+                         n_workers=0, strict=True, serial_kernels=False):
+    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, 1 if serial_kernels else 0, 0)
+    n = len(piles.begin) - 1
+    st = piles.struct()
+    f = self.lib.manta_smallsv_batch_piles
+    f.restype = ctypes.c_int
+    rc = f(self.ctx, ctypes.byref(o), ctypes.byref(sc), ctypes.c_int32(large_indel_score), ctypes.c_uint32(n), ctypes.byref(st), _p(refs),
+           _p(ref_off), _p(cuts), _p(min_wl), _p(max_wl), out.res, out.contigs, out.aligns, ctypes.c_uint64(out.ccap), _p(out.seq),
+           ctypes.c_uint64(len(out.seq)), ctypes.byref(out.used[0]), _p(out.bits), ctypes.c_uint64(len(out.bits)), ctypes.byref(out.used[1]),
+           _p(out.cig), ctypes.c_uint64(len(out.cig)), ctypes.byref(out.used[2]), ctypes.byref(plan), ctypes.byref(out.stats))
+    self._check(rc, allow=() if strict else (-4, -5, -7))
+    return rc
+
+
+Lib.smallsv_batch_piles = _smallsv_batch_piles

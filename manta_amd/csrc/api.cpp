@@ -287,6 +287,10 @@ struct AsmStage {
   uint32_t              maxWordLen = 0;
   bool                  useLds = false;  // assemble_lds_kernel (LDS-resident graph, general path as in-kernel fallback)
   int                   gridLds = 1;
+  // packed piles of the uploaded batch (manta_packed_piles_t), device side; dPlCodes == nullptr: 1 byte per base input
+  DevBuf                bPlCodes, bPlMask, bPlLen, bPlCodeOff, bPlMaskOff;
+  uint32_t *            dPlCodes = nullptr, *dPlMask = nullptr, *dPlLen = nullptr;
+  uint64_t *            dPlCodeOff = nullptr, *dPlMaskOff = nullptr;
   uint32_t*             dMinWl = nullptr;
   uint32_t*             dMaxWl = nullptr;
   uint32_t*             dOrder = nullptr;
@@ -301,7 +305,9 @@ struct AsmStage {
   uint8_t*            dWs    = nullptr;
   uint32_t*           dGrowth = nullptr;
 
-  int plan(const manta_asm_options_t& o, uint32_t n_loci, const uint64_t* read_off, const uint32_t* locus_read_begin)
+  /// exactly one of read_off (1 byte per base input) / read_len (packed piles) is set
+  int plan(const manta_asm_options_t& o, uint32_t n_loci, const uint64_t* read_off, const uint32_t* locus_read_begin,
+           const uint32_t* read_len = nullptr)
   {
     if (o.min_word_length == 0 || o.word_step_size == 0 || o.min_coverage == 0 || o.max_assembly_count == 0)
       return fail(ctx, MANTA_E_INVALID_ARG, "assembler options: word length, step, minCoverage and maxAssemblyCount must be >= 1");
@@ -321,7 +327,7 @@ struct AsmStage {
         maxWordLen = std::max(maxWordLen, locusMaxWl[l]);
       }
     }
-    nBases      = read_off[nReadsTotal];
+    nBases      = read_off ? read_off[nReadsTotal] : 0;
     uint64_t maxLocusBases = 0, maxLocusWords = 0, bitsBound = 0;
     uint32_t maxLocusReads = 0, maxReadLen = 0;
     std::vector<uint64_t> cost(n_loci);
@@ -331,8 +337,8 @@ struct AsmStage {
       if (re < rb || re > nReadsTotal) return fail(ctx, MANTA_E_INVALID_ARG, "locus_read_begin not monotone");
       uint64_t b = 0, w = 0;
       for (uint32_t r = rb; r < re; ++r) {
-        if (read_off[r + 1] < read_off[r]) return fail(ctx, MANTA_E_INVALID_ARG, "read_off not monotone");
-        const uint64_t len = read_off[r + 1] - read_off[r];
+        if (read_off && read_off[r + 1] < read_off[r]) return fail(ctx, MANTA_E_INVALID_ARG, "read_off not monotone");
+        const uint64_t len = read_off ? (read_off[r + 1] - read_off[r]) : uint64_t(read_len[r]);
         b += len;
         w += (len + 15) / 16 + 1;
         maxReadLen = std::max<uint32_t>(maxReadLen, uint32_t(len));
@@ -388,8 +394,39 @@ struct AsmStage {
     return MANTA_OK;
   }
 
+  /// packed piles: offsets are rebased so that the first read of this batch starts at dword 0
+  void uploadPiles(const manta_packed_piles_t& pl)
+  {
+    const uint64_t c0 = pl.read_code_off[0], c1 = pl.read_code_off[nReadsTotal], m0 = pl.read_mask_off[0], m1 = pl.read_mask_off[nReadsTotal];
+    dPlCodes   = bPlCodes.as<uint32_t>(c1 - c0 + 4);
+    dPlMask    = bPlMask.as<uint32_t>(m1 - m0 + 4);
+    dPlLen     = bPlLen.as<uint32_t>(nReadsTotal + 1);
+    dPlCodeOff = bPlCodeOff.as<uint64_t>(nReadsTotal + 1);
+    dPlMaskOff = bPlMaskOff.as<uint64_t>(nReadsTotal + 1);
+    rt::h2d(dPlCodes, pl.codes + c0, sizeof(uint32_t) * (c1 - c0));
+    rt::h2d(dPlMask, pl.nmask + m0, sizeof(uint32_t) * (m1 - m0));
+    rt::h2d(dPlLen, pl.read_len, sizeof(uint32_t) * nReadsTotal);
+    if (c0 == 0 && m0 == 0) {
+      rt::h2d(dPlCodeOff, pl.read_code_off, sizeof(uint64_t) * (nReadsTotal + 1));
+      rt::h2d(dPlMaskOff, pl.read_mask_off, sizeof(uint64_t) * (nReadsTotal + 1));
+    } else {
+      plRebased.resize(2 * (size_t(nReadsTotal) + 1));
+      for (uint32_t r = 0; r <= nReadsTotal; ++r) {
+        plRebased[r]                   = pl.read_code_off[r] - c0;
+        plRebased[nReadsTotal + 1 + r] = pl.read_mask_off[r] - m0;
+      }
+      rt::h2d(dPlCodeOff, plRebased.data(), sizeof(uint64_t) * (nReadsTotal + 1));
+      rt::h2d(dPlMaskOff, plRebased.data() + nReadsTotal + 1, sizeof(uint64_t) * (nReadsTotal + 1));
+    }
+    plBytes = 4 * (c1 - c0) + 4 * (m1 - m0) + 20ull * nReadsTotal;
+    upload(nullptr, nullptr, pl.locus_read_begin);
+  }
+  std::vector<uint64_t> plRebased;
+  uint64_t              plBytes = 0;
+
   void upload(const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin)
   {
+    if (bases) dPlCodes = nullptr;
     dBases  = bBases.as<uint8_t>(nBases + 16);
     dOff    = bReadOff.as<uint64_t>(nReadsTotal + 1);
     dBegin  = bLocusBegin.as<uint32_t>(nLoci + 1);
@@ -409,8 +446,10 @@ struct AsmStage {
       rt::h2d(dMinWl, locusMinWl.data(), sizeof(uint32_t) * nLoci);
       rt::h2d(dMaxWl, locusMaxWl.data(), sizeof(uint32_t) * nLoci);
     }
-    rt::h2d(dBases, bases, nBases);
-    rt::h2d(dOff, read_off, sizeof(uint64_t) * (nReadsTotal + 1));
+    if (bases) {
+      rt::h2d(dBases, bases, nBases);
+      rt::h2d(dOff, read_off, sizeof(uint64_t) * (nReadsTotal + 1));
+    }
     rt::h2d(dBegin, locus_read_begin, sizeof(uint32_t) * (nLoci + 1));
     rt::h2d(dGrowth, ctx->growthSize.data(), sizeof(uint32_t) * ctx->growthSize.size());
     rt::h2d(dGrowth + ctx->growthSize.size(), ctx->growthBuckets.data(), sizeof(uint32_t) * ctx->growthBuckets.size());
@@ -452,7 +491,12 @@ struct AsmStage {
     P.locus_min_wl   = dMinWl;
     P.locus_max_wl   = dMaxWl;
     P.locus_ids      = dOrder;
-    if (useLds) {
+    P.pl_codes       = dPlCodes;
+    P.pl_nmask       = dPlMask;
+    P.pl_read_len    = dPlLen;
+    P.pl_code_off    = dPlCodeOff;
+    P.pl_mask_off    = dPlMaskOff;
+    if (useLds && !dPlCodes) {
       if (std::getenv("MANTA_AMD_LDS_OFF")) P.flags |= ASM_FLAG_NO_LDS_PATH;  // A/B: same kernel, every locus through the general path
       rt::launchSingle(assemble_lds_kernel, gridLds, LN_BUDGET, P);
     } else {
@@ -992,6 +1036,51 @@ int manta_smallsv_upload(
   }
 }
 
+namespace {
+int checkPiles(manta_ctx_t* ctx, const manta_packed_piles_t* pl, const char* who)
+{
+  if (!pl || !pl->codes || !pl->nmask || !pl->read_len || !pl->read_code_off || !pl->read_mask_off || !pl->locus_read_begin)
+    return fail(ctx, MANTA_E_INVALID_ARG, std::string(who) + ": null pointer in the packed piles");
+  return MANTA_OK;
+}
+}  // namespace
+
+int manta_smallsv_upload_piles(
+    manta_smallsv_t* b, uint32_t n_loci, const manta_packed_piles_t* piles, const uint8_t* refs, const uint64_t* ref_off,
+    const manta_ref_cuts_t* cuts)
+{
+  if (!b) return MANTA_E_INVALID_ARG;
+  manta_ctx_t* ctx = b->ctx;
+  if (n_loci == 0 || !refs || !ref_off || !cuts) return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_upload_piles: null argument or empty batch");
+  int rc = checkPiles(ctx, piles, "manta_smallsv_upload_piles");
+  if (rc != MANTA_OK) return rc;
+  try {
+    rt::setDevice(ctx->deviceId);
+    rt::ScopedStream onStream(b->main);
+    b->uploaded = false;
+    rc          = b->asmStage.plan(b->opt, n_loci, nullptr, piles->locus_read_begin, piles->read_len);
+    if (rc != MANTA_OK) return rc;
+    b->asmStage.uploadPiles(*piles);
+    b->nLoci    = n_loci;
+    b->refBytes = ref_off[n_loci];
+    b->maxRef   = 0;
+    for (uint32_t l = 0; l < n_loci; ++l) {
+      if (ref_off[l + 1] < ref_off[l]) return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_upload_piles: ref_off not monotone");
+      b->maxRef = std::max<uint64_t>(b->maxRef, ref_off[l + 1] - ref_off[l]);
+      if (cuts[l].leading_cut < 0 || cuts[l].trailing_cut < 0 || cuts[l].max_leading_cut < 0 || cuts[l].max_trailing_cut < 0)
+        return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_upload_piles: negative reference cut");
+    }
+    rt::h2d(b->dRefs.as<uint8_t>(b->refBytes + 16), refs, b->refBytes);
+    rt::h2d(b->dRefOff.as<uint64_t>(n_loci + 1), ref_off, sizeof(uint64_t) * (n_loci + 1));
+    rt::h2d(b->dCuts.as<SmallSvCuts>(n_loci), cuts, sizeof(SmallSvCuts) * n_loci);
+    rt::sync();
+    b->uploaded = true;
+    return MANTA_OK;
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
+}
+
 int manta_smallsv_run(manta_smallsv_t* b)
 {
   if (!b) return MANTA_E_INVALID_ARG;
@@ -1333,6 +1422,47 @@ int manta_spanning_upload(
   }
 }
 
+int manta_spanning_upload_piles(
+    manta_spanning_t* b, uint32_t n_loci, const manta_packed_piles_t* piles, const uint8_t* refs1, const uint64_t* ref1_off,
+    const uint8_t* refs2, const uint64_t* ref2_off, const manta_jump_cuts_t* cuts)
+{
+  if (!b) return MANTA_E_INVALID_ARG;
+  manta_ctx_t* ctx = b->ctx;
+  if (n_loci == 0 || !refs1 || !ref1_off || !refs2 || !ref2_off || !cuts)
+    return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_upload_piles: null argument or empty batch");
+  int rc = checkPiles(ctx, piles, "manta_spanning_upload_piles");
+  if (rc != MANTA_OK) return rc;
+  try {
+    rt::setDevice(ctx->deviceId);
+    rt::ScopedStream onStream(b->main);
+    b->uploaded = false;
+    rc          = b->asmStage.plan(b->opt, n_loci, nullptr, piles->locus_read_begin, piles->read_len);
+    if (rc != MANTA_OK) return rc;
+    b->asmStage.uploadPiles(*piles);
+    b->nLoci     = n_loci;
+    b->ref1Bytes = ref1_off[n_loci];
+    b->ref2Bytes = ref2_off[n_loci];
+    for (uint32_t l = 0; l < n_loci; ++l) {
+      if (ref1_off[l + 1] < ref1_off[l] || ref2_off[l + 1] < ref2_off[l])
+        return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_upload_piles: reference offsets not monotone");
+      const manta_jump_cuts_t& c(cuts[l]);
+      if (c.align1_leading_cut < 0 || c.align1_trailing_cut < 0 || c.align2_leading_cut < 0 || c.align2_trailing_cut < 0)
+        return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_upload_piles: negative reference cut");
+    }
+    rt::h2d(b->dRefs1.as<uint8_t>(b->ref1Bytes + 16), refs1, b->ref1Bytes);
+    rt::h2d(b->dRef1Off.as<uint64_t>(n_loci + 1), ref1_off, sizeof(uint64_t) * (n_loci + 1));
+    rt::h2d(b->dRefs2.as<uint8_t>(b->ref2Bytes + 16), refs2, b->ref2Bytes);
+    rt::h2d(b->dRef2Off.as<uint64_t>(n_loci + 1), ref2_off, sizeof(uint64_t) * (n_loci + 1));
+    rt::h2d(b->dCuts.as<JumpCuts>(n_loci), cuts, sizeof(JumpCuts) * n_loci);
+    b->hostCuts.assign(reinterpret_cast<const JumpCuts*>(cuts), reinterpret_cast<const JumpCuts*>(cuts) + n_loci);
+    rt::sync();
+    b->uploaded = true;
+    return MANTA_OK;
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
+}
+
 int manta_spanning_run(manta_spanning_t* b)
 {
   if (!b) return MANTA_E_INVALID_ARG;
@@ -1645,7 +1775,8 @@ struct BatchShared {
 
 /// contiguous blocks of `blockLoci` loci, ordered by decreasing cost (reads x bases, the same estimate the kernels'
 /// work queue uses): EdgeRetrieverBin.cpp:38-57 hands out contiguous edge ranges too, but statically
-void planBlocks(BatchShared& sh, uint32_t n_loci, uint32_t blockLoci, const uint64_t* read_off, const uint32_t* locus_read_begin)
+void planBlocks(BatchShared& sh, uint32_t n_loci, uint32_t blockLoci, const uint64_t* read_off, const uint32_t* locus_read_begin,
+                const uint32_t* read_len = nullptr)
 {
   const uint32_t        nBlocks = (n_loci + blockLoci - 1) / blockLoci;
   std::vector<uint64_t> cost(nBlocks, 0);
@@ -1653,7 +1784,12 @@ void planBlocks(BatchShared& sh, uint32_t n_loci, uint32_t blockLoci, const uint
     const uint32_t l0 = b * blockLoci, l1 = std::min(n_loci, l0 + blockLoci);
     for (uint32_t l = l0; l < l1; ++l) {
       const uint32_t rb = locus_read_begin[l], re = locus_read_begin[l + 1];
-      cost[b] += (read_off[re] - read_off[rb]) * uint64_t(re - rb);
+      uint64_t bases = 0;
+      if (read_off)
+        bases = read_off[re] - read_off[rb];
+      else
+        for (uint32_t r = rb; r < re; ++r) bases += read_len[r];
+      cost[b] += bases * uint64_t(re - rb);
     }
   }
   sh.blockOrder.resize(nBlocks);
@@ -1703,18 +1839,19 @@ int manta_spanning_set_word_lengths(manta_spanning_t* b, uint32_t n_loci, const 
   return setWordLengths(b->ctx, b->asmStage, n_loci, min_word_length, max_word_length);
 }
 
-int manta_smallsv_batch(
+namespace {
+int smallsvBatchImpl(
     manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t large_indel_score, uint32_t n_loci,
-    const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const uint8_t* refs, const uint64_t* ref_off,
-    const manta_ref_cuts_t* cuts, const uint32_t* locus_min_word_length, const uint32_t* locus_max_word_length,
+    const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const manta_packed_piles_t* piles, const uint8_t* refs,
+    const uint64_t* ref_off, const manta_ref_cuts_t* cuts, const uint32_t* locus_min_word_length, const uint32_t* locus_max_word_length,
     manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_smallsv_alignment_t* alignments, uint64_t contigs_cap,
     uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
     uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap, uint64_t* cigar_arena_used,
     const manta_batch_plan_t* plan, manta_batch_stats_t* stats)
 {
   if (!ctx) return MANTA_E_INVALID_ARG;
-  if (!opt || !scores || n_loci == 0 || !bases || !read_off || !locus_read_begin || !refs || !ref_off || !cuts || !loci || !contigs ||
-      !alignments || !seq_arena || !bits_arena || !cigar_arena)
+  if (!opt || !scores || n_loci == 0 || (!piles && (!bases || !read_off)) || !locus_read_begin || !refs || !ref_off || !cuts || !loci ||
+      !contigs || !alignments || !seq_arena || !bits_arena || !cigar_arena)
     return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_batch: null argument or empty batch");
   if ((locus_min_word_length == nullptr) != (locus_max_word_length == nullptr))
     return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_batch: per-locus word lengths need both arrays");
@@ -1724,7 +1861,7 @@ int manta_smallsv_batch(
   const uint32_t blockLoci = (plan && plan->block_loci) ? plan->block_loci : 2048u;
   BatchShared    sh;
   sh.serialKernels = plan && (plan->flags & MANTA_BATCH_SERIAL_KERNELS);
-  planBlocks(sh, n_loci, blockLoci, read_off, locus_read_begin);
+  planBlocks(sh, n_loci, blockLoci, piles ? nullptr : read_off, locus_read_begin, piles ? piles->read_len : nullptr);
   const uint32_t nBlocks  = uint32_t(sh.blockOrder.size());
   const uint32_t nWorkers = std::max(1u, std::min(nBlocks, (plan && plan->n_workers) ? plan->n_workers : 4u));
   try {
@@ -1749,13 +1886,23 @@ int manta_smallsv_batch(
         const uint32_t blk = sh.blockOrder[qi];
         const uint32_t l0 = blk * blockLoci, l1 = std::min(n_loci, l0 + blockLoci), n = l1 - l0;
         const uint32_t r0 = locus_read_begin[l0], r1 = locus_read_begin[l1];
-        rebase(rOff, read_off, r0, size_t(r1 - r0) + 1);
+        if (!piles) rebase(rOff, read_off, r0, size_t(r1 - r0) + 1);
         rebase(lBeg, locus_read_begin, l0, size_t(n) + 1);
         rebase(fOff, ref_off, l0, size_t(n) + 1);
         setWordLengths(ctx, b->asmStage, n, locus_min_word_length ? locus_min_word_length + l0 : nullptr,
                        locus_max_word_length ? locus_max_word_length + l0 : nullptr);
         const double t0 = nowMs();
-        int          rc = manta_smallsv_upload(b, n, bases + read_off[r0], rOff.data(), lBeg.data(), refs + ref_off[l0], fOff.data(), cuts + l0);
+        int          rc;
+        if (piles) {
+          manta_packed_piles_t pl = *piles;
+          pl.read_len            = piles->read_len + r0;
+          pl.read_code_off       = piles->read_code_off + r0;
+          pl.read_mask_off       = piles->read_mask_off + r0;
+          pl.locus_read_begin    = lBeg.data();
+          rc                     = manta_smallsv_upload_piles(b, n, &pl, refs + ref_off[l0], fOff.data(), cuts + l0);
+        } else {
+          rc = manta_smallsv_upload(b, n, bases + read_off[r0], rOff.data(), lBeg.data(), refs + ref_off[l0], fOff.data(), cuts + l0);
+        }
         if (perItemCode(rc)) {  // a locus outside the supported envelope: this block's loci carry the code, the batch goes on
           for (uint32_t l = l0; l < l1; ++l) {
             std::memset(&loci[l], 0, sizeof(loci[l]));
@@ -1810,7 +1957,8 @@ int manta_smallsv_batch(
         sh.st.n_align_launches += b->stats.n_align_launches;
         sh.st.dp_cells += b->stats.dp_cells;
         sh.st.ptr_matrix_bytes += b->stats.ptr_matrix_bytes;
-        sh.st.h2d_bytes += (read_off[r1] - read_off[r0]) + (ref_off[l1] - ref_off[l0]) + 8ull * (r1 - r0 + 1) + 12ull * (n + 1) + 16ull * n;
+        sh.st.h2d_bytes += (piles ? b->asmStage.plBytes : (read_off[r1] - read_off[r0]) + 8ull * (r1 - r0 + 1)) + (ref_off[l1] - ref_off[l0]) +
+                           12ull * (n + 1) + 16ull * n;
         sh.st.d2h_bytes += pipeStagedBytes(b);
       }
     } catch (const std::exception& e) {
@@ -1831,6 +1979,37 @@ int manta_smallsv_batch(
   if (sh.fatal != MANTA_OK) return fail(ctx, sh.fatal, sh.msg);
   if (sh.worst != MANTA_OK) return fail(ctx, sh.worst, sh.msg);
   return MANTA_OK;
+}
+}  // namespace
+
+int manta_smallsv_batch(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t large_indel_score, uint32_t n_loci,
+    const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const uint8_t* refs, const uint64_t* ref_off,
+    const manta_ref_cuts_t* cuts, const uint32_t* locus_min_word_length, const uint32_t* locus_max_word_length,
+    manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_smallsv_alignment_t* alignments, uint64_t contigs_cap,
+    uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
+    uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap, uint64_t* cigar_arena_used,
+    const manta_batch_plan_t* plan, manta_batch_stats_t* stats)
+{
+  return smallsvBatchImpl(ctx, opt, scores, large_indel_score, n_loci, bases, read_off, locus_read_begin, nullptr, refs, ref_off, cuts,
+                          locus_min_word_length, locus_max_word_length, loci, contigs, alignments, contigs_cap, seq_arena, seq_arena_cap,
+                          seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used, cigar_arena, cigar_arena_cap, cigar_arena_used, plan, stats);
+}
+
+int manta_smallsv_batch_piles(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t large_indel_score, uint32_t n_loci,
+    const manta_packed_piles_t* piles, const uint8_t* refs, const uint64_t* ref_off, const manta_ref_cuts_t* cuts,
+    const uint32_t* locus_min_word_length, const uint32_t* locus_max_word_length, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs,
+    manta_smallsv_alignment_t* alignments, uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used,
+    uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
+    uint64_t* cigar_arena_used, const manta_batch_plan_t* plan, manta_batch_stats_t* stats)
+{
+  if (!ctx) return MANTA_E_INVALID_ARG;
+  const int rc = checkPiles(ctx, piles, "manta_smallsv_batch_piles");
+  if (rc != MANTA_OK) return rc;
+  return smallsvBatchImpl(ctx, opt, scores, large_indel_score, n_loci, nullptr, nullptr, piles->locus_read_begin, piles, refs, ref_off, cuts,
+                          locus_min_word_length, locus_max_word_length, loci, contigs, alignments, contigs_cap, seq_arena, seq_arena_cap,
+                          seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used, cigar_arena, cigar_arena_cap, cigar_arena_used, plan, stats);
 }
 
 int manta_spanning_batch(

@@ -115,6 +115,13 @@ struct AsmParams {
   const uint32_t* locus_max_wl;
   // optional locus list of this launch (the kernel then works on loci[locus_ids[i]], i < n_loci); nullptr = identity
   const uint32_t* locus_ids;
+  // optional packed read piles (manta_packed_piles_t): when pl_codes is set, bases / read_off are unused
+  // and stage 0 is a copy -- the piles arrive in the layout this kernel packs into (2-bit codes MSB first + N bitmap)
+  const uint32_t* pl_codes;
+  const uint32_t* pl_nmask;
+  const uint32_t* pl_read_len;
+  const uint64_t* pl_code_off;  ///< per read, dwords
+  const uint64_t* pl_mask_off;
 };
 
 // --------------------------------------------------------------------------------------------------
@@ -530,7 +537,7 @@ struct Assembler {
     for (unsigned base = 0; base < nNormal; base += 64) {
       const unsigned r   = base + unsigned(wv::lane());
       unsigned       len = 0;
-      if (r < nNormal) len = unsigned(P.read_off[rBegin + r + 1] - P.read_off[rBegin + r]);
+      if (r < nNormal) len = P.pl_codes ? P.pl_read_len[rBegin + r] : unsigned(P.read_off[rBegin + r + 1] - P.read_off[rBegin + r]);
       const unsigned myC = (r < nNormal) ? (len + 15) / 16 + 1 : 0u;  // +1 padding dword so codes16() may read one past
       const unsigned myM = (r < nNormal) ? (len + 31) / 32 + 1 : 0u;
       // inclusive scan over lanes
@@ -558,6 +565,26 @@ struct Assembler {
     nCodeWordsNormal = cw;
     nMaskWordsNormal = mw;
     wv::sync();
+    if (P.pl_codes) {  // packed piles: copy (8 lanes per read, as below), add the pad dwords, note which reads hold an 'N'
+      const unsigned lane = unsigned(wv::lane());
+      for (unsigned base = 0; base < nNormal; base += 8) {
+        const unsigned r = base + (lane >> 3);
+        if (r >= nNormal) continue;
+        const unsigned  len = rd_len[r], cwo = rd_cw[r], mwo = rd_mw[r];
+        const unsigned  nCw = (len + 15) / 16, nMw = (len + 31) / 32;
+        const uint32_t* sc  = P.pl_codes + P.pl_code_off[rBegin + r];
+        const uint32_t* sm  = P.pl_nmask + P.pl_mask_off[rBegin + r];
+        for (unsigned wi = (lane & 7); wi <= nCw; wi += 8) codes[cwo + wi] = (wi < nCw) ? sc[wi] : 0u;
+        bool sawN = false;
+        for (unsigned wi = (lane & 7); wi <= nMw; wi += 8) {
+          const uint32_t m = (wi < nMw) ? sm[wi] : 0u;
+          nmask[mwo + wi]  = m;
+          sawN             = sawN || (m != 0);
+        }
+        if (sawN) wv::atomic_or(&rd_hasn[r], 1u);
+      }
+      return;
+    }
     bool badAlphabet = false;
     // 8 lanes per read, 8 reads per pass: lane (g, i) converts code dwords i, i+8, ... of read (base + g)
     const unsigned lane = unsigned(wv::lane());
