@@ -3,17 +3,29 @@
 # and PMC passes (each counter group in its own run; never combined with sys/hip/hsa traces).  Every step has its own
 # timeout.  Outputs land in gpurun_out/; tools/summarize_profiles.py turns them into the files under profiles/.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
-timeout 400 python $R/bench.py > $O/bench_line.json 2> $O/bench.err
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> /dev/null
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/pmc_sq -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+B="python $R/bench.py"
+timeout 400 $B > $O/bench_line.json 2> $O/bench.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $B --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2> /dev/null
+P="--steps 1 --warmup 0 --no-cpu-baseline --no-extras"
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- $B $P > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- $B $P > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/pmc_sq -o p -- $B $P > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq2 -o p -- $B $P > /dev/null 2>&1
+# the opt-in LDS-resident assembler, same passes (evidence for DESIGN.md: traffic vs time)
+export MANTA_AMD_ASM_PATH=lds
+mkdir -p $O/lds
+timeout 300 $B --no-cpu-baseline --no-extras > $O/lds/bench_line.json 2> $O/lds/bench.err
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/lds/pmc_fetch -o p -- $B $P > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/lds/pmc_write -o p -- $B $P > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/lds/pmc_sq -o p -- $B $P > /dev/null 2>&1
+unset MANTA_AMD_ASM_PATH
 if [ "$2" = "spanning" ]; then
-  timeout 400 python $R/bench.py --workload spanning --loci 22000 --steps 2 --warmup 1 > $O/bench_spanning_line.json 2> $O/bench_spanning.err
+  timeout 600 $B --workload spanning --steps 2 --warmup 1 > $O/bench_spanning_line.json 2> $O/bench_spanning.err
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_spanning -o bench -- $B --workload spanning --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 fi
 # keep only the small files (gpurun_out merges back <= 64 MiB)
 find $O -name "*_kernel_trace.csv" -size +8M -delete

@@ -4,7 +4,7 @@ rocprofv3 kernel-stats table, one PMC row per kernel, and profiles/traffic.json 
 reports as roofline.traffic)."""
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 
@@ -23,30 +23,36 @@ if os.path.exists(sp) and os.path.getsize(sp):
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     open(os.path.join(dst, tag + "_bench_kernel_stats.csv"), "w").write(open(stats[0]).read())
-per = {}
-for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+per, launches = {}, {}
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     for f in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
+        seen = {}
         for row in csv.DictReader(open(f)):
             k = short(row["Kernel_Name"])
             if "rocclr" in k:
                 continue
             per.setdefault(k, {}).setdefault(row["Counter_Name"], 0.0)
             per[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            seen.setdefault(k, set()).add(row.get("Dispatch_Id", row.get("Correlation_Id", "")))
+        for k, ids in seen.items():
+            launches[k] = max(launches.get(k, 0), len(ids))
 cols = sorted({c for v in per.values() for c in v})
 with open(os.path.join(dst, tag + "_pmc_summary.csv"), "w") as out:
     out.write("# rocprofv3 --pmc passes over `python bench.py --steps 1 --warmup 0 --no-cpu-baseline` (10k loci, config 2), summed per kernel\n")
     out.write("# over the launches of that one step.  FETCH_SIZE / WRITE_SIZE are KiB as rocprofv3 reports them (separate passes; see\n")
     out.write("# MI355X_MICROARCH.md HBM section: FETCH_SIZE can under-count wide coalesced reads by 2x on gfx950; these reads are narrow and\n")
     out.write("# scattered, so the value is reported raw).\n")
-    out.write("kernel," + ",".join(cols) + "\n")
+    out.write("kernel,launches," + ",".join(cols) + "\n")
     for k in sorted(per):
-        out.write('"%s",' % k + ",".join("%.0f" % per[k].get(c, 0) for c in cols) + "\n")
-traffic = {"loci": 10000, "note": "HBM-side bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB * 1024, rocprofv3 --pmc, separate passes, raw "
-           "(no gfx950 x2 read correction: narrow scattered reads)"}
+        out.write('"%s",%d,' % (k, launches.get(k, 1)) + ",".join("%.0f" % per[k].get(c, 0) for c in cols) + "\n")
+traffic = {"loci": 10000, "workload": "smallsv",
+           "note": "HBM-side bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB * 1024 / launches, rocprofv3 --pmc, separate passes, raw "
+                   "(no gfx950 x2 read correction: narrow scattered reads); align_kernel: the E-bucket launches of one block together"}
 agg = {}
 for k, v in per.items():
     name = "align_kernel<LARGE_INDEL>" if k.startswith("align_kernel<1") else k
-    agg[name] = agg.get(name, 0) + (v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024
+    n = 1 if name.startswith("align_kernel") else max(1, launches.get(k, 1))
+    agg[name] = agg.get(name, 0) + (v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 / n
 for k, v in agg.items():
     traffic[k] = int(v)
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
