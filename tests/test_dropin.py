@@ -1,0 +1,64 @@
+"""The drop-in proof against the REAL Manta headers: oracle/_ref/libmanta_ref_dropin_{emu,gpu}.so is the
+reference's own SVCandidateAssemblyRefiner.cpp -- unmodified, real SVCandidate / SVCandidateAssemblyData / GSCOptions types -- built
+with manta_amd/host/dropin/ in front of the reference headers (INTEGRATION.md section A applied mechanically): its assembler and
+its three aligners run in libmanta_amd.  It must produce, call for call, what the all-reference build produces."""
+import json
+import os
+import subprocess
+
+import pytest
+
+from refiner_loci import RefinerLib
+from test_refiner import GOLDEN, scenario_cases
+from test_vcf_candidate import GOLDEN_VCF, vcf_cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+DEMO = os.path.join(ROOT, "tests", "golden", "demo_cases.json")
+
+
+def lib(name):
+    path = os.path.join(REF_DIR, name)
+    if not os.path.exists(path):
+        pytest.skip("%s not built (reference sources unavailable)" % name)
+    return RefinerLib(path, "ref")
+
+
+@pytest.fixture(scope="module")
+def dropin_emu(emu):
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref", "_ref/libmanta_ref_dropin_emu.so"])
+    return lib("libmanta_ref_dropin_emu.so")
+
+
+def test_dropin_refiner_equals_reference_refiner(dropin_emu):
+    ref = lib("libmanta_ref_refiner.so")
+    n = 0
+    for seed in (41, 42):
+        for name, c in scenario_cases(seed):
+            assert dropin_emu.run(c) == ref.run(c), (seed, name)
+            n += 1
+    for name, c in vcf_cases(43):
+        assert dropin_emu.vcf(c) == ref.vcf(c), name
+    assert n >= 50
+
+
+def test_dropin_refiner_on_demo_piles(dropin_emu):
+    for c in json.load(open(DEMO))["cases"]:
+        assert dropin_emu.run(c["case"]) == c["ref_text"], c["name"]
+        assert dropin_emu.vcf(c["case"]) == c["ref_vcf"], c["name"]
+
+
+@pytest.mark.gpu
+def test_gpu_dropin_refiner_golden(gpu):
+    """the prebuilt device variant travels to the GPU box in oracle/_ref (it cannot be rebuilt there: no /root/reference)"""
+    d = lib("libmanta_ref_dropin_gpu.so")
+    g = json.load(open(GOLDEN))
+    for (name, c), want in zip(scenario_cases(g["seed"]), g["texts"]):
+        assert d.run(c) == want, name
+    gv = json.load(open(GOLDEN_VCF))
+    for (name, c), want in zip(vcf_cases(gv["seed"]), gv["records"]):
+        assert d.vcf(c) == want, name
+    for c in json.load(open(DEMO))["cases"]:
+        assert d.run(c["case"]) == c["ref_text"], c["name"]
+        assert d.vcf(c["case"]) == c["ref_vcf"], c["name"]
