@@ -125,10 +125,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is HIP-only (no CPU fallback)")
+    # MANTA_BENCH_BACKEND=gloo: developer knob to exercise the N>1 control flow (self-spawn, barriers, the result gather) on a box
+    # with fewer GPUs than ranks -- ranks then share devices and the gather goes through host memory.  The driver's runs use RCCL.
+    backend = os.environ.get("MANTA_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from manta_amd._capi import BatchOutput, Lib, SmallSvBatch, pack_spanning, pinned_copy, small_sv_text, assembly_text
     from manta_amd.shard import gather_bytes
@@ -170,7 +177,7 @@ def main():
         else:
             lib.smallsv_batch(opts, SCORES, LARGE_INDEL, dev_batch, out, block_loci=block, n_workers=workers, serial_kernels=args.serial_kernels)
         if world > 1:  # the final candidate gather (north star: "RCCL over xGMI only for the final candidate gather")
-            return gather_bytes(result_blob(out), device="cuda")
+            return gather_bytes(result_blob(out), device="cuda" if backend == "nccl" else "cpu")
         return None
 
     def barrier():
@@ -196,7 +203,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -64,6 +64,63 @@ struct VcfWriterCandidateSV {
     }
   }
 
+  /// VcfWriterSV::writeHeader (format/VcfWriterSV.cpp:58-131) with VcfWriterCandidateSV::addHeaderInfo
+  /// (format/VcfWriterCandidateSV.cpp:26-32): the header block of candidateSV.vcf.  `fileDate` is the reference's
+  /// vcf_fileDate (format/VcfWriterSV.cpp:70: the run's date, one of the five header keys every Manta comparison skips,
+  /// src/demo/runMantaWorkflowDemo.py `rexclude`); the text is fixed by the VCF output contract.
+  void writeHeader(const char* progName, const char* progVersion, const std::string& referenceFilename, const std::string& fileDate,
+                   const std::vector<std::string>& sampleNames = std::vector<std::string>()) const
+  {
+    std::ostream& os(_os);
+    os << "##fileformat=VCFv4.1\n";
+    os << "##fileDate=" << fileDate << "\n";
+    os << "##source=" << progName << " " << progVersion << "\n";
+    os << "##reference=file://" << referenceFilename << "\n";
+    for (const bam_header_info::chrom_info& cdata : _header.chrom_data) os << "##contig=<ID=" << cdata.label << ",length=" << cdata.length << ">\n";
+    static const char* const reservedInfo[][4] = {
+        {"IMPRECISE", "0", "Flag", "Imprecise structural variation"},
+        {"SVTYPE", "1", "String", "Type of structural variant"},
+        {"SVLEN", ".", "Integer", "Difference in length between REF and ALT alleles"},
+        {"END", "1", "Integer", "End position of the variant described in this record"},
+        {"CIPOS", "2", "Integer", "Confidence interval around POS"},
+        {"CIEND", "2", "Integer", "Confidence interval around END"},
+        {"CIGAR", "A", "String", "CIGAR alignment for each alternate indel allele"},
+        {"MATEID", ".", "String", "ID of mate breakend"},
+        {"EVENT", "1", "String", "ID of event associated to breakend"},
+        {"HOMLEN", ".", "Integer", "Length of base pair identical homology at event breakpoints"},
+        {"HOMSEQ", ".", "String", "Sequence of base pair identical homology at event breakpoints"},
+        {"SVINSLEN", ".", "Integer", "Length of insertion"},
+        {"SVINSSEQ", ".", "String", "Sequence of insertion"},
+        {"LEFT_SVINSSEQ", ".", "String", "Known left side of insertion for an insertion of unknown length"},
+        {"RIGHT_SVINSSEQ", ".", "String", "Known right side of insertion for an insertion of unknown length"}};
+    auto info = [&](const char* const* t) {
+      os << "##INFO=<ID=" << t[0] << ",Number=" << t[1] << ",Type=" << t[2] << ",Description=\"" << t[3] << "\">\n";
+    };
+    for (const auto& t : reservedInfo) info(t);
+    if (_isOutputContig) {
+      static const char* const contig[4] = {"CONTIG", "1", "String", "Assembled contig sequence"};
+      info(contig);
+    }
+    static const char* const candidateInfo[][4] = {
+        {"PAIR_COUNT", "1", "Integer", "Read pairs supporting this variant where both reads are confidently mapped"},
+        {"BND_PAIR_COUNT", "1", "Integer",
+         "Confidently mapped reads supporting this variant at this breakend (mapping may not be confident at remote breakend)"},
+        {"UPSTREAM_PAIR_COUNT", "1", "Integer",
+         "Confidently mapped reads supporting this variant at the upstream breakend (mapping may not be confident at downstream breakend)"},
+        {"DOWNSTREAM_PAIR_COUNT", "1", "Integer",
+         "Confidently mapped reads supporting this variant at this downstream breakend (mapping may not be confident at upstream breakend)"}};
+    for (const auto& t : candidateInfo) info(t);
+    os << "##ALT=<ID=DEL,Description=\"Deletion\">\n";
+    os << "##ALT=<ID=INS,Description=\"Insertion\">\n";
+    os << "##ALT=<ID=DUP:TANDEM,Description=\"Tandem Duplication\">\n";
+    os << "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO";
+    if (!sampleNames.empty()) {
+      os << "\tFORMAT";
+      for (const std::string& sampleName : sampleNames) os << '\t' << sampleName;
+    }
+    os << '\n';
+  }
+
 private:
   typedef std::vector<std::string> InfoTag_t;
 

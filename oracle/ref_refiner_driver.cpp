@@ -417,3 +417,32 @@ REF_EXPORT int ref_candidate_vcf_records(const ref_refine_input_t* in, char* out
     return emit(std::string("EXCEPTION ") + e.what(), out, cap);
   }
 }
+
+/// The header block of candidateSV.vcf: VcfWriterSV::writeHeader (format/VcfWriterSV.cpp:58-131) through the reference's own
+/// VcfWriterCandidateSV object (addHeaderInfo, format/VcfWriterCandidateSV.cpp:26-32).  Chromosomes: "<label>:<length>" strings.
+REF_EXPORT int ref_candidate_vcf_header(
+    int nChrom, const char* const* chromLabels, const unsigned* chromLengths, const char* referenceFilename, int isOutputContig,
+    const char* progName, const char* progVersion, int nSamples, const char* const* sampleNames, char* out, int cap)
+{
+  try {
+    bam_header_info header;
+    for (int i = 0; i < nChrom; ++i) header.chrom_data.emplace_back(chromLabels[i], chromLengths[i]);
+    char      tmpl[] = "/tmp/manta_ref_vcfh_XXXXXX";
+    const int fd     = mkstemp(tmpl);
+    if (fd >= 0) close(fd);
+    const std::string vcfName(tmpl);
+    {
+      const VcfWriterCandidateSV writer(referenceFilename, header, vcfName, isOutputContig != 0);
+      std::vector<std::string>   samples;
+      for (int i = 0; i < nSamples; ++i) samples.emplace_back(sampleNames[i]);
+      writer.writeHeader(progName, progVersion, samples);
+    }
+    std::ifstream      ifs(vcfName);
+    std::ostringstream text;
+    text << ifs.rdbuf();
+    std::remove(vcfName.c_str());
+    return emit(text.str(), out, cap);
+  } catch (const std::exception& e) {
+    return emit(std::string("EXCEPTION ") + e.what(), out, cap);
+  }
+}

@@ -238,3 +238,23 @@ MINE_EXPORT int mine_get_candidate_assembly_data(const ref_refine_input_t* in, c
 {
   return mine_get_candidate_assembly_data_multi(in, 1, 0, out, cap);
 }
+
+/// same signature as ref_candidate_vcf_header; the fileDate line is written as the placeholder the test strips on both sides
+MINE_EXPORT int mine_candidate_vcf_header(
+    int nChrom, const char* const* chromLabels, const unsigned* chromLengths, const char* referenceFilename, int isOutputContig,
+    const char* progName, const char* progVersion, int nSamples, const char* const* sampleNames, char* out, int cap)
+{
+  try {
+    MemorySource    source;
+    bam_header_info header;
+    for (int i = 0; i < nChrom; ++i) header.chrom_data.emplace_back(chromLabels[i], chromLengths[i]);
+    std::ostringstream         os;
+    const VcfWriterCandidateSV writer(source, header, os, isOutputContig != 0);
+    std::vector<std::string>   samples;
+    for (int i = 0; i < nSamples; ++i) samples.emplace_back(sampleNames[i]);
+    writer.writeHeader(progName, progVersion, referenceFilename, "DATE", samples);
+    return emit(os.str(), out, cap);
+  } catch (const std::exception& e) {
+    return emit(std::string("EXCEPTION ") + e.what(), out, cap);
+  }
+}

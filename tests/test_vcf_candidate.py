@@ -55,3 +55,22 @@ def test_records_on_gpu(mine_gpu):
     g = json.load(open(GOLDEN_VCF))
     for (name, c), want in zip(vcf_cases(g["seed"]), g["records"]):
         assert mine_gpu.vcf(c) == want, name
+
+
+def _header(lib, prefix, chroms, ref_name, output_contig, samples):
+    import ctypes
+    n, m = len(chroms), len(samples)
+    buf = ctypes.create_string_buffer(1 << 16)
+    getattr(lib.lib, prefix + "_candidate_vcf_header")(
+        n, (ctypes.c_char_p * n)(*[c[0].encode() for c in chroms]), (ctypes.c_uint * n)(*[c[1] for c in chroms]), ref_name.encode(),
+        int(output_contig), b"GenerateSVCandidates", b"1.6.0", m, (ctypes.c_char_p * max(1, m))(*([s.encode() for s in samples] or [b""])), buf, 1 << 16)
+    # the run date is one of the five header keys every Manta comparison skips (src/demo/runMantaWorkflowDemo.py rexclude)
+    return [l for l in buf.value.decode().splitlines() if not l.startswith("##fileDate=")]
+
+
+def test_header_block_against_reference_writer(mine_emu, ref):
+    """the candidateSV.vcf header (format/VcfWriterSV.cpp:58-131 + VcfWriterCandidateSV::addHeaderInfo) byte for byte"""
+    for chroms, samples, oc in (([("8", 146364022), ("11", 135006516)], [], False), ([("chr1", 1000)], ["NORMAL", "TUMOR"], True)):
+        want = _header(ref, "ref", chroms, "/data/genome.fa", oc, samples)
+        assert want[0] == "##fileformat=VCFv4.1" and want[-1].startswith("#CHROM\tPOS")
+        assert _header(mine_emu, "mine", chroms, "/data/genome.fa", oc, samples) == want
