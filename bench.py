@@ -229,7 +229,7 @@ def main():
                        for a in r["aligns"]]
                 mism += hashlib.sha256(c5_text(assembly_text(r), got).encode("latin-1")).digest() != raw[32 * i:32 * i + 32]
             checked, how = n_dig, "reference digests (tests/golden/config5_digests.bin)"
-        elif n_loci == 10000 or n_dig == n_loci:
+        elif n_loci == 10000:  # the digest workload (config2_batch draws every locus of a batch from one stream: other sizes differ)
             for l in range(n_dig):
                 mism += hashlib.sha256(small_sv_text(results[l]).encode("latin-1")).digest() != raw[32 * l:32 * l + 32]
             checked, how = n_dig, "reference digests (tests/golden/config2_digests.bin)"

@@ -323,6 +323,8 @@ void manta_host_free(void* p);
  * the call returns the code, every other item is valid.
  * ---------------------------------------------------------------------------------------------------- */
 #define MANTA_BATCH_SERIAL_KERNELS 1u /* one block's kernels at a time; uploads / downloads of the others still overlap them */
+#define MANTA_BATCH_NO_STREAMED_UPLOAD 2u /* wait for a block's read bases before its kernels start (default: the assembler
+                                             is launched at once and consumes the bases chunk by chunk as they land) */
 typedef struct {
   uint32_t block_loci; /* 0 = 2048 */
   uint32_t n_workers;  /* 0 = 4 */

@@ -262,7 +262,11 @@ int asmStatusToAbi(int st)
 struct AsmStage {
   manta_ctx_t* ctx;
   explicit AsmStage(manta_ctx_t* c) : ctx(c) { g_liveWorkspaces++; }
-  ~AsmStage() { g_liveWorkspaces--; }
+  ~AsmStage()
+  {
+    g_liveWorkspaces--;
+    if (dChunksDone) rt::dfree(dChunksDone);
+  }
   AsmStage(const AsmStage&) = delete;
   AsmStage& operator=(const AsmStage&) = delete;
   // device -> host staging (pinned), filled by stageOut()
@@ -424,9 +428,67 @@ struct AsmStage {
   std::vector<uint64_t> plRebased;
   uint64_t              plBytes = 0;
 
+  // ---- streamed upload (whole-batch calls): the read bases arrive chunk by chunk on `copyStream` while assemble_kernel,
+  // launched right away on the pipeline's stream, works through the loci whose chunk has landed (AsmParams::upload_*)
+  static const uint32_t kStreamChunks = 8;
+  DevBuf                bStream;  // chunk shifts
+  uint32_t*             dStream = nullptr;
+  uint32_t*             dChunksDone = nullptr;  // fine-grained device word the copy engine bumps after every chunk
+  PinnedBuf             pChunkIds;              // the values 0..kStreamChunks it is bumped to (DMA sources)
+  uint32_t              chunkLoci = 0;
+  bool                  streaming = false;
+
+  /// like upload(), but only ENQUEUES the copy of the read bases (in kStreamChunks pieces, each followed by its completion
+  /// signal) on copyStream and returns; launch() passes the counters to the kernel.  The caller keeps `bases` alive and
+  /// synchronises copyStream before it touches them again.
+  void uploadStreamed(const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, rt::Stream& copyStream)
+  {
+    chunkLoci = std::max<uint32_t>(1, (nLoci + kStreamChunks - 1) / kStreamChunks);
+    const uint32_t nChunks = (nLoci + chunkLoci - 1) / chunkLoci;
+    std::vector<uint32_t> host(1 + kStreamChunks, 0u);
+    std::vector<uint64_t> hostBegin(nChunks + 1), devBegin(nChunks + 1);
+    uint64_t              cursor = 0;
+    for (uint32_t c = 0; c < nChunks; ++c) {
+      const uint32_t l0 = c * chunkLoci, l1 = std::min(nLoci, l0 + chunkLoci);
+      hostBegin[c]      = read_off[locus_read_begin[l0]];
+      const uint64_t len = read_off[locus_read_begin[l1]] - hostBegin[c];
+      devBegin[c]        = cursor;
+      host[1 + c]        = uint32_t(devBegin[c] - hostBegin[c]);  // modulo 2^32: the kernel adds it in 32-bit arithmetic to a 64-bit offset
+      cursor             = (cursor + len + 64 + 255) & ~uint64_t(255);
+    }
+    hostBegin[nChunks] = read_off[nReadsTotal];
+    // shifts must be exact in 64 bits: keep them small by construction (device offsets only grow by the padding)
+    for (uint32_t c = 0; c < nChunks; ++c) host[1 + c] = uint32_t(devBegin[c] - hostBegin[c]);
+    const uint64_t savedBases = nBases;
+    nBases                    = cursor + 64;  // device arena incl. the per-chunk padding
+    upload(nullptr, nullptr, locus_read_begin);  // allocations + the small arrays (order, word lengths, growth schedule, locus begins)
+    nBases  = savedBases;
+    dPlCodes = nullptr;
+    rt::h2d(dOff, read_off, sizeof(uint64_t) * (nReadsTotal + 1));
+    dStream = bStream.as<uint32_t>(1 + kStreamChunks);
+    rt::h2d(dStream, host.data(), sizeof(uint32_t) * (1 + kStreamChunks));
+    if (!dChunksDone) dChunksDone = static_cast<uint32_t*>(rt::dmallocFine(64));
+    uint32_t* ids = pChunkIds.as<uint32_t>(kStreamChunks + 1);
+    for (uint32_t c = 0; c <= kStreamChunks; ++c) ids[c] = c;
+    rt::h2d(dChunksDone, ids, sizeof(uint32_t));  // = 0
+    rt::sync();  // the counter is zero and the small arrays are in place before the first chunk can land
+    {
+      // one copy per chunk, each followed by a 4-byte copy that bumps the counter: the copy engine executes a stream's
+      // copies in order, so the counter says c+1 only after chunk c is in HBM.  No kernel is involved: the persistent
+      // assembler may own every register of the device.
+      rt::ScopedStream onCopy(copyStream);
+      for (uint32_t c = 0; c < nChunks; ++c) {
+        rt::h2d(dBases + devBegin[c], bases + hostBegin[c], hostBegin[c + 1] - hostBegin[c]);
+        rt::h2d(dChunksDone, ids + c + 1, sizeof(uint32_t));
+      }
+    }
+    streaming = true;
+  }
+
   void upload(const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin)
   {
     if (bases) dPlCodes = nullptr;
+    streaming = false;
     dBases  = bBases.as<uint8_t>(nBases + 16);
     dOff    = bReadOff.as<uint64_t>(nReadsTotal + 1);
     dBegin  = bLocusBegin.as<uint32_t>(nLoci + 1);
@@ -496,11 +558,19 @@ struct AsmStage {
     P.pl_read_len    = dPlLen;
     P.pl_code_off    = dPlCodeOff;
     P.pl_mask_off    = dPlMaskOff;
-    if (useLds && !dPlCodes) {
+    P.upload_chunks_done = streaming ? dChunksDone : nullptr;
+    P.chunk_shift        = streaming ? dStream + 1 : nullptr;
+    P.chunk_loci         = streaming ? chunkLoci : 0;
+    P.reserved2          = 0;
+    if (useLds && !dPlCodes && !streaming) {
       if (std::getenv("MANTA_AMD_LDS_OFF")) P.flags |= ASM_FLAG_NO_LDS_PATH;  // A/B: same kernel, every locus through the general path
       rt::launchSingle(assemble_lds_kernel, gridLds, LN_BUDGET, P);
     } else {
-      rt::launch(assemble_kernel, grid, ASM_LDS_BYTES, P);
+      // streamed upload: if the runtime moves a chunk with a shader copy instead of the DMA engine, that copy needs a free
+      // workgroup slot while this persistent kernel runs -- leave one slot free on a quarter of the CUs
+      int g = grid;
+      if (streaming && g >= ctx->cuCount * 16) g = rt::roundGrid(g - ctx->cuCount);
+      rt::launch(assemble_kernel, g, ASM_LDS_BYTES, P);
     }
   }
 
@@ -681,6 +751,8 @@ struct manta_smallsv {
   DevBuf                dRefs, dRefOff, dCuts, dTasks, dInfo, dResults, dBucketIds, dSmall, dCigar, dTable, dPtrWs;
   rt::Event             evStart, evAsm, evSched, evAlign;
   rt::Stream            main;  // everything of this pipeline except the aligner buckets
+  rt::Stream            copy;  // streamed upload of the read bases (whole-batch calls)
+  bool                  streamUploads = false;
   rt::Stream            side[3];
   rt::Event             sideDone[3];
   manta_smallsv_stats_t stats{};
@@ -1009,9 +1081,10 @@ int manta_smallsv_upload(
   try {
     rt::ScopedStream onStream(b->main);
     b->uploaded = false;
+    const double tP0 = nowMs();
     int rc      = b->asmStage.plan(b->opt, n_loci, read_off, locus_read_begin);
     if (rc != MANTA_OK) return rc;
-    b->asmStage.upload(bases, read_off, locus_read_begin);
+    const double tP1 = nowMs();
     b->nLoci    = n_loci;
     b->refBytes = ref_off[n_loci];
     b->maxRef   = 0;
@@ -1021,6 +1094,8 @@ int manta_smallsv_upload(
       if (cuts[l].leading_cut < 0 || cuts[l].trailing_cut < 0 || cuts[l].max_leading_cut < 0 || cuts[l].max_trailing_cut < 0)
         return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_upload: negative reference cut");
     }
+    // the reference windows first: the copy engine serves the streams in submission order, and in streamed mode the (large)
+    // read-base copies below must be the LAST thing queued, or everything after them would wait for them
     uint8_t*  dRefs   = b->dRefs.as<uint8_t>(b->refBytes + 16);
     uint64_t* dRefOff = b->dRefOff.as<uint64_t>(n_loci + 1);
     auto*     dCuts   = b->dCuts.as<SmallSvCuts>(n_loci);
@@ -1028,7 +1103,14 @@ int manta_smallsv_upload(
     rt::h2d(dRefOff, ref_off, sizeof(uint64_t) * (n_loci + 1));
     static_assert(sizeof(SmallSvCuts) == sizeof(manta_ref_cuts_t), "cuts layout");
     rt::h2d(dCuts, cuts, sizeof(SmallSvCuts) * n_loci);
-    rt::sync();
+    if (b->streamUploads && !b->asmStage.useLds && !std::getenv("MANTA_AMD_NO_STREAM_UPLOAD")) {
+      b->asmStage.uploadStreamed(bases, read_off, locus_read_begin, b->copy);  // syncs the small copies, returns with the bases in flight
+    } else {
+      b->asmStage.upload(bases, read_off, locus_read_begin);
+      rt::sync();
+    }
+    if (std::getenv("MANTA_AMD_DEBUG_TIMING"))
+      std::fprintf(stderr, "manta_amd: smallsv_upload plan %.2f ms, upload (%s) %.2f ms\n", tP1 - tP0, b->asmStage.streaming ? "streamed" : "blocking", nowMs() - tP1);
     b->uploaded = true;
     return MANTA_OK;
   } catch (const std::exception& e) {
@@ -1207,6 +1289,10 @@ int manta_smallsv_run(manta_smallsv_t* b)
     launchPack(b, dTasks, nullptr, dResults, nullptr, dInfo, nullptr, dCigar, cigarCap);
     b->evAlign.record();
     rt::sync();
+    if (as.streaming) {  // all chunks were consumed by the kernel, so this returns at once; it closes the stream's error state
+      rt::ScopedStream onCopy(b->copy);
+      rt::sync();
+    }
     stage("aligned");
     b->stats.assemble_ms = rt::elapsedMs(b->evStart, b->evAsm);
     b->stats.schedule_ms = rt::elapsedMs(b->evAsm, b->evSched);
@@ -1875,9 +1961,10 @@ int smallsvBatchImpl(
     manta_smallsv* b = ctx->smallPool[w];
     try {
       rt::setDevice(ctx->deviceId);
-      b->opt        = *opt;
-      b->scores     = *scores;
-      b->largeIndel = large_indel_score;
+      b->opt           = *opt;
+      b->scores        = *scores;
+      b->largeIndel    = large_indel_score;
+      b->streamUploads = !(plan && (plan->flags & MANTA_BATCH_NO_STREAMED_UPLOAD));
       std::vector<uint64_t> rOff, fOff;
       std::vector<uint32_t> lBeg;
       while (!sh.stop()) {

@@ -122,7 +122,17 @@ struct AsmParams {
   const uint32_t* pl_read_len;
   const uint64_t* pl_code_off;  ///< per read, dwords
   const uint64_t* pl_mask_off;
+  // optional streamed upload (whole-batch calls): the kernel is launched while the read bases are still arriving.  The
+  // upload goes chunk by chunk (chunk_loci loci each, every chunk at a 256-byte aligned device offset so that no cache
+  // line is shared between chunks); *upload_chunks_done (fine-grained device memory, bumped by a 4-byte copy queued behind
+  // every chunk on the copy stream) counts the chunks that have landed.  chunk_shift[c] = device offset - caller offset of chunk c.
+  const uint32_t* upload_chunks_done;
+  const uint32_t* chunk_shift;
+  uint32_t        chunk_loci;
+  uint32_t        reserved2;
 };
+
+
 
 // --------------------------------------------------------------------------------------------------
 // per-workgroup workspace carve (host and device agree through asmWorkspaceLayout)
@@ -591,7 +601,7 @@ struct Assembler {
     for (unsigned base = 0; base < nNormal; base += 8) {
       const unsigned r = base + (lane >> 3);
       if (r >= nNormal) continue;
-      const uint8_t* src = P.bases + P.read_off[rBegin + r];
+      const uint8_t* src = P.bases + P.read_off[rBegin + r] + (P.chunk_shift ? P.chunk_shift[locus / P.chunk_loci] : 0u);
       const unsigned len = rd_len[r], cwo = rd_cw[r], mwo = rd_mw[r];
       const unsigned nCw = (len + 15) / 16 + 1;
       for (unsigned wi = (lane & 7); wi < nCw; wi += 8) {
@@ -1454,6 +1464,27 @@ struct Assembler {
 
 namespace manta_dev {
 
+/// streamed upload: wait until the chunk holding `locus` has landed.  Polls an agent-scope counter with back-off; gives
+/// up after ~4 s of shader clocks (a copy that never completes must not hang the device).
+WV_DEV bool asmWaitUploaded(const AsmParams& P, const unsigned locus)
+{
+  const unsigned need = locus / P.chunk_loci + 1;
+  bool           ok   = true;
+  if (wv::lane() == 0) {
+    const uint64_t t0 = wv::clock();
+    while (wv::atomic_load_system(P.upload_chunks_done) < need) {
+      wv::sleep();
+      if (wv::clock() - t0 > 10000000000ull) {
+        ok = false;
+        break;
+      }
+    }
+  }
+  ok = wv::first(int(ok)) != 0;
+  wv::sync();
+  return ok;
+}
+
 #ifndef MANTA_ASM_OCC
 #define MANTA_ASM_OCC 4
 #endif
@@ -1465,8 +1496,20 @@ WV_KERNEL_OCC(MANTA_ASM_OCC) void assemble_kernel(const AsmParams P)
     if (wv::lane() == 0) slot = wv::atomic_add(P.counter, 1u);
     slot = wv::first(slot);
     if (slot >= P.n_loci) break;
-    Assembler a(P, wsBase);
-    a.run(P.locus_ids ? P.locus_ids[slot] : slot);
+    const unsigned locus = P.locus_ids ? P.locus_ids[slot] : slot;
+    Assembler      a(P, wsBase);
+    // (single reconvergence point per work item: both outcomes fall through to the sync below)
+    const bool arrived = !P.upload_chunks_done || asmWaitUploaded(P, locus);
+    if (arrived) {
+      a.run(locus);
+    } else if (wv::lane() == 0) {  // the chunk never arrived: report, do not hang
+      AsmLocusOut out;
+      out.status = ASM_E_INTERNAL;
+      out.n_contigs = out.n_words = out.n_pseudo = 0;
+      out.pseudo_off = out.pseudo_len_off = 0;
+      out.final_word_length = out.n_iterations = out.cyclic_iterations = out.reserved = 0;
+      P.loci[locus] = out;
+    }
     wv::sync();
   }
 }

@@ -20,6 +20,7 @@ inline size_t freeBytes() { return size_t(1) << 30; }
 inline int   poisonByte() { const char* e = std::getenv("MANTA_EMU_POISON"); return e ? std::atoi(e) : 0xab; }  // "uninitialised" memory pattern
 inline void* dmalloc(size_t n) { void* p = std::malloc(n ? n : 1); if (!p) throw Error("emu malloc failed"); std::memset(p, poisonByte(), n); return p; }
 inline void  dfree(void* p) { std::free(p); }
+inline void* dmallocFine(size_t n) { return dmalloc(n); }
 inline void  h2d(void* d, const void* h, size_t n) { if (n) std::memcpy(d, h, n); }
 inline void  d2h(void* h, const void* d, size_t n) { if (n) std::memcpy(h, d, n); }
 inline void  d2hAsync(void* h, const void* d, size_t n) { if (n) std::memcpy(h, d, n); }
@@ -93,6 +94,14 @@ inline void* dmalloc(size_t n)
   return p;
 }
 inline void dfree(void* p) { (void)hipFree(p); }
+/// fine-grained device memory: not cached in the (per-XCD, mutually incoherent) L2s, so a kernel that polls it sees a value the
+/// copy engine writes while the kernel runs
+inline void* dmallocFine(size_t n)
+{
+  void* p = nullptr;
+  check(hipExtMallocWithFlags(&p, n ? n : 1, hipDeviceMallocFinegrained), "hipExtMallocWithFlags(finegrained)");
+  return p;
+}
 /// a non-blocking stream.  Every pipeline object / context owns one and makes it the calling thread's CURRENT stream for
 /// the duration of an API call (ScopedStream): copies, memsets, launches and events below all go to the current stream, so
 /// pipelines driven by different host threads overlap on the device (nothing here touches the null stream or

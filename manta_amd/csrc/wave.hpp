@@ -87,6 +87,10 @@ WV_DEV unsigned long long atomic_add(unsigned long long* p, unsigned long long v
 /// L1-bypassing load of a word other lanes update with atomics
 WV_DEV unsigned atomic_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 WV_DEV unsigned long long atomic_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+/// system-scope load of a word in fine-grained memory that the copy engine updates while the kernel runs
+WV_DEV unsigned atomic_load_system(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+/// back-off inside a polling loop
+WV_DEV void sleep() { __builtin_amdgcn_s_sleep(32); }
 /// drop this CU's (possibly stale) L1 lines: needed before plain re-reads of memory that was updated by L2 atomics
 WV_DEV void fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 

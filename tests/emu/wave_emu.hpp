@@ -194,6 +194,8 @@ inline unsigned long long atomic_or(unsigned long long* p, unsigned long long v)
 inline unsigned long long atomic_add(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
 inline unsigned atomic_load(const unsigned* p) { return *p; }
 inline unsigned long long atomic_load(const unsigned long long* p) { return *p; }
+inline unsigned atomic_load_system(const unsigned* p) { return *p; }
+inline void sleep() {}
 inline void fence_acquire() {}
 
 inline uint64_t clock() { return 0; }
