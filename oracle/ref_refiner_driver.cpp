@@ -432,7 +432,9 @@ REF_EXPORT int ref_candidate_vcf_header(
     if (fd >= 0) close(fd);
     const std::string vcfName(tmpl);
     {
-      const VcfWriterCandidateSV writer(referenceFilename, header, vcfName, isOutputContig != 0);
+      const bool                 oc(isOutputContig != 0);  // the writer keeps a REFERENCE to this flag (format/VcfWriterSV.hpp:44)
+      const std::string          refName(referenceFilename);
+      const VcfWriterCandidateSV writer(refName, header, vcfName, oc);
       std::vector<std::string>   samples;
       for (int i = 0; i < nSamples; ++i) samples.emplace_back(sampleNames[i]);
       writer.writeHeader(progName, progVersion, samples);
