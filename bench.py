@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--loci", type=int, default=0, help="loci per GPU (default: 10000 smallsv = config 2; 16384 spanning)")
+    ap.add_argument("--loci", type=int, default=0, help="loci per GPU (default: 10000 smallsv = config 2; 65536 spanning)")
     ap.add_argument("--workload", choices=("smallsv", "spanning"), default="smallsv",
                     help="smallsv = BASELINE config[1] (the metric's configuration, default); spanning = config[4] shape "
                          "(breakend loci, 200 reads x 250 bp, mixed k), an extra measurement")
@@ -143,7 +143,7 @@ def main():
     from synth import config2_batch, config5_locus, unpack_locus
 
     spanning = args.workload == "spanning"
-    n_loci = args.loci or (16384 if spanning else 10000)
+    n_loci = args.loci or (65536 if spanning else 10000)
     lib = Lib(device=local_rank)
     # measured on MI355X: one block's kernels already fill the device and concurrent blocks contend for the
     # per-wave HBM slabs, so the default is ONE block per call; --workers / --block-loci select the pipelined form
@@ -154,13 +154,24 @@ def main():
     if spanning:
         distinct = min(n_loci, 2048)  # generating a config-5 locus costs ~10 ms of numpy: larger batches repeat the 2048 digest loci
         base = [config5_locus(i, seed0=555000 + 1000003 * rank) for i in range(distinct)]
+        reps = (n_loci + distinct - 1) // distinct
+        n_loci = reps * distinct
         loci = [base[i % distinct] for i in range(n_loci)]
-        cuts = [(100, 100, 100, 100)] * n_loci
-        batch = pack_spanning([l[0] for l in loci], [l[1] for l in loci], [l[2] for l in loci], cuts)
-        min_wl = np.array([l[3] for l in loci], dtype=np.uint32)
-        max_wl = np.array([l[4] for l in loci], dtype=np.uint32)
+        cuts = [(100, 100, 100, 100)] * distinct
+        pb = pack_spanning([l[0] for l in base], [l[1] for l in base], [l[2] for l in base], cuts)
+
+        def tile_off(off):  # offsets of `reps` copies laid end to end
+            body = off[:-1]
+            return np.concatenate([body + off[-1] * np.uint64(r) for r in range(reps)] + [off[-1:] * np.uint64(reps)]).astype(off.dtype)
+        nb, n1, n2 = int(pb[1][-1]), int(pb[4][-1]), int(pb[6][-1])
+        begin = np.concatenate([pb[2][:-1] + pb[2][-1] * np.uint32(r) for r in range(reps)] + [pb[2][-1:] * np.uint32(reps)]).astype(np.uint32)
+        batch = (np.tile(pb[0][:nb], reps), tile_off(pb[1]), begin, np.tile(pb[3][:n1], reps), tile_off(pb[4]), np.tile(pb[5][:n2], reps),
+                 tile_off(pb[6]), np.tile(pb[7], (reps, 1)))
+        batch = tuple(np.ascontiguousarray(a) for a in batch)
+        min_wl = np.tile(np.array([l[3] for l in base], dtype=np.uint32), reps)
+        max_wl = np.tile(np.array([l[4] for l in base], dtype=np.uint32), reps)
         opts = asm_opts(minWordLength=41, minContigLength=75)
-        out = BatchOutput(lib, "spanning", n_loci, 10, 16384 * n_loci + (1 << 20), 256 * n_loci + 4096, 1024 * n_loci + 4096,
+        out = BatchOutput(lib, "spanning", n_loci, 10, 8192 * n_loci + (1 << 20), 256 * n_loci + 4096, 1024 * n_loci + 4096,
                           pinned=not args.pageable)
     else:
         batch = config2_batch(n_loci, seed=12345 + 1000003 * rank)
@@ -276,7 +287,7 @@ def main():
         avg_launch_ms = dom_ms / dom_launches
         achieved = (dom_bytes / dom_launches) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic_spanning.json" if spanning else "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))

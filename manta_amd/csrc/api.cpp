@@ -1569,8 +1569,6 @@ int manta_spanning_run(manta_spanning_t* b)
     uint32_t*       dBuckets2 = b->dBucketIds2.as<uint32_t>(nSlots * kNumESet);
     // [0..15] counts, [16..31] maxref, [32..47] counts2, [48..63] maxref2, [64..65] cigar_used, [72..87] / [88..103] align counters
     uint32_t*      dSmall   = b->dSmall.as<uint32_t>(128);
-    const uint64_t cigarCap = 2 * nSlots * (4ull * std::min<uint64_t>(as.maxContigLen, 4096) + 16);
-    uint32_t*      dCigar   = b->dCigar.as<uint32_t>(cigarCap + 16);
     rt::dzero(dSmall, sizeof(uint32_t) * 128);
     rt::dzero(dResults, sizeof(AlignResultDev) * nSlots);
     rt::dzero(dResults2, sizeof(AlignResultDev) * nSlots);
@@ -1586,6 +1584,16 @@ int manta_spanning_run(manta_spanning_t* b)
     as.launch();
     b->evAsm.record();
     stage("assembled");
+    // CIGAR scratch, sized from what the assembler produced: a task takes 4 * contig length + 16 words (spanFileTask), every
+    // contig is aligned at most twice (second round: spanning_realign_kernel), and the text arena counter bounds the summed
+    // contig lengths.  (A fixed worst case of max_contig_len per slot is ~40x the real need at 200 x 250 bp loci.)
+    uint64_t asmCnt[3];
+    rt::d2h(asmCnt, as.dCnt, sizeof(asmCnt));
+    const uint64_t cigarCap = 2 * (4ull * std::min<uint64_t>(asmCnt[1], as.devSeqCap) + 16ull * nSlots) + 64;
+    if (cigarCap + 16 > 0xffffffffull)
+      return fail(ctx, MANTA_E_UNSUPPORTED, "manta_spanning_run: alignment scratch of this block exceeds 2^32 words; use smaller blocks "
+                                         "(manta_spanning_batch splits a batch into blocks, manta_batch_plan_t::block_loci)");
+    uint32_t* dCigar = b->dCigar.as<uint32_t>(cigarCap + 16);
 
     SpanParams S;
     S.loci               = as.dLoci;

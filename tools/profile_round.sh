@@ -26,6 +26,8 @@ unset MANTA_AMD_ASM_PATH
 if [ "$2" = "spanning" ]; then
   timeout 600 $B --workload spanning --steps 2 --warmup 1 > $O/bench_spanning_line.json 2> $O/bench_spanning.err
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_spanning -o bench -- $B --workload spanning --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/spanning_pmc_fetch -o p -- $B --workload spanning --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/spanning_pmc_write -o p -- $B --workload spanning --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
 fi
 # keep only the small files (gpurun_out merges back <= 64 MiB)
 find $O -name "*_kernel_trace.csv" -size +8M -delete

@@ -56,5 +56,27 @@ for k, v in per.items():
 for k, v in agg.items():
     traffic[k] = int(v)
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+# the spanning workload's passes (tools/profile_round.sh <tag> spanning)
+sper, slaunch = {}, {}
+for d in ("spanning_pmc_fetch", "spanning_pmc_write"):
+    for f in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
+        seen = {}
+        for row in csv.DictReader(open(f)):
+            k = short(row["Kernel_Name"])
+            if "rocclr" in k:
+                continue
+            sper.setdefault(k, {}).setdefault(row["Counter_Name"], 0.0)
+            sper[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            seen.setdefault(k, set()).add(row.get("Dispatch_Id", row.get("Correlation_Id", "")))
+        for k, ids in seen.items():
+            slaunch[k] = max(slaunch.get(k, 0), len(ids))
+if sper:
+    st = {"loci": 16384, "workload": "spanning", "note": traffic["note"]}
+    for k, v in sper.items():
+        name = "align_kernel<JUMP>" if k.startswith("align_kernel<2") else k
+        n = 1 if name.startswith("align_kernel") else max(1, slaunch.get(k, 1))
+        st[name] = int(st.get(name, 0) + (v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 / n)
+    json.dump(st, open(os.path.join(dst, "traffic_spanning.json"), "w"), indent=1)
+    print(json.dumps(st, indent=1))
 print(json.dumps(traffic, indent=1))
 print(line[:300])
