@@ -326,8 +326,11 @@ void manta_host_free(void* p);
 #define MANTA_BATCH_NO_STREAMED_UPLOAD 2u /* wait for a block's read bases before its kernels start (default: the assembler
                                              is launched at once and consumes the bases chunk by chunk as they land) */
 typedef struct {
-  uint32_t block_loci; /* 0 = 2048 */
-  uint32_t n_workers;  /* 0 = 4 */
+  uint32_t block_loci; /* 0 = automatic: the whole batch as one block when it fits the device-side budget (measured optimum,
+                          DESIGN.md 5), otherwise equal blocks of at most 65536 loci / 4 GiB of read bases */
+  uint32_t n_workers;  /* 0 = 1: blocks one after the other (measured optimum: two blocks' kernels sharing the device lose more
+                          than the hidden transfers win).  With several workers at most one block assembles and
+                          one block aligns at any time (stage gates); the others upload / download / compact meanwhile */
   uint32_t flags;      /* MANTA_BATCH_* */
   uint32_t reserved;
 } manta_batch_plan_t;

@@ -736,8 +736,10 @@ inline uint64_t alignPtrSlabBytes(const int kind, const int E, const uint64_t to
   return (totalRefLen + 64 + 1) * uint64_t(E) * 64 * cellBytes;
 }
 
+// E = 8 is held to 128 VGPRs (it needs 137 unconstrained): 4 waves per SIMD, and it still fits the slot a pipelined
+// batch call's assembler leaves free (api.cpp: StageGates)
 template <int KIND, int E>
-WV_KERNEL void align_kernel(const AlignParams P)
+WV_KERNEL_OCC(E == 8 ? 4 : 1) void align_kernel(const AlignParams P)
 {
   uint8_t*       slab   = P.ptr_ws + uint64_t(wv::block()) * P.ptr_ws_stride;
   const unsigned nTasks = P.n_tasks_dev ? *P.n_tasks_dev : P.n_tasks;

@@ -107,6 +107,7 @@ struct manta_ctx {
   std::vector<manta_spanning*> spanPool;
   ~manta_ctx();
   std::vector<uint32_t> growthSize, growthBuckets;  // libstdc++ bucket growth schedule (see repeat_exact.hpp)
+  std::once_flag         growthOnce;
 };
 
 namespace {
@@ -289,6 +290,7 @@ struct AsmStage {
   std::vector<uint32_t> locusMinWl, locusMaxWl;
   std::vector<uint32_t> order;  // loci by decreasing estimated cost: the work queue hands out the long ones first
   uint32_t              maxWordLen = 0;
+  int                   wavesPerCuCap = 0;  // > 0: leave wave slots free for another block's aligners (pipelined batch calls)
   bool                  useLds = false;  // assemble_lds_kernel (LDS-resident graph, general path as in-kernel fallback)
   int                   gridLds = 1;
   // packed piles of the uploaded batch (manta_packed_piles_t), device side; dPlCodes == nullptr: 1 byte per base input
@@ -377,7 +379,8 @@ struct AsmStage {
     // that keep several batches resident at once)
     const size_t wsCapGb  = std::getenv("MANTA_AMD_WS_BUDGET_GB") ? size_t(std::max(1, std::atoi(std::getenv("MANTA_AMD_WS_BUDGET_GB")))) : size_t(64);
     const size_t wsBudget = workspaceBudget(wsCapGb << 30);
-    const int wavesPerCu  = std::getenv("MANTA_AMD_ASM_WAVES_PER_CU") ? std::atoi(std::getenv("MANTA_AMD_ASM_WAVES_PER_CU")) : 16;
+    int wavesPerCu = std::getenv("MANTA_AMD_ASM_WAVES_PER_CU") ? std::atoi(std::getenv("MANTA_AMD_ASM_WAVES_PER_CU")) : 16;
+    if (wavesPerCuCap > 0) wavesPerCu = std::min(wavesPerCu, wavesPerCuCap);
     grid                  = int(std::min<uint64_t>(n_loci, uint64_t(std::max(1, ctx->cuCount * wavesPerCu))));
     grid                  = rt::roundGrid(int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(grid), wsBudget / stride))));
     // The LDS-resident fast path (asm_lds.hpp) is opt-in: MANTA_AMD_ASM_PATH=lds.  Measured on MI355X: it cuts
@@ -394,7 +397,7 @@ struct AsmStage {
     const uint64_t worstLocusSeq = uint64_t(opt.max_assembly_count) * maxContigLen + uint64_t(nCandMax) * pseudoLen;
     devSeqCap  = uint64_t(n_loci) * std::min<uint64_t>(worstLocusSeq, 65536) + worstLocusSeq + 4096;
     devBitsCap = bitsBound + 64;
-    if (ctx->growthSize.empty()) recordGrowthSchedule(ctx->growthSize, ctx->growthBuckets, 4u << 20);
+    std::call_once(ctx->growthOnce, [&] { recordGrowthSchedule(ctx->growthSize, ctx->growthBuckets, 4u << 20); });  // (workers of a batch call plan concurrently)
     return MANTA_OK;
   }
 
@@ -683,7 +686,7 @@ struct AsmStage {
       o.first_contig = uint32_t(contigBase + nContigs);
       if (o.status != MANTA_OK) {
         worst = o.status;
-        if (std::getenv("MANTA_AMD_DEBUG"))
+        if (std::getenv("MANTA_AMD_DEBUG") || std::getenv("MANTA_AMD_DEBUG_STATUS"))
           std::fprintf(stderr, "manta_amd: locus %u device status %d (k=%u iter=%u)\n", l, h.status, h.final_word_length, h.n_iterations);
         continue;
       }
@@ -1163,7 +1166,24 @@ int manta_smallsv_upload_piles(
   }
 }
 
-int manta_smallsv_run(manta_smallsv_t* b)
+}  // extern "C"
+
+/// Stage gates of a whole-batch call with several workers: at most one block assembles and at most one block
+/// aligns at any time, so that block B's (memory-bound) assembler overlaps block A's (VALU-bound) aligners and transfers
+/// instead of two persistent assemblers fighting for the same wave slots.
+/// assembler waves per CU while another block's aligners share the device: 3 of the 4 wave slots per SIMD (128 VGPRs each)
+static const int kPipelinedAsmWavesPerCu = std::getenv("MANTA_AMD_PIPELINED_ASM_WAVES") ? std::atoi(std::getenv("MANTA_AMD_PIPELINED_ASM_WAVES")) : 12;
+struct StageGates {
+  std::mutex asmMu, alignMu;
+};
+static std::mutex g_streamedAsmMu;  // see smallsvRunImpl
+struct GateLock {
+  std::unique_lock<std::mutex> l;
+  GateLock(StageGates* g, std::mutex StageGates::*m) { if (g) l = std::unique_lock<std::mutex>(g->*m); }
+  void release() { if (l.owns_lock()) l.unlock(); }
+};
+
+int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
 {
   if (!b) return MANTA_E_INVALID_ARG;
   manta_ctx_t* ctx = b->ctx;
@@ -1196,10 +1216,20 @@ int manta_smallsv_run(manta_smallsv_t* b)
       std::fflush(stderr);
     };
     stage("start");
-    b->evStart.record();
-    as.launch();
-    b->evAsm.record();
+    {
+      GateLock only(gates, &StageGates::asmMu);
+      // A streamed-upload assembler polls for chunks whose copies may need a free workgroup slot (launch() leaves some);
+      // a second persistent assembler would take exactly those slots and both would spin until the kernels' time-out.
+      // Process-wide: never two streamed assemblers on the device at once.
+      std::unique_lock<std::mutex> streamedOnly(g_streamedAsmMu, std::defer_lock);
+      if (as.streaming) streamedOnly.lock();
+      b->evStart.record();
+      as.launch();
+      b->evAsm.record();
+      if (gates || as.streaming) rt::sync();  // the gate opens when the assembler has left the device
+    }
     stage("assembled");
+    GateLock alignOnly(gates, &StageGates::alignMu);
 
     ScheduleParams S;
     S.loci               = as.dLoci;
@@ -1289,6 +1319,7 @@ int manta_smallsv_run(manta_smallsv_t* b)
     launchPack(b, dTasks, nullptr, dResults, nullptr, dInfo, nullptr, dCigar, cigarCap);
     b->evAlign.record();
     rt::sync();
+    alignOnly.release();
     if (as.streaming) {  // all chunks were consumed by the kernel, so this returns at once; it closes the stream's error state
       rt::ScopedStream onCopy(b->copy);
       rt::sync();
@@ -1304,6 +1335,10 @@ int manta_smallsv_run(manta_smallsv_t* b)
     return fail(ctx, MANTA_E_HIP, e.what());
   }
 }
+
+extern "C" {
+
+int manta_smallsv_run(manta_smallsv_t* b) { return smallsvRunImpl(b, nullptr); }
 
 int manta_smallsv_stats(const manta_smallsv_t* b, manta_smallsv_stats_t* stats)
 {
@@ -1398,6 +1433,8 @@ int smallsvCompact(
       if (h.info_status != 0 || h.bucket < 0 || h.res_status != 0) {
         a.align.status = (h.info_status == 5) ? MANTA_E_DEVICE_FAULT : MANTA_E_UNSUPPORTED;
         worst          = a.align.status;
+        if (std::getenv("MANTA_AMD_DEBUG") || std::getenv("MANTA_AMD_DEBUG_STATUS"))
+          std::fprintf(stderr, "manta_amd: locus %u contig %u schedule status %d bucket %d align status %d\n", l, c, h.info_status, h.bucket, h.res_status);
         continue;
       }
       const uint64_t n = h.cigar1_len;
@@ -1549,7 +1586,9 @@ int manta_spanning_upload_piles(
   }
 }
 
-int manta_spanning_run(manta_spanning_t* b)
+}  // extern "C"
+
+int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
 {
   if (!b) return MANTA_E_INVALID_ARG;
   manta_ctx_t* ctx = b->ctx;
@@ -1580,15 +1619,19 @@ int manta_spanning_run(manta_spanning_t* b)
       std::fprintf(stderr, "manta_amd: spanning_run %s\n", what);
       std::fflush(stderr);
     };
-    b->evStart.record();
-    as.launch();
-    b->evAsm.record();
+    uint64_t asmCnt[3];
+    {
+      GateLock only(gates, &StageGates::asmMu);
+      b->evStart.record();
+      as.launch();
+      b->evAsm.record();
+      rt::d2h(asmCnt, as.dCnt, sizeof(asmCnt));  // (waits for the assembler)
+    }
     stage("assembled");
+    GateLock alignOnly(gates, &StageGates::alignMu);
     // CIGAR scratch, sized from what the assembler produced: a task takes 4 * contig length + 16 words (spanFileTask), every
     // contig is aligned at most twice (second round: spanning_realign_kernel), and the text arena counter bounds the summed
     // contig lengths.  (A fixed worst case of max_contig_len per slot is ~40x the real need at 200 x 250 bp loci.)
-    uint64_t asmCnt[3];
-    rt::d2h(asmCnt, as.dCnt, sizeof(asmCnt));
     const uint64_t cigarCap = 2 * (4ull * std::min<uint64_t>(asmCnt[1], as.devSeqCap) + 16ull * nSlots) + 64;
     if (cigarCap + 16 > 0xffffffffull)
       return fail(ctx, MANTA_E_UNSUPPORTED, "manta_spanning_run: alignment scratch of this block exceeds 2^32 words; use smaller blocks "
@@ -1692,6 +1735,7 @@ int manta_spanning_run(manta_spanning_t* b)
     launchPack(b, dTasks, dTasks2, dResults, dResults2, nullptr, dInfo, dCigar, cigarCap);
     b->evAlign.record();
     rt::sync();
+    alignOnly.release();
     stage("aligned round 2");
     b->stats.assemble_ms = rt::elapsedMs(b->evStart, b->evAsm);
     b->stats.schedule_ms = rt::elapsedMs(b->evAsm, b->evSched);
@@ -1703,6 +1747,10 @@ int manta_spanning_run(manta_spanning_t* b)
     return fail(ctx, MANTA_E_HIP, e.what());
   }
 }
+
+extern "C" {
+
+int manta_spanning_run(manta_spanning_t* b) { return spanningRunImpl(b, nullptr); }
 
 int manta_spanning_stats(const manta_spanning_t* b, manta_smallsv_stats_t* stats)
 {
@@ -1844,6 +1892,8 @@ struct BatchShared {
   std::mutex            mu;
   std::mutex            kernelMu;  // MANTA_BATCH_SERIAL_KERNELS
   bool                  serialKernels = false;
+  StageGates            gates;     // used whenever the call has more than one worker
+  bool                  pipelineStages = false;
   int                   fatal = MANTA_OK, worst = MANTA_OK;
   std::string           msg;
   manta_batch_stats_t   st{};
@@ -1866,6 +1916,16 @@ struct BatchShared {
     return fatal != MANTA_OK;
   }
 };
+
+/// default block size of a whole-batch call: one block per call is the measured optimum as long as the
+/// device-side arenas stay moderate; beyond that, equal blocks of at most 65536 loci / 4 GiB of read bases
+uint32_t autoBlockLoci(const uint32_t n_loci, const uint64_t totalBases)
+{
+  const uint64_t byLoci  = (uint64_t(n_loci) + 65535) / 65536;
+  const uint64_t byBases = (totalBases + (uint64_t(4) << 30) - 1) / (uint64_t(4) << 30);
+  const uint64_t nBlocks = std::max<uint64_t>(1, std::max(byLoci, byBases));
+  return uint32_t((uint64_t(n_loci) + nBlocks - 1) / nBlocks);
+}
 
 /// contiguous blocks of `blockLoci` loci, ordered by decreasing cost (reads x bases, the same estimate the kernels'
 /// work queue uses): EdgeRetrieverBin.cpp:38-57 hands out contiguous edge ranges too, but statically
@@ -1952,12 +2012,14 @@ int smallsvBatchImpl(
   for (uint32_t l = 0; l < n_loci; ++l)
     if (locus_read_begin[l + 1] < locus_read_begin[l] || ref_off[l + 1] < ref_off[l])
       return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_batch: offsets not monotone");
-  const uint32_t blockLoci = (plan && plan->block_loci) ? plan->block_loci : 2048u;
+  const uint64_t totalBases = piles ? 0 : read_off[locus_read_begin[n_loci]] - read_off[locus_read_begin[0]];
+  const uint32_t blockLoci  = (plan && plan->block_loci) ? plan->block_loci : autoBlockLoci(n_loci, totalBases);
   BatchShared    sh;
-  sh.serialKernels = plan && (plan->flags & MANTA_BATCH_SERIAL_KERNELS);
+  sh.serialKernels  = plan && (plan->flags & MANTA_BATCH_SERIAL_KERNELS);
   planBlocks(sh, n_loci, blockLoci, piles ? nullptr : read_off, locus_read_begin, piles ? piles->read_len : nullptr);
   const uint32_t nBlocks  = uint32_t(sh.blockOrder.size());
-  const uint32_t nWorkers = std::max(1u, std::min(nBlocks, (plan && plan->n_workers) ? plan->n_workers : 4u));
+  const uint32_t nWorkers = std::max(1u, std::min(nBlocks, (plan && plan->n_workers) ? plan->n_workers : 1u));
+  sh.pipelineStages       = nWorkers > 1;
   try {
     rt::setDevice(ctx->deviceId);
     while (ctx->smallPool.size() < nWorkers) ctx->smallPool.push_back(new manta_smallsv(ctx));
@@ -1973,6 +2035,7 @@ int smallsvBatchImpl(
       b->scores        = *scores;
       b->largeIndel    = large_indel_score;
       b->streamUploads = !(plan && (plan->flags & MANTA_BATCH_NO_STREAMED_UPLOAD));
+      b->asmStage.wavesPerCuCap = sh.pipelineStages ? kPipelinedAsmWavesPerCu : 0;
       std::vector<uint64_t> rOff, fOff;
       std::vector<uint32_t> lBeg;
       while (!sh.stop()) {
@@ -2014,7 +2077,7 @@ int smallsvBatchImpl(
         {
           std::unique_lock<std::mutex> only(sh.kernelMu, std::defer_lock);
           if (sh.serialKernels) only.lock();
-          rc = manta_smallsv_run(b);
+          rc = smallsvRunImpl(b, sh.pipelineStages ? &sh.gates : nullptr);
         }
         if (rc != MANTA_OK) {
           sh.error(rc, lastErrorOf(ctx), true);
@@ -2126,12 +2189,14 @@ int manta_spanning_batch(
   for (uint32_t l = 0; l < n_loci; ++l)
     if (locus_read_begin[l + 1] < locus_read_begin[l] || ref1_off[l + 1] < ref1_off[l] || ref2_off[l + 1] < ref2_off[l])
       return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_batch: offsets not monotone");
-  const uint32_t blockLoci = (plan && plan->block_loci) ? plan->block_loci : 2048u;
+  const uint32_t blockLoci = (plan && plan->block_loci) ? plan->block_loci
+                                                        : autoBlockLoci(n_loci, read_off[locus_read_begin[n_loci]] - read_off[locus_read_begin[0]]);
   BatchShared    sh;
-  sh.serialKernels = plan && (plan->flags & MANTA_BATCH_SERIAL_KERNELS);
+  sh.serialKernels  = plan && (plan->flags & MANTA_BATCH_SERIAL_KERNELS);
   planBlocks(sh, n_loci, blockLoci, read_off, locus_read_begin);
   const uint32_t nBlocks  = uint32_t(sh.blockOrder.size());
-  const uint32_t nWorkers = std::max(1u, std::min(nBlocks, (plan && plan->n_workers) ? plan->n_workers : 4u));
+  const uint32_t nWorkers = std::max(1u, std::min(nBlocks, (plan && plan->n_workers) ? plan->n_workers : 1u));
+  sh.pipelineStages       = nWorkers > 1;
   try {
     rt::setDevice(ctx->deviceId);
     while (ctx->spanPool.size() < nWorkers) ctx->spanPool.push_back(new manta_spanning(ctx));
@@ -2146,6 +2211,7 @@ int manta_spanning_batch(
       b->opt       = *opt;
       b->scores    = *scores;
       b->jumpScore = jump_score;
+      b->asmStage.wavesPerCuCap = sh.pipelineStages ? kPipelinedAsmWavesPerCu : 0;
       std::vector<uint64_t> rOff, f1Off, f2Off;
       std::vector<uint32_t> lBeg;
       while (!sh.stop()) {
@@ -2179,7 +2245,7 @@ int manta_spanning_batch(
         {
           std::unique_lock<std::mutex> only(sh.kernelMu, std::defer_lock);
           if (sh.serialKernels) only.lock();
-          rc = manta_spanning_run(b);
+          rc = spanningRunImpl(b, sh.pipelineStages ? &sh.gates : nullptr);
         }
         if (rc != MANTA_OK) {
           sh.error(rc, lastErrorOf(ctx), true);

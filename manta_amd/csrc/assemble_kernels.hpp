@@ -1464,8 +1464,9 @@ struct Assembler {
 
 namespace manta_dev {
 
-/// streamed upload: wait until the chunk holding `locus` has landed.  Polls an agent-scope counter with back-off; gives
-/// up after ~4 s of shader clocks (a copy that never completes must not hang the device).
+/// streamed upload: wait until the chunk holding `locus` has landed.  Polls a system-scope counter with back-off; gives
+/// up after ~1 minute of shader clocks (a copy that never completes must not hang the device for good).  The host side
+/// never runs two streamed assemblers at once (api.cpp: g_streamedAsmMu), so a copy always finds a free workgroup slot.
 WV_DEV bool asmWaitUploaded(const AsmParams& P, const unsigned locus)
 {
   const unsigned need = locus / P.chunk_loci + 1;
@@ -1474,7 +1475,7 @@ WV_DEV bool asmWaitUploaded(const AsmParams& P, const unsigned locus)
     const uint64_t t0 = wv::clock();
     while (wv::atomic_load_system(P.upload_chunks_done) < need) {
       wv::sleep();
-      if (wv::clock() - t0 > 10000000000ull) {
+      if (wv::clock() - t0 > 150000000000ull) {
         ok = false;
         break;
       }

@@ -79,9 +79,17 @@ def test_emulated_spanning_batch_mixed_word_lengths(emu, oracle):
     check_spanning(emu, oracle, 7, block=3, workers=2)
 
 
+def test_emulated_batches_with_stage_gates(emu, oracle):
+    """several workers: the blocks take turns in the assemble and align stages (stage gates); results are the same"""
+    check_smallsv(emu, oracle, 11, block=3, workers=3, mixed=True)
+    check_spanning(emu, oracle, 7, block=2, workers=2)
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
 def test_gpu_batch_calls(gpu, oracle):
     check_smallsv(gpu, oracle, 300, block=64, workers=4, mixed=False)
     check_smallsv(gpu, oracle, 96, block=32, workers=3, mixed=True)
     check_spanning(gpu, oracle, 60, block=16, workers=4)
+    check_smallsv(gpu, oracle, 300, block=64, workers=2, mixed=True)
+    check_spanning(gpu, oracle, 60, block=16, workers=2)
