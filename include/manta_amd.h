@@ -146,6 +146,32 @@ int manta_assemble_batch(
     uint64_t* bits_arena_used);
 
 /* ------------------------------------------------------------------------------------------------------
+ * SmallAssembler.  Replaces
+ *   void runSmallAssembler(const SmallAssemblerOptions&, const AssemblyReadInput& reads,
+ *                          AssemblyReadOutput& assembledReadInfo, Assembly& contigs)
+ *                                                   assembly/SmallAssembler.hpp:43-47 (SmallAssembler.cpp:622-685)
+ * for a batch of read piles.  (The reference has no production caller for this assembler; its unit tests are
+ * assembly/test/SmallAssemblerTest.cpp.)  Input layout and output records as manta_assemble_batch, with
+ *   - n_words = ceil(reads / 64), no pseudo reads;
+ *   - seed_read_count = contig.seedReadCount (SmallAssembler.cpp:577-580);
+ *   - n_contigs = contigs.size() + 1: the LAST record of a locus (seq_len 0, seed_read_count 0xffffffff) carries the reads the
+ *     reference marks isUsed && isFiltered (repeat reads at the last word length, :496-503) in its support bitset.
+ *   readInfo: read r isUsed <=> it is in that set or in some contig's support; contigIds = {the one contig that holds it}.
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* options/SmallAssemblerOptions.hpp:24-56; alphabet "ACGT"; minQval / maxError / minContigLength are not read by the assembler */
+typedef struct {
+  uint32_t min_word_length, max_word_length, word_step_size, min_contig_length;
+  uint32_t min_coverage, min_conservative_coverage, min_seed_reads, max_assembly_iterations; /* <= 31 */
+} manta_small_asm_options_t;
+
+int manta_small_assemble_batch(
+    manta_ctx_t* ctx, const manta_small_asm_options_t* opt, uint32_t n_loci, const uint8_t* bases, const uint64_t* read_off,
+    const uint32_t* locus_read_begin, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, uint64_t contigs_cap,
+    uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
+    uint64_t* bits_arena_used);
+
+/* ------------------------------------------------------------------------------------------------------
  * Fused "small SV" locus pipeline: the arithmetic core of
  *   SVCandidateAssemblyRefiner::getSmallSVAssembly   applications/GenerateSVCandidates/SVCandidateAssemblyRefiner.cpp:1860-2038
  * for a batch of candidate loci:  runIterativeAssembler (:1921-1926 via SVCandidateAssembler.cpp:661-675)

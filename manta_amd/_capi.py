@@ -222,6 +222,74 @@ def _assemble_batch(self, opts, loci_reads, strict=True):
 Lib.assemble_batch = _assemble_batch
 
 
+class SmallAsmOptions(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in ("min_word_length", "max_word_length", "word_step_size", "min_contig_length",
+                                               "min_coverage", "min_conservative_coverage", "min_seed_reads",
+                                               "max_assembly_iterations")]
+
+
+SMALL_FILTERED_MARK = 0xffffffff
+
+
+def _small_assemble_batch(self, opts, loci_reads, strict=True):
+    """manta_small_assemble_batch (runSmallAssembler).  opts: 8 values in manta_small_asm_options_t order.  One dict per
+    locus: contigs as assemble_batch, plus `filtered` = the reads the reference marks isUsed && isFiltered."""
+    bases, read_off, begin = pack_loci(loci_reads)
+    n_loci = len(loci_reads)
+    o = SmallAsmOptions(*opts)
+    res = (AsmLocusResult * max(1, n_loci))()
+    ccap = n_loci * (o.max_assembly_iterations + 1) + 1
+    contigs = (AsmContig * ccap)()
+    seq_cap = int(read_off[-1]) * 2 + 65536 * max(1, n_loci)
+    seq = np.zeros(seq_cap, dtype=np.uint8)
+    bits_cap = n_loci * ((o.max_assembly_iterations + 1) * 2 * 16 + 64) + 64
+    bits = np.zeros(bits_cap, dtype=np.uint64)
+    su, bu = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    rc = self.lib.manta_small_assemble_batch(self.ctx, ctypes.byref(o), n_loci, bases.ctypes.data_as(ctypes.c_void_p),
+                                             read_off.ctypes.data_as(ctypes.c_void_p), begin.ctypes.data_as(ctypes.c_void_p), res,
+                                             contigs, ctypes.c_uint64(ccap), seq.ctypes.data_as(ctypes.c_void_p),
+                                             ctypes.c_uint64(seq_cap), ctypes.byref(su), bits.ctypes.data_as(ctypes.c_void_p),
+                                             ctypes.c_uint64(bits_cap), ctypes.byref(bu))
+    self._check(rc, allow=() if strict else (-5, -6, -7))
+    out = []
+    for l in range(n_loci):
+        r = res[l]
+        d = dict(status=r.status, n_reads=len(loci_reads[l]), n_words=r.n_words, final_word_length=r.final_word_length,
+                 n_iterations=r.n_iterations, contigs=[], pseudo=[], filtered=[])
+        if r.status == 0:
+            for c in range(r.n_contigs):
+                cc = contigs[r.first_contig + c]
+                support = _bits_members(bits[cc.support_off:cc.support_off + r.n_words])
+                if cc.seed_read_count == SMALL_FILTERED_MARK:
+                    assert c == r.n_contigs - 1 and cc.seq_len == 0
+                    d["filtered"] = support
+                    continue
+                d["contigs"].append(dict(seq=seq[cc.seq_off:cc.seq_off + cc.seq_len].tobytes().decode("latin-1"),
+                                         seed=cc.seed_read_count, cons=(cc.conservative_begin, cc.conservative_end),
+                                         support=support,
+                                         reject=_bits_members(bits[cc.reject_off:cc.reject_off + r.n_words])))
+        out.append(d)
+    return out
+
+
+Lib.small_assemble_batch = _small_assemble_batch
+
+
+def small_assembly_text(d):
+    """canonical text of oracle/ref_driver.cpp (ref_small_assemble) for one small_assemble_batch locus dict"""
+    lines = ["contigs %d" % len(d["contigs"])]
+    for i, c in enumerate(d["contigs"]):
+        lines.append("contig %d seq=%s seed=%d cons=%d,%d support=%s reject=%s" % (
+            i, c["seq"], c["seed"], c["cons"][0], c["cons"][1], ",".join(map(str, c["support"])), ",".join(map(str, c["reject"]))))
+    lines.append("reads %d normal %d" % (d["n_reads"], d["n_reads"]))
+    filt = set(d["filtered"])
+    for r in range(d["n_reads"]):
+        ids = [i for i, c in enumerate(d["contigs"]) if r in c["support"]][:1]
+        lines.append("read %d used=%d filtered=%d pseudo=0 ids=%s" % (r, 1 if (ids or r in filt) else 0, 1 if r in filt else 0,
+                                                                      ",".join(map(str, ids))))
+    return "\n".join(lines) + "\n"
+
+
 def _decode_loci(kind, n_reads, res, contigs, aligns, seq, bits, cig):
     """raw result records/arenas -> one dict per locus (kind: "smallsv" | "spanning")"""
     out = []

@@ -18,6 +18,7 @@
 #include "align_kernels.hpp"
 #include "assemble_kernels.hpp"
 #include "asm_lds.hpp"
+#include "small_asm.hpp"
 #include "pipeline_kernels.hpp"
 #include "split_kernels.hpp"
 #include <unordered_map>
@@ -290,6 +291,8 @@ struct AsmStage {
   std::vector<uint32_t> locusMinWl, locusMaxWl;
   std::vector<uint32_t> order;  // loci by decreasing estimated cost: the work queue hands out the long ones first
   uint32_t              maxWordLen = 0;
+  bool                  smallMode = false;  // small_assemble_kernel (SmallAssembler) instead of the iterative assembler
+  uint32_t              smallMinSeedReads = 0, smallMaxIterations = 0;
   int                   wavesPerCuCap = 0;  // > 0: leave wave slots free for another block's aligners (pipelined batch calls)
   bool                  useLds = false;  // assemble_lds_kernel (LDS-resident graph, general path as in-kernel fallback)
   int                   gridLds = 1;
@@ -565,6 +568,12 @@ struct AsmStage {
     P.chunk_shift        = streaming ? dStream + 1 : nullptr;
     P.chunk_loci         = streaming ? chunkLoci : 0;
     P.reserved2          = 0;
+    P.small_min_seed_reads = smallMinSeedReads;
+    P.small_max_iterations = smallMaxIterations;
+    if (smallMode) {
+      rt::launch(small_assemble_kernel, grid, 0, P);
+      return;
+    }
     if (useLds && !dPlCodes && !streaming) {
       if (std::getenv("MANTA_AMD_LDS_OFF")) P.flags |= ASM_FLAG_NO_LDS_PATH;  // A/B: same kernel, every locus through the general path
       rt::launchSingle(assemble_lds_kernel, gridLds, LN_BUDGET, P);
@@ -708,7 +717,7 @@ struct AsmStage {
         oc.seq_len            = hc.seq_len;
         oc.support_off        = bitsBase + bitsUsed;
         oc.reject_off         = bitsBase + bitsUsed + h.n_words;
-        oc.seed_read_count    = 0;
+        oc.seed_read_count    = smallMode ? hc.reserved : 0u;  // (runIterativeAssembler never writes it; runSmallAssembler does)
         oc.conservative_begin = hc.cons_begin;
         oc.conservative_end   = hc.cons_end;
         seqUsed += hc.seq_len;
@@ -1045,6 +1054,48 @@ int manta_assemble_batch(
     rt::sync();
     if (std::getenv("MANTA_AMD_DEBUG"))
       std::fprintf(stderr, "manta_amd: assemble_kernel %u loci %.3f ms\n", n_loci, rt::elapsedMs(e0, e1));
+    return st.fetch(loci, contigs, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used);
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
+}
+
+int manta_small_assemble_batch(
+    manta_ctx_t* ctx, const manta_small_asm_options_t* opt, uint32_t n_loci, const uint8_t* bases, const uint64_t* read_off,
+    const uint32_t* locus_read_begin, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, uint64_t contigs_cap,
+    uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
+    uint64_t* bits_arena_used)
+{
+  if (!ctx) return MANTA_E_INVALID_ARG;
+  if (!opt || (n_loci && (!bases || !read_off || !locus_read_begin || !loci || !contigs || !seq_arena || !bits_arena)))
+    return fail(ctx, MANTA_E_INVALID_ARG, "manta_small_assemble_batch: null argument");
+  if (opt->word_step_size == 0 || opt->min_word_length < 2 || opt->max_assembly_iterations > 31)
+    return fail(ctx, MANTA_E_INVALID_ARG, "manta_small_assemble_batch: wordStepSize 0, minWordLength < 2 or more than 31 iterations");
+  if (seq_arena_used) *seq_arena_used = 0;
+  if (bits_arena_used) *bits_arena_used = 0;
+  if (n_loci == 0) return MANTA_OK;
+  try {
+    rt::ScopedStream onStream(ctx->stream);
+    AsmStage st(ctx);
+    // the slab and the record slots are those of the iterative assembler: one slot per iteration's contig + the isFiltered record
+    manta_asm_options_t o{};
+    o.min_word_length           = opt->min_word_length;
+    o.max_word_length           = opt->max_word_length;
+    o.word_step_size            = opt->word_step_size;
+    o.min_contig_length         = opt->min_contig_length;
+    o.min_coverage              = opt->min_coverage;
+    o.min_conservative_coverage = opt->min_conservative_coverage;
+    o.min_unused_reads          = 0;
+    o.min_support_reads         = 0;
+    o.max_assembly_count        = opt->max_assembly_iterations + 1;
+    st.smallMode                = true;
+    st.smallMinSeedReads        = opt->min_seed_reads;
+    st.smallMaxIterations       = opt->max_assembly_iterations;
+    int rc = st.plan(o, n_loci, read_off, locus_read_begin);
+    if (rc != MANTA_OK) return rc;
+    st.upload(bases, read_off, locus_read_begin);
+    st.launch();
+    rt::sync();
     return st.fetch(loci, contigs, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used);
   } catch (const std::exception& e) {
     return fail(ctx, MANTA_E_HIP, e.what());

@@ -130,6 +130,9 @@ struct AsmParams {
   const uint32_t* chunk_shift;
   uint32_t        chunk_loci;
   uint32_t        reserved2;
+  // small_assemble_kernel only (small_asm.hpp): SmallAssemblerOptions::minSeedReads / maxAssemblyIterations
+  uint32_t        small_min_seed_reads;
+  uint32_t        small_max_iterations;
 };
 
 
@@ -252,6 +255,7 @@ struct Assembler {
   uint32_t* pseudo_len;
   uint32_t* exact_ws;
   uint32_t *node_k32, *tent_raw, *tent_sorted, *lane_vis, *unused_bits;
+  uint64_t *small_active, *small_repeat;  // SmallAssembler read sets (alias lane_bits: the lane walks are not used there)
   uint8_t*  lane_seq;
   uint64_t* lane_bits;
   int32_t*  lane_meta;
@@ -294,6 +298,8 @@ struct Assembler {
     tent_sorted = tent_raw + TENT_CAP;
     lane_seq   = ws + L.lane_seq;
     lane_bits  = reinterpret_cast<uint64_t*>(ws + L.lane_bits);
+    small_active = lane_bits;
+    small_repeat = lane_bits + ASM_MAX_W;
     lane_meta  = reinterpret_cast<int32_t*>(ws + L.lane_meta);
     lane_vis   = reinterpret_cast<uint32_t*>(ws + L.lane_vis);
     unused_bits = reinterpret_cast<uint32_t*>(ws + L.unused);
@@ -646,7 +652,9 @@ struct Assembler {
   // ------------------------------------------------------------------------------------------------
   // k-mer graph for the current word length
   // ------------------------------------------------------------------------------------------------
-  template <int KW>
+  /// SMALL = the SmallAssembler's k-mer pass (assembly/SmallAssembler.cpp:396-455): only the reads of small_active[]
+  /// take part, and a read that holds a word twice is noted in small_repeat[] (both: bitsets over read indices in the slab)
+  template <int KW, bool SMALL = false>
   WV_DEV void buildGraph()
   {
     const unsigned lane = unsigned(wv::lane());
@@ -676,6 +684,10 @@ struct Assembler {
       bool           overflow = false;
       full                    = false;  // a lane can run out of slots while the table overflows; only the final pass counts
       nNodes                  = 0;
+      if (SMALL) {
+        if (lane < ASM_MAX_W) small_repeat[lane] = 0;
+        wv::sync();
+      }
       for (unsigned rBase = 0; rBase < nReads && !overflow; rBase += 64) {
         // read descriptors of up to 64 reads live in lane registers; v_readlane hands them out per read
         const unsigned rMine = rBase + lane;
@@ -688,6 +700,8 @@ struct Assembler {
           const unsigned r   = rBase + ri;
           const unsigned len = wv::readlane(lenV, int(ri));
           if (len < k) continue;  // :522
+          if (SMALL && !((small_active[r >> 6] >> (r & 63)) & 1u)) continue;  // SmallAssembler.cpp:413 (isUsed)
+          bool twice = false;
           const unsigned cwo = wv::readlane(cwoV, int(ri)), mwo = wv::readlane(mwoV, int(ri));
           const bool     rdHasN = wv::readlane(hasnV, int(ri)) != 0;  // most reads have no 'N': skip the bitmap test
           const uint64_t bit = uint64_t(1) << (r & 63);
@@ -744,8 +758,12 @@ struct Assembler {
               wv::sync();
               if (slot != ASM_NONE && myId == ASM_NONE) myId = wv::atomic_load(&slots[2 * size_t(slot) + 1]);
             }
-            if (slot != ASM_NONE) wv::atomic_or(reinterpret_cast<unsigned long long*>(&recSup(myId)[r >> 6]), bit);
+            if (slot != ASM_NONE) {
+              const unsigned long long before = wv::atomic_or(reinterpret_cast<unsigned long long*>(&recSup(myId)[r >> 6]), bit);
+              if (SMALL && (before & bit)) twice = true;  // the word is already in this read's word set (SmallAssembler.cpp:432)
+            }
           }
+          if (SMALL && wv::any(twice) && lane == 0) small_repeat[r >> 6] |= bit;
         }
       }
       wv::sync();

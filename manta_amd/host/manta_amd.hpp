@@ -201,6 +201,78 @@ inline void runIterativeAssembler(
   }
 }
 
+/// options/SmallAssemblerOptions.hpp:24-56
+struct SmallAssemblerOptions {
+  std::string alphabet                = "ACGT";
+  uint8_t     minQval                 = 5;
+  unsigned    minWordLength           = 41;
+  unsigned    maxWordLength           = 76;
+  unsigned    wordStepSize            = 5;
+  unsigned    minContigLength         = 15;
+  unsigned    minCoverage             = 1;
+  unsigned    minConservativeCoverage = 2;
+  double      maxError                = 0.35;
+  unsigned    minSeedReads            = 3;
+  unsigned    maxAssemblyIterations   = 10;
+};
+
+/// assembly/SmallAssembler.hpp:43-47 -- same contract: `assembledReadInfo` and `contigs` are cleared then filled.
+inline void runSmallAssembler(
+    const SmallAssemblerOptions& opt, const AssemblyReadInput& reads, AssemblyReadOutput& assembledReadInfo, Assembly& contigs)
+{
+  if (opt.alphabet != "ACGT") throw GeneralException("manta_amd: only the default assembly alphabet \"ACGT\" is supported");
+  manta_ctx_t*                    ctx = threadContext();
+  const manta_small_asm_options_t o{opt.minWordLength, opt.maxWordLength, opt.wordStepSize, opt.minContigLength, opt.minCoverage,
+                                    opt.minConservativeCoverage, opt.minSeedReads, opt.maxAssemblyIterations};
+  const unsigned        nReads = unsigned(reads.size());
+  std::vector<uint8_t>  bases;
+  std::vector<uint64_t> readOff(nReads + 1, 0);
+  for (unsigned r = 0; r < nReads; ++r) {
+    bases.insert(bases.end(), reads[r].begin(), reads[r].end());
+    readOff[r + 1] = bases.size();
+  }
+  bases.push_back(0);
+  const uint32_t                  locusBegin[2] = {0, nReads};
+  const unsigned                  nSlots = o.max_assembly_iterations + 1;  // one per iteration's contig + the isFiltered record
+  manta_asm_locus_result_t        locus;
+  std::vector<manta_asm_contig_t> recs(nSlots + 1);
+  std::vector<uint8_t>            seqArena(bases.size() * (size_t(nSlots) + 1) + 65536);
+  std::vector<uint64_t>           bitsArena(size_t(nSlots) * 2 * 16 + 64);
+  uint64_t                        seqUsed = 0, bitsUsed = 0;
+  const int rc = manta_small_assemble_batch(
+      ctx, &o, 1, bases.data(), readOff.data(), locusBegin, &locus, recs.data(), recs.size(), seqArena.data(), seqArena.size(),
+      &seqUsed, bitsArena.data(), bitsArena.size(), &bitsUsed);
+  if (rc != MANTA_OK) throw GeneralException(std::string("manta_amd::runSmallAssembler: ") + manta_last_error(ctx), rc);
+
+  contigs.clear();
+  assembledReadInfo.clear();
+  assembledReadInfo.resize(nReads);
+  for (unsigned c = 0; c < locus.n_contigs; ++c) {
+    const manta_asm_contig_t& rec(recs[locus.first_contig + c]);
+    std::set<unsigned>        support;
+    detail::bitsToSet(bitsArena.data() + rec.support_off, locus.n_words, support);
+    if (rec.seed_read_count == 0xffffffffu) {  // reads dropped for holding a word twice (SmallAssembler.cpp:496-503)
+      for (const unsigned rd : support) {
+        assembledReadInfo[rd].isUsed     = true;
+        assembledReadInfo[rd].isFiltered = true;
+      }
+      continue;
+    }
+    contigs.emplace_back();
+    AssembledContig& ctg(contigs.back());
+    ctg.seq.assign(reinterpret_cast<const char*>(seqArena.data() + rec.seq_off), rec.seq_len);
+    ctg.seedReadCount = rec.seed_read_count;
+    ctg.supportReads  = support;
+    detail::bitsToSet(bitsArena.data() + rec.reject_off, locus.n_words, ctg.rejectReads);
+    ctg.conservativeRange.set_begin_pos(rec.conservative_begin);
+    ctg.conservativeRange.set_end_pos(rec.conservative_end);
+    for (const unsigned rd : support) {  // :594-606 (a contig's support holds reads that were unused until then)
+      assembledReadInfo[rd].isUsed = true;
+      assembledReadInfo[rd].contigIds.push_back(unsigned(contigs.size() - 1));
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // alignment
 // ------------------------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@
 #include "alignment/GlobalJumpAligner.hpp"
 #include "alignment/GlobalLargeIndelAligner.hpp"
 #include "assembly/IterativeAssembler.hpp"
+#include "assembly/SmallAssembler.hpp"
 #include "blt_util/align_path.hpp"
 
 #include <atomic>
@@ -138,6 +139,33 @@ int ref_assemble(
     AssemblyReadOutput info;
     Assembly           contigs;
     runIterativeAssembler(opt, in, info, contigs);
+    return emit(assemblyText(static_cast<unsigned>(n_reads), in, info, contigs), out, cap);
+  } catch (const std::exception& e) {
+    emit(std::string("EXCEPTION ") + e.what(), out, cap);
+    return -1;
+  }
+}
+
+/// runSmallAssembler (assembly/SmallAssembler.cpp:622-685), same canonical text.
+/// opts = {minWordLength,maxWordLength,wordStepSize,minCoverage,minConservativeCoverage,minSeedReads,maxAssemblyIterations}
+int ref_small_assemble(
+    const uint32_t* opts, int n_reads, const char* const* reads, const uint32_t* read_lens, char* out, int cap)
+{
+  try {
+    SmallAssemblerOptions opt;
+    opt.minWordLength           = opts[0];
+    opt.maxWordLength           = opts[1];
+    opt.wordStepSize            = opts[2];
+    opt.minCoverage             = opts[3];
+    opt.minConservativeCoverage = opts[4];
+    opt.minSeedReads            = opts[5];
+    opt.maxAssemblyIterations   = opts[6];
+    AssemblyReadInput in;
+    in.reserve(n_reads);
+    for (int i = 0; i < n_reads; ++i) in.emplace_back(reads[i], read_lens[i]);
+    AssemblyReadOutput info;
+    Assembly           contigs;
+    runSmallAssembler(opt, in, info, contigs);
     return emit(assemblyText(static_cast<unsigned>(n_reads), in, info, contigs), out, cap);
   } catch (const std::exception& e) {
     emit(std::string("EXCEPTION ") + e.what(), out, cap);

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <sstream>
 
+#include "assembly/SmallAssembler.hpp"
 #define REF_EXPORT extern "C" __attribute__((visibility("default")))
 
 namespace {
@@ -414,6 +415,58 @@ REF_EXPORT int ref_candidate_vcf_records(const ref_refine_input_t* in, char* out
     return emit(text.str(), out, cap);
   } catch (const std::exception& e) {
     g_locus = nullptr;
+    return emit(std::string("EXCEPTION ") + e.what(), out, cap);
+  }
+}
+
+/// runSmallAssembler (assembly/SmallAssembler.hpp:43-47) with the reference's real types: in the all-reference build this is
+/// assembly/SmallAssembler.cpp, in the drop-in builds manta_amd/host/dropin/runSmallAssembler.cpp.  Same canonical text as
+/// ref_driver.cpp's assembler exports.
+/// opts = {minWordLength,maxWordLength,wordStepSize,minCoverage,minConservativeCoverage,minSeedReads,maxAssemblyIterations}
+REF_EXPORT int ref_refiner_small_assemble(const uint32_t* opts, int n_reads, const char* const* reads, const uint32_t* read_lens, char* out, int cap)
+{
+  try {
+    SmallAssemblerOptions opt;
+    opt.minWordLength           = opts[0];
+    opt.maxWordLength           = opts[1];
+    opt.wordStepSize            = opts[2];
+    opt.minCoverage             = opts[3];
+    opt.minConservativeCoverage = opts[4];
+    opt.minSeedReads            = opts[5];
+    opt.maxAssemblyIterations   = opts[6];
+    AssemblyReadInput in;
+    for (int i = 0; i < n_reads; ++i) in.emplace_back(reads[i], read_lens[i]);
+    AssemblyReadOutput info;
+    Assembly           contigs;
+    runSmallAssembler(opt, in, info, contigs);
+    std::ostringstream os;
+    os << "contigs " << contigs.size() << '\n';
+    for (unsigned i = 0; i < contigs.size(); ++i) {
+      const AssembledContig& c(contigs[i]);
+      os << "contig " << i << " seq=" << c.seq << " seed=" << c.seedReadCount << " cons=" << c.conservativeRange.begin_pos() << ','
+         << c.conservativeRange.end_pos() << " support=";
+      bool first = true;
+      for (const unsigned r : c.supportReads) {
+        os << (first ? "" : ",") << r;
+        first = false;
+      }
+      os << " reject=";
+      first = true;
+      for (const unsigned r : c.rejectReads) {
+        os << (first ? "" : ",") << r;
+        first = false;
+      }
+      os << '\n';
+    }
+    os << "reads " << info.size() << " normal " << n_reads << '\n';
+    for (unsigned i = 0; i < info.size(); ++i) {
+      const AssemblyReadInfo& r(info[i]);
+      os << "read " << i << " used=" << r.isUsed << " filtered=" << r.isFiltered << " pseudo=" << r.isPseudo << " ids=";
+      for (unsigned j = 0; j < r.contigIds.size(); ++j) os << (j ? "," : "") << r.contigIds[j];
+      os << '\n';
+    }
+    return emit(os.str(), out, cap);
+  } catch (const std::exception& e) {
     return emit(std::string("EXCEPTION ") + e.what(), out, cap);
   }
 }

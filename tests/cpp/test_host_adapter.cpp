@@ -159,6 +159,81 @@ static void test_IterativeAssembler()
   }
 }
 
+/// the scenarios of assembly/test/SmallAssemblerTest.cpp (the junk read of its first case is outside the supported
+/// alphabet, DESIGN.md 6, and is left out here)
+static void test_SmallAssembler()
+{
+  SmallAssemblerOptions assembleOpt;
+  assembleOpt.minWordLength = 6;
+  assembleOpt.maxWordLength = 6;
+  assembleOpt.minCoverage   = 2;
+  assembleOpt.minSeedReads  = 3;
+  {  // test_SmallAssembler1
+    AssemblyReadInput reads;
+    reads.emplace_back("ACGTGTATTACC");
+    reads.emplace_back("GTGTATTACCTA");
+    reads.emplace_back("ATTACCTAGTAC");
+    reads.emplace_back("TACCTAGTACTC");
+    AssemblyReadOutput readInfo;
+    Assembly           contigs;
+    runSmallAssembler(assembleOpt, reads, readInfo, contigs);
+    REQUIRE_EQUAL(contigs.size(), 1u);
+    REQUIRE_EQUAL(contigs[0].seq, "GTGTATTACCTAGTAC");
+    for (unsigned i(0); i < 4; ++i) {
+      REQUIRE(readInfo[i].isUsed);
+      REQUIRE_EQUAL(readInfo[i].contigIds[0], 0u);
+    }
+  }
+  {  // test_PoisonRead: a read that repeats a word is dropped (used, filtered, in no contig), the assembly survives
+    AssemblyReadInput reads;
+    reads.emplace_back("ACGTGTATTACC");
+    reads.emplace_back("GTGTATTACCTA");
+    reads.emplace_back("ATTACCTAGTAC");
+    reads.emplace_back("TACCTAGTACTC");
+    reads.emplace_back("AAAAAAAAAAAAAAAAAAAA");
+    AssemblyReadOutput readInfo;
+    Assembly           contigs;
+    runSmallAssembler(assembleOpt, reads, readInfo, contigs);
+    REQUIRE_EQUAL(contigs.size(), 1u);
+    REQUIRE_EQUAL(contigs[0].seq, "GTGTATTACCTAGTAC");
+    for (unsigned i(0); i < 4; ++i) {
+      REQUIRE(readInfo[i].isUsed);
+      REQUIRE_EQUAL(readInfo[i].contigIds[0], 0u);
+    }
+    REQUIRE(readInfo[4].isUsed);
+    REQUIRE(readInfo[4].isFiltered);
+    REQUIRE_EQUAL(readInfo[4].contigIds.size(), 0u);
+  }
+  {  // test_supportingReadConsistency: two contigs, each read in exactly one
+    AssemblyReadInput reads;
+    reads.emplace_back("AAACGTGTATTA");
+    reads.emplace_back("ACGTGTATTACC");
+    reads.emplace_back("CGTGTATTACCT");
+    reads.emplace_back("GTGTATTACCTA");
+    reads.emplace_back("ATTACCTAGTAC");
+    reads.emplace_back("TACCTAGTACTC");
+    reads.emplace_back("CCCTTAGCTAAC");
+    reads.emplace_back("CTTAGCTAACGT");
+    reads.emplace_back("TAGCTAACGTGG");
+    reads.emplace_back("GCTAACGTGGCC");
+    reads.emplace_back("AACGTGGCCTAG");
+    AssemblyReadOutput readInfo;
+    Assembly           contigs;
+    runSmallAssembler(assembleOpt, reads, readInfo, contigs);
+    REQUIRE_EQUAL(contigs.size(), 2u);
+    REQUIRE_EQUAL(contigs[0].seq, "AACGTGTATTACCTAGTAC");
+    REQUIRE_EQUAL(contigs[1].seq, "CTTAGCTAACGTGGCC");
+    for (unsigned i(0); i < 6; ++i) {
+      REQUIRE(readInfo[i].isUsed);
+      REQUIRE_EQUAL(readInfo[i].contigIds[0], 0u);
+    }
+    for (unsigned i(6); i < 11; ++i) {
+      REQUIRE(readInfo[i].isUsed);
+      REQUIRE_EQUAL(readInfo[i].contigIds[0], 1u);
+    }
+  }
+}
+
 int main()
 {
   try {
@@ -166,6 +241,7 @@ int main()
     test_GlobalAligner();
     test_GlobalJumpAligner();
     test_IterativeAssembler();
+    test_SmallAssembler();
   } catch (const std::exception& e) {
     std::cerr << "EXCEPTION: " << e.what() << "\n";
     return 2;

@@ -61,6 +61,21 @@ class _TextLib:
         assert n < cap
         return txt
 
+    def small_assemble(self, opts, reads):
+        """runSmallAssembler; opts = [minWordLength, maxWordLength, wordStepSize, minCoverage, minConservativeCoverage,
+        minSeedReads, maxAssemblyIterations]"""
+        fn = getattr(self.lib, self.prefix + "small_assemble")
+        rb, arr, lens = self._reads(reads)
+        o = (ctypes.c_uint32 * 7)(*opts)
+        cap = 1 << 22
+        buf = ctypes.create_string_buffer(cap)
+        n = fn(o, len(rb), arr, lens, buf, cap)
+        txt = buf.value.decode("latin-1")
+        if n < 0:
+            raise RuntimeError(txt)
+        assert n < cap
+        return txt
+
     def align(self, kind, scores, extra, query, ref1, ref2=None):
         s = (ctypes.c_int32 * 6)(*scores)
         cap = 1 << 20

@@ -49,6 +49,39 @@ def test_dropin_refiner_on_demo_piles(dropin_emu):
         assert dropin_emu.vcf(c["case"]) == c["ref_vcf"], c["name"]
 
 
+def small_assemble_text(rl, opts7, reads):
+    """ref_refiner_small_assemble of a RefinerLib: runSmallAssembler with the reference's real types"""
+    import ctypes
+    rb = [r.encode("latin-1") for r in reads]
+    arr = (ctypes.c_char_p * len(rb))(*rb)
+    lens = (ctypes.c_uint32 * len(rb))(*[len(r) for r in rb])
+    cap = 1 << 20
+    buf = ctypes.create_string_buffer(cap)
+    n = rl.lib.ref_refiner_small_assemble((ctypes.c_uint32 * 7)(*opts7), len(rb), arr, lens, buf, cap)
+    assert 0 <= n < cap
+    return buf.value.decode("latin-1")
+
+
+def check_dropin_small_assembler(d, count):
+    import hashlib
+    from small_asm_cases import UNIT_CASES, UNIT_OPTS, random_case
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "small_assembler_cases.json")))
+    for n, reads in UNIT_CASES.items():
+        assert small_assemble_text(d, UNIT_OPTS, reads) == gold["unit"][n], n
+    for s in range(count):
+        o, reads = random_case(s)
+        assert hashlib.sha256(small_assemble_text(d, o, reads).encode("latin-1")).hexdigest() == gold["random_sha256"][s], s
+
+
+def test_dropin_small_assembler(dropin_emu):
+    """dropin/runSmallAssembler.cpp (real AssemblyReadInfo / AssembledContig / SmallAssemblerOptions) == assembly/SmallAssembler.cpp"""
+    ref = lib("libmanta_ref_refiner.so")
+    from small_asm_cases import UNIT_CASES, UNIT_OPTS
+    for n, reads in UNIT_CASES.items():
+        assert small_assemble_text(ref, UNIT_OPTS, reads) == small_assemble_text(dropin_emu, UNIT_OPTS, reads), n
+    check_dropin_small_assembler(dropin_emu, 120)
+
+
 @pytest.mark.gpu
 def test_gpu_dropin_refiner_golden(gpu):
     """the prebuilt device variant travels to the GPU box in oracle/_ref (it cannot be rebuilt there: no /root/reference)"""
@@ -62,3 +95,4 @@ def test_gpu_dropin_refiner_golden(gpu):
     for c in json.load(open(DEMO))["cases"]:
         assert d.run(c["case"]) == c["ref_text"], c["name"]
         assert d.vcf(c["case"]) == c["ref_vcf"], c["name"]
+    check_dropin_small_assembler(d, 200)

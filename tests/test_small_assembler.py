@@ -1,0 +1,81 @@
+"""SmallAssembler (assembly/SmallAssembler.cpp:622-685 -- named by BASELINE.json's north_star; the reference ships it without a
+production caller) through manta_small_assemble_batch.  Expected values come from the unmodified reference
+(tests/golden/small_assembler_cases.json, written by tests/golden/make_small_asm_golden.py): the reference's own unit-test
+scenarios as text, 600 seeded random piles as SHA-256 of the canonical text."""
+import hashlib
+import json
+import os
+
+import pytest
+
+from manta_amd._capi import small_assembly_text
+from small_asm_cases import UNIT_CASES, UNIT_OPTS, abi_opts, random_case
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "small_assembler_cases.json")))
+
+
+def run_cases(lib, cases):
+    """cases: list of (opts7, reads); piles with the same options go through the ABI as one batch"""
+    texts = [None] * len(cases)
+    groups = {}
+    for i, (o, _) in enumerate(cases):
+        groups.setdefault(tuple(o), []).append(i)
+    for o, idx in groups.items():
+        res = lib.small_assemble_batch(abi_opts(list(o)), [cases[i][1] for i in idx])
+        for i, r in zip(idx, res):
+            assert r["status"] == 0, (i, r["status"])
+            texts[i] = small_assembly_text(r)
+    return texts
+
+
+def check_unit(lib):
+    names = list(UNIT_CASES)
+    got = run_cases(lib, [(UNIT_OPTS, UNIT_CASES[n]) for n in names])
+    for n, g in zip(names, got):
+        assert g == GOLD["unit"][n], n
+    # SmallAssemblerTest.cpp's own assertions, spelled out
+    t = GOLD["unit"]["PoisonRead"]
+    assert "seq=GTGTATTACCTAGTAC " in t and "read 4 used=1 filtered=1 pseudo=0 ids=\n" in t
+    t = GOLD["unit"]["supportingReadConsistency"]
+    assert "contig 0 seq=AACGTGTATTACCTAGTAC " in t and "contig 1 seq=CTTAGCTAACGTGGCC " in t
+
+
+def check_random(lib, first, count):
+    cases = [random_case(s) for s in range(first, first + count)]
+    got = run_cases(lib, cases)
+    bad = [first + i for i, g in enumerate(got)
+           if hashlib.sha256(g.encode("latin-1")).hexdigest() != GOLD["random_sha256"][first + i]]
+    assert not bad, bad[:10]
+
+
+def test_emulated_small_assembler_unit_scenarios(emu):
+    check_unit(emu)
+
+
+def test_emulated_small_assembler_random_piles(emu):
+    check_random(emu, 0, 250)
+
+
+def test_golden_file_is_what_the_reference_says(reflib):
+    """the committed golden file against the reference itself (build container only)"""
+    for n, reads in UNIT_CASES.items():
+        assert reflib.small_assemble(UNIT_OPTS, reads) == GOLD["unit"][n]
+    for s in range(0, 600, 7):
+        o, reads = random_case(s)
+        assert hashlib.sha256(reflib.small_assemble(o, reads).encode("latin-1")).hexdigest() == GOLD["random_sha256"][s]
+    st = GOLD["stats"]
+    assert st["with_two_or_more_contigs"] > 100 and st["with_filtered_reads"] > 30 and st["with_no_contig"] > 30
+
+
+def test_small_assembler_rejects_bad_options(emu):
+    from manta_amd._capi import MantaError
+    with pytest.raises(MantaError):
+        emu.small_assemble_batch([6, 6, 0, 15, 1, 1, 1, 10], [["ACGTACGTAC"]])  # wordStepSize 0: the reference would never end
+    with pytest.raises(MantaError):
+        emu.small_assemble_batch([6, 6, 1, 15, 1, 1, 1, 40], [["ACGTACGTAC"]])  # more iterations than record slots
+
+
+@pytest.mark.gpu
+def test_gpu_small_assembler(gpu):
+    check_unit(gpu)
+    check_random(gpu, 0, 600)
