@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
+#include <condition_variable>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -236,8 +238,115 @@ bool stringHashMatchesLibstdcxx()
 /// device memory one pipeline may take for its per-wave workspaces: an equal share of half the free memory, capped
 size_t workspaceBudget(const size_t capBytes)
 {
+  // hipMemGetInfo is a driver round trip (tenths of a millisecond) and this is called on every upload and run: the
+  // budget is a soft bound (half of the free memory), so a reading that is a fraction of a second old is good enough
+  static std::mutex                            mu;
+  static size_t                                cachedFree = 0;
+  static std::chrono::steady_clock::time_point stamp;
+  size_t                                       freeNow;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    const auto                  now = std::chrono::steady_clock::now();
+    if (cachedFree == 0 || now - stamp > std::chrono::milliseconds(250)) {
+      cachedFree = rt::freeBytes();
+      stamp      = now;
+    }
+    freeNow = cachedFree;
+  }
   const int live = std::max(1, g_liveWorkspaces.load());
-  return std::min<size_t>(rt::freeBytes() / 2 / size_t(live), capBytes);
+  return std::min<size_t>(freeNow / 2 / size_t(live), capBytes);
+}
+
+/// Host loops over a whole batch (validation scan of the offset arrays, compaction of the results) split over a few
+/// threads: fn(part, begin, end) for `parts` contiguous ranges of [0, n); the caller's thread takes part 0.
+unsigned hostParts(const uint64_t n)
+{
+  static const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  if (const char* forced = std::getenv("MANTA_AMD_HOST_PARTS"))  // tests: take the multi-range paths on small batches too
+    return unsigned(std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n, 4), uint64_t(std::max(1, std::atoi(forced))))));
+  if (n < 4096) return 1;
+  return std::min(4u, hw);
+}
+/// three helper threads per process, parked on a condition variable between jobs (starting std::threads per call costs more
+/// than the loops they would share on a 256-core host)
+class HostPool {
+ public:
+  static HostPool& get()
+  {
+    static HostPool pool;
+    return pool;
+  }
+  /// fn(part, begin, end) for `parts` (<= 4) contiguous ranges of [0, n); part 0 runs on the caller's thread.  One job at a
+  /// time: concurrent callers (workers of a batch call) queue up behind runMu.
+  template <typename F>
+  void run(const uint64_t n, const unsigned parts, F fn)
+  {
+    auto begin = [&](unsigned t) { return n * t / parts; };
+    if (parts <= 1) {
+      fn(0u, uint64_t(0), n);
+      return;
+    }
+    std::lock_guard<std::mutex> only(runMu);
+    std::function<void(unsigned)> job = [&](unsigned t) { fn(t, begin(t), begin(t + 1)); };
+    {
+      std::lock_guard<std::mutex> g(mu);
+      current = &job;
+      wanted  = parts - 1;
+      pending = parts - 1;
+      ++generation;
+    }
+    cv.notify_all();
+    fn(0u, begin(0), begin(1));
+    std::unique_lock<std::mutex> g(mu);
+    done.wait(g, [&] { return pending == 0; });
+    current = nullptr;
+  }
+
+ private:
+  HostPool()
+  {
+    for (unsigned i = 0; i < 3; ++i) threads.emplace_back([this, i] { loop(i + 1); });
+  }
+  ~HostPool()
+  {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (std::thread& t : threads) t.join();
+  }
+  void loop(const unsigned id)
+  {
+    uint64_t seen = 0;
+    while (true) {
+      std::function<void(unsigned)>* job = nullptr;
+      {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return stop || generation != seen; });
+        if (stop) return;
+        seen = generation;
+        if (id <= wanted) job = current;
+      }
+      if (job) {
+        (*job)(id);
+        std::lock_guard<std::mutex> g(mu);
+        if (--pending == 0) done.notify_one();
+      }
+    }
+  }
+  std::mutex                     mu, runMu;
+  std::condition_variable        cv, done;
+  std::vector<std::thread>       threads;
+  std::function<void(unsigned)>* current = nullptr;
+  unsigned                       wanted = 0, pending = 0;
+  uint64_t                       generation = 0;
+  bool                           stop = false;
+};
+template <typename F>
+void hostParallel(const uint64_t n, const unsigned parts, F fn)
+{
+  HostPool::get().run(n, parts, fn);
 }
 
 uint32_t nextPow2(uint64_t v)
@@ -337,34 +446,85 @@ struct AsmStage {
       }
     }
     nBases      = read_off ? read_off[nReadsTotal] : 0;
+    const double tPlan0 = nowMs();
     uint64_t maxLocusBases = 0, maxLocusWords = 0, bitsBound = 0;
     uint32_t maxLocusReads = 0, maxReadLen = 0;
     std::vector<uint64_t> cost(n_loci);
     uint32_t              ldsFit = 0;  // loci small enough for the LDS-resident fast path
-    for (uint32_t l = 0; l < n_loci; ++l) {
-      const uint32_t rb = locus_read_begin[l], re = locus_read_begin[l + 1];
-      if (re < rb || re > nReadsTotal) return fail(ctx, MANTA_E_INVALID_ARG, "locus_read_begin not monotone");
-      uint64_t b = 0, w = 0;
-      for (uint32_t r = rb; r < re; ++r) {
-        if (read_off && read_off[r + 1] < read_off[r]) return fail(ctx, MANTA_E_INVALID_ARG, "read_off not monotone");
-        const uint64_t len = read_off ? (read_off[r + 1] - read_off[r]) : uint64_t(read_len[r]);
-        b += len;
-        w += (len + 15) / 16 + 1;
-        maxReadLen = std::max<uint32_t>(maxReadLen, uint32_t(len));
+    {
+      // one pass over every read offset (6.4 MB for the 800 k reads of the metric's batch): a few host threads
+      struct Part {
+        uint64_t maxLocusBases = 0, maxLocusWords = 0, bitsBound = 0;
+        uint32_t maxLocusReads = 0, maxReadLen = 0, ldsFit = 0;
+        int      bad = 0;  // 1 = locus_read_begin, 2 = read_off
+      };
+      const unsigned    parts = hostParts(nReadsTotal);
+      std::vector<Part> part(parts);
+      const uint32_t    maxAsm = opt.max_assembly_count;
+      hostParallel(n_loci, parts, [&](unsigned t, uint64_t l0, uint64_t l1) {
+        Part& p(part[t]);
+        for (uint64_t l = l0; l < l1; ++l) {
+          const uint32_t rb = locus_read_begin[l], re = locus_read_begin[l + 1];
+          if (re < rb || re > nReadsTotal) {
+            p.bad = 1;
+            return;
+          }
+          // branch-free inner loops (they vectorise): a negative step shows up as a huge unsigned length in `longest`
+          uint64_t b = 0, w = 0, longest = 0;
+          if (read_off) {
+            const uint64_t* o = read_off + rb;
+            for (uint32_t i = 0; i < re - rb; ++i) {
+              const uint64_t len = o[i + 1] - o[i];
+              w += (len + 15) >> 4;
+              longest = std::max(longest, len);
+            }
+            b = o[re - rb] - o[0];
+          } else {
+            const uint32_t* o = read_len + rb;
+            for (uint32_t i = 0; i < re - rb; ++i) {
+              const uint64_t len = o[i];
+              b += len;
+              w += (len + 15) >> 4;
+              longest = std::max(longest, len);
+            }
+          }
+          w += re - rb;
+          if (longest > 0xffffffffull) {  // (also: a single read of 4 G bases is not a read)
+            p.bad = 2;
+            return;
+          }
+          p.maxReadLen = std::max<uint32_t>(p.maxReadLen, uint32_t(longest));
+          cost[l] = b * uint64_t(re - rb);
+          if ((re - rb) + 2 * maxAsm <= LN_MAX_READS && w + 2 <= LN_MAX_PILE) p.ldsFit++;
+          p.maxLocusBases = std::max(p.maxLocusBases, b);
+          p.maxLocusWords = std::max(p.maxLocusWords, w);
+          p.maxLocusReads = std::max(p.maxLocusReads, re - rb);
+          const uint64_t W = ((re - rb) + 2 * maxAsm + 63) / 64;
+          p.bitsBound += uint64_t(maxAsm) * 2 * W + 2 * maxAsm;
+        }
+      });
+      for (const Part& p : part) {
+        if (p.bad == 1) return fail(ctx, MANTA_E_INVALID_ARG, "locus_read_begin not monotone");
+        if (p.bad == 2) return fail(ctx, MANTA_E_INVALID_ARG, "read_off not monotone");
+        maxLocusBases = std::max(maxLocusBases, p.maxLocusBases);
+        maxLocusWords = std::max(maxLocusWords, p.maxLocusWords);
+        maxLocusReads = std::max(maxLocusReads, p.maxLocusReads);
+        maxReadLen    = std::max(maxReadLen, p.maxReadLen);
+        ldsFit += p.ldsFit;
+        bitsBound += p.bitsBound;
       }
-      cost[l]       = b * uint64_t(re - rb);
-      if ((re - rb) + 2 * opt.max_assembly_count <= LN_MAX_READS && w + 2 <= LN_MAX_PILE) ldsFit++;
-      maxLocusBases = std::max(maxLocusBases, b);
-      maxLocusWords = std::max(maxLocusWords, w);
-      maxLocusReads = std::max(maxLocusReads, re - rb);
-      const uint64_t W = ((re - rb) + 2 * opt.max_assembly_count + 63) / 64;
-      bitsBound += uint64_t(opt.max_assembly_count) * 2 * W + 2 * opt.max_assembly_count;
     }
     // work-queue order: most expensive loci first (reads x bases is what the table pass and the walks scale with), so
     // that the long ones are not the last to start
-    order.resize(n_loci);
-    for (uint32_t l = 0; l < n_loci; ++l) order[l] = l;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    const double tPlan1 = nowMs();
+    {
+      std::vector<std::pair<uint64_t, uint32_t>> keyed(n_loci);  // (inverted cost, locus): ascending = most expensive first, ties in locus order
+      for (uint32_t l = 0; l < n_loci; ++l) keyed[l] = std::make_pair(~cost[l], l);
+      std::sort(keyed.begin(), keyed.end());
+      order.resize(n_loci);
+      for (uint32_t l = 0; l < n_loci; ++l) order[l] = keyed[l].second;
+    }
+    const double   tPlan2   = nowMs();
     const uint32_t nCandMax = 2 * opt.max_assembly_count;
     wMax                    = uint32_t((maxLocusReads + nCandMax + 63) / 64);
     if (wMax > ASM_MAX_W) return fail(ctx, MANTA_E_UNSUPPORTED, "more than ~1000 reads in one locus");
@@ -400,6 +560,8 @@ struct AsmStage {
     const uint64_t worstLocusSeq = uint64_t(opt.max_assembly_count) * maxContigLen + uint64_t(nCandMax) * pseudoLen;
     devSeqCap  = uint64_t(n_loci) * std::min<uint64_t>(worstLocusSeq, 65536) + worstLocusSeq + 4096;
     devBitsCap = bitsBound + 64;
+    if (std::getenv("MANTA_AMD_DEBUG_TIMING"))
+      std::fprintf(stderr, "manta_amd: plan: scan %.2f ms, order %.2f, sizing %.2f\n", tPlan1 - tPlan0, tPlan2 - tPlan1, nowMs() - tPlan2);
     std::call_once(ctx->growthOnce, [&] { recordGrowthSchedule(ctx->growthSize, ctx->growthBuckets, 4u << 20); });  // (workers of a batch call plan concurrently)
     return MANTA_OK;
   }
@@ -658,6 +820,21 @@ struct AsmStage {
     }
   }
 
+  /// what compact() writes for the loci [lBegin, lEnd)
+  template <typename ContigAt>
+  void rangeSizes(ContigAt contigAt, uint32_t lBegin, uint32_t lEnd, uint64_t& nContigs, uint64_t& seqBytes, uint64_t& bitsWords) const
+  {
+    nContigs = seqBytes = bitsWords = 0;
+    for (uint32_t l = lBegin; l < lEnd; ++l) {
+      const AsmLocusOut& h(hLoci[l]);
+      if (h.status != ASM_OK) continue;
+      nContigs += h.n_contigs;
+      for (uint32_t c = 0; c < h.n_contigs; ++c) seqBytes += contigAt(l, c).seq_len;
+      for (uint32_t q = 0; q < h.n_pseudo; ++q) seqBytes += hBits[h.pseudo_len_off + q];
+      bitsWords += 2ull * h.n_words * h.n_contigs + h.n_pseudo;
+    }
+  }
+
   /// upper bounds of what compact() writes into the caller's arenas (cheap: counters only)
   void outputSizes(uint64_t& nContigs, uint64_t& seqBytes, uint64_t& bitsWords) const
   {
@@ -683,11 +860,13 @@ struct AsmStage {
   int compact(
       ContigAt contigAt, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, uint64_t contigs_cap, uint8_t* seq_arena,
       uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used,
-      uint64_t contigBase, uint64_t seqBase, uint64_t bitsBase)
+      uint64_t contigBase, uint64_t seqBase, uint64_t bitsBase, uint32_t lBegin = 0, uint32_t lEnd = ~0u)
   {
+    // [lBegin, lEnd): the loci this call handles; the output pointers / bases are those of that range's first record
     uint64_t seqUsed = 0, bitsUsed = 0, nContigs = 0;
     int      worst = MANTA_OK;
-    for (uint32_t l = 0; l < nLoci; ++l) {
+    lEnd           = std::min(lEnd, nLoci);
+    for (uint32_t l = lBegin; l < lEnd; ++l) {
       const AsmLocusOut&        h(hLoci[l]);
       manta_asm_locus_result_t& o(loci[l]);
       std::memset(&o, 0, sizeof(o));
@@ -761,10 +940,10 @@ struct manta_smallsv {
   uint64_t              refBytes = 0, maxRef = 0;
   bool                  uploaded = false, ran = false;
   DevBuf                dRefs, dRefOff, dCuts, dTasks, dInfo, dResults, dBucketIds, dSmall, dCigar, dTable, dPtrWs;
-  rt::Event             evStart, evAsm, evSched, evAlign;
+  rt::Event             evStart, evAsm, evSched, evAlign, refsReady;
   rt::Stream            main;  // everything of this pipeline except the aligner buckets
   rt::Stream            copy;  // streamed upload of the read bases (whole-batch calls)
-  bool                  streamUploads = false;
+  bool                  streamUploads = false, refsOnCopy = false;
   rt::Stream            side[3];
   rt::Event             sideDone[3];
   manta_smallsv_stats_t stats{};
@@ -1148,18 +1327,25 @@ int manta_smallsv_upload(
       if (cuts[l].leading_cut < 0 || cuts[l].trailing_cut < 0 || cuts[l].max_leading_cut < 0 || cuts[l].max_trailing_cut < 0)
         return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_upload: negative reference cut");
     }
-    // the reference windows first: the copy engine serves the streams in submission order, and in streamed mode the (large)
-    // read-base copies below must be the LAST thing queued, or everything after them would wait for them
     uint8_t*  dRefs   = b->dRefs.as<uint8_t>(b->refBytes + 16);
     uint64_t* dRefOff = b->dRefOff.as<uint64_t>(n_loci + 1);
     auto*     dCuts   = b->dCuts.as<SmallSvCuts>(n_loci);
-    rt::h2d(dRefs, refs, b->refBytes);
-    rt::h2d(dRefOff, ref_off, sizeof(uint64_t) * (n_loci + 1));
     static_assert(sizeof(SmallSvCuts) == sizeof(manta_ref_cuts_t), "cuts layout");
-    rt::h2d(dCuts, cuts, sizeof(SmallSvCuts) * n_loci);
-    if (b->streamUploads && !b->asmStage.useLds && !std::getenv("MANTA_AMD_NO_STREAM_UPLOAD")) {
+    const bool streamed = b->streamUploads && !b->asmStage.useLds && !std::getenv("MANTA_AMD_NO_STREAM_UPLOAD");
+    b->refsOnCopy       = streamed;
+    if (streamed) {
+      // the assembler does not read the reference windows: they travel on the copy stream BEHIND the read bases and the
+      // schedule kernel waits for them (smallsvRunImpl); nothing but the small per-read arrays is waited for here
       b->asmStage.uploadStreamed(bases, read_off, locus_read_begin, b->copy);  // syncs the small copies, returns with the bases in flight
+      rt::ScopedStream onCopy(b->copy);
+      rt::h2d(dRefs, refs, b->refBytes);
+      rt::h2d(dRefOff, ref_off, sizeof(uint64_t) * (n_loci + 1));
+      rt::h2d(dCuts, cuts, sizeof(SmallSvCuts) * n_loci);
+      b->refsReady.record();
     } else {
+      rt::h2d(dRefs, refs, b->refBytes);
+      rt::h2d(dRefOff, ref_off, sizeof(uint64_t) * (n_loci + 1));
+      rt::h2d(dCuts, cuts, sizeof(SmallSvCuts) * n_loci);
       b->asmStage.upload(bases, read_off, locus_read_begin);
       rt::sync();
     }
@@ -1194,6 +1380,7 @@ int manta_smallsv_upload_piles(
     rt::setDevice(ctx->deviceId);
     rt::ScopedStream onStream(b->main);
     b->uploaded = false;
+    b->refsOnCopy = false;
     rc          = b->asmStage.plan(b->opt, n_loci, nullptr, piles->locus_read_begin, piles->read_len);
     if (rc != MANTA_OK) return rc;
     b->asmStage.uploadPiles(*piles);
@@ -1281,6 +1468,7 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     }
     stage("assembled");
     GateLock alignOnly(gates, &StageGates::alignMu);
+    if (b->refsOnCopy) rt::curStreamWaits(b->refsReady);  // reference windows of a streamed upload (manta_smallsv_upload)
 
     ScheduleParams S;
     S.loci               = as.dLoci;
@@ -1464,16 +1652,19 @@ int smallsvCompact(
     manta_smallsv* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_smallsv_alignment_t* alignments,
     uint64_t contigBase, uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t seqBase, uint64_t* seq_arena_used,
     uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t bitsBase, uint64_t* bits_arena_used, uint32_t* cigar_arena,
-    uint64_t cigar_arena_cap, uint64_t cigarBase, uint64_t* cigar_arena_used)
+    uint64_t cigar_arena_cap, uint64_t cigarBase, uint64_t* cigar_arena_used, uint32_t lBegin = 0, uint32_t lEnd = ~0u,
+    uint64_t* cellsOut = nullptr, uint64_t* ptrBytesOut = nullptr)
 {
+  // [lBegin, lEnd): the loci of this call (a whole-batch call compacts a block in a few ranges, one host thread each); every
+  // output pointer / base is that of the range's first record
   manta_ctx_t* ctx = b->ctx;
+  lEnd             = std::min(lEnd, b->nLoci);
   int rc = b->asmStage.compact(PackedContigs<manta_smallsv>{b}, loci, contigs + contigBase, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used,
-                               bits_arena, bits_arena_cap, bits_arena_used, contigBase, seqBase, bitsBase);
+                               bits_arena, bits_arena_cap, bits_arena_used, contigBase, seqBase, bitsBase, lBegin, lEnd);
   if (rc != MANTA_OK && !perItemCode(rc)) return rc;
-  const uint32_t nLoci = b->nLoci;
   uint64_t       used = 0, cells = 0, ptrBytes = 0;
   int            worst = rc;
-  for (uint32_t l = 0; l < nLoci; ++l) {
+  for (uint32_t l = lBegin; l < lEnd; ++l) {
     if (loci[l].status != MANTA_OK) continue;
     for (uint32_t c = 0; c < loci[l].n_contigs; ++c) {
       manta_smallsv_alignment_t& a(alignments[loci[l].first_contig + c]);
@@ -1502,11 +1693,31 @@ int smallsvCompact(
       ptrBytes += 2ull * (uint64_t(h.query_len) + 1) * (uint64_t(h.ref_len) + 1);
     }
   }
-  b->stats.dp_cells         = cells;
-  b->stats.ptr_matrix_bytes = ptrBytes;
+  if (cellsOut) {  // ranged call: the caller adds the ranges up
+    *cellsOut    = cells;
+    *ptrBytesOut = ptrBytes;
+  } else {
+    b->stats.dp_cells         = cells;
+    b->stats.ptr_matrix_bytes = ptrBytes;
+  }
   if (cigar_arena_used) *cigar_arena_used = used;
   if (worst != MANTA_OK) return fail(ctx, worst, "manta_smallsv_download: one or more loci/contigs failed; see per-item status");
   return MANTA_OK;
+}
+
+/// CIGAR words smallsvCompact writes for the loci [lBegin, lEnd)
+uint64_t smallsvCigarWords(const manta_smallsv* b, uint32_t lBegin, uint32_t lEnd)
+{
+  uint64_t n = 0;
+  for (uint32_t l = lBegin; l < lEnd; ++l) {
+    const AsmLocusOut& h(b->asmStage.hLoci[l]);
+    if (h.status != ASM_OK) continue;
+    for (uint32_t c = 0; c < h.n_contigs; ++c) {
+      const PackedContigOut& pc(b->hPacked[b->hFirst[l] + c]);
+      if (pc.info_status == 0 && pc.bucket >= 0 && pc.res_status == 0) n += pc.cigar1_len;
+    }
+  }
+  return n;
 }
 
 }  // namespace
@@ -2140,17 +2351,48 @@ int smallsvBatchImpl(
           rt::ScopedStream onStream(b->main);
           pipeStage(b);
         }
-        b->asmStage.exactSizes(PackedContigs<manta_smallsv>{b}, nC, nS, nB);
-        nG = b->hPackCnt[1];
+        const double tStage = nowMs();
+        // compaction into the caller's arrays: a few contiguous locus ranges, one host thread each.  Pass 1 sizes the ranges,
+        // the block then reserves its region of the caller's arenas, pass 2 writes every range at its own offset.
+        struct Range {
+          uint64_t nC = 0, nS = 0, nB = 0, nG = 0, cells = 0, ptrBytes = 0;
+          uint64_t c0 = 0, s0 = 0, b0 = 0, g0 = 0;
+          int      rc = MANTA_OK;
+        };
+        const unsigned     parts = hostParts(uint64_t(n) * 4);  // (a block of >= 1024 loci is worth the threads)
+        std::vector<Range> rg(parts);
+        hostParallel(n, parts, [&](unsigned t, uint64_t a, uint64_t z) {
+          b->asmStage.rangeSizes(PackedContigs<manta_smallsv>{b}, uint32_t(a), uint32_t(z), rg[t].nC, rg[t].nS, rg[t].nB);
+          rg[t].nG = smallsvCigarWords(b, uint32_t(a), uint32_t(z));
+        });
+        for (unsigned t = 0; t < parts; ++t) {
+          rg[t].c0 = nC, rg[t].s0 = nS, rg[t].b0 = nB, rg[t].g0 = nG;
+          nC += rg[t].nC, nS += rg[t].nS, nB += rg[t].nB, nG += rg[t].nG;
+        }
+        const double tSizes = nowMs();
         const uint64_t cBase = sh.contigsUsed.fetch_add(nC), sBase = sh.seqUsed.fetch_add(nS), bBase = sh.bitsUsed.fetch_add(nB),
                        gBase = sh.cigarUsed.fetch_add(nG);
         if (cBase + nC > contigs_cap || sBase + nS > seq_arena_cap || bBase + nB > bits_arena_cap || gBase + nG > cigar_arena_cap) {
           sh.error(MANTA_E_CAPACITY, "manta_smallsv_batch: caller arenas too small", true);
           break;
         }
-        rc = smallsvCompact(b, loci + l0, contigs, alignments, cBase, nC, seq_arena + sBase, nS, sBase, nullptr, bits_arena + bBase, nB, bBase,
-                            nullptr, cigar_arena + gBase, nG, gBase, nullptr);
+        hostParallel(n, parts, [&](unsigned t, uint64_t a, uint64_t z) {
+          const Range& r(rg[t]);
+          rg[t].rc = smallsvCompact(b, loci + l0, contigs, alignments, cBase + r.c0, r.nC, seq_arena + sBase + r.s0, r.nS, sBase + r.s0, nullptr,
+                                    bits_arena + bBase + r.b0, r.nB, bBase + r.b0, nullptr, cigar_arena + gBase + r.g0, r.nG, gBase + r.g0,
+                                    nullptr, uint32_t(a), uint32_t(z), &rg[t].cells, &rg[t].ptrBytes);
+        });
+        rc = MANTA_OK;
+        b->stats.dp_cells = b->stats.ptr_matrix_bytes = 0;
+        for (const Range& r : rg) {
+          if (r.rc != MANTA_OK && (rc == MANTA_OK || !perItemCode(r.rc))) rc = r.rc;
+          b->stats.dp_cells += r.cells;
+          b->stats.ptr_matrix_bytes += r.ptrBytes;
+        }
         const double t3 = nowMs();
+        if (std::getenv("MANTA_AMD_DEBUG_TIMING"))
+          std::fprintf(stderr, "manta_amd: smallsv_batch block: upload %.2f ms, kernels %.2f, stage-out %.2f, sizes %.2f, compact %.2f\n", t1 - t0, t2 - t1,
+                       tStage - t2, tSizes - tStage, t3 - tSizes);
         if (rc != MANTA_OK) {
           sh.error(rc, lastErrorOf(ctx), !perItemCode(rc));
           if (!perItemCode(rc)) break;

@@ -85,6 +85,14 @@ def test_emulated_batches_with_stage_gates(emu, oracle):
     check_spanning(emu, oracle, 7, block=2, workers=2)
 
 
+def test_emulated_batch_host_ranges(emu, oracle, monkeypatch):
+    """the batch call scans its inputs and compacts its results in several host-thread ranges (forced here on a small batch)"""
+    monkeypatch.setenv("MANTA_AMD_HOST_PARTS", "3")
+    check_smallsv(emu, oracle, 11, block=11, workers=1, mixed=False)
+    check_smallsv(emu, oracle, 10, block=4, workers=2, mixed=True)
+    check_spanning(emu, oracle, 5, block=5, workers=1)
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
 def test_gpu_batch_calls(gpu, oracle):
