@@ -1339,6 +1339,46 @@ struct Assembler {
     uint64_t       alive       = (nCand >= 64) ? ~uint64_t(0) : ((uint64_t(1) << nCand) - 1);
     unsigned       finalCount  = 0;
     uint32_t*      chosenIdx   = frontier;  // scratch (the k-mer graph is no longer needed); same value from every lane
+    if (W <= WQ_MAX) {
+      // Lane-per-candidate form of the same loop for read sets of up to WQ_MAX qwords (the usual case): lane ci keeps
+      // candidate ci's support set and length in registers, the set of used reads is wave-uniform, and one selection round
+      // is a handful of popcounts plus one wave arg-max instead of a dependent slab load + reduction per candidate.
+      // Order of the reference's scan (:762-803): strict '>' on (fresh support, length) = first index wins a tie.
+      uint64_t sup[WQ_MAX], usedS[WQ_MAX], pseudoS[WQ_MAX];
+      unsigned myLen = 0;
+      for (unsigned w = 0; w < WQ_MAX; ++w) {
+        sup[w]     = (lane < nCand && w < W) ? cand_bits[size_t(lane) * 2 * W + w] : 0;
+        usedS[w]   = 0;
+        pseudoS[w] = (w < W) ? ~normalMask(w) : 0;
+      }
+      if (lane < nCand) myLen = unsigned(cand_meta[lane * 4 + 0]);
+      bool aliveL = lane < nCand;
+      while (finalCount < P.opt.maxAssemblyCount) {
+        if (!wv::any(aliveL)) break;
+        unsigned usedNormal = 0;
+        for (unsigned w = 0; w < WQ_MAX; ++w) usedNormal += unsigned(wv::popc(usedS[w] & ~pseudoS[w]));
+        if (nNormal - usedNormal < P.opt.minUnusedReads) break;  // :750
+        unsigned nFresh = 0, nFreshNormal = 0;
+        for (unsigned w = 0; w < WQ_MAX; ++w) {
+          const uint64_t fresh = sup[w] & ~usedS[w];
+          nFresh += unsigned(wv::popc(fresh));
+          nFreshNormal += unsigned(wv::popc(fresh & ~pseudoS[w]));
+        }
+        if (aliveL && nFreshNormal < P.opt.minSupportReads) aliveL = false;  // :779-788
+        uint64_t key = aliveL ? ((uint64_t(nFresh) << 40) | (uint64_t(myLen) << 8) | uint64_t(63u - lane)) : 0;
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint64_t o = wv::shfl(key, wv::lane() ^ off);
+          key              = (o > key) ? o : key;
+        }
+        if ((key >> 40) == 0) break;  // :807
+        const int selected = wv::first(int(63u - unsigned(key & 63u)));
+        chosenIdx[finalCount] = unsigned(selected);
+        if (int(lane) == selected) aliveL = false;
+        for (unsigned w = 0; w < WQ_MAX; ++w) usedS[w] |= wv::shfl(sup[w], selected);
+        finalCount++;
+      }
+      alive = 0;  // (the general loop below is skipped)
+    }
     while (alive != 0 && finalCount < P.opt.maxAssemblyCount) {
       const unsigned usedAll      = waveSum(unsigned(wv::popc(used)));
       const unsigned usedPseudo   = waveSum(unsigned(wv::popc(used & pseudoMaskW)));
