@@ -970,8 +970,10 @@ struct manta_spanning {
   bool                  uploaded = false, ran = false;
   DevBuf                dRefs1, dRef1Off, dRefs2, dRef2Off, dCuts, dTasks, dTasks2, dInfo, dResults, dResults2, dBucketIds, dBucketIds2, dSmall,
       dCigar, dPtrWs;
-  rt::Event             evStart, evAsm, evSched, evAlign;
+  rt::Event             evStart, evAsm, evSched, evAlign, refsReady;
   rt::Stream            main;
+  rt::Stream            copy;  // streamed upload of the read bases (whole-batch calls)
+  bool                  streamUploads = false, refsOnCopy = false;
   rt::Stream            side[3];
   rt::Event             sideDone[3];
   manta_smallsv_stats_t stats{};
@@ -1781,7 +1783,6 @@ int manta_spanning_upload(
     b->uploaded = false;
     int rc      = b->asmStage.plan(b->opt, n_loci, read_off, locus_read_begin);
     if (rc != MANTA_OK) return rc;
-    b->asmStage.upload(bases, read_off, locus_read_begin);
     b->nLoci     = n_loci;
     b->ref1Bytes = ref1_off[n_loci];
     b->ref2Bytes = ref2_off[n_loci];
@@ -1793,13 +1794,30 @@ int manta_spanning_upload(
         return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_upload: negative reference cut");
     }
     static_assert(sizeof(JumpCuts) == sizeof(manta_jump_cuts_t), "cuts layout");
-    rt::h2d(b->dRefs1.as<uint8_t>(b->ref1Bytes + 16), refs1, b->ref1Bytes);
-    rt::h2d(b->dRef1Off.as<uint64_t>(n_loci + 1), ref1_off, sizeof(uint64_t) * (n_loci + 1));
-    rt::h2d(b->dRefs2.as<uint8_t>(b->ref2Bytes + 16), refs2, b->ref2Bytes);
-    rt::h2d(b->dRef2Off.as<uint64_t>(n_loci + 1), ref2_off, sizeof(uint64_t) * (n_loci + 1));
-    rt::h2d(b->dCuts.as<JumpCuts>(n_loci), cuts, sizeof(JumpCuts) * n_loci);
+    uint8_t*  dRefs1   = b->dRefs1.as<uint8_t>(b->ref1Bytes + 16);
+    uint64_t* dRef1Off = b->dRef1Off.as<uint64_t>(n_loci + 1);
+    uint8_t*  dRefs2   = b->dRefs2.as<uint8_t>(b->ref2Bytes + 16);
+    uint64_t* dRef2Off = b->dRef2Off.as<uint64_t>(n_loci + 1);
+    JumpCuts* dCuts    = b->dCuts.as<JumpCuts>(n_loci);
+    auto      copyRefs = [&] {
+      rt::h2d(dRefs1, refs1, b->ref1Bytes);
+      rt::h2d(dRef1Off, ref1_off, sizeof(uint64_t) * (n_loci + 1));
+      rt::h2d(dRefs2, refs2, b->ref2Bytes);
+      rt::h2d(dRef2Off, ref2_off, sizeof(uint64_t) * (n_loci + 1));
+      rt::h2d(dCuts, cuts, sizeof(JumpCuts) * n_loci);
+    };
     b->hostCuts.assign(reinterpret_cast<const JumpCuts*>(cuts), reinterpret_cast<const JumpCuts*>(cuts) + n_loci);
-    rt::sync();
+    b->refsOnCopy = b->streamUploads && !b->asmStage.useLds && !std::getenv("MANTA_AMD_NO_STREAM_UPLOAD");
+    if (b->refsOnCopy) {  // whole-batch call: as manta_smallsv_upload -- bases in chunks behind the running assembler, references behind them
+      b->asmStage.uploadStreamed(bases, read_off, locus_read_begin, b->copy);
+      rt::ScopedStream onCopy(b->copy);
+      copyRefs();
+      b->refsReady.record();
+    } else {
+      b->asmStage.upload(bases, read_off, locus_read_begin);
+      copyRefs();
+      rt::sync();
+    }
     b->uploaded = true;
     return MANTA_OK;
   } catch (const std::exception& e) {
@@ -1821,6 +1839,7 @@ int manta_spanning_upload_piles(
     rt::setDevice(ctx->deviceId);
     rt::ScopedStream onStream(b->main);
     b->uploaded = false;
+    b->refsOnCopy = false;
     rc          = b->asmStage.plan(b->opt, n_loci, nullptr, piles->locus_read_begin, piles->read_len);
     if (rc != MANTA_OK) return rc;
     b->asmStage.uploadPiles(*piles);
@@ -1884,6 +1903,8 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
     uint64_t asmCnt[3];
     {
       GateLock only(gates, &StageGates::asmMu);
+      std::unique_lock<std::mutex> streamedOnly(g_streamedAsmMu, std::defer_lock);  // see smallsvRunImpl
+      if (as.streaming) streamedOnly.lock();
       b->evStart.record();
       as.launch();
       b->evAsm.record();
@@ -1891,6 +1912,7 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
     }
     stage("assembled");
     GateLock alignOnly(gates, &StageGates::alignMu);
+    if (b->refsOnCopy) rt::curStreamWaits(b->refsReady);  // reference windows of a streamed upload (manta_spanning_upload)
     // CIGAR scratch, sized from what the assembler produced: a task takes 4 * contig length + 16 words (spanFileTask), every
     // contig is aligned at most twice (second round: spanning_realign_kernel), and the text arena counter bounds the summed
     // contig lengths.  (A fixed worst case of max_contig_len per slot is ~40x the real need at 200 x 250 bp loci.)
@@ -1998,6 +2020,10 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
     b->evAlign.record();
     rt::sync();
     alignOnly.release();
+    if (as.streaming) {  // every chunk was consumed by the kernel, so this returns at once; it closes the copy stream's error state
+      rt::ScopedStream onCopy(b->copy);
+      rt::sync();
+    }
     stage("aligned round 2");
     b->stats.assemble_ms = rt::elapsedMs(b->evStart, b->evAsm);
     b->stats.schedule_ms = rt::elapsedMs(b->evAsm, b->evSched);
@@ -2504,6 +2530,7 @@ int manta_spanning_batch(
       b->opt       = *opt;
       b->scores    = *scores;
       b->jumpScore = jump_score;
+      b->streamUploads = !(plan && (plan->flags & MANTA_BATCH_NO_STREAMED_UPLOAD));
       b->asmStage.wavesPerCuCap = sh.pipelineStages ? kPipelinedAsmWavesPerCu : 0;
       std::vector<uint64_t> rOff, f1Off, f2Off;
       std::vector<uint32_t> lBeg;
