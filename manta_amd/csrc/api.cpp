@@ -2073,16 +2073,18 @@ int spanningCompact(
     manta_spanning* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_spanning_alignment_t* alignments,
     uint64_t contigBase, uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t seqBase, uint64_t* seq_arena_used,
     uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t bitsBase, uint64_t* bits_arena_used, uint32_t* cigar_arena,
-    uint64_t cigar_arena_cap, uint64_t cigarBase, uint64_t* cigar_arena_used)
+    uint64_t cigar_arena_cap, uint64_t cigarBase, uint64_t* cigar_arena_used, uint32_t lBegin = 0, uint32_t lEnd = ~0u,
+    uint64_t* cellsOut = nullptr, uint64_t* ptrBytesOut = nullptr)
 {
+  // [lBegin, lEnd) and the *Out totals: as smallsvCompact
   manta_ctx_t* ctx = b->ctx;
+  lEnd             = std::min(lEnd, b->nLoci);
   int rc = b->asmStage.compact(PackedContigs<manta_spanning>{b}, loci, contigs + contigBase, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used,
-                               bits_arena, bits_arena_cap, bits_arena_used, contigBase, seqBase, bitsBase);
+                               bits_arena, bits_arena_cap, bits_arena_used, contigBase, seqBase, bitsBase, lBegin, lEnd);
   if (rc != MANTA_OK && !perItemCode(rc)) return rc;
-  const uint32_t nLoci = b->nLoci;
   uint64_t       used = 0, cells = 0, ptrBytes = 0;
   int            worst = rc;
-  for (uint32_t l = 0; l < nLoci; ++l) {
+  for (uint32_t l = lBegin; l < lEnd; ++l) {
     if (loci[l].status != MANTA_OK) continue;
     for (uint32_t c = 0; c < loci[l].n_contigs; ++c) {
       manta_spanning_alignment_t& a(alignments[loci[l].first_contig + c]);
@@ -2113,11 +2115,31 @@ int spanningCompact(
       ptrBytes += (uint64_t(h.query_len) + 1) * (uint64_t(h.ref_len) + 2);
     }
   }
-  b->stats.dp_cells         = cells;
-  b->stats.ptr_matrix_bytes = ptrBytes;
+  if (cellsOut) {
+    *cellsOut    = cells;
+    *ptrBytesOut = ptrBytes;
+  } else {
+    b->stats.dp_cells         = cells;
+    b->stats.ptr_matrix_bytes = ptrBytes;
+  }
   if (cigar_arena_used) *cigar_arena_used = used;
   if (worst != MANTA_OK) return fail(ctx, worst, "manta_spanning_download: one or more loci/contigs failed; see per-item status");
   return MANTA_OK;
+}
+
+/// CIGAR words spanningCompact writes for the loci [lBegin, lEnd)
+uint64_t spanningCigarWords(const manta_spanning* b, uint32_t lBegin, uint32_t lEnd)
+{
+  uint64_t n = 0;
+  for (uint32_t l = lBegin; l < lEnd; ++l) {
+    const AsmLocusOut& h(b->asmStage.hLoci[l]);
+    if (h.status != ASM_OK) continue;
+    for (uint32_t c = 0; c < h.n_contigs; ++c) {
+      const PackedContigOut& pc(b->hPacked[b->hFirst[l] + c]);
+      if (pc.info_status == 0 && pc.res_status == 0 && pc.bucket >= 0) n += uint64_t(pc.cigar1_len) + pc.cigar2_len;
+    }
+  }
+  return n;
 }
 
 }  // namespace
@@ -2577,16 +2599,41 @@ int manta_spanning_batch(
           rt::ScopedStream onStream(b->main);
           pipeStage(b);
         }
-        b->asmStage.exactSizes(PackedContigs<manta_spanning>{b}, nC, nS, nB);
-        nG = b->hPackCnt[1];
+        // compaction in a few locus ranges, one host thread each (as smallsvBatchImpl)
+        struct Range {
+          uint64_t nC = 0, nS = 0, nB = 0, nG = 0, cells = 0, ptrBytes = 0;
+          uint64_t c0 = 0, s0 = 0, b0 = 0, g0 = 0;
+          int      rc = MANTA_OK;
+        };
+        const unsigned     parts = hostParts(uint64_t(n) * 4);
+        std::vector<Range> rg(parts);
+        hostParallel(n, parts, [&](unsigned t, uint64_t a, uint64_t z) {
+          b->asmStage.rangeSizes(PackedContigs<manta_spanning>{b}, uint32_t(a), uint32_t(z), rg[t].nC, rg[t].nS, rg[t].nB);
+          rg[t].nG = spanningCigarWords(b, uint32_t(a), uint32_t(z));
+        });
+        for (unsigned t = 0; t < parts; ++t) {
+          rg[t].c0 = nC, rg[t].s0 = nS, rg[t].b0 = nB, rg[t].g0 = nG;
+          nC += rg[t].nC, nS += rg[t].nS, nB += rg[t].nB, nG += rg[t].nG;
+        }
         const uint64_t cBase = sh.contigsUsed.fetch_add(nC), sBase = sh.seqUsed.fetch_add(nS), bBase = sh.bitsUsed.fetch_add(nB),
                        gBase = sh.cigarUsed.fetch_add(nG);
         if (cBase + nC > contigs_cap || sBase + nS > seq_arena_cap || bBase + nB > bits_arena_cap || gBase + nG > cigar_arena_cap) {
           sh.error(MANTA_E_CAPACITY, "manta_spanning_batch: caller arenas too small", true);
           break;
         }
-        rc = spanningCompact(b, loci + l0, contigs, alignments, cBase, nC, seq_arena + sBase, nS, sBase, nullptr, bits_arena + bBase, nB, bBase,
-                             nullptr, cigar_arena + gBase, nG, gBase, nullptr);
+        hostParallel(n, parts, [&](unsigned t, uint64_t a, uint64_t z) {
+          const Range& r(rg[t]);
+          rg[t].rc = spanningCompact(b, loci + l0, contigs, alignments, cBase + r.c0, r.nC, seq_arena + sBase + r.s0, r.nS, sBase + r.s0, nullptr,
+                                     bits_arena + bBase + r.b0, r.nB, bBase + r.b0, nullptr, cigar_arena + gBase + r.g0, r.nG, gBase + r.g0,
+                                     nullptr, uint32_t(a), uint32_t(z), &rg[t].cells, &rg[t].ptrBytes);
+        });
+        rc = MANTA_OK;
+        b->stats.dp_cells = b->stats.ptr_matrix_bytes = 0;
+        for (const Range& r : rg) {
+          if (r.rc != MANTA_OK && (rc == MANTA_OK || !perItemCode(r.rc))) rc = r.rc;
+          b->stats.dp_cells += r.cells;
+          b->stats.ptr_matrix_bytes += r.ptrBytes;
+        }
         const double t3 = nowMs();
         if (rc != MANTA_OK) {
           sh.error(rc, lastErrorOf(ctx), !perItemCode(rc));
