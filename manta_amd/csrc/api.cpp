@@ -1416,7 +1416,8 @@ static const int kPipelinedAsmWavesPerCu = std::getenv("MANTA_AMD_PIPELINED_ASM_
 struct StageGates {
   std::mutex asmMu, alignMu;
 };
-static std::mutex g_streamedAsmMu;  // see smallsvRunImpl
+static std::mutex g_streamedAsmMuOfDevice[16];  // see smallsvRunImpl; one per device (id modulo 16)
+static std::mutex& streamedAsmMu(const manta_ctx_t* ctx) { return g_streamedAsmMuOfDevice[unsigned(ctx->deviceId) % 16u]; }
 struct GateLock {
   std::unique_lock<std::mutex> l;
   GateLock(StageGates* g, std::mutex StageGates::*m) { if (g) l = std::unique_lock<std::mutex>(g->*m); }
@@ -1460,8 +1461,8 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
       GateLock only(gates, &StageGates::asmMu);
       // A streamed-upload assembler polls for chunks whose copies may need a free workgroup slot (launch() leaves some);
       // a second persistent assembler would take exactly those slots and both would spin until the kernels' time-out.
-      // Process-wide: never two streamed assemblers on the device at once.
-      std::unique_lock<std::mutex> streamedOnly(g_streamedAsmMu, std::defer_lock);
+      // Per device, process-wide: never two streamed assemblers on a device at once.
+      std::unique_lock<std::mutex> streamedOnly(streamedAsmMu(ctx), std::defer_lock);
       if (as.streaming) streamedOnly.lock();
       b->evStart.record();
       as.launch();
@@ -1903,7 +1904,7 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
     uint64_t asmCnt[3];
     {
       GateLock only(gates, &StageGates::asmMu);
-      std::unique_lock<std::mutex> streamedOnly(g_streamedAsmMu, std::defer_lock);  // see smallsvRunImpl
+      std::unique_lock<std::mutex> streamedOnly(streamedAsmMu(ctx), std::defer_lock);  // see smallsvRunImpl
       if (as.streaming) streamedOnly.lock();
       b->evStart.record();
       as.launch();

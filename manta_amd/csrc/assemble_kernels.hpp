@@ -1524,7 +1524,7 @@ namespace manta_dev {
 
 /// streamed upload: wait until the chunk holding `locus` has landed.  Polls a system-scope counter with back-off; gives
 /// up after ~1 minute of shader clocks (a copy that never completes must not hang the device for good).  The host side
-/// never runs two streamed assemblers at once (api.cpp: g_streamedAsmMu), so a copy always finds a free workgroup slot.
+/// never runs two streamed assemblers on one device at once (api.cpp: streamedAsmMu), so a copy always finds a free workgroup slot.
 WV_DEV bool asmWaitUploaded(const AsmParams& P, const unsigned locus)
 {
   const unsigned need = locus / P.chunk_loci + 1;

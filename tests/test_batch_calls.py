@@ -101,3 +101,36 @@ def test_gpu_batch_calls(gpu, oracle):
     check_spanning(gpu, oracle, 60, block=16, workers=4)
     check_smallsv(gpu, oracle, 300, block=64, workers=2, mixed=True)
     check_spanning(gpu, oracle, 60, block=16, workers=2)
+
+
+def staged_smallsv_texts(lib, batch, opts):
+    p = SmallSvBatch(lib, opts, SCORES, -100)
+    p.upload_packed(*batch)
+    p.run()
+    return [small_sv_text(r) for r in p.download()]
+
+
+def stress_shapes(lib, shapes, seed):
+    """whole-batch call == staged API on odd shapes: tiny batches (fewer loci than upload chunks), blocks that do not divide the
+    batch, more workers than blocks; the streamed upload, the stage gates and the host ranges all take their edge paths"""
+    opts = asm_opts(minWordLength=25, maxWordLength=45)
+    for i, (n, block, workers) in enumerate(shapes):
+        batch = small_batch(n, seed + i)
+        batch = batch[:5] + (np.tile(np.array([40, 40, 200, 200], dtype=np.int32), (n, 1)),)
+        out = BatchOutput(lib, "smallsv", n, 10, 1 << 22, 1 << 18, 1 << 20)
+        lib.smallsv_batch(opts, SCORES, -100, batch, out, block_loci=block, n_workers=workers)
+        got = [small_sv_text(r) for r in out.decode(np.diff(batch[2]))]
+        assert got == staged_smallsv_texts(lib, batch, opts), (n, block, workers)
+
+
+def test_emulated_batch_odd_shapes(emu):
+    stress_shapes(emu, [(1, 0, 0), (3, 2, 3), (9, 4, 2), (17, 0, 1)], 900)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_gpu_batch_odd_shapes_and_repeats(gpu):
+    stress_shapes(gpu, [(1, 0, 0), (3, 2, 3), (7, 0, 1), (9, 4, 2), (65, 16, 5), (333, 100, 2), (1024, 0, 1), (1500, 700, 3)], 910)
+    # the same pipelines again and again (buffers are reused, counters and events must start clean every call)
+    for rep in range(6):
+        stress_shapes(gpu, [(257, 64, 2), (40, 0, 1)], 950 + rep)
