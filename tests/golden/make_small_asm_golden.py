@@ -7,14 +7,16 @@ import hashlib, json, os, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle_lib import RefLib
-from small_asm_cases import UNIT_CASES, UNIT_OPTS, random_case
+from small_asm_cases import EDGE_CASES, UNIT_CASES, UNIT_OPTS, random_case
 
 N_RANDOM = 600
 ref = RefLib()
 out = {"source": "oracle/_ref/libmanta_ref.so: ref_small_assemble -> runSmallAssembler (assembly/SmallAssembler.cpp:622-685)",
-       "unit": {}, "random_sha256": [], "stats": {}}
+       "unit": {}, "edge": {}, "random_sha256": [], "stats": {}}
 for name, reads in UNIT_CASES.items():
     out["unit"][name] = ref.small_assemble(UNIT_OPTS, reads)
+for name, (opts, reads) in EDGE_CASES.items():
+    out["edge"][name] = ref.small_assemble(opts, reads)
 multi = filt = empty = 0
 for s in range(N_RANDOM):
     opts, reads = random_case(s)

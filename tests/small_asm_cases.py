@@ -13,6 +13,20 @@ UNIT_CASES = {
                                   "CCCTTAGCTAAC", "CTTAGCTAACGT", "TAGCTAACGTGG", "GCTAACGTGGCC", "AACGTGGCCTAG"],
 }
 
+# (opts7, reads): empty and degenerate inputs, word length == read length, unmet thresholds, several iterations, wide read sets
+EDGE_CASES = {
+    "empty": ([6, 6, 1, 1, 1, 1, 10], []),
+    "one_short_read": ([6, 6, 1, 1, 1, 1, 10], ["ACG"]),
+    "all_N": ([6, 8, 1, 1, 1, 1, 10], ["NNNNNNNNNNNN", "NNNNNNNNNN"]),
+    "no_words_minSeedReads_0": ([6, 6, 1, 1, 1, 0, 3], ["ACG", "TT"]),
+    "homopolymer_only": ([4, 8, 2, 1, 1, 1, 5], ["AAAAAAAAAAAA", "AAAAAAAAAAAAAAA", "AAAAAAAA"]),
+    "duplicate_reads": ([5, 5, 1, 2, 2, 2, 4], ["ACGTACGGTCA"] * 5),
+    "word_is_read": ([8, 8, 1, 1, 1, 1, 4], ["ACGTTGCA", "ACGTTGCA", "CGTTGCAA"]),
+    "minCoverage_unmet": ([6, 6, 1, 5, 2, 1, 4], ["ACGTGTATTACC", "GTGTATTACCTA"]),
+    "two_iterations": ([6, 6, 1, 1, 1, 1, 10], ["ACGTGTATTACC", "GTGTATTACCTA", "TTTTGGGGCCCCAAAT", "TTGGGGCCCCAAATGC"]),
+    "four_set_words": ([15, 25, 5, 2, 2, 3, 10], ["ACGTACGGTCAGGCTTAACGGATCCGATTACAGGCATTACGGA"[i % 10:i % 10 + 30] for i in range(200)]),
+}
+
 
 def random_case(seed):
     """(opts7, reads) of random case `seed`"""

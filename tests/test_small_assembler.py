@@ -9,7 +9,7 @@ import os
 import pytest
 
 from manta_amd._capi import small_assembly_text
-from small_asm_cases import UNIT_CASES, UNIT_OPTS, abi_opts, random_case
+from small_asm_cases import EDGE_CASES, UNIT_CASES, UNIT_OPTS, abi_opts, random_case
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "small_assembler_cases.json")))
 
@@ -40,6 +40,19 @@ def check_unit(lib):
     assert "contig 0 seq=AACGTGTATTACCTAGTAC " in t and "contig 1 seq=CTTAGCTAACGTGGCC " in t
 
 
+def check_edges(lib):
+    names = list(EDGE_CASES)
+    got = run_cases(lib, [EDGE_CASES[n] for n in names])
+    for n, g in zip(names, got):
+        assert g == GOLD["edge"][n], n
+    # all of them in ONE batch with one option set: empty and degenerate piles next to ordinary ones
+    o = [6, 6, 1, 1, 1, 1, 10]
+    piles = [EDGE_CASES[n][1] for n in names if EDGE_CASES[n][0] == o] + [UNIT_CASES["supportingReadConsistency"]]
+    res = lib.small_assemble_batch(abi_opts(o), piles)
+    assert [r["status"] for r in res] == [0] * len(piles)
+    assert small_assembly_text(res[0]) == GOLD["edge"]["empty"]
+
+
 def check_random(lib, first, count):
     cases = [random_case(s) for s in range(first, first + count)]
     got = run_cases(lib, cases)
@@ -52,6 +65,10 @@ def test_emulated_small_assembler_unit_scenarios(emu):
     check_unit(emu)
 
 
+def test_emulated_small_assembler_edge_cases(emu):
+    check_edges(emu)
+
+
 def test_emulated_small_assembler_random_piles(emu):
     check_random(emu, 0, 250)
 
@@ -60,6 +77,8 @@ def test_golden_file_is_what_the_reference_says(reflib):
     """the committed golden file against the reference itself (build container only)"""
     for n, reads in UNIT_CASES.items():
         assert reflib.small_assemble(UNIT_OPTS, reads) == GOLD["unit"][n]
+    for n, (o, reads) in EDGE_CASES.items():
+        assert reflib.small_assemble(o, reads) == GOLD["edge"][n]
     for s in range(0, 600, 7):
         o, reads = random_case(s)
         assert hashlib.sha256(reflib.small_assemble(o, reads).encode("latin-1")).hexdigest() == GOLD["random_sha256"][s]
@@ -78,4 +97,5 @@ def test_small_assembler_rejects_bad_options(emu):
 @pytest.mark.gpu
 def test_gpu_small_assembler(gpu):
     check_unit(gpu)
+    check_edges(gpu)
     check_random(gpu, 0, 600)
