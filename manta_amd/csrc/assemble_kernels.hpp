@@ -27,7 +27,7 @@ namespace manta_dev {
 
 enum {
   ASM_OK               = 0,
-  ASM_E_ALPHABET       = 1,  // read contains a byte outside {A,C,G,T,N}
+  ASM_E_ALPHABET       = 1,  // reads hold bytes outside {A,C,G,T,N} AND the result may depend on the words that contain them
   ASM_E_TABLE_FULL     = 2,  // more k-mer instances / nodes than the workspace was sized for
   ASM_E_CONTIG_TOO_LONG = 3,
   ASM_E_OUT_CAPACITY   = 4,  // output arenas exhausted
@@ -627,7 +627,7 @@ struct Assembler {
               unsigned       c = 0;
               if (i < len) {
                 c = baseCode(uint8_t(four >> (8 * b4)));
-                if (c == 5) badAlphabet = true;
+                if (c == 5) badAlphabet = true;  // handled below: masked like 'N' where that is provably exact
                 if (c >= 4) {
                   nbits |= (1u << b);
                   c = 0;
@@ -643,8 +643,28 @@ struct Assembler {
           wv::atomic_or(&rd_hasn[r], 1u);
         }
       }
+      if (badAlphabet) wv::atomic_or(&rd_hasn[r], 2u);  // (lane-private flag: this lane only ever works on read r in this pass)
+      badAlphabet = false;
     }
-    if (wv::any(badAlphabet)) status = ASM_E_ALPHABET;
+    // Bytes outside {A,C,G,T,N} ("junk"; the reference is byte-generic).  A word that contains one is an ordinary word for
+    // the reference, but it is never a successor or predecessor of anything (extensions append alphabet symbols only,
+    // IterativeAssembler.cpp:241-247), so it can matter in exactly two ways: as a seed -- needs wordCount >= minCoverage
+    // (:678-682) -- and through the visiting order of the repeat search, which only changes results when the graph has a
+    // cycle (:555-642).  A junk word occurs at most once per read that holds junk, so with fewer such reads than
+    // minCoverage no junk word can be a seed: the junk positions are then masked like 'N' (their words are dropped, every
+    // other word of the read counts as usual) and the locus is exact as long as its graphs stay acyclic (contigsFromGraph
+    // reports ASM_E_ALPHABET otherwise).  Anything else is reported, never guessed.
+    // (resolveJunk(), called once the flags are visible, applies the rule)
+  }
+
+  /// number of reads that hold a byte outside {A,C,G,T,N} (flag bit 1 of rd_hasn; kept in the slab, not in registers: it is
+  /// needed once per locus and again only for cyclic graphs).  Call after packNormalReads + sync + fence.
+  WV_DEV_COLD unsigned countJunkReads()
+  {
+    unsigned junkReads = 0;
+    if (!P.pl_codes && status == ASM_OK)
+      for (unsigned r = unsigned(wv::lane()); r < nNormal; r += 64) junkReads += (rd_hasn[r] >> 1) & 1u;
+    return waveSum(junkReads);
   }
 
   WV_DEV unsigned maskWordCap() const { return P.cap_words / 2 + P.cap_reads + 2; }
@@ -1233,6 +1253,10 @@ struct Assembler {
   {
     const bool cyclic = graphHasCycle();
     tick(3);
+    if (cyclic && countJunkReads() > 0) {  // the repeat search's visiting order would include the dropped junk words
+      status = ASM_E_ALPHABET;
+      return true;
+    }
     if (cyclic) {
       cyclicIters++;
       exactRepeatSearch();
@@ -1481,6 +1505,7 @@ struct Assembler {
     packNormalReads(locus);
     wv::sync();
     wv::fence_acquire();
+    if (countJunkReads() >= P.opt.minCoverage && status == ASM_OK) status = ASM_E_ALPHABET;  // see packNormalReads
     tick(0);
     W = (nNormal + 2 * P.opt.maxAssemblyCount + 63) / 64;
     if (W == 0) W = 1;

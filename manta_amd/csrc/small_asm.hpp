@@ -347,6 +347,9 @@ struct SmallAsm {
     A.packNormalReads(locus);
     wv::sync();
     wv::fence_acquire();
+    // bytes outside {A,C,G,T,N}: here a word that holds one matters whenever it repeats inside its read or ties the maximal
+    // count (:432, :508-535) -- no cheap exact rule, so the pile is reported
+    if (A.countJunkReads() > 0 && A.status == ASM_OK) A.status = ASM_E_ALPHABET;
     W = (A.nNormal + 63) / 64;
     if (W == 0) W = 1;
     A.W         = W;

@@ -112,6 +112,29 @@ static void test_GlobalJumpAligner()
 
 static void test_IterativeAssembler()
 {
+  {  // assembly/test/IterativeAssemblerTest.cpp:63-95 (test_BasicAssembler) as it stands, junk read included: one junk read
+     // at minCoverage 2 in an acyclic graph is the case where dropping its words is provably exact
+    IterativeAssemblerOptions assembleOpt;
+    assembleOpt.minWordLength = 6;
+    assembleOpt.maxWordLength = 6;
+    assembleOpt.minCoverage   = 2;
+    AssemblyReadInput reads;
+    reads.emplace_back("ACGTGTATTACC");
+    reads.emplace_back("GTGTATTACCTA");
+    reads.emplace_back("ATTACCTAGTAC");
+    reads.emplace_back("TACCTAGTACTC");
+    reads.emplace_back("123456789123");
+    AssemblyReadOutput readInfo;
+    Assembly           contigs;
+    runIterativeAssembler(assembleOpt, reads, readInfo, contigs);
+    REQUIRE_EQUAL(contigs.size(), 1u);
+    REQUIRE_EQUAL(contigs[0].seq, "GTGTATTACCTAGTAC");
+    for (unsigned i(0); i < 4; ++i) {
+      REQUIRE(readInfo[i].isUsed);
+      REQUIRE_EQUAL(readInfo[i].contigIds[0], 0u);
+    }
+    REQUIRE(!readInfo[4].isUsed);
+  }
   {  // single word size, two alleles sharing a trunk
     IterativeAssemblerOptions assembleOpt;
     assembleOpt.minWordLength   = 6;

@@ -1,0 +1,14 @@
+#!/bin/bash
+# after the junk-byte rule: GPU tier + bench lines
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/r02p
+rm -rf $O && mkdir -p $O
+cd $R
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log
+for i in 1 2; do
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/bench$i.json 2> $O/bench$i.err
+python - $O/bench$i.json <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); print("value", d["value"], "ms", d["ms_per_step"], d["pcie"]["host_ms_per_step"], d["kernels_ms_per_step"]["assemble_kernel"], d["config"].get("parity"))
+PY
+done
