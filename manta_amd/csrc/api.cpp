@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <unistd.h>
 #include <functional>
 #include <condition_variable>
 #include <chrono>
@@ -282,7 +283,7 @@ class HostPool {
   void run(const uint64_t n, const unsigned parts, F fn)
   {
     auto begin = [&](unsigned t) { return n * t / parts; };
-    if (parts <= 1) {
+    if (parts <= 1 || getpid() != owner) {  // (a fork()ed child has no helper threads: it runs the loop itself)
       fn(0u, uint64_t(0), n);
       return;
     }
@@ -303,12 +304,16 @@ class HostPool {
   }
 
  private:
-  HostPool()
+  HostPool() : owner(getpid())
   {
     for (unsigned i = 0; i < 3; ++i) threads.emplace_back([this, i] { loop(i + 1); });
   }
   ~HostPool()
   {
+    if (getpid() != owner) {  // fork()ed child: the threads do not exist here
+      for (std::thread& t : threads) t.detach();
+      return;
+    }
     {
       std::lock_guard<std::mutex> g(mu);
       stop = true;
@@ -335,6 +340,7 @@ class HostPool {
       }
     }
   }
+  const pid_t                    owner;
   std::mutex                     mu, runMu;
   std::condition_variable        cv, done;
   std::vector<std::thread>       threads;
