@@ -605,6 +605,9 @@ struct AsmStage {
   // ---- streamed upload (whole-batch calls): the read bases arrive chunk by chunk on `copyStream` while assemble_kernel,
   // launched right away on the pipeline's stream, works through the loci whose chunk has landed (AsmParams::upload_*)
   static const uint32_t kStreamChunks = 8;
+  DevBuf                bPlShift;  // streamed packed piles: three shifts per chunk
+  uint64_t*             dPlShift = nullptr;
+  bool                  streamingPiles = false;
   DevBuf                bStream;  // chunk shifts
   uint32_t*             dStream = nullptr;
   uint32_t*             dChunksDone = nullptr;  // fine-grained device word the copy engine bumps after every chunk
@@ -659,10 +662,71 @@ struct AsmStage {
     streaming = true;
   }
 
+  /// uploadStreamed() for packed piles: per chunk the slices of the five pile arrays (codes, N masks, read lengths and the two
+  /// per-read offset arrays) are copied to line-aligned device positions, then the counter is bumped; the kernel finds a
+  /// locus' slices through three per-chunk shifts (AsmParams::pl_chunk_shift).  Only the locus table goes first.
+  void uploadPilesStreamed(const manta_packed_piles_t& pl, rt::Stream& copyStream)
+  {
+    chunkLoci = std::max<uint32_t>(1, (nLoci + kStreamChunks - 1) / kStreamChunks);
+    const uint32_t nChunks = (nLoci + chunkLoci - 1) / chunkLoci;
+    struct Piece {
+      uint32_t r0, r1;
+      uint64_t c0, c1, m0, m1, dr, dc, dm;
+    };
+    std::vector<Piece>    pc(nChunks);
+    std::vector<uint64_t> shifts(3 * kStreamChunks, 0);
+    uint64_t              curR = 0, curC = 0, curM = 0;
+    auto                  lineUp = [](uint64_t v) { return (v + 63) & ~uint64_t(63); };  // 64 elements >= one 128-byte line for every array
+    for (uint32_t c = 0; c < nChunks; ++c) {
+      const uint32_t l0 = c * chunkLoci, l1 = std::min(nLoci, l0 + chunkLoci);
+      Piece&         q(pc[c]);
+      q.r0 = pl.locus_read_begin[l0], q.r1 = pl.locus_read_begin[l1];
+      q.c0 = pl.read_code_off[q.r0], q.c1 = pl.read_code_off[q.r1];
+      q.m0 = pl.read_mask_off[q.r0], q.m1 = pl.read_mask_off[q.r1];
+      q.dr = curR, q.dc = curC, q.dm = curM;
+      shifts[3 * c + 0] = q.dr - q.r0;  // modulo 2^64 on purpose
+      shifts[3 * c + 1] = q.dc - q.c0;
+      shifts[3 * c + 2] = q.dm - q.m0;
+      curR = lineUp(curR + (q.r1 - q.r0) + 1);  // +1: the offset arrays hold one more entry than there are reads
+      curC = lineUp(curC + (q.c1 - q.c0) + 4);
+      curM = lineUp(curM + (q.m1 - q.m0) + 4);
+    }
+    dPlCodes   = bPlCodes.as<uint32_t>(curC + 64);
+    dPlMask    = bPlMask.as<uint32_t>(curM + 64);
+    dPlLen     = bPlLen.as<uint32_t>(curR + 64);
+    dPlCodeOff = bPlCodeOff.as<uint64_t>(curR + 64);
+    dPlMaskOff = bPlMaskOff.as<uint64_t>(curR + 64);
+    plBytes    = 0;
+    upload(nullptr, nullptr, pl.locus_read_begin);  // allocations + order, word lengths, growth schedule, locus table
+    dPlShift = bPlShift.as<uint64_t>(3 * kStreamChunks);
+    rt::h2d(dPlShift, shifts.data(), sizeof(uint64_t) * 3 * kStreamChunks);
+    if (!dChunksDone) dChunksDone = static_cast<uint32_t*>(rt::dmallocFine(64));
+    uint32_t* ids = pChunkIds.as<uint32_t>(kStreamChunks + 1);
+    for (uint32_t c = 0; c <= kStreamChunks; ++c) ids[c] = c;
+    rt::h2d(dChunksDone, ids, sizeof(uint32_t));  // = 0
+    rt::sync();
+    {
+      rt::ScopedStream onCopy(copyStream);
+      for (uint32_t c = 0; c < nChunks; ++c) {
+        const Piece&   q(pc[c]);
+        const uint64_t nR = q.r1 - q.r0;
+        rt::h2d(dPlLen + q.dr, pl.read_len + q.r0, sizeof(uint32_t) * nR);
+        rt::h2d(dPlCodeOff + q.dr, pl.read_code_off + q.r0, sizeof(uint64_t) * (nR + 1));
+        rt::h2d(dPlMaskOff + q.dr, pl.read_mask_off + q.r0, sizeof(uint64_t) * (nR + 1));
+        rt::h2d(dPlCodes + q.dc, pl.codes + q.c0, sizeof(uint32_t) * (q.c1 - q.c0));
+        rt::h2d(dPlMask + q.dm, pl.nmask + q.m0, sizeof(uint32_t) * (q.m1 - q.m0));
+        rt::h2d(dChunksDone, ids + c + 1, sizeof(uint32_t));
+        plBytes += 4 * (q.c1 - q.c0) + 4 * (q.m1 - q.m0) + 20ull * nR;
+      }
+    }
+    streaming       = true;
+    streamingPiles  = true;
+  }
+
   void upload(const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin)
   {
     if (bases) dPlCodes = nullptr;
-    streaming = false;
+    streaming = streamingPiles = false;
     dBases  = bBases.as<uint8_t>(nBases + 16);
     dOff    = bReadOff.as<uint64_t>(nReadsTotal + 1);
     dBegin  = bLocusBegin.as<uint32_t>(nLoci + 1);
@@ -733,7 +797,8 @@ struct AsmStage {
     P.pl_code_off    = dPlCodeOff;
     P.pl_mask_off    = dPlMaskOff;
     P.upload_chunks_done = streaming ? dChunksDone : nullptr;
-    P.chunk_shift        = streaming ? dStream + 1 : nullptr;
+    P.chunk_shift        = (streaming && !streamingPiles) ? dStream + 1 : nullptr;
+    P.pl_chunk_shift     = streamingPiles ? dPlShift : nullptr;
     P.chunk_loci         = streaming ? chunkLoci : 0;
     P.reserved2          = 0;
     P.small_min_seed_reads = smallMinSeedReads;
@@ -1391,7 +1456,6 @@ int manta_smallsv_upload_piles(
     b->refsOnCopy = false;
     rc          = b->asmStage.plan(b->opt, n_loci, nullptr, piles->locus_read_begin, piles->read_len);
     if (rc != MANTA_OK) return rc;
-    b->asmStage.uploadPiles(*piles);
     b->nLoci    = n_loci;
     b->refBytes = ref_off[n_loci];
     b->maxRef   = 0;
@@ -1401,10 +1465,24 @@ int manta_smallsv_upload_piles(
       if (cuts[l].leading_cut < 0 || cuts[l].trailing_cut < 0 || cuts[l].max_leading_cut < 0 || cuts[l].max_trailing_cut < 0)
         return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_upload_piles: negative reference cut");
     }
-    rt::h2d(b->dRefs.as<uint8_t>(b->refBytes + 16), refs, b->refBytes);
-    rt::h2d(b->dRefOff.as<uint64_t>(n_loci + 1), ref_off, sizeof(uint64_t) * (n_loci + 1));
-    rt::h2d(b->dCuts.as<SmallSvCuts>(n_loci), cuts, sizeof(SmallSvCuts) * n_loci);
-    rt::sync();
+    uint8_t*  dRefs   = b->dRefs.as<uint8_t>(b->refBytes + 16);
+    uint64_t* dRefOff = b->dRefOff.as<uint64_t>(n_loci + 1);
+    auto*     dCuts   = b->dCuts.as<SmallSvCuts>(n_loci);
+    b->refsOnCopy     = b->streamUploads && !b->asmStage.useLds && !std::getenv("MANTA_AMD_NO_STREAM_UPLOAD");
+    if (b->refsOnCopy) {  // whole-batch call: piles chunk by chunk behind the running assembler, references behind them (manta_smallsv_upload)
+      b->asmStage.uploadPilesStreamed(*piles, b->copy);
+      rt::ScopedStream onCopy(b->copy);
+      rt::h2d(dRefs, refs, b->refBytes);
+      rt::h2d(dRefOff, ref_off, sizeof(uint64_t) * (n_loci + 1));
+      rt::h2d(dCuts, cuts, sizeof(SmallSvCuts) * n_loci);
+      b->refsReady.record();
+    } else {
+      b->asmStage.uploadPiles(*piles);
+      rt::h2d(dRefs, refs, b->refBytes);
+      rt::h2d(dRefOff, ref_off, sizeof(uint64_t) * (n_loci + 1));
+      rt::h2d(dCuts, cuts, sizeof(SmallSvCuts) * n_loci);
+      rt::sync();
+    }
     b->uploaded = true;
     return MANTA_OK;
   } catch (const std::exception& e) {

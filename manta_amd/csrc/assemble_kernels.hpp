@@ -130,6 +130,9 @@ struct AsmParams {
   const uint32_t* chunk_shift;
   uint32_t        chunk_loci;
   uint32_t        reserved2;
+  // streamed upload of packed piles: per chunk three shifts {read index, code dwords, mask dwords} (device position minus the
+  // caller's position, modulo 2^64): every chunk's slices of the five pile arrays start on their own cache lines
+  const uint64_t* pl_chunk_shift;
   // small_assemble_kernel only (small_asm.hpp): SmallAssemblerOptions::minSeedReads / maxAssemblyIterations
   uint32_t        small_min_seed_reads;
   uint32_t        small_max_iterations;
@@ -544,6 +547,7 @@ struct Assembler {
     const unsigned rBegin = P.locus_read_begin[locus], rEnd = P.locus_read_begin[locus + 1];
     nNormal               = rEnd - rBegin;
     status                = ASM_OK;
+
     if (nNormal + 2 * P.opt.maxAssemblyCount > P.cap_reads || nNormal + 2 * P.opt.maxAssemblyCount > 64 * P.w_max) {
       status = ASM_E_TOO_MANY_READS;
       return;
@@ -553,7 +557,7 @@ struct Assembler {
     for (unsigned base = 0; base < nNormal; base += 64) {
       const unsigned r   = base + unsigned(wv::lane());
       unsigned       len = 0;
-      if (r < nNormal) len = P.pl_codes ? P.pl_read_len[rBegin + r] : unsigned(P.read_off[rBegin + r + 1] - P.read_off[rBegin + r]);
+      if (r < nNormal) len = P.pl_codes ? P.pl_read_len[rBegin + r + plShift(locus, 0)] : unsigned(P.read_off[rBegin + r + 1] - P.read_off[rBegin + r]);
       const unsigned myC = (r < nNormal) ? (len + 15) / 16 + 1 : 0u;  // +1 padding dword so codes16() may read one past
       const unsigned myM = (r < nNormal) ? (len + 31) / 32 + 1 : 0u;
       // inclusive scan over lanes
@@ -583,13 +587,14 @@ struct Assembler {
     wv::sync();
     if (P.pl_codes) {  // packed piles: copy (8 lanes per read, as below), add the pad dwords, note which reads hold an 'N'
       const unsigned lane = unsigned(wv::lane());
+      const uint64_t plShiftR = plShift(locus, 0), plShiftC = plShift(locus, 1), plShiftM = plShift(locus, 2);
       for (unsigned base = 0; base < nNormal; base += 8) {
         const unsigned r = base + (lane >> 3);
         if (r >= nNormal) continue;
         const unsigned  len = rd_len[r], cwo = rd_cw[r], mwo = rd_mw[r];
         const unsigned  nCw = (len + 15) / 16, nMw = (len + 31) / 32;
-        const uint32_t* sc  = P.pl_codes + P.pl_code_off[rBegin + r];
-        const uint32_t* sm  = P.pl_nmask + P.pl_mask_off[rBegin + r];
+        const uint32_t* sc  = P.pl_codes + (P.pl_code_off[rBegin + r + plShiftR] + plShiftC);
+        const uint32_t* sm  = P.pl_nmask + (P.pl_mask_off[rBegin + r + plShiftR] + plShiftM);
         for (unsigned wi = (lane & 7); wi <= nCw; wi += 8) codes[cwo + wi] = (wi < nCw) ? sc[wi] : 0u;
         bool sawN = false;
         for (unsigned wi = (lane & 7); wi <= nMw; wi += 8) {
@@ -668,6 +673,12 @@ struct Assembler {
   }
 
   WV_DEV unsigned maskWordCap() const { return P.cap_words / 2 + P.cap_reads + 2; }
+
+  /// streamed packed piles: where this locus' chunk landed (i = 0 read index, 1 code dwords, 2 mask dwords); 0 otherwise
+  WV_DEV uint64_t plShift(const unsigned locus, const unsigned i) const
+  {
+    return P.pl_chunk_shift ? P.pl_chunk_shift[3 * size_t(locus / P.chunk_loci) + i] : uint64_t(0);
+  }
 
   // ------------------------------------------------------------------------------------------------
   // k-mer graph for the current word length
