@@ -11,11 +11,16 @@ B="python $R/bench.py"
 timeout 400 $B > $O/bench_line.json 2> $O/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $B --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2> /dev/null
 P="--steps 1 --warmup 0 --no-cpu-baseline --no-extras"
+# counter passes use the blocking upload: under the profiler the copies of a streamed upload are delayed and the assembler's
+# chunk-wait loop (s_sleep polling) would dominate every SQ_* counter; the kernel's work is the same
+export MANTA_AMD_NO_STREAM_UPLOAD=1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- $B $P > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- $B $P > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/pmc_sq -o p -- $B $P > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq2 -o p -- $B $P > /dev/null 2>&1
-# the opt-in LDS-resident assembler, same passes (evidence for DESIGN.md: traffic vs time)
+unset MANTA_AMD_NO_STREAM_UPLOAD
+# the opt-in LDS-resident assembler, same passes (evidence for DESIGN.md: traffic vs time); PROFILE_SKIP_LDS=1 leaves them out
+if [ -z "$PROFILE_SKIP_LDS" ]; then
 export MANTA_AMD_ASM_PATH=lds
 mkdir -p $O/lds
 timeout 300 $B --no-cpu-baseline --no-extras > $O/lds/bench_line.json 2> $O/lds/bench.err
@@ -23,6 +28,7 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/lds/pmc_write -o p -- $B $P > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/lds/pmc_sq -o p -- $B $P > /dev/null 2>&1
 unset MANTA_AMD_ASM_PATH
+fi
 if [ "$2" = "spanning" ]; then
   timeout 600 $B --workload spanning --steps 2 --warmup 1 > $O/bench_spanning_line.json 2> $O/bench_spanning.err
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_spanning -o bench -- $B --workload spanning --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
