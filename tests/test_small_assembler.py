@@ -61,6 +61,14 @@ def check_random(lib, first, count):
     assert not bad, bad[:10]
 
 
+def check_fresh_random(lib, oracle, first, count):
+    """seeds beyond the golden file: the kernel against the pinned restatement"""
+    cases = [random_case(s) for s in range(first, first + count)]
+    got = run_cases(lib, cases)
+    for i, ((o, reads), g) in enumerate(zip(cases, got)):
+        assert g == oracle.small_assemble(o, reads), first + i
+
+
 def test_emulated_small_assembler_unit_scenarios(emu):
     check_unit(emu)
 
@@ -69,8 +77,9 @@ def test_emulated_small_assembler_edge_cases(emu):
     check_edges(emu)
 
 
-def test_emulated_small_assembler_random_piles(emu):
+def test_emulated_small_assembler_random_piles(emu, oracle):
     check_random(emu, 0, 250)
+    check_fresh_random(emu, oracle, 600, 60)
 
 
 def test_golden_file_is_what_the_reference_says(reflib):
@@ -86,6 +95,20 @@ def test_golden_file_is_what_the_reference_says(reflib):
     assert st["with_two_or_more_contigs"] > 100 and st["with_filtered_reads"] > 30 and st["with_no_contig"] > 30
 
 
+def test_restatement_matches_the_reference_goldens(oracle):
+    """oracle/small_asm_oracle.cpp (the CPU restatement) against everything the golden file holds"""
+    for n, reads in UNIT_CASES.items():
+        assert oracle.small_assemble(UNIT_OPTS, reads) == GOLD["unit"][n], n
+    for n, (o, reads) in EDGE_CASES.items():
+        assert oracle.small_assemble(o, reads) == GOLD["edge"][n], n
+    bad = []
+    for s in range(600):
+        o, reads = random_case(s)
+        if hashlib.sha256(oracle.small_assemble(o, reads).encode("latin-1")).hexdigest() != GOLD["random_sha256"][s]:
+            bad.append(s)
+    assert not bad, bad[:10]
+
+
 def test_small_assembler_rejects_bad_options(emu):
     from manta_amd._capi import MantaError
     with pytest.raises(MantaError):
@@ -95,7 +118,8 @@ def test_small_assembler_rejects_bad_options(emu):
 
 
 @pytest.mark.gpu
-def test_gpu_small_assembler(gpu):
+def test_gpu_small_assembler(gpu, oracle):
+    check_fresh_random(gpu, oracle, 600, 400)
     check_unit(gpu)
     check_edges(gpu)
     check_random(gpu, 0, 600)
