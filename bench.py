@@ -104,7 +104,8 @@ def cores_available():
 
 def result_blob(out):
     """what the final candidate gather moves: the rank's result records and the used part of its arenas"""
-    n_contigs = sum(int(out.res[l].n_contigs) for l in range(out.n_loci) if out.res[l].status == 0)
+    res = np.frombuffer(out.res, dtype=np.uint32).reshape(-1, 12)[:out.n_loci]  # manta_asm_locus_result_t = 12 dwords: status, n_contigs, ...
+    n_contigs = int(res[:, 1][res[:, 0] == 0].sum())
     parts = [np.frombuffer(out.res, dtype=np.uint8),
              np.frombuffer(out.contigs, dtype=np.uint8)[:n_contigs * 40],
              np.frombuffer(out.aligns, dtype=np.uint8)[:n_contigs * (64 if out.kind == "smallsv" else 64)],
@@ -129,6 +130,10 @@ def main():
     # with fewer GPUs than ranks -- ranks then share devices and the gather goes through host memory.  The driver's runs use RCCL.
     backend = os.environ.get("MANTA_BENCH_BACKEND", "nccl")
     local_rank = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    if world > torch.cuda.device_count():
+        # ranks share a device (the gloo self-test on a one-GPU box): a streamed upload's polling kernel and another PROCESS'
+        # kernels time-slice the device against each other (measured: seconds per step) -- blocking uploads there
+        os.environ["MANTA_AMD_NO_STREAM_UPLOAD"] = "1"
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -650,13 +650,13 @@ struct AsmStage {
     rt::h2d(dChunksDone, ids, sizeof(uint32_t));  // = 0
     rt::sync();  // the counter is zero and the small arrays are in place before the first chunk can land
     {
-      // one copy per chunk, each followed by a 4-byte copy that bumps the counter: the copy engine executes a stream's
-      // copies in order, so the counter says c+1 only after chunk c is in HBM.  No kernel is involved: the persistent
-      // assembler may own every register of the device.
+      // one copy per chunk, each followed by a stream-ordered 32-bit write of the counter (command processor; a 4-byte copy
+      // if the runtime refuses): the counter says c+1 only after chunk c is in HBM.  Nothing here needs a workgroup slot --
+      // the persistent assembler, or another process' kernels, may own every one of them.
       rt::ScopedStream onCopy(copyStream);
       for (uint32_t c = 0; c < nChunks; ++c) {
         rt::h2d(dBases + devBegin[c], bases + hostBegin[c], hostBegin[c + 1] - hostBegin[c]);
-        rt::h2d(dChunksDone, ids + c + 1, sizeof(uint32_t));
+        if (!rt::streamWrite32(dChunksDone, c + 1)) rt::h2d(dChunksDone, ids + c + 1, sizeof(uint32_t));
       }
     }
     streaming = true;
@@ -715,7 +715,7 @@ struct AsmStage {
         rt::h2d(dPlMaskOff + q.dr, pl.read_mask_off + q.r0, sizeof(uint64_t) * (nR + 1));
         rt::h2d(dPlCodes + q.dc, pl.codes + q.c0, sizeof(uint32_t) * (q.c1 - q.c0));
         rt::h2d(dPlMask + q.dm, pl.nmask + q.m0, sizeof(uint32_t) * (q.m1 - q.m0));
-        rt::h2d(dChunksDone, ids + c + 1, sizeof(uint32_t));
+        if (!rt::streamWrite32(dChunksDone, c + 1)) rt::h2d(dChunksDone, ids + c + 1, sizeof(uint32_t));
         plBytes += 4 * (q.c1 - q.c0) + 4 * (q.m1 - q.m0) + 20ull * nR;
       }
     }

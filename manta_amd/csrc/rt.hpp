@@ -24,6 +24,7 @@ inline void* dmallocFine(size_t n) { return dmalloc(n); }
 inline void  h2d(void* d, const void* h, size_t n) { if (n) std::memcpy(d, h, n); }
 inline void  d2h(void* h, const void* d, size_t n) { if (n) std::memcpy(h, d, n); }
 inline void  d2hAsync(void* h, const void* d, size_t n) { if (n) std::memcpy(h, d, n); }
+inline bool  streamWrite32(void* d, uint32_t v) { *static_cast<uint32_t*>(d) = v; return true; }
 inline void  setDevice(int) {}
 inline int   currentDevice() { return 0; }
 inline void  dzero(void* d, size_t n) { if (n) std::memset(d, 0, n); }
@@ -139,6 +140,17 @@ inline void d2h(void* h, const void* d, size_t n)
 }
 /// same without the wait: several copies, then one sync()
 inline void d2hAsync(void* h, const void* d, size_t n) { if (n) check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, launchStream()), "hipMemcpy D2H"); }
+/// a 32-bit write performed by the command processor once everything queued on the current stream before it has completed: no
+/// copy kernel, no DMA engine (a tiny hipMemcpyAsync is a shader copy that needs a free workgroup slot).  False if the runtime
+/// refuses (beta API): the caller then falls back to a 4-byte copy.
+inline bool streamWrite32(void* d, uint32_t v)
+{
+  static const bool disabled = std::getenv("MANTA_AMD_NO_STREAM_WRITE") != nullptr;
+  if (disabled) return false;
+  const hipError_t e = hipStreamWriteValue32(launchStream(), d, v, 0);
+  if (e != hipSuccess) (void)hipGetLastError();
+  return e == hipSuccess;
+}
 inline void dzero(void* d, size_t n) { if (n) check(hipMemsetAsync(d, 0, n, launchStream()), "hipMemset"); }
 inline void dfill(void* d, int byte, size_t n) { if (n) check(hipMemsetAsync(d, byte, n, launchStream()), "hipMemset"); }
 /// page-locked host memory (staging buffers of the pipelines; manta_host_alloc)

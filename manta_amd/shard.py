@@ -26,25 +26,63 @@ def shard_bounds(costs, world, rank):
     return edges[rank], edges[rank + 1]
 
 
+class _GatherBuffers:
+    """Buffers of gather_bytes, kept across calls (a bench step gathers the same amount every time): on a GPU the payload goes
+    page-locked host -> device -> RCCL gather -> device -> page-locked host, each hop one DMA, no per-call allocation."""
+
+    def __init__(self):
+        self.key = None
+        self.cap = 0
+
+    def ensure(self, device, world, rank, need):
+        key = (str(device), world, rank)
+        if key == self.key and need <= self.cap:
+            return
+        self.key, self.cap = key, int(need + need // 4 + 4096)
+        on_gpu = str(device).startswith("cuda")
+        self.pay = torch.empty(self.cap, dtype=torch.uint8, device=device)
+        self.recv = torch.empty((world, self.cap), dtype=torch.uint8, device=device) if rank == 0 else None
+        self.host_pay = torch.empty(self.cap, dtype=torch.uint8, pin_memory=True) if on_gpu else None
+        self.host_recv = torch.empty((world, self.cap), dtype=torch.uint8, pin_memory=True) if (on_gpu and rank == 0) else None
+
+
+_BUFFERS = _GatherBuffers()
+
+
 def gather_bytes(local, device="cpu"):
     """one uint8 array per rank -> list of arrays on rank 0 (rank order), None elsewhere.  Only rank 0 receives the payload:
-    an all_gather of the 8-byte sizes, then ONE padded gather to rank 0."""
+    an all_gather of the 8-byte sizes, then ONE padded gather to rank 0.  The arrays returned on a GPU run are views of a
+    page-locked staging buffer that the next call overwrites."""
     local = np.ascontiguousarray(local, dtype=np.uint8)
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [local]
     world, rank = dist.get_world_size(), dist.get_rank()
+    on_gpu = str(device).startswith("cuda")
     size = torch.tensor([len(local)], dtype=torch.int64, device=device)
-    sizes = [torch.zeros_like(size) for _ in range(world)]
-    dist.all_gather(sizes, size)
-    max_bytes = max(1, int(max(s.item() for s in sizes)))
-    pay = torch.zeros(max_bytes, dtype=torch.uint8, device=device)
-    if len(local):
-        pay[:len(local)] = torch.from_numpy(local).to(device, non_blocking=True)
-    recv = [torch.zeros_like(pay) for _ in range(world)] if rank == 0 else None
-    dist.gather(pay, recv, dst=0)
+    sizes = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sizes, size) if hasattr(dist, "all_gather_into_tensor") and on_gpu else dist.all_gather(
+        list(sizes.split(1)), size)
+    sizes = [int(v) for v in sizes.cpu().tolist()]  # one device->host sync for all of them
+    max_bytes = max(1, max(sizes))
+    b = _BUFFERS
+    b.ensure(device, world, rank, max_bytes)
+    n = len(local)
+    if n:
+        if on_gpu:
+            b.host_pay[:n].copy_(torch.from_numpy(local))
+            b.pay[:n].copy_(b.host_pay[:n], non_blocking=True)
+        else:
+            b.pay[:n].copy_(torch.from_numpy(local))
+    send = b.pay[:max_bytes]
+    recv = [b.recv[r, :max_bytes] for r in range(world)] if rank == 0 else None
+    dist.gather(send, recv, dst=0)
     if rank != 0:
         return None
-    return [recv[r][:int(sizes[r].item())].cpu().numpy() for r in range(world)]
+    if on_gpu:
+        b.host_recv.copy_(b.recv, non_blocking=True)  # whole rows: one contiguous DMA
+        torch.cuda.current_stream().synchronize()
+        return [b.host_recv[r, :sizes[r]].numpy() for r in range(world)]
+    return [b.recv[r, :sizes[r]].numpy().copy() for r in range(world)]
 
 
 def gather_records(local_blobs, device="cpu"):

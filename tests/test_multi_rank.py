@@ -4,6 +4,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 from manta_amd.shard import shard_bounds
 from oracle_lib import asm_opts
 from synth import small_indel_locus
@@ -36,3 +38,24 @@ def test_two_rank_gloo_pipeline_matches_oracle(emu, oracle, tmp_path):
     for s, text in enumerate(got["texts"]):
         reads, ref = small_indel_locus(100 + s, n_reads=16 + 4 * (s % 3), read_len=50, ref_len=400)
         assert text == oracle.small_sv_locus(opts, sc, -100, reads, ref, cuts), s
+
+
+@pytest.mark.gpu
+def test_gpu_gather_staging_buffers():
+    """the page-locked / device staging of gather_bytes on a real device (the collective itself needs >= 2 GPUs: the hops around it
+    are exercised here with the gather replaced by a device copy)"""
+    import numpy as np
+    import torch
+    from manta_amd.shard import _GatherBuffers
+    b = _GatherBuffers()
+    rng = np.random.default_rng(5)
+    for need in (1000, 7_000_000, 5000):  # grow, then reuse
+        b.ensure("cuda", 2, 0, need)
+        assert b.cap >= need and b.host_pay.is_pinned() and b.host_recv.is_pinned()
+        local = rng.integers(0, 256, size=need, dtype=np.uint8)
+        b.host_pay[:need].copy_(torch.from_numpy(local))
+        b.pay[:need].copy_(b.host_pay[:need], non_blocking=True)
+        b.recv[1, :need].copy_(b.pay[:need])  # stands in for dist.gather
+        b.host_recv.copy_(b.recv, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        assert np.array_equal(b.host_recv[1, :need].numpy(), local)
