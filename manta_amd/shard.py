@@ -49,12 +49,12 @@ class _GatherBuffers:
 _BUFFERS = _GatherBuffers()
 
 
-def gather_bytes(local, device="cpu"):
+def gather_bytes(local, device="cpu", force_collectives=False):
     """one uint8 array per rank -> list of arrays on rank 0 (rank order), None elsewhere.  Only rank 0 receives the payload:
     an all_gather of the 8-byte sizes, then ONE padded gather to rank 0.  The arrays returned on a GPU run are views of a
     page-locked staging buffer that the next call overwrites."""
     local = np.ascontiguousarray(local, dtype=np.uint8)
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collectives):  # (force: tests run the collectives with one rank)
         return [local]
     world, rank = dist.get_world_size(), dist.get_rank()
     on_gpu = str(device).startswith("cuda")

@@ -59,3 +59,24 @@ def test_gpu_gather_staging_buffers():
         b.host_recv.copy_(b.recv, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         assert np.array_equal(b.host_recv[1, :need].numpy(), local)
+
+
+@pytest.mark.gpu
+def test_gpu_gather_bytes_over_rccl_single_rank():
+    """gather_bytes' collectives (all_gather_into_tensor + gather) and staging on the real backend: a one-rank RCCL group in a
+    subprocess (more ranks need more GPUs; the multi-rank logic is the gloo test above)"""
+    code = (
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from manta_amd.shard import gather_bytes\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "for n in (0, 1, 12345, 7000000, 999):\n"
+        "    x = np.random.default_rng(n).integers(0, 256, size=n, dtype=np.uint8)\n"
+        "    got = gather_bytes(x, device='cuda', force_collectives=True)\n"
+        "    assert len(got) == 1 and np.array_equal(got[0], x), n\n"
+        "dist.destroy_process_group()\n"
+        "print('rccl gather ok')\n" % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "rccl gather ok" in out.stdout, out.stderr[-2000:]
