@@ -120,6 +120,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    torch.set_num_threads(1)  # no torch CPU compute here; an OpenMP team left spinning would only fight the library's host threads
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -135,12 +136,20 @@ def main():
         # kernels time-slice the device against each other (measured: seconds per step) -- blocking uploads there
         os.environ["MANTA_AMD_NO_STREAM_UPLOAD"] = "1"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # MANTA_BENCH_FORCE_DIST=1: developer knob -- run every torch.distributed call of the N>1 path (group init, barrier, timing
+    # all-reduce, result gather) with ONE rank, so that the RCCL side can be exercised on a one-GPU box
+    multi = world > 1 or os.environ.get("MANTA_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        cores_before = len(os.sched_getaffinity(0))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if os.environ.get("MANTA_BENCH_DEBUG"):
+            print("bench: rank %d: %d -> %d cores in the affinity mask after init_process_group" % (rank, cores_before, len(os.sched_getaffinity(0))),
+                  file=sys.stderr, flush=True)
 
     from manta_amd._capi import BatchOutput, Lib, SmallSvBatch, pack_spanning, pinned_copy, small_sv_text, assembly_text
     from manta_amd.shard import gather_bytes
@@ -192,13 +201,13 @@ def main():
             lib.spanning_batch(opts, SPAN_SC, JUMP, dev_batch, out, min_wl=min_wl, max_wl=max_wl, block_loci=block, n_workers=workers, serial_kernels=args.serial_kernels)
         else:
             lib.smallsv_batch(opts, SCORES, LARGE_INDEL, dev_batch, out, block_loci=block, n_workers=workers, serial_kernels=args.serial_kernels)
-        if world > 1:  # the final candidate gather (north star: "RCCL over xGMI only for the final candidate gather")
-            return gather_bytes(result_blob(out), device="cuda" if backend == "nccl" else "cpu")
+        if multi and not os.environ.get("MANTA_BENCH_SKIP_GATHER"):  # the final candidate gather (north star: "RCCL over xGMI only for the final candidate gather")
+            return gather_bytes(result_blob(out), device="cuda" if backend == "nccl" else "cpu", force_collectives=True)
         return None
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -218,7 +227,7 @@ def main():
             gathered_bytes += sum(len(x) for x in g)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -408,7 +417,7 @@ def main():
                                                % (n_s, cores, secs, n_1, secs1),
                                      "single_thread_value": round(n_1 / secs1, 2)}
         print(json.dumps(o), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
