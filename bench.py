@@ -416,10 +416,18 @@ def main():
                                                "GenerateSVCandidates.cpp:232-266), %.1f s wall; single thread: %d loci in %.1f s"
                                                % (n_s, cores, secs, n_1, secs1),
                                      "single_thread_value": round(n_1 / secs1, 2)}
-        print(json.dumps(o), flush=True)
+        line = json.dumps(o)
+    # The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio (seen after the line when stdout
+    # is a pipe), so every rank flushes its C buffers, the group is torn down, and only then rank 0 prints.
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.fflush(None)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+        libc.fflush(None)
+    if rank == 0:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
