@@ -1,0 +1,53 @@
+"""bench.py's own control flow on CPU: main() is run with torch.cuda stubbed out and the library handle pointed at the wave
+emulator build (test infrastructure) on a tiny batch.  This is NOT a measurement and not a CPU mode of the bench -- bench.py
+itself refuses to run without a GPU; the test only makes sure the script's plumbing (argument handling, the batch call, the
+checker, the JSON line as the last stdout line, the forced single-rank torch.distributed path over gloo) cannot rot unseen."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+HARNESS = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import torch
+    torch.cuda.is_available = lambda: True
+    torch.cuda.device_count = lambda: 1
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.synchronize = lambda *a, **k: None
+    import manta_amd._capi as capi
+    emu = os.path.join(%(root)r, "tests", "emu", "libmanta_amd_emu.so")
+    capi.default_library_path = lambda: emu
+    import bench
+    sys.argv = ["bench.py"] + %(argv)r
+    bench.main()
+""")
+
+
+def run_bench(argv, extra_env=None):
+    env = dict(os.environ, **(extra_env or {}))
+    code = HARNESS % dict(root=ROOT, argv=argv)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert lines, out.stderr[-2000:]
+    return json.loads(lines[-1]), lines  # the JSON line must be the LAST line on stdout
+
+
+def test_bench_main_flow_on_the_emulator(emu):
+    d, lines = run_bench(["--loci", "6", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["unit"] == "loci/s" and d["higher_is_better"] is True
+    assert d["config"]["loci_per_gpu"] == 6 and "0 mismatches" in d["config"]["parity"]
+    assert {"roofline", "kernels_ms_per_step", "pcie"} <= set(d)
+    assert d["roofline"]["bound"] == "hbm" and "kernel" in d["roofline"]  # (the emulator has no event times: which kernel dominates is moot here)
+
+
+def test_bench_forced_single_rank_group_over_gloo(emu):
+    """the N>1 path's torch.distributed calls (group, barriers, timing all-reduce, result gather) with one rank"""
+    d, lines = run_bench(["--loci", "5", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"],
+                         dict(MANTA_BENCH_FORCE_DIST="1", MANTA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561"))
+    assert d["n_gpus"] == 1 and "gather_MB_per_step" in d["pcie"]  # (a few KB here: rounds to 0.00 MB)
