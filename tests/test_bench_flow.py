@@ -51,3 +51,8 @@ def test_bench_forced_single_rank_group_over_gloo(emu):
     d, lines = run_bench(["--loci", "5", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"],
                          dict(MANTA_BENCH_FORCE_DIST="1", MANTA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561"))
     assert d["n_gpus"] == 1 and "gather_MB_per_step" in d["pcie"]  # (a few KB here: rounds to 0.00 MB)
+
+
+def test_bench_spanning_flow_on_the_emulator(emu):
+    d, lines = run_bench(["--workload", "spanning", "--loci", "3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    assert d["config"]["loci_per_gpu"] == 3 and "0 mismatches" in d["config"]["parity"]
