@@ -56,3 +56,9 @@ def test_bench_forced_single_rank_group_over_gloo(emu):
 def test_bench_spanning_flow_on_the_emulator(emu):
     d, lines = run_bench(["--workload", "spanning", "--loci", "3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
     assert d["config"]["loci_per_gpu"] == 3 and "0 mismatches" in d["config"]["parity"]
+
+
+def test_bench_extra_legs_on_the_emulator(emu):
+    """the kernel_only and packed_input legs of the default run"""
+    d, lines = run_bench(["--loci", "5", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    assert "kernel_only" in d and "packed_input" in d and d["packed_input"]["unit"] == "loci/s"
