@@ -584,10 +584,10 @@ class BatchOutput:
         return {f[0]: getattr(self.stats, f[0]) for f in BatchStats._fields_}
 
 
-def _smallsv_batch(self, opts, scores, large_indel_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True, serial_kernels=False):
+def _smallsv_batch(self, opts, scores, large_indel_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True, serial_kernels=False, streamed_upload=True):
     """batch = (bases, read_off, begin, refs, ref_off, cuts) numpy arrays as synth.config2_batch returns them"""
     bases, read_off, begin, refs, ref_off, cuts = batch
-    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, 1 if serial_kernels else 0, 0)
+    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, (1 if serial_kernels else 0) | (0 if streamed_upload else 2), 0)
     n = len(begin) - 1
     f = self.lib.manta_smallsv_batch
     f.restype = ctypes.c_int
@@ -600,10 +600,10 @@ def _smallsv_batch(self, opts, scores, large_indel_score, batch, out, min_wl=Non
     return rc
 
 
-def _spanning_batch(self, opts, scores, jump_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True, serial_kernels=False):
+def _spanning_batch(self, opts, scores, jump_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True, serial_kernels=False, streamed_upload=True):
     """batch = (bases, read_off, begin, refs1, ref1_off, refs2, ref2_off, cuts)"""
     bases, read_off, begin, r1, o1, r2, o2, cuts = batch
-    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, 1 if serial_kernels else 0, 0)
+    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, (1 if serial_kernels else 0) | (0 if streamed_upload else 2), 0)
     n = len(begin) - 1
     f = self.lib.manta_spanning_batch
     f.restype = ctypes.c_int
@@ -715,8 +715,8 @@ SpanningBatch.upload_piles = _spanning_upload_piles
 
 
 def _smallsv_batch_piles(self, opts, scores, large_indel_score, piles, refs, ref_off, cuts, out, min_wl=None, max_wl=None, block_loci=0,
-                         n_workers=0, strict=True, serial_kernels=False):
-    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, 1 if serial_kernels else 0, 0)
+                         n_workers=0, strict=True, serial_kernels=False, streamed_upload=True):
+    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, (1 if serial_kernels else 0) | (0 if streamed_upload else 2), 0)
     n = len(piles.begin) - 1
     st = piles.struct()
     f = self.lib.manta_smallsv_batch_piles

@@ -16,7 +16,7 @@ def small_batch(n, seed):
     return config2_batch(n, seed=seed, n_reads=20, read_len=80, ref_len=500)
 
 
-def check_smallsv(lib, oracle, n, block, workers, mixed):
+def check_smallsv(lib, oracle, n, block, workers, mixed, streamed=True):
     batch = small_batch(n, 4242)
     batch = batch[:5] + (np.tile(np.array([40, 40, 200, 200], dtype=np.int32), (n, 1)),)
     opts = asm_opts(minWordLength=25, maxWordLength=45)
@@ -25,7 +25,8 @@ def check_smallsv(lib, oracle, n, block, workers, mixed):
         min_wl = np.array([21 + 4 * (l % 4) for l in range(n)], dtype=np.uint32)
         max_wl = np.maximum(min_wl + 10, 41).astype(np.uint32)
     out = BatchOutput(lib, "smallsv", n, 10, 1 << 20, 1 << 16, 1 << 18)
-    lib.smallsv_batch(opts, SCORES, -100, batch, out, min_wl=min_wl, max_wl=max_wl, block_loci=block, n_workers=workers)
+    lib.smallsv_batch(opts, SCORES, -100, batch, out, min_wl=min_wl, max_wl=max_wl, block_loci=block, n_workers=workers,
+                      streamed_upload=streamed)
     st = out.stats_dict()
     assert st["n_blocks"] == (n + block - 1) // block and st["n_workers"] == min(workers, st["n_blocks"])
     res = out.decode(np.diff(batch[2]))
@@ -57,14 +58,15 @@ def spanning_case(n):
     return loci, cuts, pack_spanning([l[0] for l in loci], [l[1] for l in loci], [l[2] for l in loci], cuts)
 
 
-def check_spanning(lib, oracle, n, block, workers):
+def check_spanning(lib, oracle, n, block, workers, streamed=True):
     loci, cuts, batch = spanning_case(n)
     ks = [25, 30, 35]
     min_wl = np.array([ks[l % 3] for l in range(n)], dtype=np.uint32)
     max_wl = np.full(n, 45, dtype=np.uint32)
     opts = asm_opts(minWordLength=25, maxWordLength=45, minContigLength=40)
     out = BatchOutput(lib, "spanning", n, 10, 1 << 20, 1 << 16, 1 << 18)
-    lib.spanning_batch(opts, SPAN_SC, -100, batch, out, min_wl=min_wl, max_wl=max_wl, block_loci=block, n_workers=workers)
+    lib.spanning_batch(opts, SPAN_SC, -100, batch, out, min_wl=min_wl, max_wl=max_wl, block_loci=block, n_workers=workers,
+                       streamed_upload=streamed)
     res = out.decode(np.diff(batch[2]))
     for l, r in enumerate(res):
         o = asm_opts(minWordLength=int(min_wl[l]), maxWordLength=45, minContigLength=40)
@@ -101,6 +103,8 @@ def test_gpu_batch_calls(gpu, oracle):
     check_spanning(gpu, oracle, 60, block=16, workers=4)
     check_smallsv(gpu, oracle, 300, block=64, workers=2, mixed=True)
     check_spanning(gpu, oracle, 60, block=16, workers=2)
+    check_smallsv(gpu, oracle, 200, block=200, workers=1, mixed=False, streamed=False)
+    check_spanning(gpu, oracle, 40, block=40, workers=1, streamed=False)
 
 
 def staged_smallsv_texts(lib, batch, opts):
@@ -121,6 +125,12 @@ def stress_shapes(lib, shapes, seed):
         lib.smallsv_batch(opts, SCORES, -100, batch, out, block_loci=block, n_workers=workers)
         got = [small_sv_text(r) for r in out.decode(np.diff(batch[2]))]
         assert got == staged_smallsv_texts(lib, batch, opts), (n, block, workers)
+
+
+def test_emulated_batches_with_blocking_upload(emu, oracle):
+    """MANTA_BATCH_NO_STREAMED_UPLOAD (what a host that shares a GPU between processes passes): same results"""
+    check_smallsv(emu, oracle, 9, block=4, workers=2, mixed=True, streamed=False)
+    check_spanning(emu, oracle, 5, block=2, workers=1, streamed=False)
 
 
 def test_emulated_batch_odd_shapes(emu):
