@@ -1297,7 +1297,14 @@ int manta_assemble_batch(
     rt::ScopedStream onStream(ctx->stream);
     AsmStage st(ctx);
     int      rc = st.plan(*opt, n_loci, read_off, locus_read_begin);
-    if (rc != MANTA_OK) return rc;
+    if (rc != MANTA_OK) {
+      // refused as a whole (a locus outside the envelope sizes the shared workspace): every record says so, nothing is left unwritten
+      for (uint32_t l = 0; l < n_loci; ++l) {
+        std::memset(&loci[l], 0, sizeof(loci[l]));
+        loci[l].status = rc;
+      }
+      return rc;
+    }
     st.upload(bases, read_off, locus_read_begin);
     rt::Event e0, e1;
     e0.record();
@@ -1344,7 +1351,13 @@ int manta_small_assemble_batch(
     st.smallMinSeedReads        = opt->min_seed_reads;
     st.smallMaxIterations       = opt->max_assembly_iterations;
     int rc = st.plan(o, n_loci, read_off, locus_read_begin);
-    if (rc != MANTA_OK) return rc;
+    if (rc != MANTA_OK) {
+      for (uint32_t l = 0; l < n_loci; ++l) {
+        std::memset(&loci[l], 0, sizeof(loci[l]));
+        loci[l].status = rc;
+      }
+      return rc;
+    }
     st.upload(bases, read_off, locus_read_begin);
     st.launch();
     rt::sync();
