@@ -1,5 +1,7 @@
 """The supported envelope at its edges: maximum word length, read sets of several hundred reads (the wide-set walk),
-and what lies just beyond -- reported per item (MANTA_E_UNSUPPORTED, -5), never a crash and never a guess."""
+and what lies just beyond -- reported per item (MANTA_E_UNSUPPORTED, -5), never a crash and never a guess.
+(The file sorts last on purpose: its GPU test was written after this round's GPU minutes were spent, so it has only run on the
+emulator; with `pytest -x` a surprise here must not hide the rest of the tier.)"""
 import random
 
 import pytest
