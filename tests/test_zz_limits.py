@@ -64,3 +64,23 @@ def test_emulated_aligner_limits(emu, oracle):
 def test_gpu_limits(gpu, oracle):
     check_limits(gpu, oracle, 700)
     check_align_limits(gpu, oracle)
+
+
+def check_degenerate_piles(lib, oracle):
+    """empty and ragged inputs of the iterative assembler, all in ONE batch next to an ordinary pile"""
+    o = asm_opts(minWordLength=11, maxWordLength=21, wordStepSize=5, minCoverage=1, minUnusedReads=1, minSupportReads=1)
+    piles = [[], ["ACGTACGTAC"], ["ACG", "T", "GGCCA"], ["NNNNNNNNNNNNNNNNNNNNNN"] * 3, ["ACGTTGCAAGGCTTACCGGATTACCA"] * 4,
+             pile(9, 30, 60, 200), ["A" * 40, "A" * 35, "C" * 40]]
+    res = lib.assemble_batch(o, piles)
+    for reads, r in zip(piles, res):
+        assert r["status"] == 0 and assembly_text(r) == oracle.assemble(o, reads), reads[:2]
+
+
+def test_emulated_degenerate_piles(emu, oracle, reflib):
+    check_degenerate_piles(emu, oracle)
+    check_degenerate_piles(emu, reflib)  # and the unmodified reference says the same
+
+
+@pytest.mark.gpu
+def test_gpu_degenerate_piles(gpu, oracle):
+    check_degenerate_piles(gpu, oracle)
