@@ -406,6 +406,11 @@ struct AsmStage {
   std::vector<uint32_t> locusMinWl, locusMaxWl;
   std::vector<uint32_t> order;  // loci by decreasing estimated cost: the work queue hands out the long ones first
   uint32_t              maxWordLen = 0;
+  uint32_t              capWords2 = 0, capNodes2 = 0, capSlots2 = 0;  // worst-case capacities (rerunCapacityFailures)
+  uint64_t              stride2 = 0;
+  DevBuf                bWs2, bFailIds;
+  uint32_t              nRerun = 0;  // loci of the last launch that needed the worst-case workspace
+  AsmParams             lastParams{};
   bool                  smallMode = false;  // small_assemble_kernel (SmallAssembler) instead of the iterative assembler
   uint32_t              smallMinSeedReads = 0, smallMaxIterations = 0;
   int                   wavesPerCuCap = 0;  // > 0: leave wave slots free for another block's aligners (pipelined batch calls)
@@ -544,6 +549,16 @@ struct AsmStage {
     capSlots                   = nextPow2(2ull * capNodes);
     const AsmWsLayout L = asmWorkspaceLayout(capSlots, capNodes, capWords, capReads, maxContigLen, wMax, opt.max_assembly_count);
     stride              = (L.total + 255) & ~uint64_t(255);
+    {
+      // worst case for the few loci the typical-case capacities above turn out too small for (rerunCapacityFailures): every
+      // candidate contig at full length comes back as a pseudo read
+      const uint64_t pseudoWorst = uint64_t(nCandMax) * maxContigLen;
+      capWords2                  = uint32_t(maxLocusWords + pseudoWorst / 16 + 2 * nCandMax + 8);
+      capNodes2                  = uint32_t(std::min<uint64_t>(maxLocusBases + pseudoWorst + 64, LINK_NONE21 - 1));
+      capSlots2                  = nextPow2(2ull * capNodes2);
+      const AsmWsLayout L2 = asmWorkspaceLayout(capSlots2, capNodes2, capWords2, capReads, maxContigLen, wMax, opt.max_assembly_count);
+      stride2              = (L2.total + 255) & ~uint64_t(255);
+    }
     // per-wave workspaces: at most half of the free HBM, 64 GiB by default (MANTA_AMD_WS_BUDGET_GB lowers it for callers
     // that keep several batches resident at once)
     const size_t wsCapGb  = std::getenv("MANTA_AMD_WS_BUDGET_GB") ? size_t(std::max(1, std::atoi(std::getenv("MANTA_AMD_WS_BUDGET_GB")))) : size_t(64);
@@ -803,6 +818,8 @@ struct AsmStage {
     P.reserved2          = 0;
     P.small_min_seed_reads = smallMinSeedReads;
     P.small_max_iterations = smallMaxIterations;
+    lastParams             = P;
+    nRerun                 = 0;
     if (smallMode) {
       rt::launch(small_assemble_kernel, grid, 0, P);
       return;
@@ -817,6 +834,47 @@ struct AsmStage {
       if (streaming && g >= ctx->cuCount * 16) g = rt::roundGrid(g - ctx->cuCount);
       rt::launch(assemble_kernel, g, ASM_LDS_BYTES, P);
     }
+    // loci that did not fit the typical-case workspace are counted into dCnt[3] (see rerunCapacityFailures)
+    CountStatusParams C;
+    C.loci    = dLoci;
+    C.n_loci  = nLoci;
+    C.code    = ASM_E_TABLE_FULL;
+    C.counter = reinterpret_cast<unsigned long long*>(dCnt + 3);
+    rt::launch(count_status_kernel, rt::roundGrid(int(std::min<uint64_t>((nLoci + 63) / 64, 64))), 0, C);
+  }
+
+  /// Call once the assembler of launch() has finished, with the value of dCnt[3] (capacity_failures).  Loci whose pile did not
+  /// fit the typical-case workspace (ASM_E_TABLE_FULL: many long contigs fed back as pseudo reads) run again, one wave each, on a
+  /// workspace sized for the worst case; they write into the same records and arenas, so nothing downstream changes.
+  void rerunCapacityFailures(const uint64_t failures)
+  {
+    if (failures == 0 || smallMode) return;
+    std::vector<AsmLocusOut> st(nLoci);
+    rt::d2h(st.data(), dLoci, sizeof(AsmLocusOut) * nLoci);
+    std::vector<uint32_t> ids;
+    for (uint32_t l = 0; l < nLoci; ++l)
+      if (st[l].status == ASM_E_TABLE_FULL) ids.push_back(l);
+    if (ids.empty()) return;
+    const size_t wsBudget = workspaceBudget(size_t(32) << 30);
+    int          g        = int(std::min<uint64_t>(ids.size(), std::max<uint64_t>(1, wsBudget / stride2)));
+    g                     = rt::roundGrid(std::min(g, std::max(1, ctx->cuCount * 4)));
+    uint32_t* dIds        = bFailIds.as<uint32_t>(ids.size());
+    rt::h2d(dIds, ids.data(), sizeof(uint32_t) * ids.size());
+    rt::dzero(dCnt + 12, sizeof(uint64_t) * 2);
+    AsmParams P            = lastParams;
+    P.ws                   = bWs2.as<uint8_t>(stride2 * uint64_t(g));
+    P.ws_stride            = stride2;
+    P.cap_slots            = capSlots2;
+    P.cap_nodes            = capNodes2;
+    P.cap_words            = capWords2;
+    P.n_loci               = uint32_t(ids.size());
+    P.locus_ids            = dIds;
+    P.counter              = reinterpret_cast<uint32_t*>(dCnt + 12);
+    rt::launch(assemble_kernel, g, ASM_LDS_BYTES, P);
+    rt::sync();
+    nRerun = uint32_t(ids.size());
+    if (std::getenv("MANTA_AMD_DEBUG"))
+      std::fprintf(stderr, "manta_amd: %zu of %u loci ran again on the worst-case workspace (%.1f MB per wave)\n", ids.size(), nLoci, double(stride2) / 1e6);
   }
 
   /// Device -> pinned host staging of everything the assembler produced, with EXACT sizes: the fixed records and the
@@ -1310,7 +1368,9 @@ int manta_assemble_batch(
     e0.record();
     st.launch();
     e1.record();
-    rt::sync();
+    uint64_t capacityFailures = 0;
+    rt::d2h(&capacityFailures, st.dCnt + 3, sizeof(uint64_t));  // (waits for the kernel)
+    st.rerunCapacityFailures(capacityFailures);
     if (std::getenv("MANTA_AMD_DEBUG"))
       std::fprintf(stderr, "manta_amd: assemble_kernel %u loci %.3f ms\n", n_loci, rt::elapsedMs(e0, e1));
     return st.fetch(loci, contigs, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used);
@@ -1564,7 +1624,11 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
       b->evStart.record();
       as.launch();
       b->evAsm.record();
-      if (gates || as.streaming) rt::sync();  // the gate opens when the assembler has left the device
+      // loci that did not fit the typical-case workspace run again here (rare; the counter rides on a wait that is there anyway
+      // in the whole-batch calls, the staged API pays one small read)
+      uint64_t capacityFailures = 0;
+      rt::d2h(&capacityFailures, as.dCnt + 3, sizeof(uint64_t));  // (also: the gate opens when the assembler has left the device)
+      as.rerunCapacityFailures(capacityFailures);
     }
     stage("assembled");
     GateLock alignOnly(gates, &StageGates::alignMu);
@@ -1998,7 +2062,7 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
       std::fprintf(stderr, "manta_amd: spanning_run %s\n", what);
       std::fflush(stderr);
     };
-    uint64_t asmCnt[3];
+    uint64_t asmCnt[4];
     {
       GateLock only(gates, &StageGates::asmMu);
       std::unique_lock<std::mutex> streamedOnly(streamedAsmMu(ctx), std::defer_lock);  // see smallsvRunImpl
@@ -2007,6 +2071,10 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
       as.launch();
       b->evAsm.record();
       rt::d2h(asmCnt, as.dCnt, sizeof(asmCnt));  // (waits for the assembler)
+      if (asmCnt[3]) {  // loci that did not fit the typical-case workspace (see smallsvRunImpl)
+        as.rerunCapacityFailures(asmCnt[3]);
+        rt::d2h(asmCnt, as.dCnt, sizeof(asmCnt));  // the text arena grew
+      }
     }
     stage("assembled");
     GateLock alignOnly(gates, &StageGates::alignMu);

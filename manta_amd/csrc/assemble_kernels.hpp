@@ -1365,7 +1365,7 @@ struct Assembler {
     out.cyclic_iterations = cyclicIters;
     out.reserved          = 0;
     if (status != ASM_OK) {
-      if (lane == 0) P.loci[locus] = out;
+      if (lane == 0) P.loci[locus] = out;  // (ASM_E_TABLE_FULL: the host runs the locus again on a worst-case workspace, api.cpp)
       return;
     }
     // index >= nNormal <=> pseudo read (see oracle/manta_oracle.cpp selectContigs on stale indices)

@@ -527,4 +527,21 @@ WV_KERNEL void pack_results_kernel(const PackParams P)
   }
 }
 
+/// how many loci ended with `code` (after assemble_kernel: ASM_E_TABLE_FULL -> AsmStage::rerunCapacityFailures).  A separate tiny
+/// launch instead of a counter inside assemble_kernel: that kernel's code stays exactly what was measured.
+struct CountStatusParams {
+  const AsmLocusOut* loci;
+  uint32_t           n_loci;
+  int32_t            code;
+  unsigned long long* counter;
+};
+WV_KERNEL void count_status_kernel(const CountStatusParams P)
+{
+  unsigned n = 0;
+  for (unsigned l = unsigned(wv::block()) * 64u + unsigned(wv::lane()); l < P.n_loci; l += unsigned(wv::nblocks()) * 64u)
+    n += (P.loci[l].status == P.code) ? 1u : 0u;
+  for (int off = 1; off < 64; off <<= 1) n += wv::shfl(n, wv::lane() ^ off);
+  if (wv::lane() == 0 && n) wv::atomic_add(P.counter, (unsigned long long)n);
+}
+
 }  // namespace manta_dev

@@ -84,3 +84,65 @@ def test_emulated_degenerate_piles(emu, oracle, reflib):
 @pytest.mark.gpu
 def test_gpu_degenerate_piles(gpu, oracle):
     check_degenerate_piles(gpu, oracle)
+
+
+# piles that do not fit the typical-case workspace (found by a random sweep against the reference: maxAssemblyCount 1 leaves almost
+# no slack for contigs that come back as pseudo reads / for the repeat search's scratch): they run again on a worst-case workspace
+CAPACITY_CASES = [
+    (610448, dict(minWordLength=6, maxWordLength=9, wordStepSize=3, minCoverage=1, minConservativeCoverage=3, minUnusedReads=2,
+                  minSupportReads=1, maxAssemblyCount=1)),
+    (549478, dict(minWordLength=11, maxWordLength=12, wordStepSize=1, minCoverage=2, minConservativeCoverage=3, minUnusedReads=2,
+                  minSupportReads=2, maxAssemblyCount=1)),
+    (192159, dict(minWordLength=11, maxWordLength=11, wordStepSize=3, minCoverage=1, minConservativeCoverage=1, minUnusedReads=3,
+                  minSupportReads=2, maxAssemblyCount=1)),
+]
+
+
+def check_capacity_rerun(lib, oracle):
+    import numpy as np
+    from manta_amd._capi import BatchOutput, small_sv_text
+    from small_asm_cases import random_case
+    from synth import config2_batch
+    for seed, o in CAPACITY_CASES:
+        reads = random_case(seed)[1]
+        opts = asm_opts(**o)
+        # next to ordinary piles in the same call: only the one that needs it runs again
+        res = lib.assemble_batch(opts, [pile(3, 20, 40, 120), reads, pile(4, 25, 40, 120)])
+        assert [r["status"] for r in res] == [0, 0, 0]
+        assert assembly_text(res[1]) == oracle.assemble(opts, reads), seed
+    # the same through the fused small-SV batch call (streamed upload, schedule + aligners behind the rerun)
+    seed, o = CAPACITY_CASES[0]
+    reads = random_case(seed)[1]
+    opts = asm_opts(**o)
+    batch = list(config2_batch(3, seed=77, n_reads=12, read_len=30, ref_len=300))  # (reads no longer than the pile's: same tight capacities)
+    bases, read_off, begin = batch[0], batch[1], batch[2]
+    # splice the pile in as locus 1 (keeping its reference window and cuts)
+    loci = []
+    for l in range(3):
+        rb, re = int(begin[l]), int(begin[l + 1])
+        loci.append([bytes(bases[int(read_off[r]):int(read_off[r + 1])]).decode("latin-1") for r in range(rb, re)])
+    loci[1] = reads
+    flat = [r.encode("latin-1") for rs in loci for r in rs]
+    new_off = np.zeros(len(flat) + 1, dtype=np.uint64)
+    np.cumsum([len(r) for r in flat], out=new_off[1:])
+    new_bases = np.frombuffer(b"".join(flat) + b"\\0" * 64, dtype=np.uint8)
+    new_begin = np.zeros(4, dtype=np.uint32)
+    np.cumsum([len(rs) for rs in loci], out=new_begin[1:])
+    cuts = np.tile(np.array([20, 20, 100, 100], dtype=np.int32), (3, 1))
+    nb = (new_bases, new_off, new_begin, batch[3], batch[4], cuts)
+    out = BatchOutput(lib, "smallsv", 3, 10, 1 << 20, 1 << 16, 1 << 18)
+    sc = [2, -8, -24, -1, -1, 0]
+    lib.smallsv_batch(opts, sc, -100, nb, out)
+    res = out.decode(np.diff(new_begin))
+    for l in range(3):
+        ref = bytes(batch[3][int(batch[4][l]):int(batch[4][l + 1])]).decode("latin-1")
+        assert small_sv_text(res[l]) == oracle.small_sv_locus(opts, sc, -100, loci[l], ref, tuple(int(x) for x in cuts[l])), l
+
+
+def test_emulated_capacity_rerun(emu, oracle):
+    check_capacity_rerun(emu, oracle)
+
+
+@pytest.mark.gpu
+def test_gpu_capacity_rerun(gpu, oracle):
+    check_capacity_rerun(gpu, oracle)
