@@ -673,7 +673,9 @@ struct Aligner {
     if (have1 && have2) {  // :204-230
       unsigned i1 = unsigned(begin1) + p1Ref, i2 = unsigned(begin2), iq = p1Read, insCount = jumpInsertSize;
       while (true) {
-        if (i1 == R1) break;
+        // (>=: with offEdge 0 path 1 can run past the end of ref1 through deletions that cross the seam; the reference then
+        // compares bytes beyond its string -- undefined, in practice a mismatch: jumpRange 0)
+        if (i1 >= R1) break;
         if (insCount > 0) {
           if (iq == Q) break;
           if (ref1[i1] != query[iq]) break;

@@ -1014,7 +1014,7 @@ static void alignJump(
     size_t   iq = readLength(res.path1);
     unsigned insCount = res.jumpInsertSize;
     while (true) {
-      if (i1 == R1) break;
+      if (i1 >= R1) break;  // (path 1 can overrun ref1 when offEdge is 0; the reference reads past its string there: taken as a mismatch)
       if (insCount > 0) {
         if (iq == Q) break;
         if (ref1[i1] != query[iq]) break;

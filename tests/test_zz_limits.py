@@ -146,3 +146,22 @@ def test_emulated_capacity_rerun(emu, oracle):
 @pytest.mark.gpu
 def test_gpu_capacity_rerun(gpu, oracle):
     check_capacity_rerun(gpu, oracle)
+
+
+def check_jump_overrun(lib, oracle):
+    """offEdge 0 (never used by Manta, legal for the aligner): path 1 runs past the end of ref1 and the reference's jumpRange loop
+    starts beyond its string (JumpAlignerBaseImpl.hpp:203-226); kernel and restatement stop there, = the reference's answer"""
+    import json
+    import os
+    c = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "jump_overrun_case.json")))
+    res = lib.align_batch(c["kind"], c["scores"], c["extra"], [(c["q"], c["r1"], c["r2"])])[0]
+    assert align_text(c["kind"], res) == c["want"] == oracle.align(c["kind"], c["scores"], c["extra"], c["q"], c["r1"], c["r2"])
+
+
+def test_emulated_jump_overrun(emu, oracle):
+    check_jump_overrun(emu, oracle)
+
+
+@pytest.mark.gpu
+def test_gpu_jump_overrun(gpu, oracle):
+    check_jump_overrun(gpu, oracle)
