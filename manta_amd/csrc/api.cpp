@@ -20,7 +20,7 @@
 
 #include "align_kernels.hpp"
 #include "assemble_kernels.hpp"
-#include "asm_lds.hpp"
+#include "asm_fast.hpp"
 #include "small_asm.hpp"
 #include "pipeline_kernels.hpp"
 #include "split_kernels.hpp"
@@ -375,6 +375,9 @@ int asmStatusToAbi(int st)
 }
 
 
+/// dynamic LDS per wave of assemble_kernel while it shares the CUs with assemble_fast_kernel (see AsmStage::plan)
+const unsigned kSharedAsmLds = 4608;
+
 /// One batch of loci through assemble_kernel: sizing, staging, launch, fetch.
 struct AsmStage {
   manta_ctx_t* ctx;
@@ -395,7 +398,7 @@ struct AsmStage {
   uint64_t*     hCnt  = nullptr;
   uint64_t      seqUsedDev = 0, bitsUsedDev = 0, nContigsOut = 0, pseudoBytesOut = 0, pseudoCountOut = 0;
   bool          staged = false;
-  uint32_t      ldsFallbacks = 0;  // loci assemble_lds_kernel handed to the general path (valid after stageOut)
+  uint32_t      ldsFallbacks = 0;  // loci assemble_fast_kernel handed to the general path (valid after stageOut)
 
   manta_asm_options_t opt{};
   uint32_t            nLoci = 0, nReadsTotal = 0, maxContigLen = 0, wMax = 0, capWords = 0, capReads = 0, capNodes = 0, capSlots = 0;
@@ -414,8 +417,14 @@ struct AsmStage {
   bool                  smallMode = false;  // small_assemble_kernel (SmallAssembler) instead of the iterative assembler
   uint32_t              smallMinSeedReads = 0, smallMaxIterations = 0;
   int                   wavesPerCuCap = 0;  // > 0: leave wave slots free for another block's aligners (pipelined batch calls)
-  bool                  useLds = false;  // assemble_lds_kernel (LDS-resident graph, general path as in-kernel fallback)
-  int                   gridLds = 1;
+  bool                  useFast = false;  // assemble_fast_kernel (LDS-resident graph); what it does not cover goes to assemble_kernel
+  bool                  coSchedule = false;  // both kernels at once on one work queue (see launch())
+  int                   gridFast = 1, gridShare = 1;
+  rt::Stream            sideStream;  // the general kernel's stream while the two run side by side
+  rt::Event             evFork, evJoin;
+  std::vector<uint32_t> fastIds, genIds;  // cost-ordered work lists of the two kernels
+  DevBuf                bPunt;
+  uint32_t*             dPunt = nullptr;   // the general kernel's list: genIds, then the loci the fast kernel punted
   // packed piles of the uploaded batch (manta_packed_piles_t), device side; dPlCodes == nullptr: 1 byte per base input
   DevBuf                bPlCodes, bPlMask, bPlLen, bPlCodeOff, bPlMaskOff;
   uint32_t *            dPlCodes = nullptr, *dPlMask = nullptr, *dPlLen = nullptr;
@@ -506,7 +515,10 @@ struct AsmStage {
           }
           p.maxReadLen = std::max<uint32_t>(p.maxReadLen, uint32_t(longest));
           cost[l] = b * uint64_t(re - rb);
-          if ((re - rb) + 2 * maxAsm <= LN_MAX_READS && w + 2 <= LN_MAX_PILE) p.ldsFit++;
+          if ((re - rb) + 2 * maxAsm <= FA_MAX_READS && w + 2 <= FA_MAX_PILE) {
+            p.ldsFit++;
+            cost[l] |= uint64_t(1) << 63;  // (marks the locus for the split below; reads x bases stays far below 2^63)
+          }
           p.maxLocusBases = std::max(p.maxLocusBases, b);
           p.maxLocusWords = std::max(p.maxLocusWords, w);
           p.maxLocusReads = std::max(p.maxLocusReads, re - rb);
@@ -530,10 +542,26 @@ struct AsmStage {
     const double tPlan1 = nowMs();
     {
       std::vector<std::pair<uint64_t, uint32_t>> keyed(n_loci);  // (inverted cost, locus): ascending = most expensive first, ties in locus order
-      for (uint32_t l = 0; l < n_loci; ++l) keyed[l] = std::make_pair(~cost[l], l);
+      for (uint32_t l = 0; l < n_loci; ++l) keyed[l] = std::make_pair(~(cost[l] & ~(uint64_t(1) << 63)), l);
       std::sort(keyed.begin(), keyed.end());
       order.resize(n_loci);
       for (uint32_t l = 0; l < n_loci; ++l) order[l] = keyed[l].second;
+    }
+    // assemble_fast_kernel (asm_fast.hpp, LDS-resident graph) is opt-in: MANTA_AMD_ASM_PATH=fast runs it on the loci whose pile
+    // fits its envelope and hands the rest -- and whatever it punts: cycles, next word length, graphs that do not fit -- to the
+    // general kernel; =both runs the two side by side on one work queue.  Measured on MI355X: it moves
+    // ~3x the algorithmic bytes instead of 142x and does not spill, but one wave per 52 KB of LDS (3 per CU) is bound by the
+    // issue latency of a single wave: 16.7 ms per 10 k config-2 loci against 12.1 ms for the general kernel at 16 waves per
+    // CU, and side by side each workgroup displaces five general waves' worth of LDS for the throughput of 3.5 (11.9 ms).
+    {
+      const char*       pathEnv = std::getenv("MANTA_AMD_ASM_PATH");
+      const std::string path    = pathEnv ? pathEnv : "";
+      useFast                   = !smallMode && ldsFit > 0 && (path == "fast" || path == "both");
+      fastIds.clear();
+      genIds.clear();
+      if (useFast) {
+        for (uint32_t i = 0; i < n_loci; ++i) ((cost[order[i]] >> 63) ? fastIds : genIds).push_back(order[i]);
+      }
     }
     const double   tPlan2   = nowMs();
     const uint32_t nCandMax = 2 * opt.max_assembly_count;
@@ -567,15 +595,24 @@ struct AsmStage {
     if (wavesPerCuCap > 0) wavesPerCu = std::min(wavesPerCu, wavesPerCuCap);
     grid                  = int(std::min<uint64_t>(n_loci, uint64_t(std::max(1, ctx->cuCount * wavesPerCu))));
     grid                  = rt::roundGrid(int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(grid), wsBudget / stride))));
-    // The LDS-resident fast path (asm_lds.hpp) is opt-in: MANTA_AMD_ASM_PATH=lds.  Measured on MI355X: it cuts
-    // the HBM traffic of the stage to about the algorithmic bytes, but only 3 loci per CU fit the LDS and one wave per
-    // SIMD cannot hide the ALU/LDS latency of the ~900 dependent walk steps of a locus -- 22.7 ms per 10 k config-2 loci
-    // against 12.3 ms for the HBM-slab kernel at 16 waves per CU.
-    const char* pathEnv = std::getenv("MANTA_AMD_ASM_PATH");
-    useLds              = pathEnv && std::string(pathEnv) == "lds" && ldsFit > 0;
-    const int ldsPerCu = int(163840 / LN_BUDGET);
-    gridLds            = int(std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n_loci, uint64_t(ctx->cuCount) * ldsPerCu), wsBudget / stride)));
-    if (useLds) grid = std::max(grid, gridLds);  // one workspace slab per workgroup of either kernel
+    // Side by side (MANTA_AMD_ASM_PATH=both): both kernels pull from ONE work queue, two fast workgroups per CU (104 KB of LDS)
+    // next to twelve general waves per CU with 4.5 KB of LDS each.
+    {
+      const char* pathEnv = std::getenv("MANTA_AMD_ASM_PATH");
+      coSchedule          = useFast && pathEnv && std::string(pathEnv) == "both";
+    }
+    const int fastPerCu = coSchedule ? 2 : int(163840 / FA_BUDGET);
+    gridFast            = int(std::max<uint64_t>(1, std::min<uint64_t>(fastIds.size(), uint64_t(ctx->cuCount) * fastPerCu)));
+    gridShare           = rt::roundGrid(int(std::max<uint64_t>(1, std::min<uint64_t>(fastIds.size(), uint64_t(ctx->cuCount) * 12))));
+    if (useFast) {
+      // workspace slabs: the general kernel's waves first, the fast kernel's workgroups behind them
+      const uint64_t fit = std::max<uint64_t>(2, wsBudget / stride);
+      if (uint64_t(gridFast) + uint64_t(coSchedule ? gridShare : 0) > fit) {
+        gridFast  = int(std::max<uint64_t>(1, std::min<uint64_t>(gridFast, fit / 4)));
+        gridShare = rt::roundGrid(int(std::max<uint64_t>(1, std::min<uint64_t>(gridShare, fit - gridFast))));
+      }
+      grid = std::max(grid, rt::roundGrid(gridFast) + (coSchedule ? gridShare : 0));
+    }
     // contig + pseudo-read text one locus can emit at worst; the arena holds the typical case for every locus plus one
     // worst case, so a single-locus call (the runIterativeAssembler adapter) can never exhaust it
     const uint64_t worstLocusSeq = uint64_t(opt.max_assembly_count) * maxContigLen + uint64_t(nCandMax) * pseudoLen;
@@ -753,7 +790,13 @@ struct AsmStage {
     dWs     = bWs.as<uint8_t>(stride * grid);
     dGrowth = bGrowth.as<uint32_t>(2 * ctx->growthSize.size() + 2);
     dOrder  = bOrder.as<uint32_t>(nLoci);
-    rt::h2d(dOrder, order.data(), sizeof(uint32_t) * nLoci);
+    if (useFast) {
+      dPunt = bPunt.as<uint32_t>(nLoci);
+      rt::h2d(dOrder, fastIds.data(), sizeof(uint32_t) * fastIds.size());
+      rt::h2d(dPunt, genIds.data(), sizeof(uint32_t) * genIds.size());
+    } else {
+      rt::h2d(dOrder, order.data(), sizeof(uint32_t) * nLoci);
+    }
     dMinWl = dMaxWl = nullptr;
     if (!locusMinWl.empty()) {
       dMinWl = bWl.as<uint32_t>(2ull * nLoci);
@@ -818,20 +861,64 @@ struct AsmStage {
     P.reserved2          = 0;
     P.small_min_seed_reads = smallMinSeedReads;
     P.small_max_iterations = smallMaxIterations;
+    P.punt_ids             = nullptr;
+    P.punt_count           = nullptr;
+    P.n_loci_dev           = nullptr;
+    P.lds_bytes            = ASM_LDS_BYTES;
+    P.stop_before          = 0;
     lastParams             = P;
     nRerun                 = 0;
     if (smallMode) {
       rt::launch(small_assemble_kernel, grid, 0, P);
       return;
     }
-    if (useLds && !dPlCodes && !streaming) {
-      if (std::getenv("MANTA_AMD_LDS_OFF")) P.flags |= ASM_FLAG_NO_LDS_PATH;  // A/B: same kernel, every locus through the general path
-      rt::launchSingle(assemble_lds_kernel, gridLds, LN_BUDGET, P);
+    // streamed upload: if the runtime moves a chunk with a shader copy instead of the DMA engine, that copy needs a free
+    // workgroup slot while a persistent kernel runs -- the general kernel leaves one slot free on a quarter of the CUs (the fast
+    // kernel's three workgroups per CU leave plenty)
+    int g = grid;
+    if (streaming && g >= ctx->cuCount * 16) g = rt::roundGrid(g - ctx->cuCount);
+    P.lds_bytes = ASM_LDS_BYTES;
+    if (useFast) {
+      // dCnt: [0] work counter of the fast kernel's list (shared with the general kernel when they run side by side),
+      // [14] length of the general kernel's own list (genIds + punts), [15] its work counter
+      const uint32_t nGen = uint32_t(genIds.size());
+      rt::h2d(reinterpret_cast<uint32_t*>(dCnt + 14), &nGen, sizeof(uint32_t));
+      AsmParams F  = P;
+      F.n_loci     = uint32_t(fastIds.size());
+      F.punt_ids   = dPunt;
+      F.punt_count = reinterpret_cast<uint32_t*>(dCnt + 14);
+      F.ws         = dWs + stride * uint64_t(coSchedule ? gridShare : 0);
+      if (coSchedule) {
+        AsmParams G = P;  // same list, same counter: whichever kernel has a free wave takes the next locus
+        G.n_loci    = uint32_t(fastIds.size());
+        G.lds_bytes = kSharedAsmLds;
+        {
+          // the end of the list belongs to the fast kernel (AsmParams::stop_before): about four loci per fast workgroup
+          const char*    e       = std::getenv("MANTA_AMD_ASM_RESERVE");
+          const uint32_t reserve = e ? uint32_t(std::max(0, std::atoi(e))) : 0u;  // (measured: any reserve loses, the fast kernel's aggregate rate is the lower one)
+          G.stop_before          = (G.n_loci > reserve) ? (G.n_loci - reserve) : 1u;
+        }
+        evFork.record();
+        rt::streamWaits(sideStream, evFork);
+        {
+          rt::ScopedStream onSide(sideStream);
+          rt::launch(assemble_kernel, gridShare, kSharedAsmLds, G);
+          evJoin.record();
+        }
+        rt::launchSingle(assemble_fast_kernel, gridFast, FA_BUDGET, F);
+        rt::curStreamWaits(evJoin);
+      } else {
+        rt::launchSingle(assemble_fast_kernel, gridFast, FA_BUDGET, F);
+      }
+      P.locus_ids  = dPunt;
+      P.n_loci     = nLoci;
+      P.n_loci_dev = reinterpret_cast<uint32_t*>(dCnt + 14);
+      P.counter    = reinterpret_cast<uint32_t*>(dCnt + 15);
+      // nothing for this launch unless the fast kernel handed something back: a small grid then (its waves find the list
+      // length in device memory); the full grid when the host already knows of loci outside the fast envelope
+      if (nGen == 0) g = std::min(g, rt::roundGrid(std::max(1, ctx->cuCount * 4)));
+      rt::launch(assemble_kernel, g, ASM_LDS_BYTES, P);
     } else {
-      // streamed upload: if the runtime moves a chunk with a shader copy instead of the DMA engine, that copy needs a free
-      // workgroup slot while this persistent kernel runs -- leave one slot free on a quarter of the CUs
-      int g = grid;
-      if (streaming && g >= ctx->cuCount * 16) g = rt::roundGrid(g - ctx->cuCount);
       rt::launch(assemble_kernel, g, ASM_LDS_BYTES, P);
     }
     // loci that did not fit the typical-case workspace are counted into dCnt[3] (see rerunCapacityFailures)
@@ -912,9 +999,9 @@ struct AsmStage {
       for (uint32_t q = 0; q < h.n_pseudo; ++q) pseudoBytesOut += hBits[h.pseudo_len_off + q];
     }
     staged = true;
-    ldsFallbacks = useLds ? uint32_t(hCnt[0] >> 32) : 0u;
-    if (std::getenv("MANTA_AMD_DEBUG") && useLds)
-      std::fprintf(stderr, "manta_amd: assemble_lds_kernel: %u of %u loci went through the general path\n", ldsFallbacks, nLoci);
+    ldsFallbacks = useFast ? uint32_t(hCnt[14] & 0xffffffffu) - uint32_t(genIds.size()) : 0u;
+    if (std::getenv("MANTA_AMD_DEBUG") && useFast)
+      std::fprintf(stderr, "manta_amd: assemble_fast_kernel: %zu loci, %u handed to the general kernel (+ %zu outside its envelope)\n", fastIds.size(), ldsFallbacks, genIds.size());
     if (std::getenv("MANTA_AMD_PROFILE")) {
       static const char* names[8] = {"pack", "table", "links", "cycle-check", "exact", "seed", "walk", "select+emit"};
       uint64_t           tot = 0;
@@ -1477,7 +1564,7 @@ int manta_smallsv_upload(
     uint64_t* dRefOff = b->dRefOff.as<uint64_t>(n_loci + 1);
     auto*     dCuts   = b->dCuts.as<SmallSvCuts>(n_loci);
     static_assert(sizeof(SmallSvCuts) == sizeof(manta_ref_cuts_t), "cuts layout");
-    const bool streamed = b->streamUploads && !b->asmStage.useLds && !std::getenv("MANTA_AMD_NO_STREAM_UPLOAD");
+    const bool streamed = b->streamUploads && !std::getenv("MANTA_AMD_NO_STREAM_UPLOAD");
     b->refsOnCopy       = streamed;
     if (streamed) {
       // the assembler does not read the reference windows: they travel on the copy stream BEHIND the read bases and the
@@ -1541,7 +1628,7 @@ int manta_smallsv_upload_piles(
     uint8_t*  dRefs   = b->dRefs.as<uint8_t>(b->refBytes + 16);
     uint64_t* dRefOff = b->dRefOff.as<uint64_t>(n_loci + 1);
     auto*     dCuts   = b->dCuts.as<SmallSvCuts>(n_loci);
-    b->refsOnCopy     = b->streamUploads && !b->asmStage.useLds && !std::getenv("MANTA_AMD_NO_STREAM_UPLOAD");
+    b->refsOnCopy     = b->streamUploads && !std::getenv("MANTA_AMD_NO_STREAM_UPLOAD");
     if (b->refsOnCopy) {  // whole-batch call: piles chunk by chunk behind the running assembler, references behind them (manta_smallsv_upload)
       b->asmStage.uploadPilesStreamed(*piles, b->copy);
       rt::ScopedStream onCopy(b->copy);
@@ -1969,7 +2056,7 @@ int manta_spanning_upload(
       rt::h2d(dCuts, cuts, sizeof(JumpCuts) * n_loci);
     };
     b->hostCuts.assign(reinterpret_cast<const JumpCuts*>(cuts), reinterpret_cast<const JumpCuts*>(cuts) + n_loci);
-    b->refsOnCopy = b->streamUploads && !b->asmStage.useLds && !std::getenv("MANTA_AMD_NO_STREAM_UPLOAD");
+    b->refsOnCopy = b->streamUploads && !std::getenv("MANTA_AMD_NO_STREAM_UPLOAD");
     if (b->refsOnCopy) {  // whole-batch call: as manta_smallsv_upload -- bases in chunks behind the running assembler, references behind them
       b->asmStage.uploadStreamed(bases, read_off, locus_read_begin, b->copy);
       rt::ScopedStream onCopy(b->copy);
@@ -2926,3 +3013,16 @@ extern "C" int manta_split_read_batch(
     return fail(ctx, MANTA_E_HIP, e.what());
   }
 }
+
+#ifdef MANTA_WAVE_EMU
+/// tests/emu only: speculation statistics of assemble_fast_kernel since the last call (loci done by it, walk rounds, walks,
+/// accepted candidates, cache evictions)
+extern "C" void manta_emu_fast_stats(unsigned long long* out)
+{
+  unsigned long long* v = manta_dev::fastStats();
+  for (int i = 0; i < 8; ++i) {
+    out[i] = v[i];
+    v[i]   = 0;
+  }
+}
+#endif

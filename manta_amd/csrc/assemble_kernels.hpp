@@ -36,7 +36,6 @@ enum {
   ASM_E_INTERNAL       = 7
 };
 
-static const unsigned ASM_FLAG_NO_LDS_PATH = 2u;  // A/B knob of assemble_lds_kernel: every locus through the general path
 static const unsigned ASM_FLAG_SERIAL_WALK = 1u;  // debug/A-B knob: build contigs one at a time even for small read sets
 static const unsigned ASM_NONE     = 0xffffffffu;
 static const int      ASM_MAX_KW   = 8;    // k <= 128
@@ -136,6 +135,19 @@ struct AsmParams {
   // small_assemble_kernel only (small_asm.hpp): SmallAssemblerOptions::minSeedReads / maxAssemblyIterations
   uint32_t        small_min_seed_reads;
   uint32_t        small_max_iterations;
+  // assemble_fast_kernel (asm_fast.hpp) hands the loci it does not cover to the general kernel through device memory:
+  // it appends their ids to punt_ids and counts them in *punt_count; the general kernel launched behind it takes
+  // locus_ids = punt_ids and reads its number of loci from *n_loci_dev (nullptr: n_loci) -- no host round trip in between
+  uint32_t*       punt_ids;
+  uint32_t*       punt_count;
+  const uint32_t* n_loci_dev;
+  /// dynamic LDS per wave of assemble_kernel (ASM_LDS_BYTES alone on the device; less when it shares the CUs with
+  /// assemble_fast_kernel, which owns most of the LDS then): peel state / visited bitmaps that do not fit go to the slab
+  uint32_t        lds_bytes;
+  /// assemble_kernel takes no further locus once the shared work counter has reached this value (0: no limit).  Side by side
+  /// with assemble_fast_kernel the end of the list is left to the fast kernel: a locus takes it a quarter of the time it
+  /// takes a wave of this kernel, so the last loci started here would be the last to finish
+  uint32_t        stop_before;
 };
 
 
@@ -881,8 +893,8 @@ struct Assembler {
     uint32_t*      cur    = frontier;
     uint32_t*      nxt    = frontier + P.cap_nodes;
     uint32_t*      cnt    = exact_ws;  // frontier sizes [0],[1]
-    const bool     inLds  = (nNodes * 2 <= ASM_LDS_BYTES);
-    uint32_t*      st     = inLds ? reinterpret_cast<uint32_t*>(wv::lds(ASM_LDS_BYTES)) : (exact_ws + 64);
+    const bool     inLds  = (nNodes * 2 <= P.lds_bytes);
+    uint32_t*      st     = inLds ? reinterpret_cast<uint32_t*>(wv::lds(P.lds_bytes)) : (exact_ws + 64);
     const unsigned nWords = (nNodes + 1) / 2;
     if (lane == 0) {
       cnt[0] = 0;
@@ -1586,11 +1598,14 @@ WV_DEV bool asmWaitUploaded(const AsmParams& P, const unsigned locus)
 WV_KERNEL_OCC(MANTA_ASM_OCC) void assemble_kernel(const AsmParams P)
 {
   uint8_t* wsBase = P.ws + uint64_t(wv::block()) * P.ws_stride;
+  const unsigned nLoci = P.n_loci_dev ? wv::first(wv::atomic_load(P.n_loci_dev)) : P.n_loci;
   while (true) {
     unsigned slot = 0;
-    if (wv::lane() == 0) slot = wv::atomic_add(P.counter, 1u);
+    if (wv::lane() == 0) {
+      slot = (P.stop_before && wv::atomic_load(P.counter) >= P.stop_before) ? nLoci : wv::atomic_add(P.counter, 1u);
+    }
     slot = wv::first(slot);
-    if (slot >= P.n_loci) break;
+    if (slot >= nLoci) break;
     const unsigned locus = P.locus_ids ? P.locus_ids[slot] : slot;
     Assembler      a(P, wsBase);
     // (single reconvergence point per work item: both outcomes fall through to the sync below)

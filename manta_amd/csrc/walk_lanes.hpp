@@ -57,7 +57,7 @@ WV_DEV unsigned Assembler::selectTentative(const unsigned T)
   if (U > T) {
     // Both thresholds come from histograms in LDS (one pass over the compacted arrays each) instead of binary searches
     // that re-read the arrays once per probe.
-    uint32_t*      hist = reinterpret_cast<uint32_t*>(wv::lds(ASM_LDS_BYTES));
+    uint32_t*      hist = reinterpret_cast<uint32_t*>(wv::lds(P.lds_bytes));
     const unsigned cmax = waveMax(myMax);
     // ---- count level: largest c with #{cnt >= c} >= T.  Counts above HBINS-1 share the top bin (they are all taken
     // when the cut falls below it; if the cut falls inside the top bin the binary search below resolves it). ----
@@ -236,8 +236,8 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
   const unsigned lane     = unsigned(wv::lane());
   const unsigned visWords = (P.cap_nodes + 31) / 32;
   const unsigned useWords = (nNodes + 31) / 32;
-  const bool     visInLds = (nT * useWords * 4 <= ASM_LDS_BYTES);
-  uint32_t*      visBase  = visInLds ? reinterpret_cast<uint32_t*>(wv::lds(ASM_LDS_BYTES)) : lane_vis;
+  const bool     visInLds = (nT * useWords * 4 <= P.lds_bytes);
+  uint32_t*      visBase  = visInLds ? reinterpret_cast<uint32_t*>(wv::lds(P.lds_bytes)) : lane_vis;
   const unsigned visStride = visInLds ? useWords : visWords;
   for (unsigned i = lane; i < nT * useWords; i += 64) visBase[size_t(i / useWords) * visStride + (i % useWords)] = 0;
   wv::sync();
@@ -534,7 +534,7 @@ WV_DEV bool Assembler::contigRounds()
     // gather is priced per instruction, not per live lane), and at least what is still needed
     unsigned T = 1;
     if (nCand != 0) {
-      const unsigned fit = ASM_LDS_BYTES / (useWords * 4 + 4);
+      const unsigned fit = P.lds_bytes / (useWords * 4 + 4);
       T                  = (fit > (capCand - nCand) + 2) ? fit : (capCand - nCand) + 2;
     }
     if (T > 64) T = 64;
@@ -592,8 +592,8 @@ WV_DEV bool Assembler::contigRounds()
       }
       // unusedWords.erase for every word of the accepted walk (:170,482)
       // the walks' visited bitmaps are still where walkLanes kept them (LDS if they fitted)
-      const bool      visInLds = (nT * useWords * 4 <= ASM_LDS_BYTES);
-      const uint32_t* vis      = visInLds ? (reinterpret_cast<const uint32_t*>(wv::lds(ASM_LDS_BYTES)) + size_t(t) * useWords)
+      const bool      visInLds = (nT * useWords * 4 <= P.lds_bytes);
+      const uint32_t* vis      = visInLds ? (reinterpret_cast<const uint32_t*>(wv::lds(P.lds_bytes)) + size_t(t) * useWords)
                                           : (lane_vis + size_t(t) * visWords);
       for (unsigned w = lane; w < useWords; w += 64) unused_bits[w] &= ~vis[w];
       wv::sync();

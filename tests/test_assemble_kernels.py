@@ -171,8 +171,9 @@ def test_emulated_serial_and_speculative_walks_agree(emu, oracle, monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# LDS-resident fast path (assemble_lds_kernel, asm_lds.hpp): same results as the oracle, and everything it cannot hold
-# (cycles, next word length, N-masked piles are fine, wide read sets) falls back to the general path inside the kernel
+# LDS-resident fast kernel (assemble_fast_kernel, asm_fast.hpp; MANTA_AMD_ASM_PATH=fast): same results as the oracle, and
+# everything it does not cover (cycles, next word length, wide read sets; N-masked piles are fine) goes to the general kernel
+# through the device-side punt list
 # ---------------------------------------------------------------------------------------------------------------
 def _lds_cases():
     cases = [(asm_opts(minWordLength=31), small_indel_locus(s)[0]) for s in range(3)]
@@ -191,15 +192,15 @@ def _lds_cases():
     return cases
 
 
-def test_emulated_lds_fast_path_matches_oracle(emu, oracle, monkeypatch):
-    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "lds")
+def test_emulated_fast_kernel_matches_oracle(emu, oracle, monkeypatch):
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
     cases = _lds_cases()
     assert _check(emu, oracle, cases) == len(cases)
 
 
-def test_emulated_lds_path_batch_with_mixed_loci(emu, oracle, monkeypatch):
+def test_emulated_fast_kernel_batch_with_mixed_loci(emu, oracle, monkeypatch):
     """one launch: fast-path loci, fallback loci (tandem repeats, > 108 reads) and an empty pile side by side"""
-    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "lds")
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
     o = asm_opts(minWordLength=21, maxWordLength=41)
     loci = [small_indel_locus(1, n_reads=30, read_len=60, ref_len=300)[0], [],
             small_indel_locus(2, n_reads=30, read_len=60, ref_len=300, tandem=True)[0],
@@ -210,11 +211,43 @@ def test_emulated_lds_path_batch_with_mixed_loci(emu, oracle, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_gpu_lds_fast_path_matches_oracle(gpu, oracle, monkeypatch):
-    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "lds")
+def test_gpu_fast_kernel_matches_oracle(gpu, oracle, monkeypatch):
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
     cases = _lds_cases() + [(asm_opts(minWordLength=31), small_indel_locus(100 + s)[0]) for s in range(64)]
     assert _check(gpu, oracle, cases) == len(cases)
     o = asm_opts(minWordLength=31)
     loci = [small_indel_locus(s, tandem=(s % 4 == 0), n_rate=(0.01 if s % 5 == 0 else 0.0))[0] for s in range(200)]
+    for reads, r in zip(loci, gpu.assemble_batch(o, loci)):
+        assert assembly_text(r) == oracle.assemble(o, reads)
+
+
+def _fast_stats(emu):
+    import ctypes
+    st = (ctypes.c_ulonglong * 8)()
+    emu.lib.manta_emu_fast_stats(st)
+    return dict(loci=st[0], rounds=st[1], walks=st[2], cands=st[3], evictions=st[4], reclaimed=st[5])
+
+
+def test_emulated_fast_kernel_speculation_hits(emu, oracle, monkeypatch):
+    """the fast kernel's contig loop runs on speculation (asm_fast.hpp): config-2 loci must come out of (close to) ONE walk round
+    each -- a regression guard for the seed prediction, which can only cost time, never results (those are checked as well)"""
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
+    o = asm_opts(minWordLength=31)
+    loci = [small_indel_locus(s)[0] for s in range(16)]
+    _fast_stats(emu)
+    res = emu.assemble_batch(o, loci)
+    st = _fast_stats(emu)
+    for reads, r in zip(loci, res):
+        assert assembly_text(r) == oracle.assemble(o, reads)
+    assert st["loci"] == 16 and st["cands"] == 16 * 20, st
+    assert st["rounds"] <= 16 * 1.5, st
+
+
+@pytest.mark.gpu
+def test_gpu_side_by_side_kernels_match_oracle(gpu, oracle, monkeypatch):
+    """MANTA_AMD_ASM_PATH=both: the fast and the general kernel on one work queue"""
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "both")
+    o = asm_opts(minWordLength=31)
+    loci = [small_indel_locus(s, tandem=(s % 7 == 0), n_rate=(0.01 if s % 5 == 0 else 0.0))[0] for s in range(300)]
     for reads, r in zip(loci, gpu.assemble_batch(o, loci)):
         assert assembly_text(r) == oracle.assemble(o, reads)

@@ -49,7 +49,10 @@ def test_digest_files_match_the_restatement_on_a_sample(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-def test_gpu_config2_all_10000_loci_match_reference_digests(gpu):
+@pytest.mark.parametrize("asm_path", ["general", "fast"])
+def test_gpu_config2_all_10000_loci_match_reference_digests(gpu, monkeypatch, asm_path):
+    """general = assemble_kernel (the default); fast = assemble_fast_kernel with its punt list (MANTA_AMD_ASM_PATH)"""
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", asm_path)
     want = digests("config2_digests.bin")
     batch = config2_batch(10000, seed=12345)
     out = BatchOutput(gpu, "smallsv", 10000, 10, 64 << 20, 8 << 20, 16 << 20)
