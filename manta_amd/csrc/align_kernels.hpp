@@ -273,8 +273,8 @@ struct Aligner {
         // candidate: candidate i is scored as value*8 + (7-i), so equal values order by state index; v_max3_i32
         // folds three at a time; value = max >> 3, and the low bits (= 7 - winning state) go straight into the
         // stored back-pointer field (ptrField undoes the 7-x).  |scores| < 2^27, so the shift cannot overflow.
-#define MANTA_PK(v, idx) (((v) << 3) + (7 - (idx)))
-#define MANTA_PKA(v, add, idx) (((v) << 3) + (((add) << 3) + (7 - (idx))))
+#define MANTA_PK(v, idx) (((v) * 8) + (7 - (idx)))  // (a multiply: left-shifting a negative int is undefined; same instruction)
+#define MANTA_PKA(v, add, idx) (((v) * 8) + (((add) * 8) + (7 - (idx))))
         // match
         {
           int m = imax(imax(MANTA_PK(diag[ST_MATCH], 0), MANTA_PK(diag[ST_DELETE], 1)), MANTA_PK(diag[ST_INSERT], 2));

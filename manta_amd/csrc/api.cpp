@@ -297,10 +297,16 @@ class HostPool {
       ++generation;
     }
     cv.notify_all();
+    struct WaitForHelpers {  // also when fn throws on the caller's part: the helpers still hold a pointer to `job`
+      HostPool& p;
+      ~WaitForHelpers()
+      {
+        std::unique_lock<std::mutex> g(p.mu);
+        p.done.wait(g, [&] { return p.pending == 0; });
+        p.current = nullptr;
+      }
+    } waitForHelpers{*this};
     fn(0u, begin(0), begin(1));
-    std::unique_lock<std::mutex> g(mu);
-    done.wait(g, [&] { return pending == 0; });
-    current = nullptr;
   }
 
  private:
@@ -699,6 +705,10 @@ struct AsmStage {
     if (!dChunksDone) dChunksDone = static_cast<uint32_t*>(rt::dmallocFine(64));
     uint32_t* ids = pChunkIds.as<uint32_t>(kStreamChunks + 1);
     for (uint32_t c = 0; c <= kStreamChunks; ++c) ids[c] = c;
+    {  // a call that failed half way may have left counter bumps queued on the copy stream: none may land after the reset
+      rt::ScopedStream onCopy(copyStream);
+      rt::sync();
+    }
     rt::h2d(dChunksDone, ids, sizeof(uint32_t));  // = 0
     rt::sync();  // the counter is zero and the small arrays are in place before the first chunk can land
     {
@@ -755,6 +765,10 @@ struct AsmStage {
     if (!dChunksDone) dChunksDone = static_cast<uint32_t*>(rt::dmallocFine(64));
     uint32_t* ids = pChunkIds.as<uint32_t>(kStreamChunks + 1);
     for (uint32_t c = 0; c <= kStreamChunks; ++c) ids[c] = c;
+    {  // a call that failed half way may have left counter bumps queued on the copy stream: none may land after the reset
+      rt::ScopedStream onCopy(copyStream);
+      rt::sync();
+    }
     rt::h2d(dChunksDone, ids, sizeof(uint32_t));  // = 0
     rt::sync();
     {
@@ -1292,6 +1306,7 @@ int manta_align_batch(
   if (n_tasks == 0) return MANTA_OK;
 
   try {
+    rt::setDevice(ctx->deviceId);  // the calling thread may have another device current (multi-GPU hosts)
     rt::ScopedStream onStream(ctx->stream);
     // ---- validate + bucket by columns-per-lane (E) ----
     std::vector<AlignTaskDev>          dev(n_tasks);
@@ -1439,6 +1454,7 @@ int manta_assemble_batch(
   if (bits_arena_used) *bits_arena_used = 0;
   if (n_loci == 0) return MANTA_OK;
   try {
+    rt::setDevice(ctx->deviceId);  // the calling thread may have another device current (multi-GPU hosts)
     rt::ScopedStream onStream(ctx->stream);
     AsmStage st(ctx);
     int      rc = st.plan(*opt, n_loci, read_off, locus_read_begin);
@@ -1481,6 +1497,7 @@ int manta_small_assemble_batch(
   if (bits_arena_used) *bits_arena_used = 0;
   if (n_loci == 0) return MANTA_OK;
   try {
+    rt::setDevice(ctx->deviceId);  // the calling thread may have another device current (multi-GPU hosts)
     rt::ScopedStream onStream(ctx->stream);
     AsmStage st(ctx);
     // the slab and the record slots are those of the iterative assembler: one slot per iteration's contig + the isFiltered record
@@ -1523,11 +1540,16 @@ int manta_smallsv_create(
 {
   if (!ctx) return MANTA_E_INVALID_ARG;
   if (!opt || !scores || !out) return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_create: null argument");
-  manta_smallsv* b = new manta_smallsv(ctx);
-  b->opt           = *opt;
-  b->scores        = *scores;
-  b->largeIndel    = large_indel_score;
-  *out             = b;
+  try {
+    rt::setDevice(ctx->deviceId);  // (the pipeline's streams and events belong to the context's device)
+    manta_smallsv* b = new manta_smallsv(ctx);
+    b->opt           = *opt;
+    b->scores        = *scores;
+    b->largeIndel    = large_indel_score;
+    *out             = b;
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
   return MANTA_OK;
 }
 
@@ -1545,6 +1567,7 @@ int manta_smallsv_upload(
   if (n_loci == 0 || !bases || !read_off || !locus_read_begin || !refs || !ref_off || !cuts)
     return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_upload: null argument or empty batch");
   try {
+    rt::setDevice(ctx->deviceId);  // the calling thread may have another device current (multi-GPU hosts)
     rt::ScopedStream onStream(b->main);
     b->uploaded = false;
     const double tP0 = nowMs();
@@ -1668,12 +1691,24 @@ struct GateLock {
   void release() { if (l.owns_lock()) l.unlock(); }
 };
 
+/// failure exit of a pipeline run: let queued DMA reads of the caller's buffers (streamed upload) finish before the call returns
+template <typename Pipe>
+void drainCopyStream(Pipe* b) noexcept
+{
+  try {
+    rt::ScopedStream onCopy(b->copy);
+    rt::sync();
+  } catch (...) {
+  }
+}
+
 int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
 {
   if (!b) return MANTA_E_INVALID_ARG;
   manta_ctx_t* ctx = b->ctx;
   if (!b->uploaded) return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_run: nothing uploaded");
   try {
+    rt::setDevice(ctx->deviceId);  // the calling thread may have another device current (multi-GPU hosts)
     rt::ScopedStream onStream(b->main);
     const uint32_t nLoci   = b->nLoci;
     const uint32_t maxAsm  = b->opt.max_assembly_count;
@@ -1685,8 +1720,6 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     AlignResultDev*  dResults = b->dResults.as<AlignResultDev>(nSlots);
     uint32_t*        dBuckets = b->dBucketIds.as<uint32_t>(nSlots * kNumESet);
     uint32_t*        dSmall   = b->dSmall.as<uint32_t>(64);  // [0..11] counts, [16..27] maxref, [32] sched counter, [34..35] cigar_used, [40..51] align counters
-    const uint64_t   cigarCap = nSlots * (4ull * std::min<uint64_t>(as.maxContigLen, 4096) + 16);
-    uint32_t*        dCigar   = b->dCigar.as<uint32_t>(cigarCap + 16);
     const uint32_t   tableCap = nextPow2(2ull * as.maxContigLen);
     const int        schedGrid = rt::roundGrid(int(std::min<uint64_t>(nLoci, uint64_t(std::max(1, ctx->cuCount * 32)))));
     uint32_t*        dTable   = b->dTable.as<uint32_t>(uint64_t(tableCap) * schedGrid);
@@ -1701,6 +1734,7 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
       std::fflush(stderr);
     };
     stage("start");
+    uint64_t asmCnt[4];  // [1] text bytes, [3] capacity failures
     {
       GateLock only(gates, &StageGates::asmMu);
       // A streamed-upload assembler polls for chunks whose copies may need a free workgroup slot (launch() leaves some);
@@ -1713,11 +1747,21 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
       b->evAsm.record();
       // loci that did not fit the typical-case workspace run again here (rare; the counter rides on a wait that is there anyway
       // in the whole-batch calls, the staged API pays one small read)
-      uint64_t capacityFailures = 0;
-      rt::d2h(&capacityFailures, as.dCnt + 3, sizeof(uint64_t));  // (also: the gate opens when the assembler has left the device)
-      as.rerunCapacityFailures(capacityFailures);
+      rt::d2h(asmCnt, as.dCnt, sizeof(asmCnt));  // (also: the gate opens when the assembler has left the device)
+      if (asmCnt[3]) {
+        as.rerunCapacityFailures(asmCnt[3]);
+        rt::d2h(asmCnt, as.dCnt, sizeof(asmCnt));  // the text arena grew
+      }
     }
     stage("assembled");
+    // CIGAR scratch, sized from what the assembler produced (as in spanningRunImpl): a task takes 4 * contig length + 16 words
+    // (smallsv_schedule_kernel), every contig is aligned once, and the text arena counter bounds the summed contig lengths.  A
+    // worst case per slot would be tens of GB at 65536-locus blocks and overflow the 32-bit offsets of the task records.
+    const uint64_t cigarCap = 4ull * std::min<uint64_t>(asmCnt[1], as.devSeqCap) + 16ull * nSlots + 64;
+    if (cigarCap + 16 > 0xffffffffull)
+      return fail(ctx, MANTA_E_UNSUPPORTED, "manta_smallsv_run: alignment scratch of this block exceeds 2^32 words; use smaller blocks "
+                                         "(manta_smallsv_batch splits a batch into blocks, manta_batch_plan_t::block_loci)");
+    uint32_t* dCigar = b->dCigar.as<uint32_t>(cigarCap + 16);
     GateLock alignOnly(gates, &StageGates::alignMu);
     if (b->refsOnCopy) rt::curStreamWaits(b->refsReady);  // reference windows of a streamed upload (manta_smallsv_upload)
 
@@ -1793,10 +1837,10 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
         P.off_edge       = b->scores.off_edge;
         P.allow_edge_ins = b->scores.is_allow_edge_insertion ? 1 : 0;
         P.extra          = b->largeIndel;
-        rt::Stream& st(b->side[i % 3]);
-        rt::useStream(&st);
-        launchAlignKind(MANTA_ALIGNER_LARGE_INDEL, l.k, l.grid, P);
-        rt::useStream(nullptr);
+        {
+          rt::ScopedStream onSide(b->side[i % 3]);  // (restores the pipeline's stream: nothing of this call runs on the null stream)
+          launchAlignKind(MANTA_ALIGNER_LARGE_INDEL, l.k, l.grid, P);
+        }
         b->stats.n_align_launches++;
         b->stats.n_alignments += hSmall[l.k];
       }
@@ -1822,6 +1866,7 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     b->ran               = true;
     return MANTA_OK;
   } catch (const std::exception& e) {
+    drainCopyStream(b);
     return fail(ctx, MANTA_E_HIP, e.what());
   }
 }
@@ -1842,6 +1887,7 @@ int manta_smallsv_output_sizes(const manta_smallsv_t* b, uint64_t* contigs, uint
   if (!b || !contigs || !seq_bytes || !bits_words || !cigar_words) return MANTA_E_INVALID_ARG;
   if (!b->ran) return fail(b->ctx, MANTA_E_INVALID_ARG, "manta_smallsv_output_sizes: run first");
   try {
+    rt::setDevice(b->ctx->deviceId);  // the calling thread may have another device current (multi-GPU hosts)
     rt::ScopedStream onStream(const_cast<manta_smallsv_t*>(b)->main);
     b->asmStage.outputSizes(*contigs, *seq_bytes, *bits_words);
     uint32_t hSmall[40];
@@ -1987,6 +2033,7 @@ int manta_smallsv_download(
   if (!loci || !contigs || !alignments || !seq_arena || !bits_arena || !cigar_arena)
     return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_download: null argument");
   try {
+    rt::setDevice(ctx->deviceId);  // the calling thread may have another device current (multi-GPU hosts)
     rt::ScopedStream onStream(b->main);
     pipeStage(b);
     return smallsvCompact(b, loci, contigs, alignments, 0, contigs_cap, seq_arena, seq_arena_cap, 0, seq_arena_used, bits_arena,
@@ -2006,11 +2053,16 @@ int manta_spanning_create(
   if (!opt || !scores || !out) return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_create: null argument");
   if (scores->is_allow_edge_insertion)
     return fail(ctx, MANTA_E_INVALID_ARG, "GlobalJumpAligner does not support isAllowEdgeInsertion");
-  manta_spanning* b = new manta_spanning(ctx);
-  b->opt            = *opt;
-  b->scores         = *scores;
-  b->jumpScore      = jump_score;
-  *out              = b;
+  try {
+    rt::setDevice(ctx->deviceId);  // (the pipeline's streams and events belong to the context's device)
+    manta_spanning* b = new manta_spanning(ctx);
+    b->opt            = *opt;
+    b->scores         = *scores;
+    b->jumpScore      = jump_score;
+    *out              = b;
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
   return MANTA_OK;
 }
 
@@ -2028,6 +2080,7 @@ int manta_spanning_upload(
   if (n_loci == 0 || !bases || !read_off || !locus_read_begin || !refs1 || !ref1_off || !refs2 || !ref2_off || !cuts)
     return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_upload: null argument or empty batch");
   try {
+    rt::setDevice(ctx->deviceId);  // the calling thread may have another device current (multi-GPU hosts)
     rt::ScopedStream onStream(b->main);
     b->uploaded = false;
     int rc      = b->asmStage.plan(b->opt, n_loci, read_off, locus_read_begin);
@@ -2124,6 +2177,7 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
   manta_ctx_t* ctx = b->ctx;
   if (!b->uploaded) return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_run: nothing uploaded");
   try {
+    rt::setDevice(ctx->deviceId);  // the calling thread may have another device current (multi-GPU hosts)
     rt::ScopedStream onStream(b->main);
     const uint32_t nLoci  = b->nLoci;
     const uint32_t maxAsm = b->opt.max_assembly_count;
@@ -2250,9 +2304,10 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
         P.off_edge       = b->scores.off_edge;
         P.allow_edge_ins = 0;
         P.extra          = b->jumpScore;
-        rt::useStream(&b->side[i % 3]);
-        launchAlignKind(MANTA_ALIGNER_JUMP, l.k, l.grid, P);
-        rt::useStream(nullptr);
+        {
+          rt::ScopedStream onSide(b->side[i % 3]);
+          launchAlignKind(MANTA_ALIGNER_JUMP, l.k, l.grid, P);
+        }
         b->stats.n_align_launches++;
         b->stats.n_alignments += hCounts[l.k];
       }
@@ -2285,6 +2340,7 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
     b->ran               = true;
     return MANTA_OK;
   } catch (const std::exception& e) {
+    drainCopyStream(b);
     return fail(ctx, MANTA_E_HIP, e.what());
   }
 }
@@ -2305,6 +2361,7 @@ int manta_spanning_output_sizes(const manta_spanning_t* b, uint64_t* contigs, ui
   if (!b || !contigs || !seq_bytes || !bits_words || !cigar_words) return MANTA_E_INVALID_ARG;
   if (!b->ran) return fail(b->ctx, MANTA_E_INVALID_ARG, "manta_spanning_output_sizes: run first");
   try {
+    rt::setDevice(b->ctx->deviceId);  // the calling thread may have another device current (multi-GPU hosts)
     rt::ScopedStream onStream(const_cast<manta_spanning_t*>(b)->main);
     b->asmStage.outputSizes(*contigs, *seq_bytes, *bits_words);
     uint32_t hSmall[72];
@@ -2411,6 +2468,7 @@ int manta_spanning_download(
   if (!loci || !contigs || !alignments || !seq_arena || !bits_arena || !cigar_arena)
     return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_download: null argument");
   try {
+    rt::setDevice(ctx->deviceId);  // the calling thread may have another device current (multi-GPU hosts)
     rt::ScopedStream onStream(b->main);
     pipeStage(b);
     return spanningCompact(b, loci, contigs, alignments, 0, contigs_cap, seq_arena, seq_arena_cap, 0, seq_arena_used, bits_arena,

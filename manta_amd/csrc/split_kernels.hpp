@@ -98,17 +98,18 @@ WV_DEV void splitReadTask(const SplitParams& P, const unsigned t)
         const uint8_t qb = T.query[i], tb = T.target[pos + unsigned(i)];
         int           bq = int(T.qual[i]);
         if (bq < 2) bq = 2;  // :65
-        if (unsigned(bq) >= P.n_q) {
-          badQ = true;
-          bq   = int(P.n_q) - 1;
-        }
+        // (the quality tables are consulted only where the reference consults them: not at 'N' positions, :75-78)
+        const bool over = unsigned(bq) >= P.n_q;
+        if (over) bq = int(P.n_q) - 1;
         if (qb != tb || qb == 'N') {
           if (qb == 'N' || tb == 'N') {
             lnLhood += P.ln_random_base;
           } else {
+            badQ    = badQ || over;
             lnLhood = float(double(lnLhood) + (P.ln_error[bq] + thirdD));
           }
         } else {
+          badQ    = badQ || over;
           lnLhood = float(double(lnLhood) + P.ln_comp_error[bq]);
         }
       }
@@ -142,8 +143,10 @@ WV_DEV void splitReadTask(const SplitParams& P, const unsigned t)
   if (int(bestPos) <= T.bp_begin + 1) leftSize = unsigned(T.bp_begin + 1 - int(bestPos));
   unsigned homSize = 0, rightSize = 0;
   if (leftSize <= unsigned(querySize)) {
-    const int a = querySize - int(leftSize), b = (T.bp_end + 1 - int(bestPos)) - int(leftSize);
-    homSize     = unsigned(a < b ? a : b);
+    // std::min over UNSIGNED operands in the reference (:320-322): a range that ends before the placement wraps around and
+    // the first operand wins
+    const unsigned a = unsigned(querySize) - leftSize, b = (unsigned(T.bp_end + 1) - bestPos) - leftSize;
+    homSize          = (a < b) ? a : b;
     if (leftSize + homSize < unsigned(querySize)) rightSize = unsigned(querySize) - (leftSize + homSize);
   }
   // calculateAlignScore (:95-121): i <= leftSize counts as left, i <= leftSize + homSize as hom

@@ -75,18 +75,19 @@ float placementLnLhood(
   for (int i = 0; i < querySize; ++i) {
     if (pos + i > scoreEnd) break;
     if (pos + i <= scoreBegin) continue;
-    const int bq = std::max(2, static_cast<int>(qual[i]));
-    if (bq > kMaxQscore) {
-      badQ = true;
-      continue;
-    }
+    int           bq   = std::max(2, static_cast<int>(qual[i]));
+    const bool    over = bq > kMaxQscore;  // the reference's table lookup throws (qscore_cache.hpp:49-52) -- where it looks up
+    if (over) bq = kMaxQscore;
     const uint8_t qb = query[i], tb = target[pos + i];
     if (qb != tb || qb == 'N') {
-      if (qb == 'N' || tb == 'N')
-        lnLhood += t.lnRandomBase;
-      else
+      if (qb == 'N' || tb == 'N') {
+        lnLhood += t.lnRandomBase;  // (SplitReadAlignment.cpp:75-78: no table lookup at an 'N')
+      } else {
+        badQ = badQ || over;
         lnLhood += t.lnErr[bq] + t.lnOneThird;
+      }
     } else {
+      badQ = badQ || over;
       lnLhood += t.lnComp[bq];
     }
   }
@@ -137,7 +138,7 @@ int orc_split_read_aligner(
   Info a;
   if (int(bestPos) <= bpBegin + 1) a.leftSize = unsigned(bpBegin + 1 - int(bestPos));
   if (a.leftSize > unsigned(querySize)) return emitText("EXCEPTION\n", out, cap);
-  a.homSize = unsigned(std::min(querySize - int(a.leftSize), (bpEnd + 1 - int(bestPos)) - int(a.leftSize)));
+  a.homSize = std::min(unsigned(querySize) - a.leftSize, (unsigned(bpEnd + 1) - bestPos) - a.leftSize);  // unsigned operands as in the reference (:320-322)
   if (a.leftSize + a.homSize < unsigned(querySize)) a.rightSize = unsigned(querySize) - (a.leftSize + a.homSize);
   a.alignLnLhood = best;
   a.alignPos     = bestPos;

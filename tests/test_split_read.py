@@ -132,6 +132,34 @@ def random_cases(seed, n):
     return out
 
 
+def unusual_cases():
+    """inputs Manta does not produce but the function accepts: a quality above the table's range (the reference's lookup throws --
+    but there is no lookup at an 'N' position), and ranges whose end lies before the best placement (the reference's std::min
+    runs on unsigned operands there)"""
+    t = "GATCACAGGTCTATCACCCTATTAACCACTCACGGGAGCTCTCCATGCATTTGGTATTTTCGTCTGGGGGGTGTGCACGCGATAGC"
+    q = t[20:50]
+    qn = q[:7] + "N" + q[8:]
+    out = [dict(query=qn, qual=[30] * 7 + [90] + [30] * 22, target=t, bp=[30, 34], flank=50),    # over-range quality at the query's N
+           dict(query=q, qual=[30] * 7 + [90] + [30] * 22, target=t[:27] + "N" + t[28:], bp=[30, 34], flank=50),  # ... at a target N
+           dict(query=q, qual=[30] * 7 + [90] + [30] * 22, target=t, bp=[30, 34], flank=50),     # ... at a scored base: exception
+           dict(query=q, qual=[90] + [30] * 29, target=t, bp=[30, 34], flank=2)]                 # ... outside the scored range
+    for b, e in ((30, 25), (40, 12), (25, 24), (60, 0)):
+        out.append(dict(query=q, qual=[30] * 30, target=t, bp=[b, e], flank=50))
+    return out
+
+
+def test_unusual_inputs_match_the_reference(ref, orc):
+    for c in unusual_cases():
+        assert orc.run(c) == ref.run(c), c
+
+
+def test_emulated_split_read_scorer_unusual_inputs(mine_emu, orc):
+    cases = unusual_cases()
+    for c in cases:
+        assert mine_emu.run(c) == orc.run(c), c
+    assert mine_emu.run_batch(cases) == [orc.run(c) for c in cases]
+
+
 def test_tables_and_restatement_match_the_reference(ref, orc):
     assert ref.get_tables() == orc.get_tables()
     for c in reference_test_cases() + random_cases(1, 400):
@@ -156,7 +184,7 @@ def test_emulated_split_read_scorer(mine_emu, orc):
 def test_gpu_split_read_scorer(mine_gpu, orc):
     g = json.load(open(GOLDEN))
     assert mine_gpu.run_batch(g["cases"]) == g["ref_texts"]  # the reference's own outputs
-    cases = random_cases(3, 3000)
+    cases = random_cases(3, 3000) + unusual_cases()
     assert mine_gpu.run_batch(cases) == [orc.run(c) for c in cases]
     # config-like shape: 150-base reads against 500-base contigs, many at once
     rng = np.random.default_rng(5)
