@@ -15,6 +15,12 @@
 // cells; the traceback then walks it with 64-lane speculative look-ahead (one HBM round trip per alignment
 // state change instead of one per cell).
 //
+// Queries longer than 64 lanes x 32 columns (2048 bases; the reference has no limit) run in STRIPS of 2048 columns on the
+// E = 32 kernel: strip s sweeps all reference rows like a whole alignment, but its left boundary is not the constant
+// column 0 -- it is the right-most column of strip s-1, which that strip left in a small boundary array (one row of DP
+// states per reference row, ping-pong between strips); every strip has its own back-pointer slab, the traceback finds a
+// cell's slab from its query column.
+//
 // Scores are int32 exactly as the reference instantiates them (AlignmentScores<int>); badVal = -10000 is a
 // finite sentinel that takes part in arithmetic (GlobalJumpAlignerImpl.hpp:68).  Arg-max ties are resolved by
 // the reference's strict '>' scan in state order (AlignerBase.hpp:46-59, JumpAlignerBase.hpp:93-111,
@@ -137,6 +143,11 @@ struct Aligner {
   const uint8_t*     ref2;
   unsigned           Q, R1, R2, G;
   cell_t*            ptr;
+  static const bool     MULTI = (E == 32);   // the widest kernel also takes longer queries, in strips
+  static const unsigned STRIPW = 64u * E;    // query columns per strip
+  unsigned           nStrips;
+  uint64_t           stripCells;             // back-pointer cells of one strip's slab
+  int*               bnd[2];                 // boundary columns between strips: (G + 2) rows x NS states each
 
   WV_DEV Aligner(const AlignParams& p) : P(p) {}
 
@@ -153,8 +164,9 @@ struct Aligner {
       if (KIND != 2 && g == 0 && state == ST_INSERT && P.allow_edge_ins) return ST_INSERT;
       return ST_MATCH;
     }
-    const unsigned l = (q - 1) / E, e = (q - 1) % E;
-    const uint64_t idx = (uint64_t(g + l) * E + e) * 64 + l;
+    const unsigned strip = MULTI ? (q - 1) / STRIPW : 0u, qs = MULTI ? (q - 1) % STRIPW : (q - 1);
+    const unsigned l = qs / E, e = qs % E;
+    const uint64_t idx = uint64_t(strip) * stripCells + (uint64_t(g + l) * E + e) * 64 + l;
     return (7 - ((int(ptr[idx]) >> (state * BITS)) & FMASK)) & FMASK;
   }
 
@@ -164,27 +176,7 @@ struct Aligner {
   WV_DEV StartCand sweep()
   {
     const int      lane = wv::lane();
-    const unsigned lQ   = (Q - 1) / E;
-    const unsigned eQ   = (Q - 1) % E;
     const int      open = P.open, extend = P.extend, L = P.extra, offEdge = P.off_edge;
-
-    int     st[NS][E];      // own columns, row (g-1) before / row g after the step
-    int     lcur[NS];       // lane l-1's right-most column, row g   (as of its previous step)
-    int     lprev[NS];      // same column, row g-1
-    uint8_t qc[E];
-    for (int e = 0; e < E; ++e) {
-      const unsigned q0 = unsigned(lane) * E + e;  // 0-based query index
-      qc[e]             = (q0 < Q) ? query[q0] : uint8_t(0);
-      // row 0 (GlobalAlignerImpl.hpp:66-80)
-      const unsigned q = q0 + 1;
-      for (int s = 0; s < NS; ++s) st[s][e] = ALIGN_BAD;
-      st[ST_MATCH][e] = int(q * unsigned(offEdge));
-      if (KIND != 2 && P.allow_edge_ins) st[ST_INSERT][e] = open + int(q * unsigned(extend));
-    }
-    // column 0 of row 0 for lane 0; other lanes get theirs through the first shifts
-    for (int s = 0; s < NS; ++s) lcur[s] = lprev[s] = ALIGN_BAD;
-    lcur[ST_MATCH] = lprev[ST_MATCH] = 0;
-    if (KIND != 2 && P.allow_edge_ins) lcur[ST_INSERT] = lprev[ST_INSERT] = open;
 
     StartCand candRows1 = {0, 0, 0, ST_MATCH, false};  // rows of ref1 (or the single reference) at q=Q
     StartCand candRows2 = {0, 0, 0, ST_MATCH, false};  // rows of ref2 at q=Q
@@ -192,11 +184,44 @@ struct Aligner {
     int       off1Val = 0, off2Val = 0;
     unsigned  off1Q = 0, off2Q = 0;
     int       lastRowIns = ALIGN_BAD;
+    unsigned  lQ = 0;
+
+    for (unsigned strip = 0; strip < nStrips; ++strip) {
+    const unsigned qBase     = strip * STRIPW;  // query columns of this strip: qBase + 1 .. qBase + 64 E
+    const bool     lastStrip = (strip + 1 == nStrips);
+    lQ                       = lastStrip ? (Q - 1 - qBase) / E : 64u;  // lane that owns column Q (last strip only)
+    const unsigned eQ        = (Q - 1 - (lastStrip ? qBase : 0u)) % E;
+    cell_t*        ptrS      = ptr + uint64_t(strip) * stripCells;
+    const int*     bndIn     = bnd[(strip & 1) ^ 1];  // written by the previous strip
+    int*           bndOut    = bnd[strip & 1];
+
+    int     st[NS][E];      // own columns, row (g-1) before / row g after the step
+    int     lcur[NS];       // lane l-1's right-most column, row g   (as of its previous step)
+    int     lprev[NS];      // same column, row g-1
+    uint8_t qc[E];
+    for (int e = 0; e < E; ++e) {
+      const unsigned q0 = qBase + unsigned(lane) * E + e;  // 0-based query index
+      qc[e]             = (q0 < Q) ? query[q0] : uint8_t(0);
+      // row 0 (GlobalAlignerImpl.hpp:66-80)
+      const unsigned q = q0 + 1;
+      for (int s = 0; s < NS; ++s) st[s][e] = ALIGN_BAD;
+      st[ST_MATCH][e] = int(q * unsigned(offEdge));
+      if (KIND != 2 && P.allow_edge_ins) st[ST_INSERT][e] = open + int(q * unsigned(extend));
+    }
+    // the strip's left boundary column, row 0, for lane 0 (column 0 in the first strip); other lanes get theirs through
+    // the first shifts
+    for (int s = 0; s < NS; ++s) lcur[s] = lprev[s] = ALIGN_BAD;
+    lcur[ST_MATCH] = lprev[ST_MATCH] = int(qBase * unsigned(offEdge));
+    if (KIND != 2 && P.allow_edge_ins) lcur[ST_INSERT] = lprev[ST_INSERT] = open + int(qBase * unsigned(extend));
 
     unsigned curBlk = 0, nextBlk = 0;
+    int      curB[NS], nextB[NS];  // boundary rows of the next 64 steps, one row per lane (strips > 0)
+    for (int s = 0; s < NS; ++s) curB[s] = nextB[s] = ALIGN_BAD;
     {
       const unsigned i0 = unsigned(lane);
       nextBlk           = (i0 < G) ? refChar(i0) : 0u;
+      if (MULTI && strip > 0 && i0 < G)
+        for (int s = 0; s < NS; ++s) nextB[s] = bndIn[size_t(i0 + 1) * NS + s];
     }
     unsigned rc = 0;  // this lane's reference symbol for its current row
 
@@ -206,19 +231,29 @@ struct Aligner {
         curBlk            = nextBlk;
         const unsigned i0 = t - 1 + 64 + unsigned(lane);
         nextBlk           = (i0 < G) ? refChar(i0) : 0u;
+        if (MULTI && strip > 0) {
+          for (int s = 0; s < NS; ++s) {
+            curB[s]  = nextB[s];
+            nextB[s] = (i0 < G) ? bndIn[size_t(i0 + 1) * NS + s] : ALIGN_BAD;
+          }
+        }
       }
       const unsigned c0 = wv::readlane(curBlk, int((t - 1) & 63));
       rc                = wv::shr1(rc, c0);
 
-      // right-most column of the left neighbour, as of the end of the previous step
+      // right-most column of the left neighbour, as of the end of the previous step; lane 0 of a later strip receives
+      // the previous strip's last column of row g = t instead
       int incoming[NS];
-      for (int s = 0; s < NS; ++s) incoming[s] = wv::shr1(st[s][E - 1], ALIGN_BAD);
+      for (int s = 0; s < NS; ++s) {
+        const int fill = (MULTI && strip > 0) ? wv::readlane(curB[s], int((t - 1) & 63)) : ALIGN_BAD;
+        incoming[s]    = wv::shr1(st[s][E - 1], fill);
+      }
       const int g = int(t) - lane;  // this lane's row
       for (int s = 0; s < NS; ++s) {
         lprev[s] = lcur[s];
         lcur[s]  = incoming[s];
       }
-      if (lane == 0) {
+      if (lane == 0 && strip == 0) {
         // column 0: rows >= 1 are (0,bad,bad,..); row 0 handled by the initial lprev
         // (GlobalAlignerImpl.hpp:98-107)
         if (g >= 2) {
@@ -236,7 +271,7 @@ struct Aligner {
         // seam (GlobalJumpAlignerImpl.hpp:181-204): off-edge candidates of the last ref1 row, then re-seed
         // match/del/ins of the live row while PRESERVING jump.
         for (int e = 0; e < E; ++e) {
-          const unsigned q = unsigned(lane) * E + e + 1;
+          const unsigned q = qBase + unsigned(lane) * E + e + 1;
           if (q < Q) {
             const int v = st[ST_MATCH][e] + int((Q - q) * unsigned(offEdge));
             if (!haveOff1 || v > off1Val) {
@@ -249,11 +284,12 @@ struct Aligner {
           st[ST_DELETE][e] = ALIGN_BAD;
           st[ST_INSERT][e] = ALIGN_BAD;
         }
-        // the diagonal neighbour (row R1 of lane l-1's last column) is re-seeded the same way
-        lprev[ST_MATCH]  = int((unsigned(lane) * E) * unsigned(offEdge));
+        // the diagonal neighbour (row R1 of the column to the left) is re-seeded the same way; its jump value stays
+        // (column 0 has none)
+        lprev[ST_MATCH]  = int((qBase + unsigned(lane) * E) * unsigned(offEdge));
         lprev[ST_DELETE] = ALIGN_BAD;
         lprev[ST_INSERT] = ALIGN_BAD;
-        if (lane == 0) lprev[ST_JUMP] = ALIGN_BAD;
+        if (lane == 0 && strip == 0) lprev[ST_JUMP] = ALIGN_BAD;
       }
 
       int diag[NS], left[NS];
@@ -265,7 +301,7 @@ struct Aligner {
       for (int e = 0; e < E; ++e) {
         int up[NS];
         for (int s = 0; s < NS; ++s) up[s] = st[s][e];
-        const bool firstCol = (e == 0) && (lane == 0);
+        const bool firstCol = (e == 0) && (lane == 0) && (strip == 0);
         const int  sub      = (unsigned(qc[e]) == rc) ? P.match : P.mismatch;
         int        nv[NS];
         unsigned   code = 0;
@@ -338,10 +374,12 @@ struct Aligner {
         }
         cells[e] = cell_t(code);
       }
-      for (int e = 0; e < E; ++e) ptr[(uint64_t(t) * E + e) * 64 + unsigned(lane)] = cells[e];
+      for (int e = 0; e < E; ++e) ptrS[(uint64_t(t) * E + e) * 64 + unsigned(lane)] = cells[e];
+      if (MULTI && !lastStrip && lane == 63)  // the next strip's left boundary: this strip's last column, row g
+        for (int s = 0; s < NS; ++s) bndOut[size_t(g) * NS + s] = st[s][E - 1];
 
       // traceback start candidates at q == Q for this row
-      if (unsigned(lane) == lQ) {
+      if (lastStrip && unsigned(lane) == lQ) {
         int vM = 0, vI = 0;
         for (int e = 0; e < E; ++e) {
           if (unsigned(e) == eQ) {
@@ -359,7 +397,7 @@ struct Aligner {
         // off-edge candidates of the last row (q < Q; the reference's extra q==Q term for the large-indel
         // aligner, GlobalLargeIndelAlignerImpl.hpp:211, can never win the strict '>' and is omitted)
         for (int e = 0; e < E; ++e) {
-          const unsigned q = unsigned(lane) * E + e + 1;
+          const unsigned q = qBase + unsigned(lane) * E + e + 1;
           if (q < Q) {
             const int v = st[ST_MATCH][e] + int((Q - q) * unsigned(offEdge));
             if (!haveOff2 || v > off2Val) {
@@ -371,6 +409,8 @@ struct Aligner {
         }
       }
     }
+    if (MULTI && !lastStrip) wv::sync();  // the boundary column is read by other lanes in the next strip
+    }  // strips
 
     // q == 0 off-edge candidates (column 0 holds match == 0 on every row >= 1)
     if (lane == 0) {
@@ -720,6 +760,13 @@ struct Aligner {
     R2    = (KIND == 2) ? T.ref2_len : 0;
     G     = R1 + R2;
     ptr   = reinterpret_cast<cell_t*>(ptrSlab);
+    nStrips    = MULTI ? (Q + STRIPW - 1) / STRIPW : 1u;
+    stripCells = uint64_t(G + 64 + 1) * E * 64;
+    {
+      const uint64_t cellsBytes = (uint64_t(nStrips) * stripCells * sizeof(cell_t) + 15) & ~uint64_t(15);
+      bnd[0] = reinterpret_cast<int*>(ptrSlab + cellsBytes);
+      bnd[1] = bnd[0] + size_t(G + 2) * NS;
+    }
     const StartCand start = sweep();
     wv::sync();  // back-pointers written by all lanes are read by all lanes below
     AlignResultDev r;
@@ -732,10 +779,23 @@ struct Aligner {
 };
 
 /// bytes of back-pointer slab one alignment needs (host + device agree on this)
-inline uint64_t alignPtrSlabBytes(const int kind, const int E, const uint64_t totalRefLen)
+WV_HD uint64_t alignPtrSlabBytes(const int kind, const int E, const uint64_t totalRefLen)
 {
   const uint64_t cellBytes = (kind == 1) ? 2 : 1;
   return (totalRefLen + 64 + 1) * uint64_t(E) * 64 * cellBytes;
+}
+
+/// The reference length to size a slab for: the real one for a query that fits one strip; for a query of several strips
+/// (E = 32 only) a larger stand-in, such that alignPtrSlabBytes() covers every strip's slab plus the two boundary columns.
+WV_HD uint64_t alignSlabRefLen(const int kind, const int E, const uint64_t queryLen, const uint64_t totalRefLen)
+{
+  const uint64_t stripW = 64ull * uint64_t(E);
+  if (E != 32 || queryLen <= stripW) return totalRefLen;
+  const uint64_t nStrips = (queryLen + stripW - 1) / stripW;
+  const uint64_t unit    = alignPtrSlabBytes(kind, E, 0) / 65;  // bytes per reference row
+  const uint64_t ns      = (kind == 1) ? 5 : ((kind == 2) ? 4 : 3);
+  const uint64_t need    = nStrips * alignPtrSlabBytes(kind, E, totalRefLen) + 2 * (totalRefLen + 2) * ns * 4 + 64;
+  return (need + unit - 1) / unit;  // (generous by the 65 rows alignPtrSlabBytes adds)
 }
 
 // E = 8 is held to 128 VGPRs (it needs 137 unconstrained): 4 waves per SIMD, and it still fits the slot a pipelined

@@ -145,7 +145,7 @@ int pickE(uint32_t qlen)
   const uint32_t need = (qlen + 63) / 64;
   for (int i = 0; i < kNumESet; ++i)
     if (uint32_t(kESet[i]) >= need) return i;
-  return -1;
+  return kNumESet - 1;  // longer than 64 x 32 columns: the widest kernel runs it in strips (align_kernels.hpp)
 }
 
 template <int KIND, int E>
@@ -1328,11 +1328,6 @@ int manta_align_batch(
         continue;
       }
       const int eIdx = pickE(t.query_len);
-      if (eIdx < 0) {
-        r.status = MANTA_E_UNSUPPORTED;
-        worst    = MANTA_E_UNSUPPORTED;
-        continue;
-      }
       AlignTaskDev& d(dev[i]);
       d.query     = reinterpret_cast<const uint8_t*>(uintptr_t(t.query_off));  // rebased onto the device arena below
       d.ref1      = reinterpret_cast<const uint8_t*>(uintptr_t(t.ref1_off));
@@ -1344,7 +1339,7 @@ int manta_align_batch(
       cigarDevWords += 4ull * t.query_len + 16;
       if (cigarDevWords > 0xffffffffull) return fail(ctx, MANTA_E_UNSUPPORTED, "manta_align_batch: batch too large (cigar workspace)");
       buckets[eIdx].push_back(i);
-      bucketMaxRef[eIdx] = std::max<uint64_t>(bucketMaxRef[eIdx], uint64_t(d.ref1_len) + d.ref2_len);
+      bucketMaxRef[eIdx] = std::max<uint64_t>(bucketMaxRef[eIdx], alignSlabRefLen(kind, kESet[eIdx], d.query_len, uint64_t(d.ref1_len) + d.ref2_len));
     }
 
     // ---- stage ----

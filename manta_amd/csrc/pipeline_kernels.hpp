@@ -211,10 +211,7 @@ WV_DEV SmallSvTaskInfo scheduleSlot(const ScheduleParams& P, const unsigned slot
       bucket = int(b);
       break;
     }
-  if (bucket < 0) {
-    info.status = 4;
-    return info;
-  }
+  if (bucket < 0) bucket = int(P.n_e) - 1;  // longer than 64 x 32 columns: the widest kernel runs it in strips (align_kernels.hpp)
   // lane 0 claims CIGAR space and files the task; the verdict is broadcast so that `info` stays wave-uniform
   unsigned claimed = 0;
   if (lane == 0) {
@@ -233,9 +230,10 @@ WV_DEV SmallSvTaskInfo scheduleSlot(const ScheduleParams& P, const unsigned slot
       const unsigned pos = wv::atomic_add(&P.bucket_count[bucket], 1u);
       P.bucket_ids[size_t(bucket) * total + pos] = slot;
       // atomic max of the window length via CAS loop
-      unsigned cur = wv::atomic_load(&P.bucket_maxref[bucket]);
-      while (cur < unsigned(winLen)) {
-        const unsigned old = wv::atomic_cas(&P.bucket_maxref[bucket], cur, unsigned(winLen));
+      const unsigned slabLen = unsigned(alignSlabRefLen(1, int(P.e_set[bucket]), clen, unsigned(winLen)));
+      unsigned       cur     = wv::atomic_load(&P.bucket_maxref[bucket]);
+      while (cur < slabLen) {
+        const unsigned old = wv::atomic_cas(&P.bucket_maxref[bucket], cur, slabLen);
         if (old == cur) break;
         cur = old;
       }
@@ -346,7 +344,7 @@ WV_DEV int spanFileTask(
       bucket = int(b);
       break;
     }
-  if (bucket < 0) return -4;
+  if (bucket < 0) bucket = int(P.n_e) - 1;  // strips on the widest kernel
   const unsigned long long words = 4ull * co.seq_len + 16;
   const unsigned long long cig   = wv::atomic_add(P.cigar_used, words);
   if (cig + words > P.cigar_cap) return -5;
@@ -361,7 +359,7 @@ WV_DEV int spanFileTask(
   tasks[slot] = t;
   const unsigned pos = wv::atomic_add(&bucketCount[bucket], 1u);
   bucketIds[size_t(bucket) * total + pos] = slot;
-  spanAtomicMax(&bucketMaxref[bucket], unsigned(r1Len + r2Len));
+  spanAtomicMax(&bucketMaxref[bucket], unsigned(alignSlabRefLen(2, int(P.e_set[bucket]), co.seq_len, unsigned(r1Len + r2Len))));
   return bucket;
 }
 

@@ -46,14 +46,76 @@ def test_emulated_assembler_limits(emu, oracle):
     check_limits(emu, oracle, 300)
 
 
+def long_query_cases(seed, n_per_kind, qlens):
+    """queries longer than one strip of the widest kernel (64 lanes x 32 columns = 2048): indel-bearing copies of the reference,
+    breakend-spanning ones for the jump aligner, plus a query unrelated to its reference"""
+    rng = random.Random(seed)
+
+    def rs(n):
+        return "".join(rng.choice("ACGT") for _ in range(n))
+
+    def mut(x):
+        out = []
+        for c in x:
+            u = rng.random()
+            if u < 0.004:
+                continue
+            if u < 0.008:
+                out.append(rng.choice("ACGT"))
+            elif u < 0.02:
+                c = rng.choice("ACGTN")
+            out.append(c)
+        return "".join(out)
+
+    cases = []
+    for kind in (0, 1, 2):
+        for i in range(n_per_kind):
+            ql = qlens[i % len(qlens)]
+            if kind == 2:
+                a, b = rs(ql // 2 + rng.randint(20, 200)), rs(ql // 2 + rng.randint(20, 200))
+                q = mut(a[-(ql // 2):] + rs(rng.choice([0, 0, 5])) + b[:ql - ql // 2])
+                cases.append((kind, (q, a, b)))
+            else:
+                q = rs(ql)
+                cut = rng.randint(100, ql - 100)
+                ref = rs(rng.randint(0, 60)) + q[:cut] + rs(rng.choice([0, 7, 40, 300])) + q[cut + rng.choice([0, 0, 25]):] + rs(rng.randint(0, 60))
+                if i == n_per_kind - 1:
+                    ref = rs(ql // 3)  # unrelated, shorter than the query
+                cases.append((kind, (mut(q), ref, None)))
+    return cases
+
+
+def check_align_long_queries(lib, checker, n_per_kind=2, qlens=(2049, 4096, 4100, 6500)):
+    """the reference has no query length limit (GlobalLargeIndelAlignerImpl.hpp:52-54, GlobalJumpAlignerImpl.hpp:60-63): neither
+    has the device path -- queries past 2048 bases run in strips of 2048 columns"""
+    by_kind = {0: ([2, -8, -12, -1, -1, 0], 0), 1: ([2, -8, -24, -1, -1, 0], -100), 2: ([2, -8, -12, -1, -1, 0], -100)}
+    for kind, (sc, extra) in by_kind.items():
+        probs = [p for k, p in long_query_cases(11 + kind, n_per_kind, qlens) if k == kind]
+        res = lib.align_batch(kind, sc, extra, [tuple(x for x in p if x is not None) for p in probs])
+        for p, r in zip(probs, res):
+            assert r["status"] == 0
+            assert align_text(kind, r) == checker.align(kind, sc, extra, *p), (kind, len(p[0]), len(p[1]))
+
+
 def check_align_limits(lib, oracle):
     rng = random.Random(7)
     sc = [2, -8, -12, -1, -1, 0]
-    q = "".join(rng.choice("ACGT") for _ in range(2048))  # the longest supported query
+    q = "".join(rng.choice("ACGT") for _ in range(2048))  # the longest query of a single strip
     ref = q[:1000] + "".join(rng.choice("ACGT") for _ in range(30)) + q[1000:]
-    res = lib.align_batch(1, sc, -24, [(q, ref), (q + "A", ref)], strict=False)
-    assert res[0]["status"] == 0 and align_text(1, res[0]) == oracle.align(1, sc, -24, q, ref)
-    assert res[1]["status"] == -5  # one base too long: that alignment only
+    res = lib.align_batch(1, sc, -24, [(q, ref), (q + "A", ref), (q + q[:77], ref + q[:60])])
+    for (a, b), r in zip([(q, ref), (q + "A", ref), (q + q[:77], ref + q[:60])], res):
+        assert r["status"] == 0 and align_text(1, r) == oracle.align(1, sc, -24, a, b)  # one base past the strip: two strips, same answer
+
+
+def test_emulated_long_queries_match_the_reference(emu, reflib):
+    check_align_long_queries(emu, reflib, n_per_kind=2, qlens=(2049, 4100))
+
+
+def test_restatement_matches_the_reference_on_long_queries(oracle, reflib):
+    by_kind = {0: ([2, -8, -12, -1, -1, 0], 0), 1: ([2, -8, -24, -1, -1, 0], -100), 2: ([2, -8, -12, -1, -1, 0], -100)}
+    for kind, p in long_query_cases(31, 2, (2049, 3000, 5000)):
+        sc, extra = by_kind[kind]
+        assert oracle.align(kind, sc, extra, *p) == reflib.align(kind, sc, extra, *p)
 
 
 def test_emulated_aligner_limits(emu, oracle):
@@ -64,6 +126,7 @@ def test_emulated_aligner_limits(emu, oracle):
 def test_gpu_limits(gpu, oracle):
     check_limits(gpu, oracle, 700)
     check_align_limits(gpu, oracle)
+    check_align_long_queries(gpu, oracle, n_per_kind=6, qlens=(2049, 2500, 4096, 4100, 6500, 8192))
 
 
 def check_degenerate_piles(lib, oracle):
