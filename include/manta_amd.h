@@ -145,6 +145,14 @@ int manta_assemble_batch(
     uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
     uint64_t* bits_arena_used);
 
+/* Introspection for tests: the repeat-word set of getRepeatKmers (assembly/IterativeAssembler.cpp:627-642) as the
+ * device computed it for ONE read pile at word length opt->min_word_length -- the observable of the reference's
+ * test_CircleDetector (assembly/test/IterativeAssemblerTest.cpp:30-61).  `out` receives the words, sorted, one per
+ * line; *n_words their number.  Not a production entry point. */
+int manta_debug_repeat_words(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, uint32_t n_reads, const uint8_t* bases, const uint64_t* read_off, char* out,
+    uint64_t out_cap, uint32_t* n_words);
+
 /* ------------------------------------------------------------------------------------------------------
  * SmallAssembler.  Replaces
  *   void runSmallAssembler(const SmallAssemblerOptions&, const AssemblyReadInput& reads,

@@ -222,6 +222,24 @@ def _assemble_batch(self, opts, loci_reads, strict=True):
 Lib.assemble_batch = _assemble_batch
 
 
+def _debug_repeat_words(self, opts, reads):
+    """manta_debug_repeat_words: the repeat-word set (getRepeatKmers) the device computed for one pile at minWordLength"""
+    bases, read_off, _ = pack_loci([reads])
+    o = AsmOptions(*opts)
+    cap = 1 << 20
+    buf = ctypes.create_string_buffer(cap)
+    n = ctypes.c_uint32(0)
+    rc = self.lib.manta_debug_repeat_words(self.ctx, ctypes.byref(o), ctypes.c_uint32(len(reads)), bases.ctypes.data_as(ctypes.c_void_p),
+                                           read_off.ctypes.data_as(ctypes.c_void_p), buf, ctypes.c_uint64(cap), ctypes.byref(n))
+    self._check(rc)
+    words = buf.value.decode().split()
+    assert len(words) == n.value
+    return set(words)
+
+
+Lib.debug_repeat_words = _debug_repeat_words
+
+
 class SmallAsmOptions(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in ("min_word_length", "max_word_length", "word_step_size", "min_contig_length",
                                                "min_coverage", "min_conservative_coverage", "min_seed_reads",

@@ -1477,6 +1477,62 @@ int manta_assemble_batch(
   }
 }
 
+int manta_debug_repeat_words(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, uint32_t n_reads, const uint8_t* bases, const uint64_t* read_off, char* out,
+    uint64_t out_cap, uint32_t* n_words)
+{
+  if (!ctx) return MANTA_E_INVALID_ARG;
+  if (!opt || !bases || !read_off || !out || !n_words) return fail(ctx, MANTA_E_INVALID_ARG, "manta_debug_repeat_words: null argument");
+  *n_words = 0;
+  try {
+    rt::setDevice(ctx->deviceId);
+    rt::ScopedStream onStream(ctx->stream);
+    manta_asm_options_t o = *opt;
+    o.max_word_length     = o.min_word_length;  // one word length: its graph is what the workspace holds afterwards
+    const uint32_t begin[2] = {0, n_reads};
+    AsmStage       st(ctx);
+    int            rc = st.plan(o, 1, read_off, begin);
+    if (rc != MANTA_OK) return rc;
+    st.useFast = st.coSchedule = false;  // the general kernel: its workspace slab is read back below
+    st.upload(bases, read_off, begin);
+    rt::dzero(st.dWs, st.stride * uint64_t(st.grid));
+    st.launch();
+    AsmLocusOut lo;
+    rt::d2h(&lo, st.dLoci, sizeof(lo));
+    if (lo.status != ASM_OK) return fail(ctx, asmStatusToAbi(lo.status), "manta_debug_repeat_words: the locus did not assemble");
+    const uint32_t nNodes = lo.reserved & 0x3ffffffu, slab = lo.reserved >> 26, k = lo.final_word_length;
+    const AsmWsLayout L = asmWorkspaceLayout(st.capSlots, st.capNodes, st.capWords, st.capReads, st.maxContigLen, st.wMax, o.max_assembly_count);
+    const uint8_t*    ws = st.dWs + st.stride * uint64_t(slab);
+    std::vector<uint32_t> flag(nNodes), key(nNodes), codes(st.capWords + 2);
+    rt::d2h(flag.data(), ws + L.node_flag, sizeof(uint32_t) * nNodes);
+    rt::d2h(key.data(), ws + L.node_key, sizeof(uint32_t) * nNodes);
+    rt::d2h(codes.data(), ws + L.codes, sizeof(uint32_t) * codes.size());
+    std::vector<std::string> words;
+    for (uint32_t nd = 0; nd < nNodes; ++nd) {
+      if (!(flag[nd] & NF_REPEAT)) continue;
+      std::string w(k, '?');
+      for (uint32_t i = 0; i < k; ++i) {
+        const uint32_t pb = key[nd] + i;
+        w[i]              = "ACGT"[(codes[pb >> 4] >> (30 - 2 * (pb & 15))) & 3];
+      }
+      words.push_back(w);
+    }
+    std::sort(words.begin(), words.end());
+    uint64_t used = 0;
+    for (const std::string& w : words) {
+      if (used + w.size() + 1 > out_cap) return fail(ctx, MANTA_E_CAPACITY, "manta_debug_repeat_words: output buffer too small");
+      std::memcpy(out + used, w.data(), w.size());
+      used += w.size();
+      out[used++] = '\n';
+    }
+    if (used < out_cap) out[used] = 0;
+    *n_words = uint32_t(words.size());
+    return MANTA_OK;
+  } catch (const std::exception& e) {
+    return fail(ctx, MANTA_E_HIP, e.what());
+  }
+}
+
 int manta_small_assemble_batch(
     manta_ctx_t* ctx, const manta_small_asm_options_t* opt, uint32_t n_loci, const uint8_t* bases, const uint64_t* read_off,
     const uint32_t* locus_read_begin, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, uint64_t contigs_cap,

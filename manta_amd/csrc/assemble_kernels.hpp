@@ -1375,7 +1375,8 @@ struct Assembler {
     out.final_word_length = k;
     out.n_iterations      = nIter;
     out.cyclic_iterations = cyclicIters;
-    out.reserved          = 0;
+    // (introspection, manta_debug_repeat_words: size of the last word length's graph and the workspace slab it sits in)
+    out.reserved          = (nNodes & 0x3ffffffu) | ((unsigned(wv::block()) & 63u) << 26);
     if (status != ASM_OK) {
       if (lane == 0) P.loci[locus] = out;  // (ASM_E_TABLE_FULL: the host runs the locus again on a worst-case workspace, api.cpp)
       return;

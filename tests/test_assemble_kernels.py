@@ -61,6 +61,31 @@ def check_reference_golden(lib):
     assert n >= 3
 
 
+def check_circle_detector(lib):
+    """test_CircleDetector (assembly/test/IterativeAssemblerTest.cpp:30-61): the reference fills wordCount with eight 5-mers by hand
+    and asks getRepeatKmers for the repeat words.  Here the same map comes out of a pile whose reads ARE those words (a read of
+    length k holds one word; three / two copies give the counts; first occurrences follow the test's insertion order, which is
+    what the hash-order-dependent search sees) and the device's repeat-word set is read back through the introspection call."""
+    words = [("TACCA", 3), ("CCACC", 3), ("CACCA", 3), ("ACCAC", 3), ("CCACA", 3), ("CACAC", 3), ("ACACA", 3), ("AAAAA", 2)]
+    reads = [w for w, _ in words] + [w for w, c in words for _ in range(c - 1)]
+    got = lib.debug_repeat_words(asm_opts(minWordLength=5, maxWordLength=5, minCoverage=1), reads)
+    for w in ("ACCAC", "CACCA", "CCACC"):  # the first circle
+        assert w in got
+    assert "TACCA" not in got and "CCACA" not in got
+    assert "CACAC" in got and "ACACA" in got  # the second circle
+    assert "AAAAA" in got  # homopolymer: self-circle
+    assert got == {"ACCAC", "CACCA", "CCACC", "CACAC", "ACACA", "AAAAA"}
+
+
+def test_emulated_circle_detector(emu):
+    check_circle_detector(emu)
+
+
+@pytest.mark.gpu
+def test_gpu_circle_detector(gpu):
+    check_circle_detector(gpu)
+
+
 def test_emulated_assembler_reference_golden(emu):
     """the reference's own assembler unit-test vectors (assembly/test/IterativeAssemblerTest.cpp:30-205), junk read included
     where it provably cannot matter"""
