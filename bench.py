@@ -10,10 +10,12 @@ queue, host workers with private pipelines (own HIP stream, pinned staging) pull
 into a staging buffer would leave them.
 
 Workload at N=1: BASELINE config[1] ("Synthetic 10k small-indel loci, 80 reads/locus x150bp, k=31, 1xMI355X", generator:
-tests/synth.py config2_batch).  N>1: every rank (one process per GPU) owns an independent batch of the same
-shape -- loci are independent units, weak scaling, no data-path collective -- and the final candidate gather (every rank's
-result blob to rank 0 over RCCL) is inside the clock.  `python bench.py --gpus N` launches the N ranks itself when it was
-not started by torchrun.
+tests/synth.py config2_batch).  N>1 (one process per GPU): the node's batch is N such batches -- weak scaling,
+loci are independent units, no data-path collective -- behind ONE work queue: every rank makes the same manta_smallsv_batch
+call on the whole node batch and blocks are handed out through a counter in shared memory (manta_batch_plan_t::shared_queue),
+so a rank that draws expensive blocks takes fewer; the final candidate gather (every rank's result blob to rank 0 over
+torch.distributed: RCCL on GPUs) is inside the clock.  `--queue rank` gives every rank its own batch and queue instead (the
+round-2 form).  `python bench.py --gpus N` launches the N ranks itself when it was not started by torchrun.
 
 `--workload spanning` = BASELINE config[4] shape (breakend loci, 200 reads x 250 bp, mixed k): an extra measurement.
 
@@ -59,6 +61,11 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (profiling passes): no kernel_only / packed_input legs")
     ap.add_argument("--cpu-sample", type=int, default=0, help="loci in the CPU baseline sample (0 = auto)")
     ap.add_argument("--pageable", action="store_true", help="keep inputs/outputs in pageable host memory (A/B knob)")
+    ap.add_argument("--queue", choices=("node", "rank"), default="node",
+                    help="N > 1: node = one block queue across the ranks (shared-memory counter; default), rank = every rank its own batch and queue")
+    ap.add_argument("--mix", action="store_true",
+                    help="N > 1, --queue node: every 4th rank part holds loci with 2.5x the reads (NOT the metric's configuration) -- makes the "
+                         "queue's balancing visible in loci_per_rank")
     return ap.parse_args()
 
 
@@ -73,15 +80,17 @@ def self_spawn(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def algorithmic_bytes_smallsv(batch, results):
+def algorithmic_bytes_smallsv(batch, results, only=None):
     """B = B_in + B_ptr + B_out summed over the batch.
     B_in  = read bases + reference bases (1 B/base as the boundary delivers them)
     B_ptr = sum over aligned contigs of P*(Q+1)*(R+1), P = 2 B (the reference's own 5x3-bit pointer cell)
     B_out = sum over contigs (Q + 2*ceil(nReads/8) + 64) + nReads*8"""
     bases, read_off, begin, refs, ref_off, cuts = batch
-    b_in = int(read_off[-1]) + int(ref_off[-1])
-    b_ptr = b_out = q_bytes = win_bytes = 0
-    for l, r in enumerate(results):
+    only = list(range(len(results))) if only is None else only
+    b_in = b_ptr = b_out = q_bytes = win_bytes = 0
+    for l in only:
+        r = results[l]
+        b_in += int(read_off[begin[l + 1]] - read_off[begin[l]]) + int(ref_off[l + 1] - ref_off[l])
         n_reads = int(begin[l + 1] - begin[l])
         ref_len = int(ref_off[l + 1] - ref_off[l])
         b_out += n_reads * 8
@@ -159,10 +168,34 @@ def main():
     spanning = args.workload == "spanning"
     n_loci = args.loci or (65536 if spanning else 10000)
     lib = Lib(device=local_rank)
+    node_queue = multi and args.queue == "node" and not spanning
+    qshm = qcount = None
+    if node_queue:
+        # one 32-bit block counter per step in POSIX shared memory (a fresh one every step: no reset to race with)
+        import ctypes as _ct
+        from multiprocessing import shared_memory
+        qname = "manta_bench_q_%s" % os.environ.get("MASTER_PORT", "0")
+        n_slots = args.steps + args.warmup + 8
+        if rank == 0:
+            try:
+                shared_memory.SharedMemory(name=qname).unlink()  # (left over from a killed run)
+            except FileNotFoundError:
+                pass
+            qshm = shared_memory.SharedMemory(name=qname, create=True, size=4 * n_slots)
+            qshm.buf[:4 * n_slots] = bytes(4 * n_slots)
+        dist.barrier()
+        if rank != 0:
+            qshm = shared_memory.SharedMemory(name=qname)
+        qcount = (_ct.c_uint32 * n_slots).from_buffer(qshm.buf)
+    step_no = [0]
     # measured on MI355X: one block's kernels already fill the device and concurrent blocks contend for the
     # per-wave HBM slabs, so the default is ONE block per call; --workers / --block-loci select the pipelined form
     workers = args.workers or 1
     block = args.block_loci or max(1, (n_loci + workers - 1) // workers)
+    if node_queue and not args.block_loci:
+        # two blocks per rank: small enough for the queue to even out unequal parts, large enough to fill a device (a block below
+        # ~4096 loci leaves assembler waves idle: one wave per locus, 16 waves per CU)
+        block = max(1, n_loci // 2)
 
     # ---- this rank's batch (outside the clock: synthetic data generation) ----
     if spanning:
@@ -188,10 +221,29 @@ def main():
         out = BatchOutput(lib, "spanning", n_loci, 10, 8192 * n_loci + (1 << 20), 256 * n_loci + 4096, 1024 * n_loci + 4096,
                           pinned=not args.pageable)
     else:
-        batch = config2_batch(n_loci, seed=12345 + 1000003 * rank)
+        if args.mix and multi and rank % 4 == 3:
+            batch = config2_batch(n_loci, seed=12345 + 1000003 * rank, n_reads=200)
+        else:
+            batch = config2_batch(n_loci, seed=12345 + 1000003 * rank)
         min_wl = max_wl = None
         opts = asm_opts(**ASM_K)
-        out = BatchOutput(lib, "smallsv", n_loci, 10, 4096 * n_loci + (1 << 20), 128 * n_loci + 4096, 512 * n_loci + 4096,
+        if node_queue:
+            # the node's batch = the ranks' parts laid end to end (part r at loci [r * n_loci, (r + 1) * n_loci)); every rank holds
+            # all of it, as every worker thread of one GenerateSVCandidates process sees the whole edge list
+            parts = [None] * world
+            dist.all_gather_object(parts, tuple(np.ascontiguousarray(a) for a in batch))
+            nb = [int(p[1][-1]) for p in parts]
+            nr = [len(p[1]) - 1 for p in parts]
+            nf = [int(p[4][-1]) for p in parts]
+            cat_off = lambda offs, tot: np.concatenate([o[:-1] + np.asarray(sum(tot[:i]), dtype=o.dtype) for i, o in enumerate(offs)]
+                                                       + [np.asarray([sum(tot)], dtype=offs[0].dtype)])
+            batch = (np.concatenate([p[0][:n] for p, n in zip(parts, nb)] + [np.zeros(64, dtype=np.uint8)]),
+                     cat_off([p[1] for p in parts], nb), cat_off([p[2] for p in parts], nr).astype(np.uint32),
+                     np.concatenate([p[3][:n] for p, n in zip(parts, nf)] + [np.zeros(64, dtype=np.uint8)]),
+                     cat_off([p[4] for p in parts], nf), np.concatenate([p[5] for p in parts]))
+            del parts
+        n_out = n_loci * (world if node_queue else 1)
+        out = BatchOutput(lib, "smallsv", n_out, 10, 4096 * n_out + (1 << 20), 128 * n_out + 4096, 512 * n_out + 4096,
                           pinned=not args.pageable)
     dev_batch = batch if args.pageable else tuple(pinned_copy(lib, a) for a in batch)
     n_reads = np.diff(batch[2])
@@ -199,6 +251,12 @@ def main():
     def step():
         if spanning:
             lib.spanning_batch(opts, SPAN_SC, JUMP, dev_batch, out, min_wl=min_wl, max_wl=max_wl, block_loci=block, n_workers=workers, serial_kernels=args.serial_kernels)
+        elif node_queue:
+            import ctypes as _ct
+            slot = step_no[0]
+            step_no[0] += 1
+            lib.smallsv_batch(opts, SCORES, LARGE_INDEL, dev_batch, out, block_loci=block, n_workers=workers, serial_kernels=args.serial_kernels,
+                              shared_queue=_ct.addressof(qcount) + 4 * slot)
         else:
             lib.smallsv_batch(opts, SCORES, LARGE_INDEL, dev_batch, out, block_loci=block, n_workers=workers, serial_kernels=args.serial_kernels)
         if multi and not os.environ.get("MANTA_BENCH_SKIP_GATHER"):  # the final candidate gather (north star: "RCCL over xGMI only for the final candidate gather")
@@ -233,9 +291,38 @@ def main():
         elapsed = float(t.item())
 
     results = out.decode(n_reads)
-    n_contigs = sum(len(r["contigs"]) for r in results)
-    n_fail = sum(1 for r in results if r["status"] != 0)
+    taken = [l for l, r in enumerate(results) if r["status"] != -10]  # (-10: another rank took the locus' block, node queue)
+    n_contigs = sum(len(results[l]["contigs"]) for l in taken)
+    n_fail = sum(1 for l in taken if results[l]["status"] != 0)
     steps = args.steps
+    loci_per_rank = [len(taken)]
+    node_check = None
+    if node_queue:
+        # every rank checks what it took: part 0 is the digest workload (config-2, seed 12345), other parts against the CPU
+        # restatement on a sample; the verdicts are summed over the ranks
+        orc_n = OracleLib()
+        dig_path = os.path.join(ROOT, "tests", "golden", "config2_digests.bin")
+        raw = open(dig_path, "rb").read() if (os.path.exists(dig_path) and n_loci == 10000 and not args.mix) else b""
+        mism = checked = 0
+        rest = [l for l in taken if l >= n_loci or not raw]
+        for l in taken:
+            if raw and l < n_loci:
+                mism += hashlib.sha256(small_sv_text(results[l]).encode("latin-1")).digest() != raw[32 * l:32 * l + 32]
+                checked += 1
+        for l in rest[::max(1, len(rest) // 16)]:
+            reads, ref, cuts = unpack_locus(batch, l)
+            mism += small_sv_text(results[l]) != orc_n.small_sv_locus(opts, SCORES, LARGE_INDEL, reads, ref, cuts)
+            checked += 1
+        dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([mism, checked, n_fail, len(taken)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(per, torch.tensor([len(taken)], dtype=torch.int64, device=dev))
+        loci_per_rank = [int(x.item()) for x in per]
+        node_check = [int(x) for x in t.tolist()]
+        if rank == 0 and (node_check[0] or node_check[2] or node_check[3] != n_loci * world):
+            raise SystemExit("PARITY FAILURE (node queue): %d of %d checked loci differ, %d loci failed, %d of %d loci taken"
+                             % (node_check[0], node_check[1], node_check[2], node_check[3], n_loci * world))
 
     if rank == 0:
         orc = OracleLib()
@@ -254,6 +341,8 @@ def main():
                        for a in r["aligns"]]
                 mism += hashlib.sha256(c5_text(assembly_text(r), got).encode("latin-1")).digest() != raw[32 * i:32 * i + 32]
             checked, how = n_dig, "reference digests (tests/golden/config5_digests.bin)"
+        elif node_queue:
+            checked, how = node_check[1], "reference digests (rank 0's part, tests/golden/config2_digests.bin) + restatement samples of the other parts, summed over the ranks"
         elif n_loci == 10000:  # the digest workload (config2_batch draws every locus of a batch from one stream: other sizes differ)
             for l in range(n_dig):
                 mism += hashlib.sha256(small_sv_text(results[l]).encode("latin-1")).digest() != raw[32 * l:32 * l + 32]
@@ -285,8 +374,9 @@ def main():
                         "tandem-repeat loci, minWordLength per locus from {25..75} in ONE launch, assemble + "
                         "GlobalJumpAligner(2,-8,-12,-1,-1;-100) on 700+700 bp windows + re-align rule")
         else:
-            b_in, b_ptr, b_out, q_bytes, win_bytes = algorithmic_bytes_smallsv(batch, results)
-            asm_bytes, align_bytes, align_name = int(batch[1][-1]) + b_out, q_bytes + win_bytes + b_ptr, "align_kernel<LARGE_INDEL>"
+            b_in, b_ptr, b_out, q_bytes, win_bytes = algorithmic_bytes_smallsv(batch, results, taken)
+            reads_in = sum(int(batch[1][batch[2][l + 1]] - batch[1][batch[2][l]]) for l in taken)
+            asm_bytes, align_bytes, align_name = reads_in + b_out, q_bytes + win_bytes + b_ptr, "align_kernel<LARGE_INDEL>"
             workload = ("BASELINE config[1]: synthetic small-indel loci, 80 reads/locus x150bp, k=31..76 step 5, "
                         "assemble + 10-mer trim + GlobalLargeIndelAligner(2,-8,-24,-1,-1;-100) on 1800 bp windows")
         # dominant kernel by HIP-event time summed over the timed region.  A launch = one block's kernel; the events of
@@ -314,12 +404,17 @@ def main():
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": workload, "loci_per_gpu": n_loci, "reads_per_locus": int(n_reads[0]),
-                       "contigs_per_locus": round(n_contigs / n_loci, 3),
+                       "contigs_per_locus": round(n_contigs / max(1, len(taken)), 3),
                        "timed_region": "batch submit -> all results host-visible: H2D + kernels + D2H"
-                                       + (" + RCCL gather of the result blobs to rank 0" if world > 1 else ""),
+                                       + ((" + gather of the result blobs to rank 0 (torch.distributed, backend %s: %s)"
+                                           % (backend, "RCCL" if backend == "nccl" else "host memory, developer self-test")) if multi else ""),
                        "host_memory": "pageable" if args.pageable else "page-locked (manta_host_alloc)",
                        "block_loci": block, "workers_per_gpu": workers,
-                       "parallelism": "loci sharded over %d rank(s); per rank a cost-ordered block queue" % world,
+                       "parallelism": ("one cost-ordered block queue across %d rank(s) (shared-memory counter, manta_batch_plan_t::shared_queue)" % world)
+                                      if node_queue else ("loci sharded over %d rank(s); per rank a cost-ordered block queue" % world),
+                       "queue": "node" if node_queue else "rank", "backend": backend if multi else None,
+                       "dist_world": dist.get_world_size() if multi else 1, "loci_per_rank": loci_per_rank,
+                       "mix": bool(args.mix and node_queue),
                        "parity": "%d loci vs %s: 0 mismatches" % (checked, how)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
@@ -332,8 +427,8 @@ def main():
                      "host_ms_per_step": {"h2d": round(acc["h2d_ms"] / steps, 2), "kernels": round(acc["kernel_ms"] / steps, 2),
                                           "d2h+compact": round(acc["d2h_ms"] / steps, 2)},
                      "gather_MB_per_step": round(gathered_bytes / steps / 1e6, 2)},
-            "algorithmic_bytes_per_locus": {"in": b_in / n_loci, "ptr": b_ptr / n_loci, "out": b_out / n_loci,
-                                            "whole_path_GBps": round((b_in + b_ptr + b_out) * world * steps / elapsed / 1e9, 2)},
+            "algorithmic_bytes_per_locus": {"in": b_in / max(1, len(taken)), "ptr": b_ptr / max(1, len(taken)), "out": b_out / max(1, len(taken)),
+                                            "whole_path_GBps": round((b_in + b_ptr + b_out) / max(1, len(taken)) * n_loci * world * steps / elapsed / 1e9, 2)},
             "dp_gcups": round(acc["dp_cells"] * world / elapsed / 1e9, 2),
         }
         # ---- device-resident kernel rate (extra key; round 1's headline): inputs in HBM, three kernels per step ----
@@ -422,8 +517,13 @@ def main():
     import ctypes
     libc = ctypes.CDLL(None)
     libc.fflush(None)
+    if qshm is not None:
+        del qcount
+        qshm.close()
     if multi:
         dist.barrier()
+        if qshm is not None and rank == 0:
+            qshm.unlink()
         dist.destroy_process_group()
         libc.fflush(None)
     if rank == 0:

@@ -35,6 +35,7 @@ extern "C" {
 #define MANTA_E_DEVICE_FAULT (-7) /* kernel reported an internal overflow for some locus/task */
 #define MANTA_E_SPLIT_QUERY_NOT_SHORTER (-8) /* splitReadAligner: querySize >= targetSize (SplitReadAlignment.cpp:237-247) */
 #define MANTA_E_SPLIT_EMPTY_SCAN (-9)        /* splitReadAligner: scanEnd < scanStart (SplitReadAlignment.cpp:265-273) */
+#define MANTA_E_NOT_TAKEN (-10)   /* whole-batch call on a shared block queue: another process of the node took this locus' block */
 
 typedef struct manta_ctx manta_ctx_t;
 
@@ -367,6 +368,12 @@ typedef struct {
                           one block aligns at any time (stage gates); the others upload / download / compact meanwhile */
   uint32_t flags;      /* MANTA_BATCH_* */
   uint32_t reserved;
+  uint32_t* shared_queue; /* nullable.  A 32-bit counter (zeroed before the calls) in memory SHARED by several processes of one node
+                             (e.g. POSIX shared memory): every process makes the same call on the same batch, each with its own GPU,
+                             and blocks are handed out through this counter instead of the call's own -- one work queue across the
+                             node's GPUs for the one-process-per-GPU deployment.  A process fills the records and arenas of the
+                             blocks it took; the loci of the others carry MANTA_E_NOT_TAKEN and the caller merges (block b covers
+                             loci [b * block_loci, ...): set block_loci explicitly so that every process cuts the same blocks) */
 } manta_batch_plan_t;
 
 typedef struct {
@@ -407,6 +414,45 @@ int manta_spanning_batch(
     uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
     uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap, uint64_t* cigar_arena_used,
     const manta_batch_plan_t* plan /* nullable */, manta_batch_stats_t* stats /* nullable */);
+
+/* ------------------------------------------------------------------------------------------------------
+ * One node, several GPUs, ONE work queue (the reference's partition primitives are the static bins of
+ * EdgeRetrieverBin.cpp:38-57 and the --threads worker pool of GenerateSVCandidates.cpp:232-266).
+ *
+ * manta_node_t owns one context per device.  manta_node_*_batch is the whole-batch call over all of them: the batch is
+ * cut into blocks (about 64 per call, at least ~1000 loci each, ordered by decreasing cost), and one host worker per
+ * device (n_workers per device) pulls blocks from the single queue -- a device that draws expensive blocks simply takes
+ * fewer.  Results land in the caller's records and arenas exactly as with the single-device call; no collective is
+ * involved: one host process owns all the GPUs, so every block's results come back over that GPU's own PCIe link
+ * (a device-to-device gather would only add a hop).  loci_per_device (nullable, n_devices entries) reports how the
+ * queue spread the loci.  For one PROCESS per GPU use manta_batch_plan_t::shared_queue instead.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct manta_node manta_node_t;
+int         manta_node_create(const int32_t* device_ids, uint32_t n_devices, manta_node_t** out);
+void        manta_node_destroy(manta_node_t* node);
+uint32_t    manta_node_device_count(const manta_node_t* node);
+const char* manta_node_last_error(const manta_node_t* node);
+
+int manta_node_smallsv_batch(
+    manta_node_t* node, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t large_indel_score,
+    uint32_t n_loci, const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const uint8_t* refs,
+    const uint64_t* ref_off, const manta_ref_cuts_t* cuts, const uint32_t* locus_min_word_length /* nullable */,
+    const uint32_t* locus_max_word_length /* nullable */, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs,
+    manta_smallsv_alignment_t* alignments, uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap,
+    uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used, uint32_t* cigar_arena,
+    uint64_t cigar_arena_cap, uint64_t* cigar_arena_used, const manta_batch_plan_t* plan /* nullable */,
+    manta_batch_stats_t* stats /* nullable */, uint32_t* loci_per_device /* nullable */);
+
+int manta_node_spanning_batch(
+    manta_node_t* node, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t jump_score, uint32_t n_loci,
+    const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const uint8_t* refs1,
+    const uint64_t* ref1_off, const uint8_t* refs2, const uint64_t* ref2_off, const manta_jump_cuts_t* cuts,
+    const uint32_t* locus_min_word_length /* nullable */, const uint32_t* locus_max_word_length /* nullable */,
+    manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_spanning_alignment_t* alignments, uint64_t contigs_cap,
+    uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
+    uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap, uint64_t* cigar_arena_used,
+    const manta_batch_plan_t* plan /* nullable */, manta_batch_stats_t* stats /* nullable */, uint32_t* loci_per_device /* nullable */);
+
 
 #ifdef __cplusplus
 }

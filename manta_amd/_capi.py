@@ -534,7 +534,8 @@ class SpanningBatch:
 # whole-batch calls (manta_smallsv_batch / manta_spanning_batch) and pinned host memory
 # ---------------------------------------------------------------------------------------------------------------
 class BatchPlan(ctypes.Structure):
-    _fields_ = [("block_loci", ctypes.c_uint32), ("n_workers", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+    _fields_ = [("block_loci", ctypes.c_uint32), ("n_workers", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("shared_queue", ctypes.c_void_p)]
 
 
 class BatchStats(ctypes.Structure):
@@ -602,10 +603,10 @@ class BatchOutput:
         return {f[0]: getattr(self.stats, f[0]) for f in BatchStats._fields_}
 
 
-def _smallsv_batch(self, opts, scores, large_indel_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True, serial_kernels=False, streamed_upload=True):
+def _smallsv_batch(self, opts, scores, large_indel_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True, serial_kernels=False, streamed_upload=True, shared_queue=None):
     """batch = (bases, read_off, begin, refs, ref_off, cuts) numpy arrays as synth.config2_batch returns them"""
     bases, read_off, begin, refs, ref_off, cuts = batch
-    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, (1 if serial_kernels else 0) | (0 if streamed_upload else 2), 0)
+    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, (1 if serial_kernels else 0) | (0 if streamed_upload else 2), 0, shared_queue)
     n = len(begin) - 1
     f = self.lib.manta_smallsv_batch
     f.restype = ctypes.c_int
@@ -614,14 +615,14 @@ def _smallsv_batch(self, opts, scores, large_indel_score, batch, out, min_wl=Non
            _p(out.seq), ctypes.c_uint64(len(out.seq)), ctypes.byref(out.used[0]), _p(out.bits), ctypes.c_uint64(len(out.bits)),
            ctypes.byref(out.used[1]), _p(out.cig), ctypes.c_uint64(len(out.cig)), ctypes.byref(out.used[2]), ctypes.byref(plan),
            ctypes.byref(out.stats))
-    self._check(rc, allow=() if strict else (-4, -5, -7))
+    self._check(rc, allow=(() if strict else (-4, -5, -7)) + ((-10,) if shared_queue else ()))
     return rc
 
 
-def _spanning_batch(self, opts, scores, jump_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True, serial_kernels=False, streamed_upload=True):
+def _spanning_batch(self, opts, scores, jump_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True, serial_kernels=False, streamed_upload=True, shared_queue=None):
     """batch = (bases, read_off, begin, refs1, ref1_off, refs2, ref2_off, cuts)"""
     bases, read_off, begin, r1, o1, r2, o2, cuts = batch
-    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, (1 if serial_kernels else 0) | (0 if streamed_upload else 2), 0)
+    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, (1 if serial_kernels else 0) | (0 if streamed_upload else 2), 0, shared_queue)
     n = len(begin) - 1
     f = self.lib.manta_spanning_batch
     f.restype = ctypes.c_int
@@ -630,12 +631,80 @@ def _spanning_batch(self, opts, scores, jump_score, batch, out, min_wl=None, max
            _p(out.seq), ctypes.c_uint64(len(out.seq)), ctypes.byref(out.used[0]), _p(out.bits), ctypes.c_uint64(len(out.bits)),
            ctypes.byref(out.used[1]), _p(out.cig), ctypes.c_uint64(len(out.cig)), ctypes.byref(out.used[2]), ctypes.byref(plan),
            ctypes.byref(out.stats))
-    self._check(rc, allow=() if strict else (-4, -5, -7))
+    self._check(rc, allow=(() if strict else (-4, -5, -7)) + ((-10,) if shared_queue else ()))
     return rc
 
 
 Lib.smallsv_batch = _smallsv_batch
 Lib.spanning_batch = _spanning_batch
+
+
+class Node:
+    """manta_node_t: the GPUs of one node behind one block queue (one context per device id)"""
+
+    def __init__(self, path=None, devices=(0,)):
+        self.path = path or default_library_path()
+        self.lib = ctypes.CDLL(self.path)
+        L = self.lib
+        L.manta_node_last_error.restype = ctypes.c_char_p
+        L.manta_node_last_error.argtypes = [ctypes.c_void_p]
+        L.manta_node_destroy.argtypes = [ctypes.c_void_p]
+        self.n_devices = len(devices)
+        self.node = ctypes.c_void_p()
+        ids = (ctypes.c_int32 * len(devices))(*devices)
+        rc = L.manta_node_create(ids, ctypes.c_uint32(len(devices)), ctypes.byref(self.node))
+        if rc != 0:
+            raise MantaError(rc, L.manta_node_last_error(None).decode())
+
+    def close(self):
+        if self.node:
+            self.lib.manta_node_destroy(self.node)
+            self.node = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow=()):
+        if rc != 0 and rc not in allow:
+            raise MantaError(rc, self.lib.manta_node_last_error(self.node).decode())
+
+    def smallsv_batch(self, opts, scores, large_indel_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True,
+                      streamed_upload=True):
+        """manta_node_smallsv_batch; returns the loci each device processed"""
+        bases, read_off, begin, refs, ref_off, cuts = batch
+        o, sc = AsmOptions(*opts), AlignScores(*scores)
+        plan = BatchPlan(block_loci, n_workers, 0 if streamed_upload else 2, 0, None)
+        per_dev = (ctypes.c_uint32 * self.n_devices)()
+        n = len(begin) - 1
+        f = self.lib.manta_node_smallsv_batch
+        f.restype = ctypes.c_int
+        rc = f(self.node, ctypes.byref(o), ctypes.byref(sc), ctypes.c_int32(large_indel_score), ctypes.c_uint32(n), _p(bases), _p(read_off),
+               _p(begin), _p(refs), _p(ref_off), _p(cuts), _p(min_wl), _p(max_wl), out.res, out.contigs, out.aligns, ctypes.c_uint64(out.ccap),
+               _p(out.seq), ctypes.c_uint64(len(out.seq)), ctypes.byref(out.used[0]), _p(out.bits), ctypes.c_uint64(len(out.bits)),
+               ctypes.byref(out.used[1]), _p(out.cig), ctypes.c_uint64(len(out.cig)), ctypes.byref(out.used[2]), ctypes.byref(plan),
+               ctypes.byref(out.stats), per_dev)
+        self._check(rc, allow=() if strict else (-4, -5, -7))
+        return list(per_dev)
+
+    def spanning_batch(self, opts, scores, jump_score, batch, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0, strict=True,
+                       streamed_upload=True):
+        bases, read_off, begin, r1, o1, r2, o2, cuts = batch
+        o, sc = AsmOptions(*opts), AlignScores(*scores)
+        plan = BatchPlan(block_loci, n_workers, 0 if streamed_upload else 2, 0, None)
+        per_dev = (ctypes.c_uint32 * self.n_devices)()
+        n = len(begin) - 1
+        f = self.lib.manta_node_spanning_batch
+        f.restype = ctypes.c_int
+        rc = f(self.node, ctypes.byref(o), ctypes.byref(sc), ctypes.c_int32(jump_score), ctypes.c_uint32(n), _p(bases), _p(read_off), _p(begin),
+               _p(r1), _p(o1), _p(r2), _p(o2), _p(cuts), _p(min_wl), _p(max_wl), out.res, out.contigs, out.aligns, ctypes.c_uint64(out.ccap),
+               _p(out.seq), ctypes.c_uint64(len(out.seq)), ctypes.byref(out.used[0]), _p(out.bits), ctypes.c_uint64(len(out.bits)),
+               ctypes.byref(out.used[1]), _p(out.cig), ctypes.c_uint64(len(out.cig)), ctypes.byref(out.used[2]), ctypes.byref(plan),
+               ctypes.byref(out.stats), per_dev)
+        self._check(rc, allow=() if strict else (-4, -5, -7))
+        return list(per_dev)
 
 
 def pack_spanning(loci_reads, refs1, refs2, cuts):
@@ -734,7 +803,7 @@ SpanningBatch.upload_piles = _spanning_upload_piles
 
 def _smallsv_batch_piles(self, opts, scores, large_indel_score, piles, refs, ref_off, cuts, out, min_wl=None, max_wl=None, block_loci=0,
                          n_workers=0, strict=True, serial_kernels=False, streamed_upload=True):
-    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, (1 if serial_kernels else 0) | (0 if streamed_upload else 2), 0)
+    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, (1 if serial_kernels else 0) | (0 if streamed_upload else 2), 0, None)
     n = len(piles.begin) - 1
     st = piles.struct()
     f = self.lib.manta_smallsv_batch_piles

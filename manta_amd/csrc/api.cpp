@@ -2564,8 +2564,12 @@ struct BatchShared {
   std::mutex            mu;
   std::mutex            kernelMu;  // MANTA_BATCH_SERIAL_KERNELS
   bool                  serialKernels = false;
-  StageGates            gates;     // used whenever the call has more than one worker
+  std::vector<StageGates> gates;   // one per device; used whenever a device has more than one worker
   bool                  pipelineStages = false;
+  uint32_t*             sharedQueue = nullptr;  // manta_batch_plan_t::shared_queue: the block counter of several processes
+  std::vector<uint32_t> lociOfCtx;  // loci processed per context (device)
+  /// next position of the block queue: this call's own counter, or the counter shared by the processes of the node
+  uint32_t takeNext() { return sharedQueue ? __atomic_fetch_add(sharedQueue, 1u, __ATOMIC_RELAXED) : next.fetch_add(1); }
   int                   fatal = MANTA_OK, worst = MANTA_OK;
   std::string           msg;
   manta_batch_stats_t   st{};
@@ -2597,6 +2601,14 @@ uint32_t autoBlockLoci(const uint32_t n_loci, const uint64_t totalBases)
   const uint64_t byBases = (totalBases + (uint64_t(4) << 30) - 1) / (uint64_t(4) << 30);
   const uint64_t nBlocks = std::max<uint64_t>(1, std::max(byLoci, byBases));
   return uint32_t((uint64_t(n_loci) + nBlocks - 1) / nBlocks);
+}
+
+/// several devices (or processes) on one queue: blocks small enough that the queue can balance uneven costs -- about eight
+/// per puller would be ideal, but a block below ~1000 loci no longer fills a device
+uint32_t nodeBlockLoci(const uint32_t n_loci, const uint64_t totalBases)
+{
+  const uint32_t one = autoBlockLoci(n_loci, totalBases);
+  return std::max<uint32_t>(1, std::min<uint32_t>(one, std::max<uint32_t>(1024, n_loci / 64)));
 }
 
 /// contiguous blocks of `blockLoci` loci, ordered by decreasing cost (reads x bases, the same estimate the kernels'
@@ -2667,7 +2679,7 @@ int manta_spanning_set_word_lengths(manta_spanning_t* b, uint32_t n_loci, const 
 
 namespace {
 int smallsvBatchImpl(
-    manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t large_indel_score, uint32_t n_loci,
+    manta_ctx_t* const* ctxs, const uint32_t nCtx, uint32_t* lociPerDevice, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t large_indel_score, uint32_t n_loci,
     const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const manta_packed_piles_t* piles, const uint8_t* refs,
     const uint64_t* ref_off, const manta_ref_cuts_t* cuts, const uint32_t* locus_min_word_length, const uint32_t* locus_max_word_length,
     manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_smallsv_alignment_t* alignments, uint64_t contigs_cap,
@@ -2675,7 +2687,8 @@ int smallsvBatchImpl(
     uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap, uint64_t* cigar_arena_used,
     const manta_batch_plan_t* plan, manta_batch_stats_t* stats)
 {
-  if (!ctx) return MANTA_E_INVALID_ARG;
+  if (!ctxs || nCtx == 0 || !ctxs[0]) return MANTA_E_INVALID_ARG;
+  manta_ctx_t* ctx = ctxs[0];  // (call-level errors are reported here)
   if (!opt || !scores || n_loci == 0 || (!piles && (!bases || !read_off)) || !locus_read_begin || !refs || !ref_off || !cuts || !loci ||
       !contigs || !alignments || !seq_arena || !bits_arena || !cigar_arena)
     return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_batch: null argument or empty batch");
@@ -2685,22 +2698,35 @@ int smallsvBatchImpl(
     if (locus_read_begin[l + 1] < locus_read_begin[l] || ref_off[l + 1] < ref_off[l])
       return fail(ctx, MANTA_E_INVALID_ARG, "manta_smallsv_batch: offsets not monotone");
   const uint64_t totalBases = piles ? 0 : read_off[locus_read_begin[n_loci]] - read_off[locus_read_begin[0]];
-  const uint32_t blockLoci  = (plan && plan->block_loci) ? plan->block_loci : autoBlockLoci(n_loci, totalBases);
+  const bool     shared     = (plan && plan->shared_queue) || nCtx > 1;  // several devices pull from the queue
+  const uint32_t blockLoci  = (plan && plan->block_loci) ? plan->block_loci : (shared ? nodeBlockLoci(n_loci, totalBases) : autoBlockLoci(n_loci, totalBases));
   BatchShared    sh;
   sh.serialKernels  = plan && (plan->flags & MANTA_BATCH_SERIAL_KERNELS);
+  sh.sharedQueue    = plan ? plan->shared_queue : nullptr;
+  sh.gates          = std::vector<StageGates>(nCtx);
+  sh.lociOfCtx.assign(nCtx, 0);
   planBlocks(sh, n_loci, blockLoci, piles ? nullptr : read_off, locus_read_begin, piles ? piles->read_len : nullptr);
-  const uint32_t nBlocks  = uint32_t(sh.blockOrder.size());
-  const uint32_t nWorkers = std::max(1u, std::min(nBlocks, (plan && plan->n_workers) ? plan->n_workers : 1u));
-  sh.pipelineStages       = nWorkers > 1;
+  const uint32_t nBlocks    = uint32_t(sh.blockOrder.size());
+  const uint32_t perCtx     = std::max(1u, (plan && plan->n_workers) ? plan->n_workers : 1u);
+  const uint32_t nWorkers   = std::max(1u, std::min(nBlocks, perCtx * nCtx));
+  sh.pipelineStages         = perCtx > 1;
+  if (sh.sharedQueue)  // blocks another process of the node takes stay marked; the caller merges (bench.py: the final gather)
+    for (uint32_t l = 0; l < n_loci; ++l) {
+      std::memset(&loci[l], 0, sizeof(loci[l]));
+      loci[l].status = MANTA_E_NOT_TAKEN;
+    }
   try {
-    rt::setDevice(ctx->deviceId);
-    while (ctx->smallPool.size() < nWorkers) ctx->smallPool.push_back(new manta_smallsv(ctx));
+    for (uint32_t c = 0; c < nCtx; ++c) {
+      rt::setDevice(ctxs[c]->deviceId);
+      while (ctxs[c]->smallPool.size() < (nWorkers + nCtx - 1) / nCtx) ctxs[c]->smallPool.push_back(new manta_smallsv(ctxs[c]));
+    }
   } catch (const std::exception& e) {
     return fail(ctx, MANTA_E_HIP, e.what());
   }
   const double tStart = nowMs();
   auto         worker = [&](const uint32_t w) {
-    manta_smallsv* b = ctx->smallPool[w];
+    manta_ctx_t*   ctx = ctxs[w % nCtx];  // (shadows the call-level context: this worker's device)
+    manta_smallsv* b   = ctx->smallPool[w / nCtx];
     try {
       rt::setDevice(ctx->deviceId);
       b->opt           = *opt;
@@ -2711,7 +2737,7 @@ int smallsvBatchImpl(
       std::vector<uint64_t> rOff, fOff;
       std::vector<uint32_t> lBeg;
       while (!sh.stop()) {
-        const uint32_t qi = sh.next.fetch_add(1);
+        const uint32_t qi = sh.takeNext();
         if (qi >= nBlocks) break;
         const uint32_t blk = sh.blockOrder[qi];
         const uint32_t l0 = blk * blockLoci, l1 = std::min(n_loci, l0 + blockLoci), n = l1 - l0;
@@ -2749,7 +2775,7 @@ int smallsvBatchImpl(
         {
           std::unique_lock<std::mutex> only(sh.kernelMu, std::defer_lock);
           if (sh.serialKernels) only.lock();
-          rc = smallsvRunImpl(b, sh.pipelineStages ? &sh.gates : nullptr);
+          rc = smallsvRunImpl(b, sh.pipelineStages ? &sh.gates[w % nCtx] : nullptr);
         }
         if (rc != MANTA_OK) {
           sh.error(rc, lastErrorOf(ctx), true);
@@ -2808,6 +2834,7 @@ int smallsvBatchImpl(
           if (!perItemCode(rc)) break;
         }
         std::lock_guard<std::mutex> g(sh.mu);
+        sh.lociOfCtx[w % nCtx] += n;
         sh.st.h2d_ms += t1 - t0;
         sh.st.kernel_ms += t2 - t1;
         sh.st.d2h_ms += t3 - t2;
@@ -2834,6 +2861,7 @@ int smallsvBatchImpl(
   sh.st.n_blocks  = nBlocks;
   sh.st.n_workers = nWorkers;
   if (stats) *stats = sh.st;
+  if (lociPerDevice) for (uint32_t c = 0; c < nCtx; ++c) lociPerDevice[c] = sh.lociOfCtx[c];
   if (seq_arena_used) *seq_arena_used = sh.seqUsed.load();
   if (bits_arena_used) *bits_arena_used = sh.bitsUsed.load();
   if (cigar_arena_used) *cigar_arena_used = sh.cigarUsed.load();
@@ -2852,7 +2880,7 @@ int manta_smallsv_batch(
     uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap, uint64_t* cigar_arena_used,
     const manta_batch_plan_t* plan, manta_batch_stats_t* stats)
 {
-  return smallsvBatchImpl(ctx, opt, scores, large_indel_score, n_loci, bases, read_off, locus_read_begin, nullptr, refs, ref_off, cuts,
+  return smallsvBatchImpl(&ctx, 1, nullptr, opt, scores, large_indel_score, n_loci, bases, read_off, locus_read_begin, nullptr, refs, ref_off, cuts,
                           locus_min_word_length, locus_max_word_length, loci, contigs, alignments, contigs_cap, seq_arena, seq_arena_cap,
                           seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used, cigar_arena, cigar_arena_cap, cigar_arena_used, plan, stats);
 }
@@ -2868,13 +2896,14 @@ int manta_smallsv_batch_piles(
   if (!ctx) return MANTA_E_INVALID_ARG;
   const int rc = checkPiles(ctx, piles, "manta_smallsv_batch_piles");
   if (rc != MANTA_OK) return rc;
-  return smallsvBatchImpl(ctx, opt, scores, large_indel_score, n_loci, nullptr, nullptr, piles->locus_read_begin, piles, refs, ref_off, cuts,
+  return smallsvBatchImpl(&ctx, 1, nullptr, opt, scores, large_indel_score, n_loci, nullptr, nullptr, piles->locus_read_begin, piles, refs, ref_off, cuts,
                           locus_min_word_length, locus_max_word_length, loci, contigs, alignments, contigs_cap, seq_arena, seq_arena_cap,
                           seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used, cigar_arena, cigar_arena_cap, cigar_arena_used, plan, stats);
 }
 
-int manta_spanning_batch(
-    manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t jump_score, uint32_t n_loci,
+namespace {
+int spanningBatchImpl(
+    manta_ctx_t* const* ctxs, const uint32_t nCtx, uint32_t* lociPerDevice, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t jump_score, uint32_t n_loci,
     const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const uint8_t* refs1, const uint64_t* ref1_off,
     const uint8_t* refs2, const uint64_t* ref2_off, const manta_jump_cuts_t* cuts, const uint32_t* locus_min_word_length,
     const uint32_t* locus_max_word_length, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs,
@@ -2882,7 +2911,8 @@ int manta_spanning_batch(
     uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
     uint64_t* cigar_arena_used, const manta_batch_plan_t* plan, manta_batch_stats_t* stats)
 {
-  if (!ctx) return MANTA_E_INVALID_ARG;
+  if (!ctxs || nCtx == 0 || !ctxs[0]) return MANTA_E_INVALID_ARG;
+  manta_ctx_t* ctx = ctxs[0];  // (call-level errors are reported here)
   if (!opt || !scores || n_loci == 0 || !bases || !read_off || !locus_read_begin || !refs1 || !ref1_off || !refs2 || !ref2_off || !cuts ||
       !loci || !contigs || !alignments || !seq_arena || !bits_arena || !cigar_arena)
     return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_batch: null argument or empty batch");
@@ -2892,23 +2922,36 @@ int manta_spanning_batch(
   for (uint32_t l = 0; l < n_loci; ++l)
     if (locus_read_begin[l + 1] < locus_read_begin[l] || ref1_off[l + 1] < ref1_off[l] || ref2_off[l + 1] < ref2_off[l])
       return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_batch: offsets not monotone");
-  const uint32_t blockLoci = (plan && plan->block_loci) ? plan->block_loci
-                                                        : autoBlockLoci(n_loci, read_off[locus_read_begin[n_loci]] - read_off[locus_read_begin[0]]);
+  const uint64_t totalBases = read_off[locus_read_begin[n_loci]] - read_off[locus_read_begin[0]];
+  const bool     shared     = (plan && plan->shared_queue) || nCtx > 1;
+  const uint32_t blockLoci  = (plan && plan->block_loci) ? plan->block_loci : (shared ? nodeBlockLoci(n_loci, totalBases) : autoBlockLoci(n_loci, totalBases));
   BatchShared    sh;
   sh.serialKernels  = plan && (plan->flags & MANTA_BATCH_SERIAL_KERNELS);
+  sh.sharedQueue    = plan ? plan->shared_queue : nullptr;
+  sh.gates          = std::vector<StageGates>(nCtx);
+  sh.lociOfCtx.assign(nCtx, 0);
   planBlocks(sh, n_loci, blockLoci, read_off, locus_read_begin);
   const uint32_t nBlocks  = uint32_t(sh.blockOrder.size());
-  const uint32_t nWorkers = std::max(1u, std::min(nBlocks, (plan && plan->n_workers) ? plan->n_workers : 1u));
-  sh.pipelineStages       = nWorkers > 1;
+  const uint32_t perCtx   = std::max(1u, (plan && plan->n_workers) ? plan->n_workers : 1u);
+  const uint32_t nWorkers = std::max(1u, std::min(nBlocks, perCtx * nCtx));
+  sh.pipelineStages       = perCtx > 1;
+  if (sh.sharedQueue)
+    for (uint32_t l = 0; l < n_loci; ++l) {
+      std::memset(&loci[l], 0, sizeof(loci[l]));
+      loci[l].status = MANTA_E_NOT_TAKEN;
+    }
   try {
-    rt::setDevice(ctx->deviceId);
-    while (ctx->spanPool.size() < nWorkers) ctx->spanPool.push_back(new manta_spanning(ctx));
+    for (uint32_t c = 0; c < nCtx; ++c) {
+      rt::setDevice(ctxs[c]->deviceId);
+      while (ctxs[c]->spanPool.size() < (nWorkers + nCtx - 1) / nCtx) ctxs[c]->spanPool.push_back(new manta_spanning(ctxs[c]));
+    }
   } catch (const std::exception& e) {
     return fail(ctx, MANTA_E_HIP, e.what());
   }
   const double tStart = nowMs();
   auto         worker = [&](const uint32_t w) {
-    manta_spanning* b = ctx->spanPool[w];
+    manta_ctx_t*    ctx = ctxs[w % nCtx];  // (shadows the call-level context: this worker's device)
+    manta_spanning* b   = ctx->spanPool[w / nCtx];
     try {
       rt::setDevice(ctx->deviceId);
       b->opt       = *opt;
@@ -2919,7 +2962,7 @@ int manta_spanning_batch(
       std::vector<uint64_t> rOff, f1Off, f2Off;
       std::vector<uint32_t> lBeg;
       while (!sh.stop()) {
-        const uint32_t qi = sh.next.fetch_add(1);
+        const uint32_t qi = sh.takeNext();
         if (qi >= nBlocks) break;
         const uint32_t blk = sh.blockOrder[qi];
         const uint32_t l0 = blk * blockLoci, l1 = std::min(n_loci, l0 + blockLoci), n = l1 - l0;
@@ -2949,7 +2992,7 @@ int manta_spanning_batch(
         {
           std::unique_lock<std::mutex> only(sh.kernelMu, std::defer_lock);
           if (sh.serialKernels) only.lock();
-          rc = spanningRunImpl(b, sh.pipelineStages ? &sh.gates : nullptr);
+          rc = spanningRunImpl(b, sh.pipelineStages ? &sh.gates[w % nCtx] : nullptr);
         }
         if (rc != MANTA_OK) {
           sh.error(rc, lastErrorOf(ctx), true);
@@ -3002,6 +3045,7 @@ int manta_spanning_batch(
           if (!perItemCode(rc)) break;
         }
         std::lock_guard<std::mutex> g(sh.mu);
+        sh.lociOfCtx[w % nCtx] += n;
         sh.st.h2d_ms += t1 - t0;
         sh.st.kernel_ms += t2 - t1;
         sh.st.d2h_ms += t3 - t2;
@@ -3028,12 +3072,98 @@ int manta_spanning_batch(
   sh.st.n_blocks  = nBlocks;
   sh.st.n_workers = nWorkers;
   if (stats) *stats = sh.st;
+  if (lociPerDevice) for (uint32_t c = 0; c < nCtx; ++c) lociPerDevice[c] = sh.lociOfCtx[c];
   if (seq_arena_used) *seq_arena_used = sh.seqUsed.load();
   if (bits_arena_used) *bits_arena_used = sh.bitsUsed.load();
   if (cigar_arena_used) *cigar_arena_used = sh.cigarUsed.load();
   if (sh.fatal != MANTA_OK) return fail(ctx, sh.fatal, sh.msg);
   if (sh.worst != MANTA_OK) return fail(ctx, sh.worst, sh.msg);
   return MANTA_OK;
+}
+}  // namespace
+
+int manta_spanning_batch(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t jump_score, uint32_t n_loci,
+    const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const uint8_t* refs1, const uint64_t* ref1_off,
+    const uint8_t* refs2, const uint64_t* ref2_off, const manta_jump_cuts_t* cuts, const uint32_t* locus_min_word_length,
+    const uint32_t* locus_max_word_length, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs,
+    manta_spanning_alignment_t* alignments, uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used,
+    uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
+    uint64_t* cigar_arena_used, const manta_batch_plan_t* plan, manta_batch_stats_t* stats)
+{
+  return spanningBatchImpl(&ctx, 1, nullptr, opt, scores, jump_score, n_loci, bases, read_off, locus_read_begin, refs1, ref1_off, refs2, ref2_off,
+                           cuts, locus_min_word_length, locus_max_word_length, loci, contigs, alignments, contigs_cap, seq_arena, seq_arena_cap,
+                           seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used, cigar_arena, cigar_arena_cap, cigar_arena_used, plan, stats);
+}
+
+/* ------------------------------------------------------------------------------------------------------
+ * manta_node_*: the GPUs of one node behind one block queue (include/manta_amd.h)
+ * ---------------------------------------------------------------------------------------------------- */
+struct manta_node {
+  std::vector<manta_ctx_t*> ctxs;
+  ~manta_node()
+  {
+    for (manta_ctx_t* c : ctxs) manta_ctx_destroy(c);
+  }
+};
+
+int manta_node_create(const int32_t* device_ids, uint32_t n_devices, manta_node_t** out)
+{
+  if (!out || !device_ids || n_devices == 0) {
+    g_createError = "manta_node_create: null argument or no device";
+    return MANTA_E_INVALID_ARG;
+  }
+  *out = nullptr;
+  std::unique_ptr<manta_node> node(new manta_node);
+  for (uint32_t d = 0; d < n_devices; ++d) {
+    manta_ctx_t* c  = nullptr;
+    const int    rc = manta_ctx_create(device_ids[d], &c);
+    if (rc != MANTA_OK) return rc;  // (the contexts created so far go with `node`)
+    node->ctxs.push_back(c);
+  }
+  *out = node.release();
+  return MANTA_OK;
+}
+
+void manta_node_destroy(manta_node_t* node) { delete node; }
+
+uint32_t manta_node_device_count(const manta_node_t* node) { return node ? uint32_t(node->ctxs.size()) : 0u; }
+
+const char* manta_node_last_error(const manta_node_t* node)
+{
+  return (node && !node->ctxs.empty()) ? manta_last_error(node->ctxs[0]) : g_createError.c_str();
+}
+
+int manta_node_smallsv_batch(
+    manta_node_t* node, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t large_indel_score, uint32_t n_loci,
+    const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const uint8_t* refs, const uint64_t* ref_off,
+    const manta_ref_cuts_t* cuts, const uint32_t* locus_min_word_length, const uint32_t* locus_max_word_length,
+    manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_smallsv_alignment_t* alignments, uint64_t contigs_cap,
+    uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
+    uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap, uint64_t* cigar_arena_used,
+    const manta_batch_plan_t* plan, manta_batch_stats_t* stats, uint32_t* loci_per_device)
+{
+  if (!node) return MANTA_E_INVALID_ARG;
+  return smallsvBatchImpl(node->ctxs.data(), uint32_t(node->ctxs.size()), loci_per_device, opt, scores, large_indel_score, n_loci, bases, read_off,
+                          locus_read_begin, nullptr, refs, ref_off, cuts, locus_min_word_length, locus_max_word_length, loci, contigs, alignments,
+                          contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used, cigar_arena,
+                          cigar_arena_cap, cigar_arena_used, plan, stats);
+}
+
+int manta_node_spanning_batch(
+    manta_node_t* node, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t jump_score, uint32_t n_loci,
+    const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const uint8_t* refs1, const uint64_t* ref1_off,
+    const uint8_t* refs2, const uint64_t* ref2_off, const manta_jump_cuts_t* cuts, const uint32_t* locus_min_word_length,
+    const uint32_t* locus_max_word_length, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs,
+    manta_spanning_alignment_t* alignments, uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used,
+    uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
+    uint64_t* cigar_arena_used, const manta_batch_plan_t* plan, manta_batch_stats_t* stats, uint32_t* loci_per_device)
+{
+  if (!node) return MANTA_E_INVALID_ARG;
+  return spanningBatchImpl(node->ctxs.data(), uint32_t(node->ctxs.size()), loci_per_device, opt, scores, jump_score, n_loci, bases, read_off,
+                           locus_read_begin, refs1, ref1_off, refs2, ref2_off, cuts, locus_min_word_length, locus_max_word_length, loci, contigs,
+                           alignments, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used,
+                           cigar_arena, cigar_arena_cap, cigar_arena_used, plan, stats);
 }
 
 }  // extern "C"

@@ -53,6 +53,34 @@ def test_bench_forced_single_rank_group_over_gloo(emu):
     assert d["n_gpus"] == 1 and "gather_MB_per_step" in d["pcie"]  # (a few KB here: rounds to 0.00 MB)
 
 
+def run_bench_ranks(world, argv, port, extra_env=None):
+    """`world` processes as torchrun would start them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), gloo, emulator"""
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MANTA_BENCH_BACKEND="gloo", **(extra_env or {}))
+        code = HARNESS % dict(root=ROOT, argv=argv)
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    lines = [l for l in outs[0][0].splitlines() if l.strip()]
+    assert lines and not any(l.lstrip().startswith("{") for so, _ in outs[1:] for l in so.splitlines()), "only rank 0 prints the line"
+    return json.loads(lines[-1])
+
+
+def test_bench_two_ranks_share_one_block_queue(emu):
+    """N = 2 over gloo: the node's batch behind ONE queue (shared-memory counter), every locus taken once, truthful line"""
+    d = run_bench_ranks(2, ["--gpus", "2", "--loci", "6", "--steps", "2", "--warmup", "1", "--block-loci", "2", "--no-cpu-baseline", "--no-extras"], 29571)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["queue"] == "node" and c["backend"] == "gloo" and c["dist_world"] == 2
+    assert sum(c["loci_per_rank"]) == 12 and len(c["loci_per_rank"]) == 2
+    assert "gloo" in c["timed_region"] and "RCCL" not in c["timed_region"] and "0 mismatches" in c["parity"]
+    # unequal parts (every 4th part is heavier; with two ranks: none) and the per-rank form
+    d = run_bench_ranks(2, ["--gpus", "2", "--loci", "4", "--steps", "1", "--warmup", "0", "--queue", "rank", "--no-cpu-baseline", "--no-extras"], 29573)
+    assert d["config"]["queue"] == "rank" and d["config"]["loci_per_rank"] == [4]
+
+
 def test_bench_spanning_flow_on_the_emulator(emu):
     d, lines = run_bench(["--workload", "spanning", "--loci", "3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
     assert d["config"]["loci_per_gpu"] == 3 and "0 mismatches" in d["config"]["parity"]
