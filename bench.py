@@ -186,6 +186,11 @@ def main():
         dist.barrier()
         if rank != 0:
             qshm = shared_memory.SharedMemory(name=qname)
+            try:  # (rank 0 owns the segment: keep this process' resource tracker from unlinking it a second time at exit)
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(qshm._name, "shared_memory")
+            except Exception:
+                pass
         qcount = (_ct.c_uint32 * n_slots).from_buffer(qshm.buf)
     step_no = [0]
     # measured on MI355X: one block's kernels already fill the device and concurrent blocks contend for the
@@ -195,7 +200,7 @@ def main():
     if node_queue and not args.block_loci:
         # two blocks per rank: small enough for the queue to even out unequal parts, large enough to fill a device (a block below
         # ~4096 loci leaves assembler waves idle: one wave per locus, 16 waves per CU)
-        block = max(1, n_loci // 2)
+        block = max(1, n_loci // 2) if world > 1 else n_loci
 
     # ---- this rank's batch (outside the clock: synthetic data generation) ----
     if spanning:
