@@ -936,12 +936,18 @@ struct AsmStage {
       rt::launch(assemble_kernel, g, ASM_LDS_BYTES, P);
     }
     // loci that did not fit the typical-case workspace are counted into dCnt[3] (see rerunCapacityFailures)
+    // ... and so are the loci whose reads hold bytes outside {A,C,G,T,N} that cannot be masked exactly (ASM_E_ALPHABET): the same
+    // pass runs those again on the byte-generic kernel
     CountStatusParams C;
     C.loci    = dLoci;
     C.n_loci  = nLoci;
     C.code    = ASM_E_TABLE_FULL;
     C.counter = reinterpret_cast<unsigned long long*>(dCnt + 3);
     rt::launch(count_status_kernel, rt::roundGrid(int(std::min<uint64_t>((nLoci + 63) / 64, 64))), 0, C);
+    if (!dPlCodes) {
+      C.code = ASM_E_ALPHABET;
+      rt::launch(count_status_kernel, rt::roundGrid(int(std::min<uint64_t>((nLoci + 63) / 64, 64))), 0, C);
+    }
   }
 
   /// Call once the assembler of launch() has finished, with the value of dCnt[3] (capacity_failures).  Loci whose pile did not
@@ -952,30 +958,61 @@ struct AsmStage {
     if (failures == 0 || smallMode) return;
     std::vector<AsmLocusOut> st(nLoci);
     rt::d2h(st.data(), dLoci, sizeof(AsmLocusOut) * nLoci);
-    std::vector<uint32_t> ids;
-    for (uint32_t l = 0; l < nLoci; ++l)
+    std::vector<uint32_t> ids, alphaIds;
+    for (uint32_t l = 0; l < nLoci; ++l) {
       if (st[l].status == ASM_E_TABLE_FULL) ids.push_back(l);
-    if (ids.empty()) return;
+      if (st[l].status == ASM_E_ALPHABET) alphaIds.push_back(l);
+    }
+    nRerun = 0;
     const size_t wsBudget = workspaceBudget(size_t(32) << 30);
-    int          g        = int(std::min<uint64_t>(ids.size(), std::max<uint64_t>(1, wsBudget / stride2)));
-    g                     = rt::roundGrid(std::min(g, std::max(1, ctx->cuCount * 4)));
-    uint32_t* dIds        = bFailIds.as<uint32_t>(ids.size());
-    rt::h2d(dIds, ids.data(), sizeof(uint32_t) * ids.size());
-    rt::dzero(dCnt + 12, sizeof(uint64_t) * 2);
-    AsmParams P            = lastParams;
-    P.ws                   = bWs2.as<uint8_t>(stride2 * uint64_t(g));
-    P.ws_stride            = stride2;
-    P.cap_slots            = capSlots2;
-    P.cap_nodes            = capNodes2;
-    P.cap_words            = capWords2;
-    P.n_loci               = uint32_t(ids.size());
-    P.locus_ids            = dIds;
-    P.counter              = reinterpret_cast<uint32_t*>(dCnt + 12);
-    rt::launch(assemble_kernel, g, ASM_LDS_BYTES, P);
-    rt::sync();
-    nRerun = uint32_t(ids.size());
-    if (std::getenv("MANTA_AMD_DEBUG"))
-      std::fprintf(stderr, "manta_amd: %zu of %u loci ran again on the worst-case workspace (%.1f MB per wave)\n", ids.size(), nLoci, double(stride2) / 1e6);
+    if (!ids.empty()) {
+      int g          = int(std::min<uint64_t>(ids.size(), std::max<uint64_t>(1, wsBudget / stride2)));
+      g              = rt::roundGrid(std::min(g, std::max(1, ctx->cuCount * 4)));
+      uint32_t* dIds = bFailIds.as<uint32_t>(ids.size());
+      rt::h2d(dIds, ids.data(), sizeof(uint32_t) * ids.size());
+      rt::dzero(dCnt + 12, sizeof(uint64_t) * 2);
+      AsmParams P = lastParams;
+      P.ws        = bWs2.as<uint8_t>(stride2 * uint64_t(g));
+      P.ws_stride = stride2;
+      P.cap_slots = capSlots2;
+      P.cap_nodes = capNodes2;
+      P.cap_words = capWords2;
+      P.n_loci    = uint32_t(ids.size());
+      P.locus_ids = dIds;
+      P.counter   = reinterpret_cast<uint32_t*>(dCnt + 12);
+      rt::launch(assemble_kernel, g, ASM_LDS_BYTES, P);
+      rt::sync();
+      nRerun = uint32_t(ids.size());
+      if (std::getenv("MANTA_AMD_DEBUG"))
+        std::fprintf(stderr, "manta_amd: %zu of %u loci ran again on the worst-case workspace (%.1f MB per wave)\n", ids.size(), nLoci, double(stride2) / 1e6);
+    }
+    if (!alphaIds.empty()) {
+      // byte-generic run (AssemblerT<8>: the reads' bytes as symbols, 4 per code dword) on a worst-case workspace
+      const uint64_t    nCandMax = 2ull * opt.max_assembly_count;
+      const uint32_t    capWordsG = uint32_t(std::min<uint64_t>(uint64_t(capWords2) * 4 + 64, 0x7fffffffull));
+      const AsmWsLayout LG = asmWorkspaceLayout(capSlots2, capNodes2, capWordsG, capReads, maxContigLen, wMax, opt.max_assembly_count);
+      const uint64_t    strideG = (LG.total + 255) & ~uint64_t(255);
+      (void)nCandMax;
+      int g          = int(std::min<uint64_t>(alphaIds.size(), std::max<uint64_t>(1, wsBudget / strideG)));
+      g              = rt::roundGrid(std::min(g, std::max(1, ctx->cuCount * 4)));
+      uint32_t* dIds = bFailIds.as<uint32_t>(alphaIds.size());
+      rt::h2d(dIds, alphaIds.data(), sizeof(uint32_t) * alphaIds.size());
+      rt::dzero(dCnt + 12, sizeof(uint64_t) * 2);
+      AsmParams P = lastParams;
+      P.ws        = bWs2.as<uint8_t>(strideG * uint64_t(g));
+      P.ws_stride = strideG;
+      P.cap_slots = capSlots2;
+      P.cap_nodes = capNodes2;
+      P.cap_words = capWordsG;
+      P.n_loci    = uint32_t(alphaIds.size());
+      P.locus_ids = dIds;
+      P.counter   = reinterpret_cast<uint32_t*>(dCnt + 12);
+      rt::launch(assemble_generic_kernel, g, ASM_LDS_BYTES, P);
+      rt::sync();
+      nRerun += uint32_t(alphaIds.size());
+      if (std::getenv("MANTA_AMD_DEBUG"))
+        std::fprintf(stderr, "manta_amd: %zu of %u loci ran again on the byte-generic kernel\n", alphaIds.size(), nLoci);
+    }
   }
 
   /// Device -> pinned host staging of everything the assembler produced, with EXACT sizes: the fixed records and the

@@ -229,6 +229,9 @@ WV_HD AsmWsLayout asmWorkspaceLayout(
 
 // node_flag bits
 static const unsigned NF_REPEAT = 2u;   // member of repeatWords
+static const unsigned NF_JUNK = 1u;     // byte-generic form: the word holds a byte outside the alphabet.  Such a word cannot lie on a
+                                        // cycle (its odd byte only moves towards the front and out as symbols are appended), and its
+                                        // links are not symmetric (the walks prepend / append A,C,G,T only): the cycle test leaves it out
 // bits 8.. : serial of the last contig that used the word ("wordsInContig", :182)
 
 WV_DEV unsigned baseCode(const uint8_t c)
@@ -254,7 +257,23 @@ struct Key {
   uint32_t w[KW];
 };
 
-struct Assembler {
+/// SB = bits per symbol of the packed pile.  2: the four bases as codes 0..3, 16 per dword (+ the N bitmap) -- the production
+/// form.  8: the reads' bytes as they are, 4 per dword -- the byte-generic form for piles that hold bytes outside {A,C,G,T,N}
+/// where masking them is not provably exact (the reference treats any byte as a symbol; only 'N' words are skipped and only
+/// A,C,G,T extend a contig); word lengths up to 4 x ASM_MAX_KW = 32 there.  Everything below a key is the same code.
+template <int SB>
+struct AssemblerT {
+  static const unsigned SPD      = 32u / SB;          ///< symbols per code dword
+  static const unsigned SYM_MASK = (1u << SB) - 1u;
+  static const unsigned MAX_K    = SPD * ASM_MAX_KW;  ///< longest word
+  /// code of alphabet symbol c (0..3 = A,C,G,T); alphabet index of a code (4: not in the alphabet); its character
+  WV_DEV static unsigned symOfIndex(const unsigned c) { return (SB == 2) ? c : unsigned(uint8_t("ACGT"[c & 3u])); }
+  WV_DEV static unsigned indexOfSym(const unsigned s)
+  {
+    if (SB == 2) return s;
+    return (s == 'A') ? 0u : (s == 'C') ? 1u : (s == 'G') ? 2u : (s == 'T') ? 3u : 4u;
+  }
+  WV_DEV static uint8_t charOfSym(const unsigned s) { return (SB == 2) ? uint8_t("ACGT"[s & 3u]) : uint8_t(s); }
   const AsmParams& P;
   uint8_t*         ws;
   AsmWsLayout      L;
@@ -282,7 +301,7 @@ struct Assembler {
   uint64_t tPhase[8];
   uint64_t tMark;
 
-  WV_DEV Assembler(const AsmParams& p, uint8_t* wsBase) : P(p), ws(wsBase)
+  WV_DEV AssemblerT(const AsmParams& p, uint8_t* wsBase) : P(p), ws(wsBase)
   {
     L = asmWorkspaceLayout(p.cap_slots, p.cap_nodes, p.cap_words, p.cap_reads, p.max_contig_len, p.w_max, p.opt.maxAssemblyCount);
     codes      = reinterpret_cast<uint32_t*>(ws + L.codes);
@@ -386,10 +405,12 @@ struct Assembler {
   // ------------------------------------------------------------------------------------------------
   // packed reads
   // ------------------------------------------------------------------------------------------------
-  /// 16 bases starting at packed base index pb, MSB first
+  /// the symbol at packed base index pb
+  WV_DEV unsigned symAt(const unsigned pb) const { return (codes[pb / SPD] >> (32 - SB - SB * (pb % SPD))) & SYM_MASK; }
+  /// one dword of symbols (16 bases / 4 bytes) starting at packed base index pb, MSB first
   WV_DEV uint32_t codes16(const unsigned pb) const
   {
-    const unsigned wi = pb >> 4, sh = (pb & 15) * 2;
+    const unsigned wi = pb / SPD, sh = (pb % SPD) * SB;
     const uint32_t a = codes[wi];
     if (sh == 0) return a;
     return (a << sh) | (codes[wi + 1] >> (32 - sh));
@@ -399,8 +420,8 @@ struct Assembler {
   WV_DEV Key<KW> keyAt(const unsigned pb) const
   {
     Key<KW>        key;
-    const unsigned kw = (k + 15) >> 4;
-    const unsigned wi = pb >> 4, sh = (pb & 15) * 2;
+    const unsigned kw = (k + SPD - 1) / SPD;
+    const unsigned wi = pb / SPD, sh = (pb % SPD) * SB;
     uint32_t       raw[KW + 1];
     if (KW <= 4) {
       // one wide (dword-aligned) load of KW+1 code dwords; the slab is padded, over-reading is harmless
@@ -416,8 +437,8 @@ struct Assembler {
       uint32_t v = 0;
       if (unsigned(i) < kw) {
         v = uint32_t((((uint64_t(raw[i]) << 32) | raw[i + 1]) << sh) >> 32);  // funnel shift (v_alignbit_b32)
-        const unsigned have = k - 16u * unsigned(i);  // bases that belong to the word in this dword
-        if (have < 16) v &= ~((1u << (32 - 2 * have)) - 1u);
+        const unsigned have = k - SPD * unsigned(i);  // symbols that belong to the word in this dword
+        if (have < SPD) v &= ~((1u << (32 - SB * have)) - 1u);
       }
       key.w[i] = v;
     }
@@ -428,7 +449,7 @@ struct Assembler {
   template <int KW>
   WV_DEV uint32_t keyHash(const Key<KW>& key) const
   {
-    const unsigned kw = (k + 15) >> 4;
+    const unsigned kw = (k + SPD - 1) / SPD;
     uint32_t       h  = 0x811C9DC5u;
     for (int i = 0; i < KW; ++i)
       if (unsigned(i) < kw) h = hashMix(h, key.w[i]);
@@ -452,18 +473,18 @@ struct Assembler {
     return false;
   }
   template <int KW>
-  WV_DEV void keySetBase(Key<KW>& key, const unsigned i, const unsigned c) const
+  WV_DEV void keySetBase(Key<KW>& key, const unsigned i, const unsigned c) const  // c: alphabet index 0..3
   {
-    const unsigned sh = 30 - 2 * (i & 15);
+    const unsigned sh = 32 - SB - SB * (i % SPD);
     for (int w = 0; w < KW; ++w)
-      if (unsigned(w) == (i >> 4)) key.w[w] = (key.w[w] & ~(3u << sh)) | (c << sh);
+      if (unsigned(w) == (i / SPD)) key.w[w] = (key.w[w] & ~(SYM_MASK << sh)) | (symOfIndex(c) << sh);
   }
   /// word[1..k-1] + c
   template <int KW>
   WV_DEV Key<KW> keyShiftAppend(const Key<KW>& key, const unsigned c) const
   {
     Key<KW> r;
-    for (int w = 0; w < KW; ++w) r.w[w] = (key.w[w] << 2) | ((w + 1 < KW) ? (key.w[w + 1] >> 30) : 0u);
+    for (int w = 0; w < KW; ++w) r.w[w] = (key.w[w] << SB) | ((w + 1 < KW) ? (key.w[w + 1] >> (32 - SB)) : 0u);
     keySetBase(r, k - 1, c);
     return r;
   }
@@ -472,15 +493,15 @@ struct Assembler {
   WV_DEV Key<KW> keyShiftPrepend(const Key<KW>& key, const unsigned c) const
   {
     Key<KW> r;
-    for (int w = 0; w < KW; ++w) r.w[w] = (key.w[w] >> 2) | ((w > 0) ? (key.w[w - 1] << 30) : 0u);
+    for (int w = 0; w < KW; ++w) r.w[w] = (key.w[w] >> SB) | ((w > 0) ? (key.w[w - 1] << (32 - SB)) : 0u);
     // drop the base that moved to position k
-    const unsigned kw = (k + 15) >> 4;
+    const unsigned kw = (k + SPD - 1) / SPD;
     for (int w = 0; w < KW; ++w) {
       if (unsigned(w) >= kw) {
         r.w[w] = 0;
       } else if (unsigned(w) == kw - 1) {
-        const unsigned have = k - 16u * unsigned(w);
-        if (have < 16) r.w[w] &= ~((1u << (32 - 2 * have)) - 1u);
+        const unsigned have = k - SPD * unsigned(w);
+        if (have < SPD) r.w[w] &= ~((1u << (32 - SB * have)) - 1u);
       }
     }
     keySetBase(r, 0, c);
@@ -570,7 +591,7 @@ struct Assembler {
       const unsigned r   = base + unsigned(wv::lane());
       unsigned       len = 0;
       if (r < nNormal) len = P.pl_codes ? P.pl_read_len[rBegin + r + plShift(locus, 0)] : unsigned(P.read_off[rBegin + r + 1] - P.read_off[rBegin + r]);
-      const unsigned myC = (r < nNormal) ? (len + 15) / 16 + 1 : 0u;  // +1 padding dword so codes16() may read one past
+      const unsigned myC = (r < nNormal) ? (len + SPD - 1) / SPD + 1 : 0u;  // +1 padding dword so key fetches may read one past
       const unsigned myM = (r < nNormal) ? (len + 31) / 32 + 1 : 0u;
       // inclusive scan over lanes
       unsigned sc = myC, sm = myM;
@@ -597,6 +618,38 @@ struct Assembler {
     nCodeWordsNormal = cw;
     nMaskWordsNormal = mw;
     wv::sync();
+    if (SB == 8) {
+      // byte-generic pile: the reads' bytes as they are, 4 per dword, first byte in the top bits (dword order == string
+      // order); 'N' positions go into the bitmap as usual (their words are skipped, :531), every other byte is a symbol
+      if (P.pl_codes) {
+        status = ASM_E_INTERNAL;  // (packed piles cannot hold such bytes; the host never sends them here)
+        return;
+      }
+      const unsigned lane8 = unsigned(wv::lane());
+      const uint32_t shift8 = P.chunk_shift ? P.chunk_shift[locus / P.chunk_loci] : 0u;
+      for (unsigned r = 0; r < nNormal; ++r) {
+        const uint8_t* src = P.bases + P.read_off[rBegin + r] + shift8;
+        const unsigned len = rd_len[r], cwo = rd_cw[r], mwo = rd_mw[r];
+        const unsigned nCw = (len + SPD - 1) / SPD + 1;
+        bool           sawN = false;
+        for (unsigned wi = lane8; wi < nCw; wi += 64) {
+          uint32_t code = 0;
+          for (unsigned b = 0; b < 4; ++b) {
+            const unsigned i = wi * 4 + b;
+            if (i >= len) continue;
+            const unsigned c = src[i];
+            code |= c << (24 - 8 * b);
+            if (c == 'N') {
+              wv::atomic_or(&nmask[mwo + (i >> 5)], 1u << (i & 31));
+              sawN = true;
+            }
+          }
+          codes[cwo + wi] = code;
+        }
+        if (wv::any(sawN) && lane8 == 0) rd_hasn[r] = 1u;
+      }
+      return;
+    }
     if (P.pl_codes) {  // packed piles: copy (8 lanes per read, as below), add the pad dwords, note which reads hold an 'N'
       const unsigned lane = unsigned(wv::lane());
       const uint64_t plShiftR = plShift(locus, 0), plShiftC = plShift(locus, 1), plShiftM = plShift(locus, 2);
@@ -750,7 +803,7 @@ struct Assembler {
           const uint64_t bit = uint64_t(1) << (r & 63);
           for (unsigned j0 = 0; j0 + k <= len && !overflow; j0 += 64) {
             const unsigned j    = j0 + lane;
-            const unsigned pb   = cwo * 16 + j;
+            const unsigned pb   = cwo * SPD + j;
             unsigned       slot = ASM_NONE;
             bool           won  = false;
             unsigned       foundId = ASM_NONE;
@@ -839,15 +892,25 @@ struct Assembler {
       }
       // Predecessor links are not looked up: nd is the predecessor of each of its successors through nd's own first
       // base, so the successor lookups scatter them (every (word, symbol) slot has exactly one writer).
-      const unsigned firstBase = key.w[0] >> 30;
+      // (a word whose first symbol is not in the alphabet is nobody's predecessor candidate: extensions prepend A,C,G,T only)
+      const unsigned firstBase = indexOfSym(key.w[0] >> (32 - SB));
       for (unsigned c = 0; c < 4; ++c) {
         const unsigned s = sIds[c];
         recSucc(nd)[c]   = s;
-        if (s != ASM_NONE) recPred(s)[firstBase] = nd;
+        if (s != ASM_NONE && firstBase < 4) recPred(s)[firstBase] = nd;
         if (s == nd) selfLoop = true;  // homopolymer (:574-577)
       }
+      bool hasJunk = false;
+      if (SB == 8)
+        for (unsigned i = 0; i < k; ++i) hasJunk = hasJunk || indexOfSym(symAt(node_key[nd] + i)) >= 4;
+      if (SB == 8 && indexOfSym(symAt(node_key[nd] + k - 1)) >= 4) {
+        // a word that ENDS in a byte outside the alphabet is nobody's successor (extensions append A,C,G,T only), so no scatter
+        // reaches its predecessor slots: look its predecessors up (c + word[0..k-2] drops that byte and may well exist) -- the
+        // walk to the left takes them (:241-251), the successor graph of the cycle test / repeat search does not have them
+        for (unsigned c = 0; c < 4; ++c) recPred(nd)[c] = lookup<KW>(keyShiftPrepend<KW>(key, c));
+      }
       packLinks(sIds, cnt, recPacked(nd, 0)[0], recPacked(nd, 0)[1]);
-      node_flag[nd] = selfLoop ? NF_REPEAT : 0u;
+      node_flag[nd] = (selfLoop ? NF_REPEAT : 0u) | (hasJunk ? NF_JUNK : 0u);
     }
     wv::sync();
     wv::fence_acquire();
@@ -856,7 +919,7 @@ struct Assembler {
       for (unsigned c = 0; c < 4; ++c) {
         const unsigned p = recPred(nd)[c];
         pIds[c]          = p;
-        if (p != ASM_NONE && p != nd) indeg++;
+        if (p != ASM_NONE && p != nd && !(SB == 8 && ((node_flag[nd] | node_flag[p]) & NF_JUNK))) indeg++;
       }
       packLinks(pIds, node_cnt[nd], recPacked(nd, 16)[0], recPacked(nd, 16)[1]);
       node_aux[nd] = indeg;
@@ -887,6 +950,13 @@ struct Assembler {
   /// cycle.  Peeling from both ends halves the number of rounds on the (mostly linear) graphs.
   /// Per-node state = one 16-bit field {in-degree:4, out-degree:4, peeled:1}, two nodes per dword, updated with
   /// atomics; it lives in LDS when the graph is small enough (<= ASM_LDS_BYTES/2 nodes), else in global scratch.
+  /// byte-generic form only: is the edge between a and b outside the cycle test (one of them holds a non-alphabet byte)?
+  WV_DEV bool isJunk(const unsigned a, const unsigned b) const
+  {
+    if (SB != 8 || b == ASM_NONE) return false;
+    return ((node_flag[a] | node_flag[b]) & NF_JUNK) != 0;
+  }
+
   WV_DEV bool graphHasCycle()
   {
     const unsigned lane   = unsigned(wv::lane());
@@ -908,7 +978,7 @@ struct Assembler {
         unsigned od = 0, only = ASM_NONE;
         for (unsigned c = 0; c < 4; ++c) {
           const unsigned s = recSucc(nd)[c];
-          if (s != ASM_NONE && s != nd) {
+          if (s != ASM_NONE && s != nd && !isJunk(nd, s)) {
             od++;
             only = s;
           }
@@ -934,14 +1004,14 @@ struct Assembler {
       for (unsigned i = lane; i < nCur; i += 64) {
         const unsigned nd = cur[i];
         for (unsigned c = 0; c < 4; ++c) {
-          const unsigned s = recSucc(nd)[c];
+          const unsigned s = isJunk(nd, recSucc(nd)[c]) ? ASM_NONE : recSucc(nd)[c];
           if (s != ASM_NONE && s != nd) {
             const unsigned sh  = 16 * (s & 1);
             const unsigned old = wv::atomic_sub(&st[s >> 1], 1u << sh) >> sh;
             if ((old & 0xfu) == 1u && !(wv::atomic_or(&st[s >> 1], 0x100u << sh) & (0x100u << sh)))
               nxt[wv::atomic_add(&cnt[which ^ 1], 1u)] = s;
           }
-          const unsigned p = recPred(nd)[c];
+          const unsigned p = isJunk(nd, recPred(nd)[c]) ? ASM_NONE : recPred(nd)[c];
           if (p != ASM_NONE && p != nd) {
             const unsigned sh  = 16 * (p & 1);
             const unsigned old = wv::atomic_sub(&st[p >> 1], 0x10u << sh) >> sh;
@@ -1095,7 +1165,7 @@ struct Assembler {
     const unsigned seedPb = node_key[seed];
     for (unsigned i = lane; i < k; i += 64) {
       const unsigned pb = seedPb + i;
-      outSeq[i]         = "ACGT"[(codes[pb >> 4] >> (30 - 2 * (pb & 15))) & 3];
+      outSeq[i]         = charOfSym(symAt(pb));
     }
     if (seedIsRepeat) {  // :172-179
       if (lane < W) {
@@ -1114,7 +1184,7 @@ struct Assembler {
     // reads of the unselected siblings of the seed (same (k-1)-prefix) reject the contig (:185-210)
     {
       const Key<KW>  key      = keyAt<KW>(seedPb);
-      const unsigned lastBase = (codes[(seedPb + k - 1) >> 4] >> (30 - 2 * ((seedPb + k - 1) & 15))) & 3;
+      const unsigned lastBase = indexOfSym(symAt(seedPb + k - 1));
       for (unsigned c = 0; c < 4; ++c) {
         if (c == lastBase) continue;
         Key<KW> sib = key;
@@ -1234,7 +1304,7 @@ struct Assembler {
         ch = walk_left[nLeft - 1 - i];
       } else if (i < nLeft + k) {
         const unsigned pb = seedPb + (i - nLeft);
-        ch                = uint8_t("ACGT"[(codes[pb >> 4] >> (30 - 2 * (pb & 15))) & 3]);
+        ch                = charOfSym(symAt(pb));
       } else {
         ch = walk_right[i - nLeft - k];
       }
@@ -1276,7 +1346,10 @@ struct Assembler {
   {
     const bool cyclic = graphHasCycle();
     tick(3);
-    if (cyclic && countJunkReads() > 0) {  // the repeat search's visiting order would include the dropped junk words
+#ifdef MANTA_WAVE_EMU
+    if (std::getenv("MANTA_EMU_DUMP_REPEATS") && wv::lane() == 0) std::fprintf(stderr, "DEV SB=%d k=%u nodes=%u cyclic=%d\n", SB, k, nNodes, int(cyclic));
+#endif
+    if (SB == 2 && cyclic && countJunkReads() > 0) {  // the repeat search's visiting order would include the dropped junk words
       status = ASM_E_ALPHABET;
       return true;
     }
@@ -1285,6 +1358,17 @@ struct Assembler {
       exactRepeatSearch();
       tick(4);
       if (status != ASM_OK) return true;
+#ifdef MANTA_WAVE_EMU
+      if (std::getenv("MANTA_EMU_DUMP_REPEATS") && wv::lane() == 0) {
+        std::fprintf(stderr, "DEV repeats k=%u:", k);
+        for (unsigned nd = 0; nd < nNodes; ++nd)
+          if (node_flag[nd] & NF_REPEAT) {
+            std::fprintf(stderr, " ");
+            for (unsigned i = 0; i < k; ++i) std::fputc(charOfSym(symAt(node_key[nd] + i)), stderr);
+          }
+        std::fprintf(stderr, "\n");
+      }
+#endif
     }
     if (!(P.flags & ASM_FLAG_SERIAL_WALK)) {
       if (W <= 2) return contigRounds<2>();
@@ -1308,7 +1392,7 @@ struct Assembler {
 
   WV_DEV bool buildContigsForK()
   {
-    const unsigned kw = (k + 15) >> 4;
+    const unsigned kw = (k + SPD - 1) / SPD;
     if (kw <= 2) return buildContigs<2>();
     if (kw <= 4) return buildContigs<4>();
     return buildContigs<8>();
@@ -1325,7 +1409,7 @@ struct Assembler {
     for (unsigned ci = 0; ci < nCand; ++ci) {
       const unsigned len = unsigned(cand_meta[ci * 4 + 0]);
       if (!(len > k + P.opt.wordStepSize)) continue;  // :898
-      const unsigned nCw = (len + 15) / 16 + 1, nMw = (len + 31) / 32 + 1;
+      const unsigned nCw = (len + SPD - 1) / SPD + 1, nMw = (len + 31) / 32 + 1;
       if (cw + nCw + 2 > P.cap_words || mw + nMw + 2 > maskWordCap() || nNormal + nPseudo >= P.cap_reads) {
         status = ASM_E_TABLE_FULL;
         return 0;
@@ -1334,10 +1418,10 @@ struct Assembler {
       const unsigned r   = nNormal + nPseudo;
       for (unsigned wi = lane; wi < nCw; wi += 64) {
         uint32_t code = 0;
-        for (unsigned b = 0; b < 16; ++b) {
-          const unsigned i = wi * 16 + b;
-          const unsigned c = (i < len) ? baseCode(src[i]) : 0u;
-          code |= (c & 3u) << (30 - 2 * b);
+        for (unsigned b = 0; b < SPD; ++b) {
+          const unsigned i = wi * SPD + b;
+          const unsigned c = (i < len) ? ((SB == 2) ? (baseCode(src[i]) & 3u) : unsigned(src[i])) : 0u;
+          code |= c << (32 - SB - SB * b);
         }
         codes[cw + wi] = code;
       }
@@ -1529,12 +1613,12 @@ struct Assembler {
     packNormalReads(locus);
     wv::sync();
     wv::fence_acquire();
-    if (countJunkReads() >= P.opt.minCoverage && status == ASM_OK) status = ASM_E_ALPHABET;  // see packNormalReads
+    if (SB == 2 && countJunkReads() >= P.opt.minCoverage && status == ASM_OK) status = ASM_E_ALPHABET;  // see packNormalReads
     tick(0);
     W = (nNormal + 2 * P.opt.maxAssemblyCount + 63) / 64;
     if (W == 0) W = 1;
     recStride = asmRecStride(W);
-    if (status == ASM_OK && (maxWL > 16u * ASM_MAX_KW || minWL == 0)) status = ASM_E_WORD_TOO_LONG;
+    if (status == ASM_OK && (maxWL > MAX_K || minWL == 0)) status = ASM_E_WORD_TOO_LONG;
     if (status == ASM_OK && 2 * P.opt.maxAssemblyCount > ASM_MAX_CAND) status = ASM_E_INTERNAL;
 
     nReads            = nNormal;
@@ -1563,6 +1647,8 @@ struct Assembler {
 #endif
   }
 };
+
+typedef AssemblerT<2> Assembler;  ///< the production form: 2-bit codes
 
 }  // namespace manta_dev
 
@@ -1614,6 +1700,35 @@ WV_KERNEL_OCC(MANTA_ASM_OCC) void assemble_kernel(const AsmParams P)
     if (arrived) {
       a.run(locus);
     } else if (wv::lane() == 0) {  // the chunk never arrived: report, do not hang
+      AsmLocusOut out;
+      out.status = ASM_E_INTERNAL;
+      out.n_contigs = out.n_words = out.n_pseudo = 0;
+      out.pseudo_off = out.pseudo_len_off = 0;
+      out.final_word_length = out.n_iterations = out.cyclic_iterations = out.reserved = 0;
+      P.loci[locus] = out;
+    }
+    wv::sync();
+  }
+}
+
+/// the byte-generic form (AssemblerT<8>) for the loci assemble_kernel reports ASM_E_ALPHABET for: same launch contract; the
+/// workspace capacities count code dwords of 4 symbols.  Rare by construction (a byte outside {A,C,G,T,N} that cannot be
+/// masked exactly), so this kernel is about being right, not fast.
+WV_KERNEL_OCC(MANTA_ASM_OCC) void assemble_generic_kernel(const AsmParams P)
+{
+  uint8_t*       wsBase = P.ws + uint64_t(wv::block()) * P.ws_stride;
+  const unsigned nLoci  = P.n_loci_dev ? wv::first(wv::atomic_load(P.n_loci_dev)) : P.n_loci;
+  while (true) {
+    unsigned slot = 0;
+    if (wv::lane() == 0) slot = wv::atomic_add(P.counter, 1u);
+    slot = wv::first(slot);
+    if (slot >= nLoci) break;
+    const unsigned locus = P.locus_ids ? P.locus_ids[slot] : slot;
+    AssemblerT<8>  a(P, wsBase);
+    const bool     arrived = !P.upload_chunks_done || asmWaitUploaded(P, locus);
+    if (arrived) {
+      a.run(locus);
+    } else if (wv::lane() == 0) {
       AsmLocusOut out;
       out.status = ASM_E_INTERNAL;
       out.n_contigs = out.n_words = out.n_pseudo = 0;

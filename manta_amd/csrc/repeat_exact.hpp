@@ -26,32 +26,36 @@ WV_DEV uint64_t murmurShiftMix(const uint64_t v)
   return v ^ (v >> 47);
 }
 
-/// 64-bit little-endian word of ASCII bases i..i+n-1 (n <= 8) of the k-mer starting at packed base index pb
+/// 64-bit little-endian word of the characters i..i+n-1 (n <= 8) of the k-mer starting at packed base index pb
+/// (SB = 2: base codes, 16 per dword; SB = 8: the bytes themselves, 4 per dword)
+template <int SB>
 WV_DEV uint64_t asciiChunk(const uint32_t* codes, const unsigned pb, const unsigned i, const unsigned n)
 {
-  uint64_t data = 0;
+  const unsigned spd  = 32u / SB;
+  uint64_t       data = 0;
   for (unsigned b = 0; b < n; ++b) {
     const unsigned p = pb + i + b;
-    const unsigned c = (codes[p >> 4] >> (30 - 2 * (p & 15))) & 3;
-    data |= uint64_t(uint8_t("ACGT"[c])) << (8 * b);
+    const unsigned c = (codes[p / spd] >> (32 - SB - SB * (p % spd))) & ((1u << SB) - 1u);
+    data |= uint64_t((SB == 2) ? uint8_t("ACGT"[c & 3u]) : uint8_t(c)) << (8 * b);
   }
   return data;
 }
 
 /// std::hash<std::string> of libstdc++ (libsupc++ hash_bytes.cc, 64-bit): checked against the live library
 /// by the host at context creation and by tests/test_oracle_vs_ref.py
+template <int SB>
 WV_DEV uint64_t libstdcxxStringHash(const uint32_t* codes, const unsigned pb, const unsigned len)
 {
   const uint64_t mul  = (uint64_t(0xc6a4a793UL) << 32) + uint64_t(0x5bd1e995UL);
   uint64_t       hash = uint64_t(0xc70f6907UL) ^ (uint64_t(len) * mul);
   const unsigned lenAligned = len & ~7u;
   for (unsigned i = 0; i < lenAligned; i += 8) {
-    const uint64_t data = murmurShiftMix(asciiChunk(codes, pb, i, 8) * mul) * mul;
+    const uint64_t data = murmurShiftMix(asciiChunk<SB>(codes, pb, i, 8) * mul) * mul;
     hash ^= data;
     hash *= mul;
   }
   if (len & 7u) {
-    hash ^= asciiChunk(codes, pb, lenAligned, len & 7u);
+    hash ^= asciiChunk<SB>(codes, pb, lenAligned, len & 7u);
     hash *= mul;
   }
   hash = murmurShiftMix(hash) * mul;
@@ -159,7 +163,8 @@ WV_DEV uint32_t* unorderedOrderWave(
   return cur;
 }
 
-WV_DEV_COLD void Assembler::exactRepeatSearch()
+template <int SB>
+WV_DEV_COLD void AssemblerT<SB>::exactRepeatSearch()
 {
   static const int KW = ASM_MAX_KW;
   const unsigned lane = unsigned(wv::lane());
@@ -205,7 +210,7 @@ WV_DEV_COLD void Assembler::exactRepeatSearch()
     }
     firstRd[nd] = fr;
     wv::atomic_add(&grpCnt[fr], 1u);
-    h[nd] = libstdcxxStringHash(codes, node_key[nd], k);
+    h[nd] = libstdcxxStringHash<SB>(codes, node_key[nd], k);
   }
   wv::sync();
   wv::fence_acquire();

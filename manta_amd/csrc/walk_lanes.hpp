@@ -21,7 +21,8 @@ namespace manta_dev {
 /// '>' on the count, :689-696).  Top-T selection without a sort: compact the unused words once, find the count level
 /// and then the 16-base-prefix threshold that cut off T words by two binary searches over coalesced arrays, gather
 /// the (about T) survivors and order only those exactly.
-WV_DEV unsigned Assembler::selectTentative(const unsigned T)
+template <int SB>
+WV_DEV unsigned AssemblerT<SB>::selectTentative(const unsigned T)
 {
   static const int KW = ASM_MAX_KW;
   const unsigned lane = unsigned(wv::lane());
@@ -229,8 +230,9 @@ struct StepData {
 ///   * the lane-private visited bitmaps live in LDS when they fit.
 /// All lanes execute the same instruction stream (finished lanes are predicated off), so the wave-level votes that
 /// skip empty candidate slots are convergent.
+template <int SB>
 template <int WQ>
-WV_DEV void Assembler::walkLanes(const unsigned nT)
+WV_DEV void AssemblerT<SB>::walkLanes(const unsigned nT)
 {
   static const int KW = ASM_MAX_KW;
   const unsigned lane     = unsigned(wv::lane());
@@ -267,7 +269,7 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
     } else {  // unselected siblings of the seed reject the contig (:185-210)
       const unsigned seedPb   = node_key[seed];
       const Key<KW>  key      = keyAt<KW>(seedPb);
-      const unsigned lastBase = (codes[(seedPb + k - 1) >> 4] >> (30 - 2 * ((seedPb + k - 1) & 15))) & 3;
+      const unsigned lastBase = indexOfSym(symAt(seedPb + k - 1));
       for (unsigned c = 0; c < 4; ++c) {
         if (c == lastBase) continue;
         Key<KW> sib = key;
@@ -518,8 +520,9 @@ WV_DEV void Assembler::walkLanes(const unsigned nT)
 }
 
 /// buildContigs' contig loop (:685-713) by speculative rounds.  Returns isAssemblySuccess.
+template <int SB>
 template <int WQ>
-WV_DEV bool Assembler::contigRounds()
+WV_DEV bool AssemblerT<SB>::contigRounds()
 {
   const unsigned lane     = unsigned(wv::lane());
   const unsigned capCand  = 2 * P.opt.maxAssemblyCount;
@@ -562,18 +565,17 @@ WV_DEV bool Assembler::contigRounds()
       const uint32_t* rightBuf = reinterpret_cast<const uint32_t*>(lane_seq) + size_t(t) * 2 * seqWords;
       const uint32_t* leftBuf  = rightBuf + seqWords;
       for (unsigned i = lane; i < len; i += 64) {
-        unsigned code;
+        uint8_t ch;  // (the walked bases are alphabet symbols, 2 bits each; the seed's text comes from the pile)
         if (i < nLeft) {
           const unsigned j = nLeft - 1 - i;
-          code             = (leftBuf[j >> 4] >> (2 * (j & 15))) & 3;
+          ch               = uint8_t("ACGT"[(leftBuf[j >> 4] >> (2 * (j & 15))) & 3]);
         } else if (i < nLeft + k) {
-          const unsigned pb = seedPb + (i - nLeft);
-          code              = (codes[pb >> 4] >> (30 - 2 * (pb & 15))) & 3;
+          ch = charOfSym(symAt(seedPb + (i - nLeft)));
         } else {
           const unsigned j = i - nLeft - k;
-          code             = (rightBuf[j >> 4] >> (2 * (j & 15))) & 3;
+          ch               = uint8_t("ACGT"[(rightBuf[j >> 4] >> (2 * (j & 15))) & 3]);
         }
-        outSeq[i] = uint8_t("ACGT"[code]);
+        outSeq[i] = ch;
       }
       if (lane < 2 * W) {
         const unsigned half = lane / W, w = lane % W;

@@ -19,6 +19,8 @@
 #include <atomic>
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <set>
@@ -354,6 +356,12 @@ static void repeatNodes(const KmerGraph& g, std::vector<bool>& isRepeat)
         low[p]      = std::min(low[p], low[n]);
       }
     }
+  }
+  if (std::getenv("MANTA_ORACLE_DUMP_REPEATS")) {  // developer aid: compare with the emulator build's MANTA_EMU_DUMP_REPEATS
+    std::fprintf(stderr, "ORC repeats k=%u:", g.k);
+    for (size_t n = 0; n < g.key.size(); ++n)
+      if (isRepeat[n]) std::fprintf(stderr, " %s", g.key[n].c_str());
+    std::fprintf(stderr, "\n");
   }
 }
 
