@@ -395,13 +395,16 @@ def main():
             dom_note = "one launch per block"
         avg_launch_ms = dom_ms / dom_launches
         achieved = (dom_bytes / dom_launches) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        traffic = None
+        # roofline.traffic is NOT measured in this run: it is the HBM-side byte count of the builder's own rocprofv3 --pmc passes
+        # (tools/profile_round.sh -> profiles/traffic*.json), quoted with its source and date
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_spanning.json" if spanning else "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("loci") == n_loci and tj.get("workload", "smallsv") == args.workload:
                     traffic = tj.get(dom)
+                    traffic_source = "%s: %s, %s" % (os.path.relpath(tpath, ROOT), tj.get("source", "builder-run rocprofv3 --pmc passes"), tj.get("date", "round 2"))
             except Exception:
                 traffic = None
         o = {
@@ -422,7 +425,7 @@ def main():
                        "mix": bool(args.mix and node_queue),
                        "parity": "%d loci vs %s: 0 mismatches" % (checked, how)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": int(dom_bytes / dom_launches), "avg_launch_ms": round(avg_launch_ms, 3),
                          "launches": dom_launches, "note": dom_note},
             "kernels_ms_per_step": {"assemble_kernel": round(asm_sum / steps, 3), "schedule_kernel": round(acc["schedule_ms"] / steps, 3),

@@ -579,6 +579,10 @@ struct AsmStage {
     capWords                   = uint32_t(maxLocusWords + pseudoBases / 16 + 2 * nCandMax + 8);
     capReads                   = maxLocusReads + nCandMax + 1;
     capNodes                   = uint32_t(maxLocusBases + pseudoBases + 64);
+    if (const char* e = std::getenv("MANTA_AMD_ASM_NODE_DIV")) {  // experiment: typical-case node capacity = bases / div (overflows run again, rerunCapacityFailures)
+      const uint64_t div = uint64_t(std::max(1, std::atoi(e)));
+      capNodes           = uint32_t(std::max<uint64_t>(1024, (maxLocusBases + pseudoBases) / div + 64));
+    }
     if (capNodes >= LINK_NONE21) return fail(ctx, MANTA_E_UNSUPPORTED, "a locus with more than ~2M read bases is not supported");
     capSlots                   = nextPow2(2ull * capNodes);
     const AsmWsLayout L = asmWorkspaceLayout(capSlots, capNodes, capWords, capReads, maxContigLen, wMax, opt.max_assembly_count);

@@ -1339,6 +1339,10 @@ struct AssemblerT {
   {
     buildGraph<KW>();
     if (status != ASM_OK) return true;
+#ifdef MANTA_ASM_STOP_AFTER_GRAPH  // timing experiments only (tools/ab_probe.py): pack + table + links, no contigs
+    nCand = 0;
+    return true;
+#endif
     return contigsFromGraph();
   }
 

@@ -4,7 +4,7 @@ rocprofv3 kernel-stats table, one PMC row per kernel, and profiles/traffic.json 
 reports as roofline.traffic)."""
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 
@@ -23,6 +23,46 @@ if os.path.exists(sp) and os.path.getsize(sp):
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     open(os.path.join(dst, tag + "_bench_kernel_stats.csv"), "w").write(open(stats[0]).read())
+# the spanning workload's kernel stats (round 2 forgot to copy them: the committed file was a stale one)
+sstats = glob.glob(os.path.join(src, "stats_spanning", "**", "*kernel_stats.csv"), recursive=True)
+if sstats:
+    open(os.path.join(dst, tag + "_bench_spanning_kernel_stats.csv"), "w").write(open(sstats[0]).read())
+# one kernel trace of the default step (start / end of every dispatch: the host turnarounds between kernels are the gaps)
+trace = glob.glob(os.path.join(src, "trace_step", "**", "*kernel_trace.csv"), recursive=True)
+if trace:
+    rows = list(csv.DictReader(open(trace[0])))
+    t0 = min(int(r["Start_Timestamp"]) for r in rows)
+    with open(os.path.join(dst, tag + "_step_kernel_trace.csv"), "w") as out:
+        out.write("# rocprofv3 --kernel-trace of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras`: every dispatch, ms since the first\n")
+        out.write("kernel,start_ms,end_ms,duration_ms,stream,lds_bytes,vgpr,scratch\n")
+        for r in rows:
+            a, b = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
+            out.write('"%s",%.3f,%.3f,%.3f,%s,%s,%s,%s\n' % (short(r["Kernel_Name"]), a, b, b - a, r.get("Stream_Id", ""), r.get("LDS_Block_Size", ""),
+                                                            r.get("VGPR_Count", ""), r.get("Scratch_Size", "")))
+# the opt-in fast assembler's lines and counters (tools/profile_round.sh: MANTA_AMD_ASM_PATH=fast)
+fl = os.path.join(src, "fast", "bench_line.json")
+if os.path.exists(fl) and os.path.getsize(fl):
+    open(os.path.join(dst, tag + "_fast_path_bench_line.json"), "w").write(open(fl).read().strip().splitlines()[-1] + "\n")
+fper, flaunch = {}, {}
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    for f in glob.glob(os.path.join(src, "fast", d, "**", "*counter_collection.csv"), recursive=True):
+        seen = {}
+        for row in csv.DictReader(open(f)):
+            k = short(row["Kernel_Name"])
+            if "rocclr" in k:
+                continue
+            fper.setdefault(k, {}).setdefault(row["Counter_Name"], 0.0)
+            fper[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            seen.setdefault(k, set()).add(row.get("Dispatch_Id", row.get("Correlation_Id", "")))
+        for k, ids in seen.items():
+            flaunch[k] = max(flaunch.get(k, 0), len(ids))
+if fper:
+    fcols = sorted({c for v in fper.values() for c in v})
+    with open(os.path.join(dst, tag + "_fast_path_pmc_summary.csv"), "w") as out:
+        out.write("# same passes with MANTA_AMD_ASM_PATH=fast (assemble_fast_kernel + the general kernel for its punts)\n")
+        out.write("kernel,launches," + ",".join(fcols) + "\n")
+        for k in sorted(fper):
+            out.write('"%s",%d,' % (k, flaunch.get(k, 1)) + ",".join("%.0f" % fper[k].get(c, 0) for c in fcols) + "\n")
 per, launches = {}, {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     for f in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
@@ -45,7 +85,8 @@ with open(os.path.join(dst, tag + "_pmc_summary.csv"), "w") as out:
     out.write("kernel,launches," + ",".join(cols) + "\n")
     for k in sorted(per):
         out.write('"%s",%d,' % (k, launches.get(k, 1)) + ",".join("%.0f" % per[k].get(c, 0) for c in cols) + "\n")
-traffic = {"loci": 10000, "workload": "smallsv",
+traffic = {"loci": 10000, "workload": "smallsv", "source": "tools/profile_round.sh " + tag + " (builder-run counter passes, not the driver's run)",
+           "date": __import__("datetime").date.today().isoformat(),
            "note": "HBM-side bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB * 1024 / launches, rocprofv3 --pmc, separate passes, raw "
                    "(no gfx950 x2 read correction: narrow scattered reads); align_kernel: the E-bucket launches of one block together"}
 agg = {}
