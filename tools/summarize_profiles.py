@@ -115,7 +115,7 @@ if sper:
     span_loci = 65536
     if os.path.exists(sp) and os.path.getsize(sp):
         span_loci = json.loads(open(sp).read().strip().splitlines()[-1])["config"]["loci_per_gpu"]
-    st = {"loci": span_loci, "workload": "spanning", "note": traffic["note"]}
+    st = {"loci": span_loci, "workload": "spanning", "source": traffic["source"], "date": traffic["date"], "note": traffic["note"]}
     for k, v in sper.items():
         name = "align_kernel<JUMP>" if k.startswith("align_kernel<2") else k
         n = 1 if name.startswith("align_kernel") else max(1, slaunch.get(k, 1))
