@@ -385,6 +385,17 @@ int asmStatusToAbi(int st)
 const unsigned kSharedAsmLds = 4608;
 
 /// One batch of loci through assemble_kernel: sizing, staging, launch, fetch.
+/// wavefronts per workgroup of assemble_fast_kernel.  Three workgroups fit a CU's LDS; at the kernel's ~200 VGPRs a SIMD holds
+/// two waves, so teams of two (6 waves per CU) keep all three workgroups resident -- measured 12.9 ms per 10 000 config-2 loci
+/// against 14.9 ms for teams of four (only two workgroups resident) and 17.2 ms for single waves.  MANTA_AMD_FAST_TEAM = 1..4
+/// overrides (experiments).
+static int fastTeam()
+{
+  const char* e = std::getenv("MANTA_AMD_FAST_TEAM");  // (read at every launch: the tests switch it)
+  const int   v = e ? std::atoi(e) : 2;
+  return (v >= 1 && v <= int(FA_TEAM)) ? v : 2;
+}
+
 struct AsmStage {
   manta_ctx_t* ctx;
   explicit AsmStage(manta_ctx_t* c) : ctx(c) { g_liveWorkspaces++; }
@@ -923,10 +934,10 @@ struct AsmStage {
           rt::launch(assemble_kernel, gridShare, kSharedAsmLds, G);
           evJoin.record();
         }
-        rt::launchSingle(assemble_fast_kernel, gridFast, FA_BUDGET, F);
+        rt::launchWG(assemble_fast_kernel, gridFast, fastTeam(), FA_BUDGET, F);
         rt::curStreamWaits(evJoin);
       } else {
-        rt::launchSingle(assemble_fast_kernel, gridFast, FA_BUDGET, F);
+        rt::launchWG(assemble_fast_kernel, gridFast, fastTeam(), FA_BUDGET, F);
       }
       P.locus_ids  = dPunt;
       P.n_loci     = nLoci;

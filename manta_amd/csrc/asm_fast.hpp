@@ -40,6 +40,10 @@ static const unsigned FA_EMPTY      = 0xffffffffu;
 static const unsigned FA_ID_PENDING = 0x7ffu;             // slot claimed, node id not assigned yet
 static const unsigned FA_FAT        = 0x800u;             // support reference (12 bits): index into the bitset pool (else: a read)
 static const unsigned FA_NO_SLOT    = 0xffffu;
+#ifndef MANTA_FAST_TEAM
+#define MANTA_FAST_TEAM 4
+#endif
+static const unsigned FA_TEAM       = MANTA_FAST_TEAM;    // wavefronts that share one locus (the launch may use fewer)
 
 // fixed part of the LDS map (bytes)
 static const unsigned FA_OFF_SLOTS  = 0;
@@ -49,7 +53,24 @@ static const unsigned FA_OFF_TENT   = FA_OFF_REPEAT + 256;           // u16[128]
 static const unsigned FA_OFF_SLOTND = FA_OFF_TENT + 256;             // u16[64]: word walked by cache slot s
 static const unsigned FA_OFF_RD     = FA_OFF_SLOTND + 128;           // read descriptors {code dword offset : 11, length : 16, has N : 1}
 static const unsigned FA_OFF_RDM    = FA_OFF_RD + 4 * FA_MAX_READS;  // u16[128]: N-bitmap dword offset of a read
-static const unsigned FA_OFF_DYN    = FA_OFF_RDM + 2 * FA_MAX_READS; // codes, N bitmap, nodes ... pool
+static const unsigned FA_OFF_HDR    = FA_OFF_RDM + 2 * FA_MAX_READS; // u32[16]: what the waves of the workgroup share (FA_H_*)
+static const unsigned FA_OFF_DYN    = FA_OFF_HDR + 64;              // codes, N bitmap, nodes ... pool
+// header words
+enum {
+  FA_H_ALLOC = 0,  ///< node records in use | bitsets in use << 16 | "does not fit" << 31: one word, so that a reservation sees both ends
+  FA_H_FLAG  = 1,  ///< pack: a byte outside the alphabet was seen
+  FA_H_SLOT  = 2,  ///< kernel loop: the queue slot of the workgroup's current locus
+  FA_H_CMD   = 3,  ///< what the first wave asks the team to do next (FA_CMD_*), with two arguments
+  FA_H_ARG0  = 4,
+  FA_H_ARG1  = 5,
+  FA_H_ARG2  = 6,
+  FA_H_ACC0  = 7,  ///< accumulators of the team operations (counts, maxima)
+  FA_H_ACC1  = 8,
+  FA_H_BEST  = 12  ///< [4] selectSeed: the best word of each wave of the team
+};
+// team operations: after the graph is built the first wave runs the contig loop; the other waves of the team wait for these
+enum { FA_CMD_EXIT = 0, FA_CMD_SEED = 1, FA_CMD_TENT = 2 };
+static const uint32_t FA_ALLOC_FAIL = 0x80000000u;
 
 struct alignas(16) FRec {
   uint64_t w0;  ///< successor links 4 x 11 (id+1; packed from field 0 up in A,C,G,T order, 0 ends the list) | count << 44 (8 bit) | first occurrence, low 12 bits << 52
@@ -80,7 +101,8 @@ struct FastAsm {
   Assembler&       A;  // HBM workspace views (walk results per cache slot), parameters
   const AsmParams& P;
   char*            lds;
-  uint32_t *       slots, *unused_bits, *repeat_bits, *rd, *codes, *nmask;
+  uint32_t *       slots, *unused_bits, *repeat_bits, *rd, *codes, *nmask, *hdr;
+  unsigned         tw, tn;  // this wave's index in the workgroup's team and the team's size (waves that share the locus)
   uint16_t *       tent, *slotNode, *rdm;
   FRec*            nodes;
   unsigned         nNormal, W, k, nNodes, nodesOff, poolCount, nCand;
@@ -92,15 +114,25 @@ struct FastAsm {
   {
 #ifdef MANTA_ASM_PROFILE
     const uint64_t now = wv::clock();
-    if (P.phase_cycles && wv::lane() == 0) wv::atomic_add(&P.phase_cycles[phase], (unsigned long long)(now - tMark));
+    if (P.phase_cycles && tw == 0 && wv::lane() == 0) wv::atomic_add(&P.phase_cycles[phase], (unsigned long long)(now - tMark));
     tMark = now;
 #else
     (void)phase;
 #endif
   }
 
+  /// every wave of the team has written what the others read next
+  WV_DEV void teamSync() const
+  {
+    wv::sync();
+    if (tn > 1) wv::wg_barrier();
+  }
+
   WV_DEV FastAsm(Assembler& a, char* ldsBase) : A(a), P(a.P), lds(ldsBase)
   {
+    tw          = unsigned(wv::wave_in_wg());
+    tn          = unsigned(wv::wg_waves());
+    hdr         = reinterpret_cast<uint32_t*>(lds + FA_OFF_HDR);
     slots       = reinterpret_cast<uint32_t*>(lds + FA_OFF_SLOTS);
     unused_bits = reinterpret_cast<uint32_t*>(lds + FA_OFF_UNUSED);
     repeat_bits = reinterpret_cast<uint32_t*>(lds + FA_OFF_REPEAT);
@@ -251,7 +283,7 @@ struct FastAsm {
         }
       }
       const unsigned cwo = cw + sc - myC, mwo = mw + sm - myM;
-      if (r < nNormal && cwo <= 0x7ffu) {
+      if (tw == 0 && r < nNormal && cwo <= 0x7ffu) {
         rd[r]  = cwo | ((len & 0xffffu) << 11);
         rdm[r] = uint16_t(mwo);
       }
@@ -263,10 +295,12 @@ struct FastAsm {
     nodesOff = FA_OFF_DYN + 4 * (((cw + 2 + 3) & ~3u) + ((mw + 2 + 3) & ~3u));
     if (nodesOff + 4096 > FA_BUDGET) return false;
     nodes = reinterpret_cast<FRec*>(lds + nodesOff);
-    for (unsigned i = lane; i < mw + 2; i += 64) nmask[i] = 0;
-    wv::sync();
+    for (unsigned i = lane + 64 * tw; i < mw + 2; i += 64 * tn) nmask[i] = 0;
+    if (tw == 0 && lane == 0) hdr[FA_H_FLAG] = 0;
+    teamSync();
+    // (the reads are dealt out to the team's waves eight at a time)
     if (P.pl_codes) {  // packed piles arrive in this layout: copy, 8 lanes per read
-      for (unsigned base = 0; base < nNormal; base += 8) {
+      for (unsigned base = 8 * tw; base < nNormal; base += 8 * tn) {
         const unsigned r = base + (lane >> 3);
         if (r >= nNormal) continue;
         const unsigned  d = rd[r], cwo = d & 0x7ffu, len = (d >> 11) & 0xffffu, mwo = rdm[r];
@@ -282,13 +316,13 @@ struct FastAsm {
         }
         if (sawN) wv::atomic_or(&rd[r], 1u << 27);
       }
-      wv::sync();
+      teamSync();
       return true;
     }
     bool           bad   = false;
     const uint32_t shift = P.chunk_shift ? P.chunk_shift[locus / P.chunk_loci] : 0u;
     // 8 lanes per read, 8 reads per pass: lane (g, i) converts code dwords i, i+8, ... of read (base + g)
-    for (unsigned base = 0; base < nNormal; base += 8) {
+    for (unsigned base = 8 * tw; base < nNormal; base += 8 * tn) {
       const unsigned r = base + (lane >> 3);
       if (r >= nNormal) continue;
       const uint8_t* src = P.bases + P.read_off[rBegin + r] + shift;
@@ -330,9 +364,9 @@ struct FastAsm {
       }
       if (sawN) wv::atomic_or(&rd[r], 1u << 27);
     }
-    const bool anyBad = wv::any(bad);  // bytes outside {A,C,G,T,N}: the general path decides what is exact
-    wv::sync();
-    return !anyBad;
+    if (wv::any(bad) && lane == 0) wv::atomic_or(&hdr[FA_H_FLAG], 1u);  // bytes outside {A,C,G,T,N}: the general path decides what is exact
+    teamSync();
+    return wv::atomic_load(&hdr[FA_H_FLAG]) == 0;
   }
 
   // ------------------------------------------------------------------------------------------------
@@ -342,11 +376,14 @@ struct FastAsm {
   WV_DEV bool buildGraph()
   {
     const unsigned lane = unsigned(wv::lane());
-    for (unsigned s = lane; s < FA_SLOTS; s += 64) slots[s] = FA_EMPTY;
-    poolCount = 0;
-    nNodes    = 0;
-    wv::sync();
-    bool fail = false;
+    for (unsigned s = lane + 64 * tw; s < FA_SLOTS; s += 64 * tn) slots[s] = FA_EMPTY;
+    if (tw == 0 && lane == 0) hdr[FA_H_ALLOC] = 0;
+    teamSync();
+    // The reads are dealt out to the team's waves (read r: wave r mod team size); slots, records and bitsets are shared.
+    // Node records grow up from nodesOff, bitsets down from the end of the budget: both counts live in one header word, so
+    // the atomic that reserves either sees where the other end stands (FA_ALLOC_FAIL set by whoever does not fit).
+    const uint64_t below = (uint64_t(1) << lane) - 1;
+    bool           fail  = false;
     for (unsigned rBase = 0; rBase < nNormal && !fail; rBase += 64) {
       // descriptors of up to 64 reads in lane registers; v_readlane hands them out per read
       const unsigned rMine = rBase + lane;
@@ -355,16 +392,12 @@ struct FastAsm {
       const unsigned rEnd  = (nNormal - rBase < 64) ? (nNormal - rBase) : 64u;
       for (unsigned ri = 0; ri < rEnd && !fail; ++ri) {
         const unsigned r = rBase + ri;
+        if (r % tn != tw) continue;
         const unsigned d = wv::readlane(dV, int(ri)), cwo = d & 0x7ffu, len = (d >> 11) & 0xffffu;
         if (len < k) continue;  // :522
         const bool     rdHasN = (d >> 27) & 1u;
         const unsigned mwo    = wv::readlane(mV, int(ri));
         for (unsigned j0 = 0; j0 + k <= len; j0 += 64) {
-          // room for this step's worst case: 64 new records below, 64 new bitsets above
-          if (nodesOff + 16 * (nNodes + 64) + 16 * (poolCount + 64) > FA_BUDGET || nNodes + 64 > FA_MAX_NODES) {
-            fail = true;
-            break;
-          }
           const unsigned j    = j0 + lane;
           const unsigned pb   = cwo * 16 + j;
           bool           have = false, won = false;
@@ -405,60 +438,111 @@ struct FastAsm {
             }
             if (!have) fail = true;  // table full (cannot happen below FA_MAX_NODES)
           }
-          const uint64_t m  = wv::ballot(won);
-          const unsigned id = nNodes + unsigned(wv::popc(m & ((uint64_t(1) << lane) - 1)));
-          nNodes += unsigned(wv::popc(m));
-          if (won) {
-            slots[slot] = (mine & ~(0x7ffu << 15)) | (id << 15);
-            FRec rec;
-            rec.w0    = uint64_t(pb & 0xfffu) << 52;
-            rec.w1    = (uint64_t(r) << 44) | (uint64_t(firstLast) << 56) | (uint64_t(pb >> 12) << 60);  // support = {r}
-            nodes[id] = rec;
-          }
-          if (m) wv::sync();
-          // add read r to the support of the words that existed already
-          bool     needFat = false;
-          uint32_t curHi   = 0;
-          uint32_t* hi     = nullptr;
-          if (have && !won) {
-            if (foundId == FA_ID_PENDING) foundId = (wv::atomic_load(&slots[slot]) >> 15) & 0x7ffu;
-            hi                 = reinterpret_cast<uint32_t*>(&nodes[foundId].w1) + 1;
-            curHi              = wv::atomic_load(hi);
-            const unsigned ref = (curHi >> 12) & 0xfffu;
-            if (ref & FA_FAT) {
-              unsigned long long* w = reinterpret_cast<unsigned long long*>(&pool(ref & 0x7ffu)->w[r >> 6]);
-              wv::atomic_or(w, (unsigned long long)(uint64_t(1) << (r & 63)));
-            } else if (ref != r) {
-              needFat = true;  // second read of a so far single-read word: it gets a bitset
+          // new words: records reserved for the whole step with one atomic; the record is written before the slot names it
+          const uint64_t m = wv::ballot(won);
+          if (m) {
+            const unsigned c   = unsigned(wv::popc(m));
+            unsigned       old = 0;
+            if (lane == 0) old = wv::atomic_add(&hdr[FA_H_ALLOC], c);
+            old               = wv::first(old);
+            const unsigned n0 = old & 0x7fffu, p0 = (old >> 16) & 0x7fffu;
+            if ((old & FA_ALLOC_FAIL) || nodesOff + 16 * (n0 + c) + 16 * p0 > FA_BUDGET || n0 + c > FA_MAX_NODES) {
+              fail = true;
+            } else if (won) {
+              const unsigned id = n0 + unsigned(wv::popc(m & below));
+              FRec           rec;
+              rec.w0    = uint64_t(pb & 0xfffu) << 52;
+              rec.w1    = (uint64_t(r) << 44) | (uint64_t(firstLast) << 56) | (uint64_t(pb >> 12) << 60);  // support = {r}
+              nodes[id] = rec;
+              wv::fence_wg();
+              wv::atomic_store(&slots[slot], (mine & ~(0x7ffu << 15)) | (id << 15));
             }
+            wv::sync();
           }
-          const uint64_t mf = wv::ballot(needFat);
-          if (mf) {
+          if (wv::any(fail)) {
+            fail = true;
+            if (lane == 0) wv::atomic_or(&hdr[FA_H_ALLOC], FA_ALLOC_FAIL);
+            break;
+          }
+          // add read r to the support of the words that existed already.  A slot may still carry the pending id (claimed by
+          // another wave -- or a twin lane -- that has not named its record yet): wait for it.
+          bool todo = have && !won;
+          while (wv::any(todo && foundId == FA_ID_PENDING)) {
+            if (todo && foundId == FA_ID_PENDING) foundId = (wv::atomic_load(&slots[slot]) >> 15) & 0x7ffu;
+            if (wv::atomic_load(&hdr[FA_H_ALLOC]) & FA_ALLOC_FAIL) {
+              fail = true;
+              break;
+            }
+            if (wv::any(todo && foundId == FA_ID_PENDING)) wv::spin();
+          }
+          if (wv::any(fail)) {
+            fail = true;
+            break;
+          }
+          wv::fence_wg();
+          // A word starts with its first read's index in the record; the second read gives it a bitset.  Several lanes (of
+          // several waves) may find the same word at that point: each brings a bitset, one compare-and-swap wins, the others
+          // find the winner's bitset on their next turn and add their read there (their own bitset stays unused).
+          unsigned myF = ASM_NONE;
+          while (wv::any(todo)) {
+            bool      needFat = false;
+            uint32_t  curHi   = 0;
+            uint32_t* hi      = nullptr;
+            if (todo) {
+              hi                 = reinterpret_cast<uint32_t*>(&nodes[foundId].w1) + 1;
+              curHi              = wv::atomic_load(hi);
+              const unsigned ref = (curHi >> 12) & 0xfffu;
+              if (ref & FA_FAT) {
+                unsigned long long* w = reinterpret_cast<unsigned long long*>(&pool(ref & 0x7ffu)->w[r >> 6]);
+                wv::atomic_or(w, (unsigned long long)(uint64_t(1) << (r & 63)));
+                todo = false;
+              } else if (ref == r) {
+                todo = false;
+              } else {
+                needFat = true;
+              }
+            }
+            const uint64_t mf = wv::ballot(needFat && myF == ASM_NONE);
+            if (mf) {
+              const unsigned c   = unsigned(wv::popc(mf));
+              unsigned       old = 0;
+              if (lane == 0) old = wv::atomic_add(&hdr[FA_H_ALLOC], c << 16);
+              old               = wv::first(old);
+              const unsigned n0 = old & 0x7fffu, p0 = (old >> 16) & 0x7fffu;
+              if ((old & FA_ALLOC_FAIL) || nodesOff + 16 * n0 + 16 * (p0 + c) > FA_BUDGET || p0 + c > 0x7ffu) {
+                fail = true;
+                if (lane == 0) wv::atomic_or(&hdr[FA_H_ALLOC], FA_ALLOC_FAIL);
+                break;
+              }
+              if (needFat && myF == ASM_NONE) myF = p0 + unsigned(wv::popc(mf & below));
+            }
             if (needFat) {
-              const unsigned f   = poolCount + unsigned(wv::popc(mf & ((uint64_t(1) << lane) - 1)));
               const unsigned ref = (curHi >> 12) & 0xfffu;
               FSet           v;
               v.w[0] = ((ref < 64) ? (uint64_t(1) << ref) : 0) | ((r < 64) ? (uint64_t(1) << r) : 0);
               v.w[1] = ((ref >= 64) ? (uint64_t(1) << (ref - 64)) : 0) | ((r >= 64) ? (uint64_t(1) << (r - 64)) : 0);
-              *pool(f) = v;
-              const uint32_t want = (curHi & ~(0xfffu << 12)) | ((FA_FAT | f) << 12);
-              // (a twin of this k-mer in the same read may get there first: its bitset holds the same two reads; ours is abandoned)
-              wv::atomic_cas(hi, curHi, want);
+              *pool(myF) = v;
+              wv::fence_wg();
+              const uint32_t want = (curHi & ~(0xfffu << 12)) | ((FA_FAT | myF) << 12);
+              if (wv::atomic_cas(hi, curHi, want) == curHi) todo = false;
             }
-            poolCount += unsigned(wv::popc(mf));
             wv::sync();
           }
-          if (wv::any(fail)) fail = true;
           if (fail) break;
         }
       }
     }
-    wv::sync();
-    if (fail) return false;
+    teamSync();
+    {
+      const uint32_t al = wv::atomic_load(&hdr[FA_H_ALLOC]);
+      if (al & FA_ALLOC_FAIL) return false;
+      nNodes    = al & 0x7fffu;
+      poolCount = (al >> 16) & 0x7fffu;
+    }
     tick(1);
 
     // counts, successor lookups, predecessor scatter
-    for (unsigned nb = 0; nb < nNodes; nb += 64) {
+    for (unsigned nb = 64 * tw; nb < nNodes; nb += 64 * tn) {
       const unsigned nd = nb + lane;
       if (nd < nNodes) {
         const FRec     rec = nodes[nd];
@@ -482,9 +566,9 @@ struct FastAsm {
         if (selfLoop) wv::atomic_or(&repeat_bits[nd >> 5], 1u << (nd & 31));
       }
     }
-    wv::sync();
+    teamSync();
     // predecessor lists packed like the successor lists (the scatter above addressed them by symbol)
-    for (unsigned nd = lane; nd < nNodes; nd += 64) {
+    for (unsigned nd = lane + 64 * tw; nd < nNodes; nd += 64 * tn) {
       const uint64_t w1 = nodes[nd].w1;
       uint64_t       pk = 0;
       unsigned       m  = 0;
@@ -496,14 +580,13 @@ struct FastAsm {
       }
       nodes[nd].w1 = (w1 & ~((uint64_t(1) << 44) - 1)) | pk;
     }
-    wv::sync();
-    // seed eligibility (:679-682)
-    for (unsigned nb = 0; nb < ((nNodes + 63) & ~63u); nb += 64) {
+    // seed eligibility (:679-682; the counts are final since the barrier above)
+    for (unsigned nb = 64 * tw; nb < ((nNodes + 63) & ~63u); nb += 64 * tn) {
       const unsigned nd = nb + lane;
       const uint64_t m  = wv::ballot(nd < nNodes && recCnt(nodes[nd < nNodes ? nd : 0].w0) >= P.opt.minCoverage);
       if (lane < 2) unused_bits[(nb >> 5) + lane] = uint32_t(m >> (32 * lane));
     }
-    wv::sync();
+    teamSync();
     tick(2);
     return true;
   }
@@ -664,22 +747,31 @@ struct FastAsm {
   // ------------------------------------------------------------------------------------------------
   // seed order (:686-696): count descending, k-mer ascending
   // ------------------------------------------------------------------------------------------------
+  /// (a team operation: every wave of the team runs it; see command())
   template <int KW>
   WV_DEV unsigned selectSeed()
   {
-    const unsigned lane = unsigned(wv::lane());
-    unsigned       best = 0;
-    for (unsigned nd = lane; nd < nNodes; nd += 64)
+    const unsigned lane  = unsigned(wv::lane());
+    uint32_t*      bestW = hdr + FA_H_BEST;
+    if (tw == 0 && lane == 0) hdr[FA_H_ACC0] = 0;
+    teamSync();
+    unsigned best = 0;
+    for (unsigned nd = lane + 64 * tw; nd < nNodes; nd += 64 * tn)
       if (isUnused(nd)) {
         const unsigned c = recCnt(nodes[nd].w0);
         best             = (c > best) ? c : best;
       }
     best = Assembler::waveMax(best);
+    if (tn > 1) {
+      if (lane == 0) wv::atomic_max(&hdr[FA_H_ACC0], best);
+      teamSync();
+      best = wv::atomic_load(&hdr[FA_H_ACC0]);
+    }
     if (best == 0) return ASM_NONE;
     unsigned mine = ASM_NONE;
     Key<KW>  mineKey;
     for (int i = 0; i < KW; ++i) mineKey.w[i] = 0xffffffffu;
-    for (unsigned nd = lane; nd < nNodes; nd += 64) {
+    for (unsigned nd = lane + 64 * tw; nd < nNodes; nd += 64 * tn) {
       const FRec rec = nodes[nd];
       if (isUnused(nd) && recCnt(rec.w0) == best) {
         const Key<KW> key = keyAt<KW>(recPb(rec.w0, rec.w1));
@@ -699,12 +791,28 @@ struct FastAsm {
         mineKey = ok;
       }
     }
+    if (tn > 1) {  // the best of each wave, then the best of those
+      if (lane == 0) bestW[tw] = mine;
+      teamSync();
+      mine = ASM_NONE;
+      for (unsigned v = 0; v < tn; ++v) {
+        const unsigned on = wv::atomic_load(&bestW[v]);
+        if (on == ASM_NONE) continue;
+        const FRec    rec = nodes[on];
+        const Key<KW> ok  = keyAt<KW>(recPb(rec.w0, rec.w1));
+        if (mine == ASM_NONE || Assembler::keyLess(ok, mineKey)) {
+          mine    = on;
+          mineKey = ok;
+        }
+      }
+    }
     return mine;
   }
 
   /// next <= T unused words WITH COUNT <= maxCount in exact seed order into tent[0..nT) (u16 node ids, LDS); see
   /// Assembler::selectTentative.  `area`/`areaBytes`: scratch for the histogram (1 KB) and the raw candidate list.
   /// maxCount = 255 is the reference's order over all unused words; a smaller bound orders one tier of them (speculation).
+  /// (a team operation like selectSeed: the passes over the words and the ranking are dealt out to the team's waves)
   template <int KW>
   WV_DEV unsigned selectTentative(const unsigned T, const unsigned maxCount, char* area, const unsigned areaBytes)
   {
@@ -713,17 +821,21 @@ struct FastAsm {
       if (maxCount < 255) return 0;  // (speculation only: nothing is lost)
       const unsigned s = selectSeed<KW>();
       if (s == ASM_NONE) return 0;
-      if (lane == 0) tent[0] = uint16_t(s);
-      wv::sync();
+      if (tw == 0 && lane == 0) tent[0] = uint16_t(s);
+      teamSync();
       return 1;
     }
     uint32_t* hist = reinterpret_cast<uint32_t*>(area);
     uint16_t* raw  = reinterpret_cast<uint16_t*>(area + 1024);
     // count level: counts are <= 255 here (no pseudo reads) -> one 256-bin histogram over the unused words
-    for (unsigned i = lane; i < 256; i += 64) hist[i] = 0;
-    wv::sync();
+    for (unsigned i = lane + 64 * tw; i < 256; i += 64 * tn) hist[i] = 0;
+    if (tw == 0 && lane == 0) {
+      hdr[FA_H_ACC0] = 0;
+      hdr[FA_H_ACC1] = 0;
+    }
+    teamSync();
     unsigned U = 0;
-    for (unsigned nb = 0; nb < nNodes; nb += 64) {
+    for (unsigned nb = 64 * tw; nb < nNodes; nb += 64 * tn) {
       const unsigned nd = nb + lane;
       if (nd < nNodes && isUnused(nd)) {
         const unsigned c = recCnt(nodes[nd].w0);
@@ -734,10 +846,17 @@ struct FastAsm {
       }
     }
     U = Assembler::waveSum(U);
-    wv::sync();
+    if (tn > 1) {
+      if (lane == 0 && U) wv::atomic_add(&hdr[FA_H_ACC0], U);
+      teamSync();
+      U = wv::atomic_load(&hdr[FA_H_ACC0]);
+    } else {
+      wv::sync();
+    }
     if (U == 0) return 0;
     unsigned cStar = 1, pStar = 0xffffffffu;
     if (U > T) {
+      // (every wave reads the same histogram and arrives at the same numbers)
       unsigned carry = 0, found = 0;
       for (unsigned top = 256; top > 0 && !found; top -= 64) {
         const unsigned bin = top - 1 - lane;
@@ -758,13 +877,13 @@ struct FastAsm {
       unsigned above = 0;
       for (unsigned c = cStar + 1 + lane; c < 256; c += 64) above += hist[c];
       unsigned need = T - Assembler::waveSum(above);
-      wv::sync();
       // tie level: radix select on the 16-base prefix among the words with count == cStar
       unsigned prefix = 0;
       for (int shift = 24; shift >= 0; shift -= 8) {
-        for (unsigned i = lane; i < 256; i += 64) hist[i] = 0;
-        wv::sync();
-        for (unsigned nb = 0; nb < nNodes; nb += 64) {
+        teamSync();  // (everybody is done reading the histogram)
+        for (unsigned i = lane + 64 * tw; i < 256; i += 64 * tn) hist[i] = 0;
+        teamSync();
+        for (unsigned nb = 64 * tw; nb < nNodes; nb += 64 * tn) {
           const unsigned nd = nb + lane;
           if (nd >= nNodes || !isUnused(nd)) continue;
           const FRec rec = nodes[nd];
@@ -773,7 +892,7 @@ struct FastAsm {
           if (shift < 24 && (p >> (shift + 8)) != (prefix >> (shift + 8))) continue;
           wv::atomic_add(&hist[(p >> shift) & 255u], 1u);
         }
-        wv::sync();
+        teamSync();
         const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
         const unsigned mine = h0 + h1 + h2 + h3;
         unsigned       inc  = mine;
@@ -800,13 +919,11 @@ struct FastAsm {
         }
         prefix |= digit << shift;
         need -= acc;
-        wv::sync();
       }
       pStar = prefix;
     }
-    // gather the survivors
-    unsigned total = 0;
-    for (unsigned nb = 0; nb < ((nNodes + 63) & ~63u); nb += 64) {
+    // gather the survivors (in any order: the ranking below is what orders them)
+    for (unsigned nb = 64 * tw; nb < ((nNodes + 63) & ~63u); nb += 64 * tn) {
       const unsigned nd  = nb + lane;
       bool           sel = false;
       if (nd < nNodes && isUnused(nd)) {
@@ -814,23 +931,27 @@ struct FastAsm {
         const unsigned c   = recCnt(rec.w0);
         sel                = (c <= maxCount) && ((U <= T) || (c > cStar) || (c == cStar && codes16(recPb(rec.w0, rec.w1)) <= pStar));
       }
-      const uint64_t m   = wv::ballot(sel);
-      const unsigned pos = total + unsigned(wv::popc(m & ((uint64_t(1) << lane) - 1)));
+      const uint64_t m = wv::ballot(sel);
+      if (m == 0) continue;
+      unsigned at = 0;
+      if (lane == 0) at = wv::atomic_add(&hdr[FA_H_ACC1], unsigned(wv::popc(m)));
+      at                 = wv::first(at);
+      const unsigned pos = at + unsigned(wv::popc(m & ((uint64_t(1) << lane) - 1)));
       if (sel && pos < TENT_CAP) raw[pos] = uint16_t(nd);
-      total += unsigned(wv::popc(m));
     }
-    wv::sync();
+    teamSync();
+    const unsigned total = wv::atomic_load(&hdr[FA_H_ACC1]);
     if (total > TENT_CAP) {  // pathological tie group (hundreds of words sharing a 16-base prefix)
       if (maxCount < 255) return 0;
       const unsigned s = selectSeed<KW>();
       if (s == ASM_NONE) return 0;
-      if (lane == 0) tent[0] = uint16_t(s);
-      wv::sync();
+      if (tw == 0 && lane == 0) tent[0] = uint16_t(s);
+      teamSync();
       return 1;
     }
     // exact rank inside the list
     const unsigned keep = (total < T) ? total : T;
-    for (unsigned i = lane; i < total; i += 64) {
+    for (unsigned i = lane + 64 * tw; i < total; i += 64 * tn) {
       const unsigned x  = raw[i];
       const FRec     rx = nodes[x];
       const unsigned cx = recCnt(rx.w0), pbx = recPb(rx.w0, rx.w1), px = codes16(pbx);
@@ -849,7 +970,7 @@ struct FastAsm {
       }
       if (rank < keep) tent[rank] = uint16_t(x);
     }
-    wv::sync();
+    teamSync();
     return keep;
   }
 
@@ -1149,7 +1270,7 @@ struct FastAsm {
     uint64_t accAll = 0;  // slots that hold accepted candidates (never evicted)
     // ---- round 0: the first seed and, beside it, the two lowest count tiers in exact seed order (error branches, also
     // those two reads share; the low-coverage ends of the main path that slip in cost a lane each, nothing else) ----
-    const unsigned s1 = selectSeed<KW>();
+    const unsigned s1 = teamSeed<KW>();
     if (s1 == ASM_NONE) return 0;
     {
       // Up to 128 words of those tiers in exact order, thinned per unbranched stretch (chain ids, graphHasCycle): a walk
@@ -1158,7 +1279,7 @@ struct FastAsm {
       // fill the cache with walks nobody asks for.  What lies on the other side of a walked word may survive (the walk back
       // from the seed can have lost the stretch's read by then): those words stay in.
       // (A heuristic like the rest of the speculation: what it drops or keeps wrongly costs a later round, never a result.)
-      const unsigned nE = selectTentative<KW>(128, P.opt.minCoverage + 1, sc, scBytes);
+      const unsigned nE = teamTentative<KW>(128, P.opt.minCoverage + 1, sc, scBytes);
       unsigned eN[2], eCh[2];
       for (unsigned h = 0; h < 2; ++h) {
         const unsigned i = lane + 64 * h;
@@ -1196,7 +1317,7 @@ struct FastAsm {
         if (lane == 0) tent[0] = uint16_t(s1);
         wv::sync();
       } else {
-        nL = selectTentative<KW>(64, 255, sc, scBytes);
+        nL = teamTentative<KW>(64, 255, sc, scBytes);
         if (nL == 0) break;
       }
       first = false;
@@ -1458,6 +1579,62 @@ struct FastAsm {
   WV_DEV int runK(const unsigned locus)
   {
     if (!buildGraph<KW>()) return FA_PUNT;
+    // from here on the first wave works alone (the walks are one dependent chain per lane); the others wait at the barrier
+    int rc = FA_PUNT;
+    if (tw == 0) {
+      rc = afterGraph<KW>(locus);
+      command(FA_CMD_EXIT);
+    } else {
+      workerLoop<KW>();
+    }
+    return rc;
+  }
+
+  /// first wave: the team runs operation `cmd` next (the caller goes on to run it too)
+  WV_DEV void command(const unsigned cmd, const unsigned a0 = 0, const unsigned a1 = 0, const unsigned a2 = 0)
+  {
+    if (tn == 1) return;
+    if (wv::lane() == 0) {
+      hdr[FA_H_CMD]  = cmd;
+      hdr[FA_H_ARG0] = a0;
+      hdr[FA_H_ARG1] = a1;
+      hdr[FA_H_ARG2] = a2;
+    }
+    teamSync();
+  }
+  /// the other waves: run what the first wave asks for until it is done with the locus
+  template <int KW>
+  WV_DEV void workerLoop()
+  {
+    while (true) {
+      teamSync();
+      const unsigned cmd = wv::first(wv::atomic_load(&hdr[FA_H_CMD]));
+      if (cmd == FA_CMD_EXIT) break;
+      const unsigned a0 = wv::first(wv::atomic_load(&hdr[FA_H_ARG0])), a1 = wv::first(wv::atomic_load(&hdr[FA_H_ARG1])),
+                     a2 = wv::first(wv::atomic_load(&hdr[FA_H_ARG2]));
+      if (cmd == FA_CMD_SEED) {
+        (void)selectSeed<KW>();
+      } else if (cmd == FA_CMD_TENT) {
+        (void)selectTentative<KW>(a0 & 0xffffu, a0 >> 16, lds + a1, a2);
+      }
+    }
+  }
+  template <int KW>
+  WV_DEV unsigned teamSeed()
+  {
+    command(FA_CMD_SEED);
+    return selectSeed<KW>();
+  }
+  template <int KW>
+  WV_DEV unsigned teamTentative(const unsigned T, const unsigned maxCount, char* area, const unsigned areaBytes)
+  {
+    command(FA_CMD_TENT, T | (maxCount << 16), unsigned(area - lds), areaBytes);
+    return selectTentative<KW>(T, maxCount, area, areaBytes);
+  }
+
+  template <int KW>
+  WV_DEV int afterGraph(const unsigned locus)
+  {
     if (graphHasCycle() != 0) return FA_PUNT;  // cyclic (exact repeat search) or no room: general path
     tick(3);
     if (contigRounds<KW>() != 0) return FA_PUNT;
@@ -1480,9 +1657,11 @@ struct FastAsm {
     tMark = wv::clock();
     if (!pack(locus)) return FA_PUNT;
     tick(0);
-    unused_bits[wv::lane()] = 0;
-    repeat_bits[wv::lane()] = 0;
-    wv::sync();
+    if (tw == 0) {
+      unused_bits[wv::lane()] = 0;
+      repeat_bits[wv::lane()] = 0;
+    }
+    wv::sync();  // (buildGraph's first barrier comes before anything reads these)
     const unsigned kw = (k + 15) >> 4;
     if (kw <= 2) return runK<2>(locus);
     if (kw <= 4) return runK<4>(locus);
@@ -1490,17 +1669,28 @@ struct FastAsm {
   }
 };
 
-/// persistent single-wave workgroups, FA_BUDGET bytes of dynamic LDS each; params as assemble_kernel.
-/// Loci this path does not cover are appended to P.punt_ids (P.punt_count counts them); assemble_kernel, launched behind
-/// this kernel with n_loci_dev = punt_count and locus_ids = punt_ids, runs them.
-WV_KERNEL_SINGLE void assemble_fast_kernel(const AsmParams P)
+/// persistent workgroups of FA_TEAM cooperating wavefronts (one per SIMD of the CU), FA_BUDGET bytes of dynamic LDS each: one
+/// locus at a time per workgroup; params as assemble_kernel.  (The block size chooses the team: 64 threads run the same code
+/// with one wave.)  Loci this path does not cover are appended to P.punt_ids (P.punt_count counts them); assemble_kernel,
+/// launched behind this kernel with n_loci_dev = punt_count and locus_ids = punt_ids, runs them.
+// Register budget.  The walk loop (walkSlots inlined into contigRounds) needs ~200 VGPRs; a budget of 168 (three waves per
+// SIMD, i.e. three workgroups of four waves per CU) makes the compiler spill 31 of them around that loop, and the spilled
+// build produced wrong contig sets on the hardware for loci with more than one walk round (round 3, digests of 73 of 10 000
+// loci; the unspilled build is exact) -- so the budget stays at two waves per SIMD and the launch uses teams of two.
+#ifndef MANTA_FAST_WAVES_PER_SIMD
+#define MANTA_FAST_WAVES_PER_SIMD 2
+#endif
+WV_KERNEL_WG(FA_TEAM) WV_WAVES_PER_SIMD(MANTA_FAST_WAVES_PER_SIMD) void assemble_fast_kernel(const AsmParams P)
 {
-  uint8_t* wsBase = P.ws + uint64_t(wv::block_single()) * P.ws_stride;
-  char*    lds    = wv::lds_single();
+  uint8_t*       wsBase = P.ws + uint64_t(wv::block_single()) * P.ws_stride;
+  char*          lds    = wv::lds_single();
+  uint32_t*      hdr    = reinterpret_cast<uint32_t*>(lds + FA_OFF_HDR);
+  const unsigned tw     = unsigned(wv::wave_in_wg());
   while (true) {
-    unsigned slot = 0;
-    if (wv::lane() == 0) slot = wv::atomic_add(P.counter, 1u);
-    slot = wv::first(slot);
+    if (tw == 0 && wv::lane() == 0) hdr[FA_H_SLOT] = wv::atomic_add(P.counter, 1u);
+    wv::sync();
+    wv::wg_barrier();
+    const unsigned slot = wv::first(wv::atomic_load(&hdr[FA_H_SLOT]));
     if (slot >= P.n_loci) break;
     const unsigned locus = P.locus_ids ? P.locus_ids[slot] : slot;
     Assembler      a(P, wsBase);
@@ -1511,8 +1701,9 @@ WV_KERNEL_SINGLE void assemble_fast_kernel(const AsmParams P)
       rc = f.run(locus);
     }
     wv::sync();
-    if (rc != FA_DONE && wv::lane() == 0) P.punt_ids[wv::atomic_add(P.punt_count, 1u)] = locus;
+    if (tw == 0 && rc != FA_DONE && wv::lane() == 0) P.punt_ids[wv::atomic_add(P.punt_count, 1u)] = locus;
     wv::sync();
+    wv::wg_barrier();  // (the slot word is rewritten next)
   }
 }
 

@@ -970,6 +970,7 @@ struct AssemblerT {
       cnt[0] = 0;
       cnt[1] = 0;
     }
+    wv::sync();  // (the other lanes' atomics on cnt[0] below must find the zero)
     for (unsigned w = lane; w < nWords; w += 64) {
       uint32_t v = 0;
       for (unsigned h = 0; h < 2; ++h) {

@@ -34,6 +34,8 @@ template <typename K, typename P>
 inline void launch(K kernel, int grid, size_t ldsBytes, const P& params) { wv_emu::launch(grid, ldsBytes, [&]() { kernel(params); }); }
 template <typename K, typename P>
 inline void launchSingle(K kernel, int grid, size_t ldsBytes, const P& params) { wv_emu::launch(grid, ldsBytes, [&]() { kernel(params); }); }
+template <typename K, typename P>
+inline void launchWG(K kernel, int grid, int nWaves, size_t ldsBytes, const P& params) { wv_emu::launchWG(grid, nWaves, ldsBytes, [&]() { kernel(params); }); }
 inline int roundGrid(int waves) { return waves; }
 struct Stream {};
 inline void useStream(Stream*) {}
@@ -179,6 +181,19 @@ inline void launchSingle(K kernel, int grid, size_t ldsBytes, const P& params)
     prepared = reinterpret_cast<const void*>(kernel);
   }
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), ldsBytes, launchStream(), params);
+  check(hipGetLastError(), "kernel launch");
+}
+/// `grid` cooperative workgroups of `nWaves` wavefronts with `ldsBytes` of dynamic LDS each
+template <typename K, typename P>
+inline void launchWG(K kernel, int grid, int nWaves, size_t ldsBytes, const P& params)
+{
+  static thread_local const void* prepared = nullptr;
+  if (prepared != reinterpret_cast<const void*>(kernel)) {
+    check(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)),
+          "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    prepared = reinterpret_cast<const void*>(kernel);
+  }
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * nWaves), ldsBytes, launchStream(), params);
   check(hipGetLastError(), "kernel launch");
 }
 inline int roundGrid(int waves) { return ((waves + WV_WAVES_PER_WG - 1) / WV_WAVES_PER_WG) * WV_WAVES_PER_WG; }

@@ -22,6 +22,10 @@
 #define WV_KERNEL_OCC(w) __global__ __launch_bounds__(64 * WV_WAVES_PER_WG, w)
 // single-wave workgroups (the LDS-resident assembler: one locus per workgroup, the workgroup's LDS is the wave's)
 #define WV_KERNEL_SINGLE __global__ __launch_bounds__(64)
+// cooperative workgroups of `n` wavefronts working on ONE item (shared LDS, workgroup barrier)
+#define WV_KERNEL_WG(n) __global__ __launch_bounds__(64 * (n))
+// register budget: the kernel must fit `n` of its wavefronts on a SIMD (512 / n VGPRs)
+#define WV_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #define WV_HD __host__ __device__ inline
 // cold paths (measured: real out-of-line calls cost more than they save on gfx950, so this is still inline)
 #define WV_DEV_COLD __device__ __forceinline__
@@ -40,6 +44,15 @@ WV_DEV char* lds(const unsigned bytesPerWave) { return wv_dyn_lds + size_t(__bui
 /// single-wave workgroups: workgroup index and the whole dynamic LDS
 WV_DEV int   block_single() { return int(blockIdx.x); }
 WV_DEV char* lds_single() { return wv_dyn_lds; }
+/// cooperative workgroups: this wave's index in its workgroup, the wave count, the workgroup barrier (s_barrier behind a full
+/// wait for this wave's memory operations: LDS writes of all waves are visible to all afterwards), a polling back-off
+WV_DEV int  wave_in_wg() { return __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)); }
+WV_DEV int  wg_waves() { return int(blockDim.x >> 6); }
+WV_DEV void wg_barrier() { __syncthreads(); }
+WV_DEV void spin() { __builtin_amdgcn_s_sleep(2); }
+/// orders this lane's earlier LDS / memory writes before its later ones as the other waves of the workgroup see them
+WV_DEV void fence_wg() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+WV_DEV void atomic_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 /// lane l receives lane (l-1)'s value; lane 0 receives `fill`   (v_mov_b32_dpp wave_shr:1)
 WV_DEV int shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
@@ -82,6 +95,7 @@ WV_DEV unsigned atomic_or(unsigned* p, unsigned v) { return atomicOr(p, v); }
 WV_DEV unsigned atomic_sub(unsigned* p, unsigned v) { return atomicSub(p, v); }
 WV_DEV unsigned atomic_exch(unsigned* p, unsigned v) { return atomicExch(p, v); }
 WV_DEV unsigned atomic_min(unsigned* p, unsigned v) { return atomicMin(p, v); }
+WV_DEV unsigned atomic_max(unsigned* p, unsigned v) { return atomicMax(p, v); }
 WV_DEV unsigned long long atomic_or(unsigned long long* p, unsigned long long v) { return atomicOr(p, v); }
 WV_DEV unsigned long long atomic_add(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 /// L1-bypassing load of a word other lanes update with atomics

@@ -19,6 +19,8 @@
 #define WV_KERNEL
 #define WV_KERNEL_OCC(w)
 #define WV_KERNEL_SINGLE
+#define WV_KERNEL_WG(n)
+#define WV_WAVES_PER_SIMD(n)
 #define WV_WAVES_PER_WG 1
 #define WV_HD inline
 #define WV_DEV_COLD inline
@@ -35,8 +37,11 @@ struct Wave {
   uint64_t              xbuf[2][N];
   unsigned              opSeq[N];    // number of rendezvous each lane has executed (convergence check)
   const char*           opTag[N];
-  std::vector<char>     ldsMem;
+  std::vector<char>     ldsMem;   // single-wave launches: the wave's own LDS
+  char*                 ldsBase = nullptr;  // the (16-byte aligned) LDS this wave sees (shared by the waves of a workgroup)
   int                   block = 0, nblocks = 1;
+  int                   waveInWg = 0, wgWaves = 1;
+  bool                  atBarrier = false;
   std::function<void()> body;
 };
 
@@ -62,6 +67,17 @@ inline void yieldLane(const char* tag)
   swapcontext(&w->lanes[w->cur], &w->sched);
 }
 
+/// MANTA_EMU_LANE_ORDER=reverse steps the lanes of a wave from 63 down to 0 between rendezvous.  A kernel whose result depends on
+/// the order in which lanes run between two rendezvous is missing a wv::sync(): the tests run the sensitive suites both ways.
+inline bool laneOrderReversed()
+{
+  static const bool rev = [] {
+    const char* e = std::getenv("MANTA_EMU_LANE_ORDER");
+    return e && std::strcmp(e, "reverse") == 0;
+  }();
+  return rev;
+}
+
 /// run `grid` workgroups (one wave each) sequentially
 inline void launch(int grid, size_t ldsBytes, const std::function<void()>& body)
 {
@@ -73,6 +89,10 @@ inline void launch(int grid, size_t ldsBytes, const std::function<void()>& body)
   w.nblocks = grid;
   Wave* saved = W();
   W()         = &w;
+  {
+    char* p   = w.ldsMem.data();
+    w.ldsBase = p + ((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15);
+  }
   for (int b = 0; b < grid; ++b) {
     w.block = b;
     std::fill(w.ldsMem.begin(), w.ldsMem.end(), char(0xcd));  // LDS is NOT zero-initialised on hardware
@@ -88,7 +108,8 @@ inline void launch(int grid, size_t ldsBytes, const std::function<void()>& body)
     }
     while (true) {
       bool anyLive = false;
-      for (int l = 0; l < Wave::N; ++l) {
+      for (int li = 0; li < Wave::N; ++li) {
+        const int l = laneOrderReversed() ? Wave::N - 1 - li : li;
         if (w.done[l]) continue;
         anyLive = true;
         w.cur   = l;
@@ -108,6 +129,91 @@ inline void launch(int grid, size_t ldsBytes, const std::function<void()>& body)
                        w.opSeq[l], tag, seq, b);
           std::abort();
         }
+      }
+    }
+  }
+  W() = saved;
+}
+
+/// run `grid` workgroups of `nWaves` cooperating wavefronts (shared LDS, workgroup barrier) one after the other.  The waves of a
+/// workgroup are stepped round-robin, one rendezvous at a time; a wave that sits at the workgroup barrier is held until every
+/// wave that has not finished sits there too (finished waves leave the barrier's count, as on the hardware).
+inline void launchWG(int grid, int nWaves, size_t ldsBytes, const std::function<void()>& body)
+{
+  static const size_t STACK = 256 * 1024;
+  std::vector<Wave>   waves(nWaves);
+  std::vector<char>   lds(ldsBytes + 64, 0);
+  char*               ldsAligned = lds.data() + ((16 - (reinterpret_cast<uintptr_t>(lds.data()) & 15)) & 15);
+  for (int v = 0; v < nWaves; ++v) {
+    Wave& w(waves[v]);
+    w.stacks.resize(STACK * Wave::N);
+    w.body     = body;
+    w.nblocks  = grid;
+    w.waveInWg = v;
+    w.wgWaves  = nWaves;
+    w.ldsBase  = ldsAligned;
+  }
+  Wave* saved = W();
+  for (int b = 0; b < grid; ++b) {
+    std::fill(lds.begin(), lds.end(), char(0xcd));
+    for (Wave& w : waves) {
+      w.block     = b;
+      w.atBarrier = false;
+      W()         = &w;
+      for (int l = 0; l < Wave::N; ++l) {
+        w.done[l]  = false;
+        w.opSeq[l] = 0;
+        w.opTag[l] = "start";
+        getcontext(&w.lanes[l]);
+        w.lanes[l].uc_stack.ss_sp   = w.stacks.data() + STACK * l;
+        w.lanes[l].uc_stack.ss_size = STACK;
+        w.lanes[l].uc_link          = &w.sched;
+        makecontext(&w.lanes[l], (void (*)())trampoline, 0);
+      }
+    }
+    while (true) {
+      bool anyLive = false, progressed = false;
+      for (Wave& w : waves) {
+        bool live = false;
+        for (int l = 0; l < Wave::N; ++l) live = live || !w.done[l];
+        if (!live) continue;
+        anyLive = true;
+        if (w.atBarrier) continue;
+        W() = &w;
+        for (int li = 0; li < Wave::N; ++li) {
+          const int l = laneOrderReversed() ? Wave::N - 1 - li : li;
+          if (w.done[l]) continue;
+          w.cur = l;
+          swapcontext(&w.sched, &w.lanes[l]);
+        }
+        progressed      = true;
+        unsigned    seq = 0;
+        const char* tag = nullptr;
+        for (int l = 0; l < Wave::N; ++l) {
+          if (w.done[l]) continue;
+          if (!tag) {
+            seq = w.opSeq[l];
+            tag = w.opTag[l];
+          } else if (w.opSeq[l] != seq || w.opTag[l] != tag) {
+            std::fprintf(stderr, "wave_emu: divergent rendezvous: wave %d lane %d at '%s'#%u vs '%s'#%u (workgroup %d)\n", w.waveInWg, l,
+                         w.opTag[l], w.opSeq[l], tag, seq, b);
+            std::abort();
+          }
+        }
+        if (tag && std::strcmp(tag, "wgbarrier") == 0) w.atBarrier = true;
+      }
+      if (!anyLive) break;
+      bool allThere = true;
+      for (Wave& w : waves) {
+        bool live = false;
+        for (int l = 0; l < Wave::N; ++l) live = live || !w.done[l];
+        if (live && !w.atBarrier) allThere = false;
+      }
+      if (allThere) {
+        for (Wave& w : waves) w.atBarrier = false;
+      } else if (!progressed) {
+        std::fprintf(stderr, "wave_emu: workgroup %d is stuck: some waves wait at the barrier, the others have no lane to run\n", b);
+        std::abort();
       }
     }
   }
@@ -135,14 +241,18 @@ namespace wv {
 inline int lane() { return wv_emu::W()->cur; }
 inline int block() { return wv_emu::W()->block; }
 inline int nblocks() { return wv_emu::W()->nblocks; }
-inline char* lds(const unsigned)
-{
-  char* p = wv_emu::W()->ldsMem.data();
-  return p + ((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15);
-}
+inline char* lds(const unsigned) { return wv_emu::W()->ldsBase; }
 
 inline int   block_single() { return block(); }
 inline char* lds_single() { return lds(0); }
+/// cooperative workgroups (launchWG): this wave's index in its workgroup, the workgroup's wave count, the workgroup barrier, and
+/// a polling step that lets the other waves of the workgroup run
+inline int  wave_in_wg() { return wv_emu::W()->waveInWg; }
+inline int  wg_waves() { return wv_emu::W()->wgWaves; }
+inline void wg_barrier() { wv_emu::yieldLane("wgbarrier"); }
+inline void spin() { wv_emu::yieldLane("spin"); }
+inline void fence_wg() {}
+inline void atomic_store(unsigned* p, unsigned v) { *p = v; }
 
 inline int shr1(int v, int fill)
 {
@@ -188,6 +298,7 @@ inline unsigned atomic_add(unsigned* p, unsigned v) { const unsigned o = *p; *p 
 inline unsigned atomic_sub(unsigned* p, unsigned v) { const unsigned o = *p; *p = o - v; return o; }
 inline unsigned atomic_exch(unsigned* p, unsigned v) { const unsigned o = *p; *p = v; return o; }
 inline unsigned atomic_min(unsigned* p, unsigned v) { const unsigned o = *p; if (v < o) *p = v; return o; }
+inline unsigned atomic_max(unsigned* p, unsigned v) { const unsigned o = *p; if (v > o) *p = v; return o; }
 inline unsigned atomic_cas(unsigned* p, unsigned cmp, unsigned v) { const unsigned o = *p; if (o == cmp) *p = v; return o; }
 inline unsigned atomic_or(unsigned* p, unsigned v) { const unsigned o = *p; *p = o | v; return o; }
 inline unsigned long long atomic_or(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o | v; return o; }

@@ -9,6 +9,8 @@ from manta_amd._capi import assembly_text
 from oracle_lib import asm_opts
 from synth import small_indel_locus, breakend_locus, repeat_rich_pile
 
+EMU_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libmanta_amd_emu.so")
+
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ASM = json.load(open(os.path.join(GOLD, "assembler_reference_tests.json")))
 
@@ -282,6 +284,40 @@ def test_emulated_fast_kernel_matches_oracle(emu, oracle, monkeypatch):
     monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
     cases = _lds_cases()
     assert _check(emu, oracle, cases) == len(cases)
+
+
+@pytest.mark.parametrize("team", [1, 4])
+def test_emulated_fast_kernel_team_sizes(emu, oracle, monkeypatch, team):
+    """assemble_fast_kernel runs a locus on a team of cooperating wavefronts (default 2; the emulator interleaves the waves of
+    a workgroup at every rendezvous): single waves and teams of four must give the same results"""
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
+    monkeypatch.setenv("MANTA_AMD_FAST_TEAM", str(team))
+    cases = _lds_cases()[:24]
+    assert _check(emu, oracle, cases) == len(cases)
+
+
+def test_emulated_kernels_do_not_depend_on_lane_order(emu, oracle):
+    """The emulator steps the lanes of a wave 0..63 between two rendezvous; MANTA_EMU_LANE_ORDER=reverse steps them 63..0.  A
+    kernel that gives different results that way reads what another lane writes without a wv::sync() in between -- which the
+    hardware (lock step) would resolve in yet another way.  Both assembler kernels, a sample of the cases, in a fresh process
+    (the order is read once)."""
+    import subprocess
+    import sys
+    code = ("import os, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "import conftest, test_assemble_kernels as t\n"
+            "from oracle_lib import OracleLib\n"
+            "from manta_amd._capi import Lib\n"
+            "lib, oracle = Lib(path=t.EMU_PATH), OracleLib()\n"
+            "cases = t._lds_cases()\n"
+            "cases = cases[:6] + cases[8:14] + cases[38:46]\n"
+            "for path in ('fast', 'general'):\n"
+            "    os.environ['MANTA_AMD_ASM_PATH'] = path\n"
+            "    assert t._check(lib, oracle, cases) == len(cases)\n"
+            "print('lane-order-ok')\n") % os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MANTA_EMU_LANE_ORDER="reverse")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert "lane-order-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
 def test_emulated_fast_kernel_batch_with_mixed_loci(emu, oracle, monkeypatch):
