@@ -454,6 +454,107 @@ int manta_node_spanning_batch(
     const manta_batch_plan_t* plan /* nullable */, manta_batch_stats_t* stats /* nullable */, uint32_t* loci_per_device /* nullable */);
 
 
+/* ------------------------------------------------------------------------------------------------------
+ * Read-pile construction (second half): the per-read tests of SVCandidateAssembler::getBreakendReads
+ * (manta/SVCandidateAssembler.cpp:271-659) over DECODED BAM records, emitting the packed piles above.
+ *
+ * What stays with the caller: the BAM layer.  The caller runs the region queries the reference runs -- for every breakend of a
+ * candidate and every alignment file, bamStream.resetRegion(tid, searchBegin, searchEnd) (:381; the search range is the
+ * breakend interval widened to 400 bases, :285-303, see manta_read_search_range) -- and hands over the records in file order.
+ * What this call does, per candidate, with the reference's order-dependent rules intact:
+ *   isReadFilteredCore (ReadFilter.cpp:32-50), the normal-sample depth estimate and its two thresholds (:85-100, :404-425),
+ *   isNonStrictSupplement (bam_record.hpp:139-144), the indel test (:473-483), the semi-aligned / soft-clip test
+ *   (getSVBreakendCandidateSemiAligned, SVLocusScannerSemiAligned.cpp:25-330, incl. is_overlapping_pair / is_adapter_pair,
+ *   bam_record_util.cpp:54-108), ShadowReadFinder::check (ShadowReadFinder.cpp:33-113), the remote-mate candidate tests
+ *   (RemoteMateReadUtil.cpp:29-55; flags only -- fetching the mates is a BAM seek and stays with the caller), the read-key
+ *   de-duplication and the 1000-read cap of insertAssemblyRead / the scan loop (:102-119, :387-393), then the string handling
+ *   of insertAssemblyRead (:121-135: Q mask, reverse complement) straight into 2 bit + N bitmap.
+ * Coordinates are htslib's: 0-based pos / mate_pos (bam1_core_t), i.e. the reference's bam_record::pos() - 1.
+ * ---------------------------------------------------------------------------------------------------- */
+#define MANTA_READ_TAG_SA 1u /* the record carries an SA tag (bam_record::isSASplit) */
+#define MANTA_READ_TAG_MC 2u /* the record carries an MC tag; its cigar is given as mate_cigar (bam_record::hasMateCigar) */
+
+typedef struct {
+  int32_t  tid, pos;           /* bam1_core_t::tid, ::pos */
+  int32_t  mate_tid, mate_pos; /* ::mtid, ::mpos */
+  uint16_t flag;               /* ::flag (BAM_F*) */
+  uint8_t  mapq;               /* ::qual */
+  uint8_t  tags;               /* MANTA_READ_TAG_* */
+  uint32_t read_len;           /* ::l_qseq */
+  uint32_t n_cigar, cigar_off; /* BAM cigar words (length << 4 | op) in the cigar arena, as bam_get_cigar */
+  uint32_t n_mate_cigar, mate_cigar_off; /* the MC tag in the same encoding, P and zero-length operations dropped
+                                            (cigar_to_apath, blt_util/align_path.cpp:66-95) */
+  uint32_t qname_len, qname_off; /* bytes in the name arena (no terminator needed) */
+  uint64_t seq_off;            /* bam_get_seq: 4-bit codes, two bases per byte, (read_len + 1) / 2 bytes in the sequence arena */
+  uint64_t qual_off;           /* bam_get_qual: read_len bytes in the quality arena */
+} manta_bam_read_t;
+
+/* one region query of getBreakendReads (:371-384): one breakend x one alignment file */
+typedef struct {
+  uint32_t read_begin, read_end; /* the query's records in file order */
+  uint32_t bam_index;            /* alignment file: part of the read key (:110-111) */
+  uint8_t  is_tumor;             /* _isAlignmentTumor[bamIndex] (:372): normal samples feed the depth estimate */
+  uint8_t  is_locus_reversed;    /* getBreakendReads' isLocusReversed */
+  uint8_t  first_of_breakend;    /* 1 on the first file of a breakend: the depth buffer starts over (:340) */
+  uint8_t  reserved;
+  int32_t  bp_begin, bp_end;     /* SVBreakend::interval.range */
+  int32_t  bp_state;             /* SVBreakendState::index_t (manta/SVBreakend.hpp:146-153): 1 RIGHT_OPEN, 2 LEFT_OPEN, other: both */
+  int32_t  ref_begin;            /* reference_contig_segment::get_offset() of the window the refiner fetched */
+  uint32_t ref_len;
+  uint64_t ref_off;              /* its text in the reference arena */
+} manta_read_scan_t;
+
+typedef struct {
+  uint32_t scan_begin, scan_end; /* the candidate's queries in the reference's order: breakend 1 x files, breakend 2 x files */
+  uint8_t  is_max_depth;         /* ChromDepthFilterUtil::isMaxDepthFilter() */
+  uint8_t  search_remote;        /* isSearchRemoteInsertionReads: also flag remote-mate candidates */
+  uint8_t  reserved[2];
+  float    max_depth;            /* _dFilter.maxDepth(tid) as the reference's float (:333) */
+  float    max_local_depth_remote; /* _dFilterLocalDepthForRemoteReadRetrieval.maxDepth(tid) (:334) */
+} manta_read_locus_t;
+
+typedef struct {
+  uint32_t min_qval;                      /* IterativeAssemblerOptions::minQval (5) */
+  uint32_t min_candidate_variant_size;    /* ReadScannerOptions (10): indels of at least half of it keep a read (:317) */
+  uint32_t min_singleton_mapq_candidates; /* ReadScannerOptions (15): shadow anchors */
+  uint32_t min_mapq;                      /* ReadScannerOptions (15): remote-mate candidates */
+  uint32_t use_overlap_pair_evidence;     /* ReadScannerOptions (0) */
+  uint32_t max_reads;                     /* 0: the reference's 1000 (:342) */
+} manta_read_class_options_t;
+
+/* per-record decision bits */
+#define MANTA_READ_INDEL 1u        /* isIndelKeeper */
+#define MANTA_READ_SEMI_ALIGNED 2u /* isSemiAlignedKeeper */
+#define MANTA_READ_SHADOW 4u       /* isShadowKeeper */
+#define MANTA_READ_IN_PILE 8u      /* inserted: pile_index is valid */
+#define MANTA_READ_REVERSED 16u    /* inserted reverse-complemented */
+#define MANTA_READ_REMOTE_MATE 32u /* remoteReads.emplace_back (:449-456): the caller may fetch the mate */
+#define MANTA_READ_DEPTH_FILTERED 64u
+#define MANTA_READ_DUPLICATE_KEY 128u /* kept by the tests, dropped by the read index (:112-119) */
+
+typedef struct {
+  int32_t  status;          /* MANTA_OK; MANTA_E_UNSUPPORTED: a kept read holds the BAM code '=' (not representable in two bits;
+                               decisions are valid, the pile is not -- run the locus through the text interface) */
+  uint32_t n_pile_reads;
+  uint32_t retrieve_remote; /* isRetrieveRemoteReads (:575): no record tripped the local depth threshold */
+  uint32_t reserved;
+} manta_read_locus_result_t;
+
+/* [searchBegin, searchEnd) of a breakend interval (:285-303) */
+void manta_read_search_range(int32_t bp_begin, int32_t bp_end, int32_t* search_begin, int32_t* search_end);
+
+/* Piles of n_loci candidates.  Outputs: decision / pile_index per record (pile_index: position inside the candidate's pile,
+ * 0xffffffff when not inserted); the piles in manta_packed_piles_t layout in caller memory: codes_cap / mask_cap dwords,
+ * reads_cap reads (MANTA_E_CAPACITY if exceeded; *_used report what is needed); pile_read[r] = record of pile read r. */
+int manta_read_piles_batch(
+    manta_ctx_t* ctx, const manta_read_class_options_t* opt, uint32_t n_loci, const manta_read_locus_t* loci, uint32_t n_scans,
+    const manta_read_scan_t* scans, uint32_t n_reads, const manta_bam_read_t* reads, const uint32_t* cigars, uint64_t n_cigar_words,
+    const uint8_t* names, uint64_t names_bytes, const uint8_t* seqs, uint64_t seqs_bytes, const uint8_t* quals, uint64_t quals_bytes,
+    const uint8_t* refs, uint64_t refs_bytes, uint8_t* decision, uint32_t* pile_index, manta_read_locus_result_t* results,
+    uint32_t* codes, uint64_t codes_cap, uint64_t* codes_used, uint32_t* nmask, uint64_t mask_cap, uint64_t* mask_used,
+    uint32_t* read_len, uint64_t* read_code_off, uint64_t* read_mask_off, uint32_t* pile_read, uint64_t reads_cap,
+    uint64_t* reads_used, uint32_t* locus_read_begin);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,45 @@ def _b(s):
     return s if isinstance(s, (bytes, bytearray)) else s.encode("latin-1")
 
 
+# ---- read-pile construction (manta_read_piles_batch) ----
+class BamRead(ctypes.Structure):
+    _fields_ = [("tid", ctypes.c_int32), ("pos", ctypes.c_int32), ("mate_tid", ctypes.c_int32), ("mate_pos", ctypes.c_int32),
+                ("flag", ctypes.c_uint16), ("mapq", ctypes.c_uint8), ("tags", ctypes.c_uint8), ("read_len", ctypes.c_uint32),
+                ("n_cigar", ctypes.c_uint32), ("cigar_off", ctypes.c_uint32), ("n_mate_cigar", ctypes.c_uint32),
+                ("mate_cigar_off", ctypes.c_uint32), ("qname_len", ctypes.c_uint32), ("qname_off", ctypes.c_uint32),
+                ("seq_off", ctypes.c_uint64), ("qual_off", ctypes.c_uint64)]
+
+
+class ReadScan(ctypes.Structure):
+    _fields_ = [("read_begin", ctypes.c_uint32), ("read_end", ctypes.c_uint32), ("bam_index", ctypes.c_uint32), ("is_tumor", ctypes.c_uint8),
+                ("is_locus_reversed", ctypes.c_uint8), ("first_of_breakend", ctypes.c_uint8), ("reserved", ctypes.c_uint8),
+                ("bp_begin", ctypes.c_int32), ("bp_end", ctypes.c_int32), ("bp_state", ctypes.c_int32), ("ref_begin", ctypes.c_int32),
+                ("ref_len", ctypes.c_uint32), ("ref_off", ctypes.c_uint64)]
+
+
+class ReadLocus(ctypes.Structure):
+    _fields_ = [("scan_begin", ctypes.c_uint32), ("scan_end", ctypes.c_uint32), ("is_max_depth", ctypes.c_uint8),
+                ("search_remote", ctypes.c_uint8), ("reserved", ctypes.c_uint8 * 2), ("max_depth", ctypes.c_float),
+                ("max_local_depth_remote", ctypes.c_float)]
+
+
+class ReadClassOptions(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in ("min_qval", "min_candidate_variant_size", "min_singleton_mapq_candidates", "min_mapq",
+                                               "use_overlap_pair_evidence", "max_reads")]
+
+
+class ReadLocusResult(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int32), ("n_pile_reads", ctypes.c_uint32), ("retrieve_remote", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+def read_class_options(**kw):
+    """the reference's defaults (IterativeAssemblerOptions::minQval, ReadScannerOptions)"""
+    o = ReadClassOptions(5, 10, 15, 15, 0, 0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
 class Lib:
     def __init__(self, path=None, device=-1):
         self.path = path or default_library_path()
@@ -131,6 +170,43 @@ class Lib:
     def _check(self, rc, allow=()):
         if rc != 0 and rc not in allow:
             raise MantaError(rc, self.lib.manta_last_error(self.ctx).decode())
+
+    # ------------------------------------------------------------------ read piles
+    def read_piles_batch(self, opt, loci, scans, reads, cigars, names, seqs, quals, refs, strict=True):
+        """loci / scans / reads: ctypes arrays of ReadLocus / ReadScan / BamRead; the arenas: numpy (cigars uint32, the others uint8).
+        -> dict(decision, pile_index, results, piles=PackedPiles, pile_read)"""
+        n_loci, n_scans, n_reads = len(loci), len(scans), len(reads)
+        decision = np.zeros(max(n_reads, 1), dtype=np.uint8)
+        pile_index = np.zeros(max(n_reads, 1), dtype=np.uint32)
+        results = (ReadLocusResult * max(n_loci, 1))()
+        total_len = sum(int(r.read_len) for r in reads)
+        codes = np.zeros(total_len // 16 + n_reads + 4, dtype=np.uint32)
+        nmask = np.zeros(total_len // 32 + n_reads + 4, dtype=np.uint32)
+        read_len = np.zeros(n_reads + 1, dtype=np.uint32)
+        code_off = np.zeros(n_reads + 2, dtype=np.uint64)
+        mask_off = np.zeros(n_reads + 2, dtype=np.uint64)
+        pile_read = np.zeros(n_reads + 1, dtype=np.uint32)
+        begin = np.zeros(n_loci + 1, dtype=np.uint32)
+        used = (ctypes.c_uint64 * 3)()
+        arenas = [np.ascontiguousarray(a) for a in (cigars, names, seqs, quals, refs)]
+        f = self.lib.manta_read_piles_batch
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32,
+                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
+                      ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                      ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
+                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+        rc = f(self.ctx, ctypes.byref(opt), n_loci, ctypes.cast(loci, ctypes.c_void_p), n_scans, ctypes.cast(scans, ctypes.c_void_p), n_reads,
+               ctypes.cast(reads, ctypes.c_void_p), arenas[0].ctypes.data, len(arenas[0]), arenas[1].ctypes.data, len(arenas[1]),
+               arenas[2].ctypes.data, len(arenas[2]), arenas[3].ctypes.data, len(arenas[3]), arenas[4].ctypes.data, len(arenas[4]),
+               decision.ctypes.data, pile_index.ctypes.data, ctypes.cast(results, ctypes.c_void_p), codes.ctypes.data, len(codes),
+               ctypes.byref(used, 0), nmask.ctypes.data, len(nmask), ctypes.byref(used, 8), read_len.ctypes.data, code_off.ctypes.data,
+               mask_off.ctypes.data, pile_read.ctypes.data, n_reads, ctypes.byref(used, 16), begin.ctypes.data)
+        self._check(rc, allow=() if strict else (-5, -7))
+        r = int(used[2])
+        piles = PackedPiles(codes[:int(used[0])], nmask[:int(used[1])], read_len[:r], code_off[:r + 1], mask_off[:r + 1], begin)
+        return dict(decision=decision[:n_reads], pile_index=pile_index[:n_reads], results=[results[i] for i in range(n_loci)], piles=piles,
+                    pile_read=pile_read[:r])
 
     # ------------------------------------------------------------------ aligners
     def align_batch(self, kind, scores, extra, problems, strict=True):

@@ -162,3 +162,131 @@ REF_EXPORT int ref_bam_records(const char* bamPath, const char* fastaPath, int t
   }
   return emitText(os.str(), out, cap);
 }
+
+/// Every record of one region query, field by field, for the read-gathering tests (tests/test_read_class.py):
+///   "<qname> <flag> <tid> <pos0> <mapq> <mtid> <mpos0> <cigar|*> <seq4 hex> <qual hex> <hasSA> <MC|*>"
+/// exactly what bamStream.resetRegion(tid, begin, end) + next() hands getBreakendReads (:381-395), in file order.
+REF_EXPORT int ref_region_records(const char* bamPath, const char* fastaPath, int tid, int begin, int end, char* out, int cap)
+{
+  std::ostringstream os;
+  try {
+    bam_streamer bs(bamPath, fastaPath);
+    bs.resetRegion(tid, begin, end);
+    static const char hex[] = "0123456789abcdef";
+    while (bs.next()) {
+      const bam_record& rec(*bs.get_record_ptr());
+      const bam1_t*     b   = rec.get_data();
+      const unsigned    len = rec.read_size();
+      os << rec.qname() << " " << b->core.flag << " " << b->core.tid << " " << b->core.pos << " " << int(b->core.qual) << " " << b->core.mtid
+         << " " << b->core.mpos << " ";
+      if (b->core.n_cigar == 0) os << "*";
+      const uint32_t* cig = bam_get_cigar(b);
+      for (unsigned i = 0; i < b->core.n_cigar; ++i) os << (cig[i] >> 4) << "MIDNSHP=XB"[cig[i] & 15];
+      os << " ";
+      const uint8_t* seq  = bam_get_seq(b);
+      const uint8_t* qual = rec.qual();
+      if (len == 0) os << "*";
+      for (unsigned i = 0; i < (len + 1) / 2; ++i) os << hex[seq[i] >> 4] << hex[seq[i] & 15];
+      os << " ";
+      if (len == 0) os << "*";
+      for (unsigned i = 0; i < len; ++i) os << hex[qual[i] >> 4] << hex[qual[i] & 15];
+      static const char mc[] = {'M', 'C'};
+      const char*       mcs  = rec.get_string_tag(mc);
+      os << " " << (rec.isSASplit() ? 1 : 0) << " " << (mcs ? mcs : "*") << "\n";
+    }
+  } catch (const std::exception& e) {
+    os.str("");
+    os << "EXCEPTION " << e.what() << "\n";
+  }
+  return emitText(os.str(), out, cap);
+}
+
+/// SAM text -> BAM + index with the htslib of the reference's redist (so that synthetic alignments can go through the reference's
+/// own BAM layer)
+REF_EXPORT int ref_sam_to_bam(const char* samPath, const char* bamPath)
+{
+  samFile* in = sam_open(samPath, "r");
+  if (!in) return -1;
+  bam_hdr_t* hdr = sam_hdr_read(in);
+  if (!hdr) return -2;
+  samFile* outf = sam_open(bamPath, "wb");
+  if (!outf) return -3;
+  if (sam_hdr_write(outf, hdr) != 0) return -4;
+  bam1_t* b = bam_init1();
+  int     rc;
+  while ((rc = sam_read1(in, hdr, b)) >= 0)
+    if (sam_write1(outf, hdr, b) < 0) return -5;
+  bam_destroy1(b);
+  bam_hdr_destroy(hdr);
+  sam_close(in);
+  sam_close(outf);
+  if (rc < -1) return -6;
+  return sam_index_build(bamPath, 0) == 0 ? 0 : -7;
+}
+
+/// The reference's read gathering for one candidate with everything that shapes it under the caller's control:
+/// chromDepthPath ("" = no depth filter), isSearchRemote (complex candidates), minCandidateVariantSize.  state2 < 0: complex
+/// candidate on breakend 1 (assembleComplexSVCandidate); else spanning (assembleSpanningSVCandidate, orientation rule of
+/// getJumpAssembly as in ref_demo_pile).  Text: "reads <n>" + the pile + "ref1 <offset> <seq>" / "ref2 ...".
+REF_EXPORT int ref_breakend_pile(
+    int nBams, const char* const* bamPaths, const int* isTumor, const char* fastaPath, const char* chromDepthPath, int minCandidateVariantSize,
+    int isSearchRemote, int tid1, int begin1, int end1, int state1, int tid2, int begin2, int end2, int state2, char* out, int cap)
+{
+  std::ostringstream os;
+  try {
+    AlignmentFileOptions alignOpt;
+    for (int i = 0; i < nBams; ++i) {
+      alignOpt.alignmentFilenames.push_back(bamPaths[i]);
+      alignOpt.isAlignmentTumor.push_back(isTumor[i] != 0);
+    }
+    bam_streamer          first(bamPaths[0], fastaPath);
+    const bam_header_info header(first.get_header());
+    ReadScannerOptions    scanOpt;
+    scanOpt.minCandidateVariantSize = unsigned(minCandidateVariantSize);
+    IterativeAssemblerOptions asmOpt;
+    AllSampleReadCounts       counts;
+    counts.setSampleCount(nBams);
+    TimeTracker          tt;
+    SVCandidateAssembler assembler(scanOpt, asmOpt, alignOpt, fastaPath, "", chromDepthPath, header, counts, false, tt);
+    SVBreakend           bp1, bp2;
+    bp1.interval = GenomeInterval(tid1, begin1, end1);
+    bp1.state    = static_cast<SVBreakendState::index_t>(state1);
+    AssemblyReadInput pile;
+    g_captured = &pile;
+    Assembly                 as;
+    reference_contig_segment r1, r2;
+    if (state2 >= 0) {
+      bp2.interval = GenomeInterval(tid2, begin2, end2);
+      bp2.state    = static_cast<SVBreakendState::index_t>(state2);
+      SVCandidate sv;
+      sv.bp1 = bp1;
+      sv.bp2 = bp2;
+      static const pos_t extraRefEdgeSize(250);
+      unsigned           t1, t2, t3, t4;
+      getSVReferenceSegments(fastaPath, header, extraRefEdgeSize, sv, r1, r2, t1, t2, t3, t4);
+      bool isBp1Reversed(false), isBp2Reversed(false);
+      if (bp1.state == bp2.state) {
+        if (bp1.state == SVBreakendState::RIGHT_OPEN)
+          isBp2Reversed = true;
+        else
+          isBp1Reversed = true;
+      }
+      assembler.assembleSpanningSVCandidate(bp1, bp2, isBp1Reversed, isBp2Reversed, r1, r2, as);
+    } else {
+      static const pos_t extraRefEdgeSize(700);
+      getIntervalReferenceSegment(fastaPath, header, extraRefEdgeSize, bp1.interval, r1);
+      RemoteReadCache remote;
+      assembler.assembleComplexSVCandidate(bp1, r1, isSearchRemote != 0, remote, as);
+    }
+    g_captured = nullptr;
+    os << "reads " << pile.size() << "\n";
+    for (const std::string& r : pile) os << r << "\n";
+    os << "ref1 " << r1.get_offset() << " " << r1.seq() << "\n";
+    os << "ref2 " << r2.get_offset() << " " << r2.seq() << "\n";
+    os << "maxdepth " << (scanOpt.maxDepthFactor) << " " << scanOpt.maxLocalDepthFactorForRemoteReadRetrieval << "\n";
+  } catch (const std::exception& e) {
+    os.str("");
+    os << "EXCEPTION " << e.what() << "\n";
+  }
+  return emitText(os.str(), out, cap);
+}

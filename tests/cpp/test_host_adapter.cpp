@@ -8,6 +8,7 @@
 #include <sstream>
 
 #include "../../manta_amd/host/manta_amd.hpp"
+#include "../../manta_amd/host/read_gather.hpp"
 
 using namespace manta_amd;
 using ALIGNPATH::apath_to_cigar;
@@ -257,6 +258,50 @@ static void test_SmallAssembler()
   }
 }
 
+// the read gathering through the host adapter (manta_amd/host/read_gather.hpp): a plain read is left out, a soft-clipped read and
+// a read with a 12-base insertion are kept, a duplicate-flagged copy is filtered (SVCandidateAssembler.cpp:387-567)
+static void test_ReadGather()
+{
+  using namespace manta_amd;
+  std::string ref;
+  for (int i = 0; i < 1200; ++i) ref += "ACGTTGCAAGCTTCGA"[(i * 7 + i / 16) % 16];
+  auto other = [](char c) { return c == 'A' ? 'C' : c == 'C' ? 'G' : c == 'G' ? 'T' : 'A'; };
+  auto pack  = [](const std::string& s) {
+    std::vector<uint8_t> v((s.size() + 1) / 2, 0);
+    for (size_t i = 0; i < s.size(); ++i) {
+      const uint8_t c = s[i] == 'A' ? 1 : s[i] == 'C' ? 2 : s[i] == 'G' ? 4 : s[i] == 'T' ? 8 : 15;
+      v[i / 2] |= uint8_t(c << (4 * (1 - (i % 2))));
+    }
+    return v;
+  };
+  const std::vector<uint8_t> qual(50, 30);
+  ReadGatherBatch batch;
+  batch.beginCandidate(false, 0.f, 0.f, false);
+  batch.beginQuery(590, 610, 3 /* COMPLEX */, false, 0, false, true, 0, ref);
+  REQUIRE_EQUAL(batch.searchBegin(), 400);
+  REQUIRE_EQUAL(batch.searchEnd(), 800);
+  const std::string plain = ref.substr(500, 50);
+  std::string       clipped = ref.substr(520, 30);
+  for (int i = 0; i < 20; ++i) clipped += other(ref[550 + i]);
+  std::string inserted = ref.substr(560, 20) + std::string("TTTTTTTTTTTT") + ref.substr(580, 18);
+  const uint32_t cPlain[] = {50u << 4}, cClip[] = {30u << 4, (20u << 4) | 4u}, cIns[] = {20u << 4, (12u << 4) | 1u, 18u << 4};
+  batch.addRecord(0, 500, -1, -1, 0, 60, cPlain, 1, "plain", pack(plain).data(), qual.data(), 50, false, nullptr);
+  batch.addRecord(0, 520, -1, -1, 0, 60, cClip, 2, "clipped", pack(clipped).data(), qual.data(), 50, false, nullptr);
+  batch.addRecord(0, 520, -1, -1, 0x400, 60, cClip, 2, "clipped_dup", pack(clipped).data(), qual.data(), 50, false, nullptr);
+  batch.addRecord(0, 560, -1, -1, 0, 60, cIns, 3, "inserted", pack(inserted).data(), qual.data(), 50, false, "50M");
+  batch.run(threadContext(), ReadGatherBatch::defaultOptions());
+  REQUIRE_EQUAL(batch.results[0].status, 0);
+  REQUIRE_EQUAL(batch.results[0].n_pile_reads, 2u);
+  REQUIRE_EQUAL(batch.nPileReads(), uint64_t(2));
+  REQUIRE_EQUAL(batch.pileReadText(0), clipped);
+  REQUIRE_EQUAL(batch.pileReadText(1), inserted);
+  REQUIRE_EQUAL(unsigned(batch.decision[0]), 0u);
+  REQUIRE_EQUAL(unsigned(batch.decision[1]), unsigned(MANTA_READ_SEMI_ALIGNED | MANTA_READ_IN_PILE));
+  REQUIRE_EQUAL(unsigned(batch.decision[2]), 0u);
+  REQUIRE_EQUAL(unsigned(batch.decision[3] & (MANTA_READ_INDEL | MANTA_READ_IN_PILE)), unsigned(MANTA_READ_INDEL | MANTA_READ_IN_PILE));
+  REQUIRE_EQUAL(batch.piles().locus_read_begin[1], 2u);
+}
+
 int main()
 {
   try {
@@ -265,6 +310,7 @@ int main()
     test_GlobalJumpAligner();
     test_IterativeAssembler();
     test_SmallAssembler();
+    test_ReadGather();
   } catch (const std::exception& e) {
     std::cerr << "EXCEPTION: " << e.what() << "\n";
     return 2;

@@ -106,6 +106,7 @@ def test_oracle_recipe_builds_from_clean(tmp_path):
     src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
     dst = tmp_path / "oracle"
     shutil.copytree(src, dst, ignore=shutil.ignore_patterns("_ref", "*.so"))
+    shutil.copytree(os.path.join(os.path.dirname(src), "include"), tmp_path / "include")  # (the read-gathering restatement uses the ABI structs)
     subprocess.check_call(["make", "-s", "-C", str(dst), "-j4", "all"])
     for f in ("libmanta_oracle.so", "_ref/libmanta_ref.so", "_ref/libmanta_ref_refiner.so"):
         assert (dst / f).exists(), f

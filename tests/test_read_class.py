@@ -1,0 +1,197 @@
+"""Read-pile construction (second half): SVCandidateAssembler::getBreakendReads' per-read tests as a kernel
+(manta_read_piles_batch, manta_amd/csrc/read_class_kernels.hpp).
+
+Pinning chain:
+  * the restatement (oracle/read_class_oracle.cpp) against the UNMODIFIED reference (oracle/_ref/libmanta_ref_bam.so: the real
+    SVCandidateAssembler.cpp + htsapi + htslib over BAM files): on the demo BAMs through tests/golden/read_class_demo.json.gz
+    (records and reference piles stored by tests/golden/make_read_class_golden.py) and, where the _ref library is present, live on
+    synthetic BAM files written for the purpose (SAM -> BAM with the redist htslib);
+  * the kernel against the restatement on random record batches (decisions, pile positions, per-candidate results, pile text),
+    and directly against the reference piles of the demo."""
+import ctypes
+import gzip
+import json
+import os
+import random
+import tempfile
+
+import numpy as np
+import pytest
+
+import read_class_util as u
+from manta_amd._capi import BatchOutput, read_class_options, small_sv_text
+from oracle_lib import asm_opts
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = json.loads(gzip.open(os.path.join(ROOT, "tests", "golden", "read_class_demo.json.gz")).read())
+
+
+def demo_batch(cases):
+    b = u.Batch()
+    for c in cases:
+        scans = [dict(s, records=[u.parse_record(l) for l in G["regions"][s["region"]]]) for s in c["scans"]]
+        f = np.float32(c["chrom_depth"])
+        b.add_locus(scans, is_max_depth=c["is_max_depth"], search_remote=False, max_depth=float(f * np.float32(12)),
+                    max_local=float(f * np.float32(7)))
+    return b
+
+
+def demo_groups():
+    """candidates grouped by the one option that differs between them"""
+    groups = {}
+    for c in G["cases"]:
+        groups.setdefault(c["min_variant"], []).append(c)
+    return groups
+
+
+def test_restatement_reproduces_the_reference_piles_of_the_demo():
+    assert len(G["cases"]) == 11
+    for minvar, cases in demo_groups().items():
+        o = u.run_oracle(demo_batch(cases), read_class_options(min_candidate_variant_size=minvar))
+        for l, c in enumerate(cases):
+            assert o["piles"][l] == c["pile"], c["name"]
+            assert o["results"][l].status == 0
+    assert sum(len(c["pile"]) for c in G["cases"]) > 200
+
+
+def synthetic_bam_case(rb, tmp, seed):
+    """random alignments -> SAM -> BAM; the candidate through the reference and through the restatement"""
+    rng = random.Random(seed)
+    chrom0 = "".join(rng.choice("ACGT") for _ in range(9000))
+    chroms = [("chrA", chrom0), ("chrB", "".join(rng.choice("ACGT") for _ in range(100000)))]
+    fa = os.path.join(tmp, "g%d.fa" % seed)
+    u.write_fasta(fa, chroms)
+    n_bam, n_bp = rng.choice([1, 2, 3]), rng.choice([1, 2])
+    bps = []
+    for _ in range(n_bp):
+        centre, half = rng.randrange(2500, 6000), rng.choice([10, 60, 150, 260])
+        state = rng.choice([u.RIGHT_OPEN, u.LEFT_OPEN]) if n_bp == 2 else rng.choice([u.COMPLEX, u.RIGHT_OPEN, u.LEFT_OPEN, u.UNKNOWN])
+        bps.append((0, centre - half, centre + half, state))
+    bams, tumor, pool = [], [], ["shared%d" % k for k in range(12)]
+    for bi in range(n_bam):
+        recs = []
+        for bp in bps:
+            recs += u.random_scan(rng, rng.randrange(5, 120), bp[1], bp[2], bp[3], 0, chrom0, bi, False, True, False, pool)["records"]
+        recs = [r for r in recs if r["pos"] >= 0 and r["mpos"] >= 0]
+        recs = [recs[i] for i in sorted(range(len(recs)), key=lambda i: (recs[i]["pos"], i))]  # (a shadow stays behind its anchor)
+        sam = os.path.join(tmp, "s%d_%d.sam" % (seed, bi))
+        u.write_sam(sam, chroms, recs)
+        rb.sam_to_bam(sam, sam[:-3] + "bam")
+        bams.append(sam[:-3] + "bam")
+        tumor.append(bi >= max(1, n_bam - 1) and n_bam > 1)
+    depth, chrom_depth, cd = rng.random() < 0.6, rng.choice([0.3, 0.8, 2.0]), ""
+    if depth:
+        cd = os.path.join(tmp, "cd%d.txt" % seed)
+        open(cd, "w").write("chrA\t%g\nchrB\t%g\n" % (chrom_depth, chrom_depth))
+    minvar = rng.choice([10, 4, 30])
+    ref = rb.pile(bams, tumor, fa, cd, minvar, False, bps[0], bps[1] if n_bp == 2 else None)
+    rev = [False, False]
+    if n_bp == 2 and bps[0][3] == bps[1][3]:  # SVCandidateAssemblyRefiner.cpp:1795-1808
+        rev = [False, True] if bps[0][3] == u.RIGHT_OPEN else [True, False]
+    scans = []
+    for k, bp in enumerate(bps):
+        sb, se = ctypes.c_int32(), ctypes.c_int32()
+        u._oracle_lib().oracle_read_search_range(bp[1], bp[2], ctypes.byref(sb), ctypes.byref(se))
+        roff, rseq = ref["ref%d" % (k + 1)]
+        for bi in range(n_bam):
+            scans.append(dict(records=rb.region_records(bams[bi], fa, 0, sb.value, se.value), bam_index=bi, is_tumor=tumor[bi],
+                              is_locus_reversed=rev[k], first_of_breakend=(bi == 0), bp_begin=bp[1], bp_end=bp[2], bp_state=bp[3],
+                              ref_begin=roff, ref_seq=rseq))
+    b = u.Batch()
+    f = np.float32(chrom_depth)
+    b.add_locus(scans, is_max_depth=depth, search_remote=False, max_depth=float(f * np.float32(12)), max_local=float(f * np.float32(7)))
+    return b, read_class_options(min_candidate_variant_size=minvar), ref["reads"]
+
+
+@pytest.mark.skipif(not u.have_ref_bam(), reason="oracle/_ref/libmanta_ref_bam.so not built (reference sources unavailable)")
+def test_restatement_matches_the_reference_on_synthetic_bam_files():
+    rb = u.RefBam()
+    n_reads = 0
+    with tempfile.TemporaryDirectory(prefix="manta_rc_") as tmp:
+        for seed in range(14):
+            b, opt, want = synthetic_bam_case(rb, tmp, seed)
+            assert u.run_oracle(b, opt)["piles"][0] == want, seed
+            n_reads += len(want)
+    assert n_reads > 100
+
+
+def check_random(lib, seeds, n_loci=4, reads_per_scan=(5, 160)):
+    n = 0
+    for seed in seeds:
+        b = u.random_batch(seed, n_loci=n_loci, reads_per_scan=reads_per_scan, eq_rate=0.02 if seed % 3 == 0 else 0.0)
+        opt = read_class_options(max_reads=[0, 7, 25][seed % 3], min_candidate_variant_size=[10, 4, 30][seed % 3],
+                                 use_overlap_pair_evidence=seed % 2)
+        u.same(u.run_product(lib, b, opt), u.run_oracle(b, opt), len(b.loci))
+        n += len(b.reads)
+    return n
+
+
+def check_demo(lib):
+    for minvar, cases in demo_groups().items():
+        p = u.run_product(lib, demo_batch(cases), read_class_options(min_candidate_variant_size=minvar), strict=True)
+        for l, c in enumerate(cases):
+            assert p["piles_text"][l] == c["pile"], c["name"]
+
+
+def test_emulated_kernel_matches_restatement_on_random_records(emu):
+    assert check_random(emu, range(100, 108)) > 5000
+
+
+def test_emulated_kernel_reproduces_the_reference_piles_of_the_demo(emu):
+    check_demo(emu)
+
+
+def test_emulated_empty_and_degenerate_batches(emu):
+    b = u.Batch()
+    b.add_locus([])  # a candidate without a region query
+    b.add_locus([dict(records=[], bam_index=0, is_tumor=False, is_locus_reversed=False, first_of_breakend=True, bp_begin=100, bp_end=130,
+                      bp_state=u.COMPLEX, ref_begin=0, ref_seq="ACGT" * 100)])
+    z = u.record_from_bases("empty", 0x1, 0, 120, 60, 0, 300, "*", "", [])  # a record without sequence
+    b.add_locus([dict(records=[z], bam_index=0, is_tumor=False, is_locus_reversed=True, first_of_breakend=True, bp_begin=100, bp_end=130,
+                      bp_state=u.COMPLEX, ref_begin=0, ref_seq="ACGT" * 100)], is_max_depth=True, max_depth=1.0, max_local=1.0)
+    u.same(u.run_product(emu, b), u.run_oracle(b), 3)
+
+
+def check_piles_feed_the_pipeline(lib, oracle):
+    """the piles the kernel builds from the demo's BAM records go straight into the small-SV pipeline (manta_smallsv_batch_piles)
+    and give what the oracle gives on the reference's pile text"""
+    cases = [c for c in G["cases"] if c["min_variant"] == 10 and len(c["scans"]) == 2 and c["pile"]]
+    p = u.run_product(lib, demo_batch(cases), strict=True)
+    n = len(cases)
+    refs, cuts = [], []
+    for c in cases:
+        ref = c["scans"][0]["ref_seq"]
+        mid = len(ref) // 2
+        refs.append(ref[mid - 300:mid + 300].encode())
+        cuts.append((100, 100, 200, 200))
+    ref_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum([len(r) for r in refs], out=ref_off[1:])
+    refs_np = np.frombuffer(b"".join(refs) + b"\0" * 64, dtype=np.uint8)
+    cuts_np = np.ascontiguousarray(np.array(cuts, dtype=np.int32))
+    opts, sc = asm_opts(minWordLength=41, maxWordLength=76, wordStepSize=5), [2, -8, -24, -1, -1, 0]
+    out = BatchOutput(lib, "smallsv", n, 10, 1 << 20, 1 << 16, 1 << 18)
+    lib.smallsv_batch_piles(opts, sc, -100, p["piles"], refs_np, ref_off, cuts_np, out)
+    res = out.decode(np.diff(p["piles"].begin))
+    for l, c in enumerate(cases):
+        want = oracle.small_sv_locus(opts, sc, -100, [r.encode() for r in c["pile"]], refs[l], cuts[l])
+        assert small_sv_text(res[l]) == want, c["name"]
+
+
+def test_emulated_piles_feed_the_pipeline(emu, oracle):
+    check_piles_feed_the_pipeline(emu, oracle)
+
+
+@pytest.mark.gpu
+def test_gpu_kernel_matches_restatement_on_random_records(gpu):
+    assert check_random(gpu, range(100, 124)) > 15000
+    assert check_random(gpu, range(300, 303), n_loci=40, reads_per_scan=(100, 900)) > 100000
+
+
+@pytest.mark.gpu
+def test_gpu_kernel_reproduces_the_reference_piles_of_the_demo(gpu):
+    check_demo(gpu)
+
+
+@pytest.mark.gpu
+def test_gpu_piles_feed_the_pipeline(gpu, oracle):
+    check_piles_feed_the_pipeline(gpu, oracle)
