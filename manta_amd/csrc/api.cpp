@@ -71,14 +71,18 @@ struct PinnedBuf {
   {
     if (p) rt::hostFree(p);
   }
+  /// keep: the bytes held so far survive a growth (a second staging round appends to the first)
   template <typename T>
-  T* as(size_t count)
+  T* as(size_t count, bool keep = false)
   {
     const size_t n = count * sizeof(T);
     if (n > cap) {
+      const size_t want = n + n / 4 + 256;
+      void*        q    = rt::hostAlloc(want);
+      if (p && keep) std::memcpy(q, p, cap);
       if (p) rt::hostFree(p);
-      cap = n + n / 4 + 256;
-      p   = rt::hostAlloc(cap);
+      cap = want;
+      p   = q;
     }
     return static_cast<T*>(p);
   }
@@ -238,25 +242,30 @@ bool stringHashMatchesLibstdcxx()
   return true;
 }
 
-/// device memory one pipeline may take for its per-wave workspaces: an equal share of half the free memory, capped
+/// Device memory one pipeline may take for its per-wave workspaces: an equal share of half of what is free ON ITS DEVICE
+/// among the pipelines that live on that device, capped.  Process-wide bookkeeping per device (a node context keeps
+/// pipelines on several GPUs; a reading of another device's free memory would be the wrong number).
+static const int kMaxDevices = 64;
+std::atomic<int> g_livePerDevice[kMaxDevices];
 size_t workspaceBudget(const size_t capBytes)
 {
   // hipMemGetInfo is a driver round trip (tenths of a millisecond) and this is called on every upload and run: the
   // budget is a soft bound (half of the free memory), so a reading that is a fraction of a second old is good enough
   static std::mutex                            mu;
-  static size_t                                cachedFree = 0;
-  static std::chrono::steady_clock::time_point stamp;
+  static size_t                                cachedFree[kMaxDevices] = {0};
+  static std::chrono::steady_clock::time_point stamp[kMaxDevices];
+  const int                                    dev = std::min(kMaxDevices - 1, std::max(0, rt::currentDevice()));
   size_t                                       freeNow;
   {
     std::lock_guard<std::mutex> g(mu);
     const auto                  now = std::chrono::steady_clock::now();
-    if (cachedFree == 0 || now - stamp > std::chrono::milliseconds(250)) {
-      cachedFree = rt::freeBytes();
-      stamp      = now;
+    if (cachedFree[dev] == 0 || now - stamp[dev] > std::chrono::milliseconds(250)) {
+      cachedFree[dev] = rt::freeBytes();
+      stamp[dev]      = now;
     }
-    freeNow = cachedFree;
+    freeNow = cachedFree[dev];
   }
-  const int live = std::max(1, g_liveWorkspaces.load());
+  const int live = std::max(1, g_livePerDevice[dev].load());
   return std::min<size_t>(freeNow / 2 / size_t(live), capBytes);
 }
 
@@ -400,10 +409,15 @@ static int fastTeam()
 
 struct AsmStage {
   manta_ctx_t* ctx;
-  explicit AsmStage(manta_ctx_t* c) : ctx(c) { g_liveWorkspaces++; }
+  explicit AsmStage(manta_ctx_t* c) : ctx(c)
+  {
+    g_liveWorkspaces++;
+    g_livePerDevice[std::min(kMaxDevices - 1, std::max(0, c->deviceId))]++;
+  }
   ~AsmStage()
   {
     g_liveWorkspaces--;
+    g_livePerDevice[std::min(kMaxDevices - 1, std::max(0, ctx->deviceId))]--;
     if (dChunksDone) rt::dfree(dChunksDone);
   }
   AsmStage(const AsmStage&) = delete;
@@ -1037,8 +1051,14 @@ struct AsmStage {
   /// `moreCopies` lets a pipeline queue its own copies behind the second round so that one sync covers them.
   /// `firstCopies` / `moreCopies` let a pipeline queue its own copies in the first / second round trip; with
   /// `sparseContigs` false the (mostly empty) per-slot contig records stay on the device (the pipeline brings packed ones)
-  template <typename F0, typename F>
-  void stageOut(F0 firstCopies, F moreCopies, bool sparseContigs = true)
+  /// The staging is split so that a pipeline can queue it right behind its last kernel: stageEnqueue() queues the counters,
+  /// the locus records and -- speculatively -- the used part of the arenas as far as it is known or predicted (the sizes of
+  /// the previous run of this stage, a quarter on top: consecutive blocks of a batch look alike); stageFinish(), after the
+  /// stream has drained, fetches what the speculation missed (a second round trip only then).
+  uint64_t seqCopied = 0, bitsCopied = 0, seqLast = 0, bitsLast = 0;
+  bool     stageQueued = false;
+  template <typename F0>
+  void stageEnqueue(F0 firstCopies, bool sparseContigs = true)
   {
     hCnt  = pCnt.as<uint64_t>(16);
     hLoci = pLoci.as<AsmLocusOut>(nLoci);
@@ -1048,16 +1068,37 @@ struct AsmStage {
       hCont = pCont.as<AsmContigOut>(uint64_t(nLoci) * opt.max_assembly_count);
       rt::d2hAsync(hCont, dCont, sizeof(AsmContigOut) * uint64_t(nLoci) * opt.max_assembly_count);
     }
+    seqCopied  = std::min<uint64_t>(devSeqCap, seqLast + seqLast / 4 + (seqLast ? 4096 : 0));
+    bitsCopied = std::min<uint64_t>(devBitsCap, bitsLast + bitsLast / 4 + (bitsLast ? 512 : 0));
+    hSeq       = pSeq.as<uint8_t>(seqCopied + 1);
+    hBits      = pBits.as<uint64_t>(bitsCopied + 1);
+    rt::d2hAsync(hSeq, dSeq, seqCopied);
+    rt::d2hAsync(hBits, dBits, sizeof(uint64_t) * bitsCopied);
     firstCopies();
-    rt::sync();
+    stageQueued = true;
+  }
+  /// after the stream has drained.  moreCopies(queued&) queues what the pipeline still misses and sets `queued` if it did.
+  template <typename F>
+  void stageFinish(F moreCopies)
+  {
+    stageQueued = false;
     seqUsedDev  = std::min<uint64_t>(hCnt[1], devSeqCap);
     bitsUsedDev = std::min<uint64_t>(hCnt[2], devBitsCap);
-    hSeq        = pSeq.as<uint8_t>(seqUsedDev + 1);
-    hBits       = pBits.as<uint64_t>(bitsUsedDev + 1);
-    rt::d2hAsync(hSeq, dSeq, seqUsedDev);
-    rt::d2hAsync(hBits, dBits, sizeof(uint64_t) * bitsUsedDev);
-    moreCopies();
-    rt::sync();
+    seqLast     = seqUsedDev;
+    bitsLast    = bitsUsedDev;
+    bool queued = false;
+    if (seqUsedDev > seqCopied) {  // (the staging buffer keeps what it holds when it grows)
+      hSeq = pSeq.as<uint8_t>(seqUsedDev + 1, true);
+      rt::d2hAsync(hSeq + seqCopied, dSeq + seqCopied, seqUsedDev - seqCopied);
+      queued = true;
+    }
+    if (bitsUsedDev > bitsCopied) {
+      hBits = pBits.as<uint64_t>(bitsUsedDev + 1, true);
+      rt::d2hAsync(hBits + bitsCopied, dBits + bitsCopied, sizeof(uint64_t) * (bitsUsedDev - bitsCopied));
+      queued = true;
+    }
+    moreCopies(queued);
+    if (queued) rt::sync();
     nContigsOut = pseudoBytesOut = pseudoCountOut = 0;
     for (uint32_t l = 0; l < nLoci; ++l) {
       const AsmLocusOut& h(hLoci[l]);
@@ -1081,7 +1122,9 @@ struct AsmStage {
   }
   void stageOut()
   {
-    stageOut([] {}, [] {});
+    stageEnqueue([] {});
+    rt::sync();
+    stageFinish([](bool&) {});
   }
 
   /// exact sizes compact() will write (valid after stageOut): contig records, text bytes, bitset qwords
@@ -1238,6 +1281,11 @@ struct manta_smallsv {
   PackedContigOut*      hPacked = nullptr;
   uint32_t*             hCig    = nullptr;
   uint32_t*             hPackCnt = nullptr;  // [0] packed contigs, [1] packed cigar words
+  uint64_t              packLast[2] = {0, 0}, packedCopied = 0, cigCopied = 0;  // speculative staging (pipeStageEnqueue)
+  PinnedBuf             pSmall;
+  uint32_t              lastSmall[40] = {0};  // bucket counters of the previous run (grids of the next one)
+  bool                  bucketHistory = false;
+  bool                  stageBehindRun = false;  // whole-batch calls: the run queues the staging behind its last kernel
   bool                  staged = false;
   explicit manta_smallsv(manta_ctx_t* c) : ctx(c), asmStage(c) {}
 };
@@ -1268,6 +1316,8 @@ struct manta_spanning {
   PackedContigOut*      hPacked = nullptr;
   uint32_t*             hCig    = nullptr;
   uint32_t*             hPackCnt = nullptr;
+  uint64_t              packLast[2] = {0, 0}, packedCopied = 0, cigCopied = 0;
+  bool                  stageBehindRun = false;
   bool                  staged = false;
   explicit manta_spanning(manta_ctx_t* c) : ctx(c), asmStage(c) {}
 };
@@ -1807,6 +1857,11 @@ void drainCopyStream(Pipe* b) noexcept
   }
 }
 
+namespace {
+template <typename Pipe>
+void pipeStageEnqueue(Pipe* b);
+}
+
 int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
 {
   if (!b) return MANTA_E_INVALID_ARG;
@@ -1895,23 +1950,39 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     b->evSched.record();
     stage("scheduled");
 
-    // bucket sizes decide the alignment launches (one tiny D2H)
-    uint32_t hSmall[32];
-    rt::d2h(hSmall, dSmall, sizeof(hSmall));
-    b->stats.n_align_launches = 0;
-    b->stats.n_alignments     = 0;
-    b->stats.ptr_matrix_bytes = 0;
+    // Bucket sizes decide the alignment launches.  First run of a pipeline: one tiny D2H.  Later runs of a whole-batch call
+    // do not wait for it: every bucket is launched with the task count read on the device (AlignParams::n_tasks_dev), its
+    // grid sized from the previous run's counts (consecutive blocks look alike; the waves of a bucket pull tasks from a queue,
+    // so a grid that is off costs time, never results) and its slabs from what the host knows (longest reference window,
+    // longest possible contig).  The counts come back with the results.
+    uint32_t hSmall[40];
     const int    maxWaves = std::max(1, ctx->cuCount * alignWavesPerCu());
     const size_t wsBudget = workspaceBudget(size_t(48) << 30);
-    // The E buckets are independent launches: they run on side streams so that the tail of one overlaps the others
-    // (a launch's last alignments leave most of the device idle otherwise).  Each bucket gets its own slab region.
-    {
-      struct Launch {
-        int      k, grid;
-        uint64_t stride, slabOff;
-      };
-      std::vector<Launch> launches;
-      uint64_t            slabBytes = 0;
+    bool         fromHistory = b->bucketHistory && b->stageBehindRun && !std::getenv("MANTA_AMD_SYNC_BUCKETS");
+    struct Launch {
+      int      k, grid;
+      uint64_t stride, slabOff;
+    };
+    std::vector<Launch> launches;
+    uint64_t            slabBytes = 0;
+    if (fromHistory) {
+      for (int k = kNumESet - 1; k >= 0; --k) {
+        const uint64_t hint   = uint64_t(b->lastSmall[k]) + b->lastSmall[k] / 4 + 64;
+        const uint64_t qBound = (kESet[k] == 32) ? std::max<uint64_t>(as.maxContigLen, 64ull * 32) : 64ull * uint64_t(kESet[k]);
+        const uint64_t refLen = alignSlabRefLen(MANTA_ALIGNER_LARGE_INDEL, kESet[k], qBound, b->maxRef);
+        const uint64_t stride = (alignPtrSlabBytes(MANTA_ALIGNER_LARGE_INDEL, kESet[k], refLen) + 255) & ~uint64_t(255);
+        const int      grid   = rt::roundGrid(int(std::min<uint64_t>(hint, uint64_t(maxWaves))));
+        launches.push_back(Launch{k, grid, stride, slabBytes});
+        slabBytes += stride * uint64_t(grid);
+      }
+      if (slabBytes > wsBudget / 3) {  // too generous for this device right now: size from the real counts
+        fromHistory = false;
+        launches.clear();
+        slabBytes = 0;
+      }
+    }
+    if (!fromHistory) {
+      rt::d2h(hSmall, dSmall, sizeof(hSmall));
       for (int k = kNumESet - 1; k >= 0; --k) {  // widest (longest-running) buckets first
         const uint32_t cnt = hSmall[k];
         if (cnt == 0) continue;
@@ -1922,7 +1993,16 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
         launches.push_back(Launch{k, grid, stride, slabBytes});
         slabBytes += stride * uint64_t(grid);
       }
+    }
+    b->stats.n_align_launches = 0;
+    b->stats.n_alignments     = 0;
+    b->stats.ptr_matrix_bytes = 0;
+    // The E buckets are independent launches: they run on side streams so that the tail of one overlaps the others
+    // (a launch's last alignments leave most of the device idle otherwise).  Each bucket gets its own slab region.
+    {
       uint8_t* dWsAll = b->dPtrWs.as<uint8_t>(slabBytes + 256);
+      // (without the host read in between nothing else orders the side streams behind the schedule kernel)
+      for (int i = 0; i < 3; ++i) rt::streamWaits(b->side[i], b->evSched);
       for (size_t i = 0; i < launches.size(); ++i) {
         const Launch& l(launches[i]);
         AlignParams   P;
@@ -1930,8 +2010,8 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
         P.results        = dResults;
         P.cigar          = dCigar;
         P.task_ids       = dBuckets + uint64_t(l.k) * nSlots;
-        P.n_tasks        = hSmall[l.k];
-        P.n_tasks_dev    = nullptr;
+        P.n_tasks        = fromHistory ? uint32_t(nSlots) : hSmall[l.k];
+        P.n_tasks_dev    = fromHistory ? dSmall + l.k : nullptr;
         P.counter        = dSmall + 40 + l.k;
         P.ptr_ws         = dWsAll + l.slabOff;
         P.ptr_ws_stride  = l.stride;
@@ -1946,8 +2026,10 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
           rt::ScopedStream onSide(b->side[i % 3]);  // (restores the pipeline's stream: nothing of this call runs on the null stream)
           launchAlignKind(MANTA_ALIGNER_LARGE_INDEL, l.k, l.grid, P);
         }
-        b->stats.n_align_launches++;
-        b->stats.n_alignments += hSmall[l.k];
+        if (!fromHistory) {
+          b->stats.n_align_launches++;
+          b->stats.n_alignments += hSmall[l.k];
+        }
       }
       // the null stream (events, later copies) continues after every side stream has drained
       for (size_t i = 0; i < std::min<size_t>(launches.size(), 3); ++i) {
@@ -1957,7 +2039,18 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     }
     launchPack(b, dTasks, nullptr, dResults, nullptr, dInfo, nullptr, dCigar, cigarCap);
     b->evAlign.record();
+    uint32_t* hSmallPin = b->pSmall.as<uint32_t>(40);
+    rt::d2hAsync(hSmallPin, dSmall, sizeof(uint32_t) * 40);
+    if (b->stageBehindRun) pipeStageEnqueue(b);  // the results start for the host behind the last kernel: no wake-up in between
     rt::sync();
+    std::memcpy(b->lastSmall, hSmallPin, sizeof(b->lastSmall));
+    b->bucketHistory = true;
+    if (fromHistory)
+      for (int k = 0; k < kNumESet; ++k)
+        if (b->lastSmall[k]) {
+          b->stats.n_align_launches++;
+          b->stats.n_alignments += b->lastSmall[k];
+        }
     alignOnly.release();
     if (as.streaming) {  // all chunks were consumed by the kernel, so this returns at once; it closes the stream's error state
       rt::ScopedStream onCopy(b->copy);
@@ -2013,24 +2106,58 @@ namespace {
 /// device -> pinned staging of one finished pipeline run (both pipelines): counters + locus records + first-contig
 /// index in the first round trip, then exactly the used part of every arena
 template <typename Pipe>
-void pipeStage(Pipe* b)
+void pipeStageEnqueue(Pipe* b)
 {
   const uint32_t nLoci = b->nLoci;
   b->hPackCnt          = b->pPackCnt.template as<uint32_t>(4);
   b->hFirst            = b->pFirst.template as<uint32_t>(nLoci);
-  b->asmStage.stageOut(
+  b->asmStage.stageEnqueue(
       [&] {
         rt::d2hAsync(b->hPackCnt, b->dPackCnt.p, 16);
         rt::d2hAsync(b->hFirst, b->dFirst.p, sizeof(uint32_t) * nLoci);
-      },
-      [&] {
-        b->hPacked = b->pPacked.template as<PackedContigOut>(uint64_t(b->hPackCnt[0]) + 1);
-        b->hCig    = b->pCig.template as<uint32_t>(uint64_t(b->hPackCnt[1]) + 1);
-        rt::d2hAsync(b->hPacked, b->dPacked.p, sizeof(PackedContigOut) * uint64_t(b->hPackCnt[0]));
-        rt::d2hAsync(b->hCig, b->dCigPacked.p, sizeof(uint32_t) * uint64_t(b->hPackCnt[1]));
+        // packed contig records and CIGARs: as many as the previous run had, a quarter on top
+        b->packedCopied = b->packLast[0] + b->packLast[0] / 4 + (b->packLast[0] ? 64 : 0);
+        b->cigCopied    = b->packLast[1] + b->packLast[1] / 4 + (b->packLast[1] ? 1024 : 0);
+        b->packedCopied = std::min<uint64_t>(b->packedCopied, b->dPacked.cap / sizeof(PackedContigOut));
+        b->cigCopied    = std::min<uint64_t>(b->cigCopied, b->dCigPacked.cap / sizeof(uint32_t));
+        b->hPacked      = b->pPacked.template as<PackedContigOut>(b->packedCopied + 1);
+        b->hCig         = b->pCig.template as<uint32_t>(b->cigCopied + 1);
+        rt::d2hAsync(b->hPacked, b->dPacked.p, sizeof(PackedContigOut) * b->packedCopied);
+        rt::d2hAsync(b->hCig, b->dCigPacked.p, sizeof(uint32_t) * b->cigCopied);
       },
       false);
+}
+template <typename Pipe>
+void pipeStageFinish(Pipe* b)
+{
+  b->asmStage.stageFinish([&](bool& queued) {
+    const uint64_t nP = b->hPackCnt[0], nG = b->hPackCnt[1];
+    b->packLast[0] = nP;
+    b->packLast[1] = nG;
+    if (nP > b->packedCopied) {
+      b->hPacked = b->pPacked.template as<PackedContigOut>(nP + 1, true);
+      rt::d2hAsync(b->hPacked + b->packedCopied, static_cast<const PackedContigOut*>(b->dPacked.p) + b->packedCopied,
+                   sizeof(PackedContigOut) * (nP - b->packedCopied));
+      queued = true;
+    }
+    if (nG > b->cigCopied) {
+      b->hCig = b->pCig.template as<uint32_t>(nG + 1, true);
+      rt::d2hAsync(b->hCig + b->cigCopied, static_cast<const uint32_t*>(b->dCigPacked.p) + b->cigCopied, sizeof(uint32_t) * (nG - b->cigCopied));
+      queued = true;
+    }
+  });
   b->staged = true;
+}
+/// device -> pinned staging of one finished pipeline run (both pipelines).  A run that queued the staging behind its last
+/// kernel (stageBehindRun) has done the first half already.
+template <typename Pipe>
+void pipeStage(Pipe* b)
+{
+  if (!b->asmStage.stageQueued) {
+    pipeStageEnqueue(b);
+    rt::sync();
+  }
+  pipeStageFinish(b);
 }
 
 template <typename Pipe>
@@ -2431,6 +2558,7 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
     alignRound(hSmall + 32, hSmall + 48, dTasks2, dResults2, dBuckets2, dSmall + 88);
     launchPack(b, dTasks, dTasks2, dResults, dResults2, nullptr, dInfo, dCigar, cigarCap);
     b->evAlign.record();
+    if (b->stageBehindRun) pipeStageEnqueue(b);
     rt::sync();
     alignOnly.release();
     if (as.streaming) {  // every chunk was consumed by the kernel, so this returns at once; it closes the copy stream's error state
@@ -2829,6 +2957,7 @@ int smallsvBatchImpl(
         {
           std::unique_lock<std::mutex> only(sh.kernelMu, std::defer_lock);
           if (sh.serialKernels) only.lock();
+          b->stageBehindRun = true;
           rc = smallsvRunImpl(b, sh.pipelineStages ? &sh.gates[w % nCtx] : nullptr);
         }
         if (rc != MANTA_OK) {
@@ -3046,6 +3175,7 @@ int spanningBatchImpl(
         {
           std::unique_lock<std::mutex> only(sh.kernelMu, std::defer_lock);
           if (sh.serialKernels) only.lock();
+          b->stageBehindRun = true;
           rc = spanningRunImpl(b, sh.pipelineStages ? &sh.gates[w % nCtx] : nullptr);
         }
         if (rc != MANTA_OK) {

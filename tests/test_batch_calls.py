@@ -133,6 +133,26 @@ def test_emulated_batches_with_blocking_upload(emu, oracle):
     check_spanning(emu, oracle, 5, block=2, workers=1, streamed=False)
 
 
+def check_history_across_different_batches(lib, n):
+    """a pipeline launches its aligner buckets and stages its results from what its PREVIOUS run looked like (api.cpp: bucket
+    history, speculative staging); batches of different shapes one after the other on the same pipelines -- short contigs, then
+    long reference windows and longer reads, then bigger, then the first again -- must each equal the staged API"""
+    opts = asm_opts(minWordLength=25, maxWordLength=45)
+    shapes = [dict(n_reads=20, read_len=80, ref_len=500, cut=(40, 40, 200, 200)), dict(n_reads=30, read_len=140, ref_len=1400, cut=(10, 10, 600, 600)),
+              dict(n_reads=12, read_len=60, ref_len=300, cut=(0, 0, 100, 100)), dict(n_reads=20, read_len=80, ref_len=500, cut=(40, 40, 200, 200))]
+    for i, sh in enumerate(shapes):
+        m = n * (3 if i == 2 else 1)
+        batch = config2_batch(m, seed=7000 + i, n_reads=sh["n_reads"], read_len=sh["read_len"], ref_len=sh["ref_len"])
+        batch = batch[:5] + (np.tile(np.array(sh["cut"], dtype=np.int32), (m, 1)),)
+        out = BatchOutput(lib, "smallsv", m, 10, 1 << 22, 1 << 18, 1 << 21)
+        lib.smallsv_batch(opts, SCORES, -100, batch, out, block_loci=0, n_workers=1)
+        assert [small_sv_text(r) for r in out.decode(np.diff(batch[2]))] == staged_smallsv_texts(lib, batch, opts), i
+
+
+def test_emulated_batch_history_across_different_batches(emu):
+    check_history_across_different_batches(emu, 5)
+
+
 def test_emulated_batch_odd_shapes(emu):
     stress_shapes(emu, [(1, 0, 0), (3, 2, 3), (9, 4, 2), (17, 0, 1)], 900)
 
@@ -144,3 +164,4 @@ def test_gpu_batch_odd_shapes_and_repeats(gpu):
     # the same pipelines again and again (buffers are reused, counters and events must start clean every call)
     for rep in range(6):
         stress_shapes(gpu, [(257, 64, 2), (40, 0, 1)], 950 + rep)
+    check_history_across_different_batches(gpu, 120)
