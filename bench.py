@@ -48,8 +48,8 @@ METRIC = "candidate SV loci assembled+aligned per second (whole node)"
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--loci", type=int, default=0, help="loci per GPU (default: 10000 smallsv = config 2; 65536 spanning)")
     ap.add_argument("--workload", choices=("smallsv", "spanning"), default="smallsv",
                     help="smallsv = BASELINE config[1] (the metric's configuration, default); spanning = config[4] shape "

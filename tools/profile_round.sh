@@ -11,6 +11,7 @@ B="python $R/bench.py"
 timeout 400 $B > $O/bench_line.json 2> $O/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $B --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2> /dev/null
 P="--steps 1 --warmup 0 --no-cpu-baseline --no-extras"
+if [ -z "$PROFILE_LINES_ONLY" ]; then  # PROFILE_LINES_ONLY=1: bench line, kernel stats and the step trace only (the counter passes are kept)
 # counter passes use the blocking upload: under the profiler the copies of a streamed upload are delayed and the assembler's
 # chunk-wait loop (s_sleep polling) would dominate every SQ_* counter; the kernel's work is the same
 export MANTA_AMD_NO_STREAM_UPLOAD=1
@@ -19,10 +20,11 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/pmc_sq -o p -- $B $P > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq2 -o p -- $B $P > /dev/null 2>&1
 unset MANTA_AMD_NO_STREAM_UPLOAD
+fi
 # one plain kernel trace of the default step: every dispatch with its start / end (the gaps are the host turnarounds)
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_step -o t -- $B --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
 # the opt-in LDS-resident fast assembler (asm_fast.hpp), same passes (evidence for DESIGN.md: traffic vs time); PROFILE_SKIP_FAST=1 leaves them out
-if [ -z "$PROFILE_SKIP_FAST" ]; then
+if [ -z "$PROFILE_SKIP_FAST" ] && [ -z "$PROFILE_LINES_ONLY" ]; then
 export MANTA_AMD_ASM_PATH=fast
 mkdir -p $O/fast
 timeout 300 $B --no-cpu-baseline --no-extras > $O/fast/bench_line.json 2> $O/fast/bench.err

@@ -77,6 +77,9 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         for k, ids in seen.items():
             launches[k] = max(launches.get(k, 0), len(ids))
 cols = sorted({c for v in per.values() for c in v})
+if not per:  # a lines-only run (PROFILE_LINES_ONLY=1): the counter summaries of the full run stay
+    print(line[:300])
+    sys.exit(0)
 with open(os.path.join(dst, tag + "_pmc_summary.csv"), "w") as out:
     out.write("# rocprofv3 --pmc passes over `python bench.py --steps 1 --warmup 0 --no-cpu-baseline` (10k loci, config 2), summed per kernel\n")
     out.write("# over the launches of that one step.  FETCH_SIZE / WRITE_SIZE are KiB as rocprofv3 reports them (separate passes; see\n")
