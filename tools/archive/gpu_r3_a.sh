@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, first GPU visit: assemble_fast_kernel parity (assembler tests + full-size digests), bench A/B fast vs general
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r03a
 rm -rf $O && mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-phase shader clocks of assemble_fast_kernel (profile build)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r03b
 rm -rf $O && mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of assemble_fast_kernel (instruction mix, waits)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r03c
 rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick loop: digests + bench (fast path) + phase profile
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r03d
 rm -rf $O && mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # fast + general kernels side by side on one queue: digests in all three modes, bench A/B
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r03e
 rm -rf $O && mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel trace of the side-by-side launch: do the two assembler kernels overlap?
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r03f
 rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 #!/bin/bash
 # side-by-side assembler kernels: how many loci of the list's end to leave to the fast kernel
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r03g
 rm -rf $O && mkdir -p $O
 cd $R

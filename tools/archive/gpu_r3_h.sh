@@ -1,6 +1,6 @@
 #!/bin/bash
 # general kernel with speculative contig rounds: parity (assembler tests, digests) + bench + phase profile + spanning bench
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r03h
 rm -rf $O && mkdir -p $O
 cd $R

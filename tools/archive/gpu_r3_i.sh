@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick: digests + bench of the default path
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r03i
 rm -rf $O && mkdir -p $O
 cd $R

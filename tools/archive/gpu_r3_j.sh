@@ -1,6 +1,6 @@
 #!/bin/bash
 # whole GPU tier + default bench
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r03j
 rm -rf $O && mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # node layer on hardware: two contexts on the one GPU; the multi-rank bench paths on one GPU (RCCL with one rank; two gloo ranks sharing the device)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r03k
 rm -rf $O && mkdir -p $O
 cd $R

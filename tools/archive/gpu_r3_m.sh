@@ -1,6 +1,6 @@
 #!/bin/bash
 # experiment: smaller typical-case workspace slabs (node capacity = bases / div; overflows run again)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
 for div in 1 2 4 6 8; do
   MANTA_AMD_ASM_NODE_DIV=$div MANTA_AMD_DEBUG=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /tmp/b.json 2> /tmp/b.err
