@@ -1475,7 +1475,7 @@ struct AssemblerT {
     uint64_t       used        = 0;  // lane w owns word w
     uint64_t       alive       = (nCand >= 64) ? ~uint64_t(0) : ((uint64_t(1) << nCand) - 1);
     unsigned       finalCount  = 0;
-    uint32_t*      chosenIdx   = frontier;  // scratch (the k-mer graph is no longer needed); same value from every lane
+    unsigned       chosenReg   = 0;  // lane f: the f-th chosen candidate (maxAssemblyCount <= 32 < 64)
     if (W <= WQ_MAX) {
       // Lane-per-candidate form of the same loop for read sets of up to WQ_MAX qwords (the usual case): lane ci keeps
       // candidate ci's support set and length in registers, the set of used reads is wave-uniform, and one selection round
@@ -1509,7 +1509,7 @@ struct AssemblerT {
         }
         if ((key >> 40) == 0) break;  // :807
         const int selected = wv::first(int(63u - unsigned(key & 63u)));
-        chosenIdx[finalCount] = unsigned(selected);
+        if (lane == finalCount) chosenReg = unsigned(selected);
         if (int(lane) == selected) aliveL = false;
         for (unsigned w = 0; w < WQ_MAX; ++w) usedS[w] |= wv::shfl(sup[w], selected);
         finalCount++;
@@ -1541,17 +1541,27 @@ struct AssemblerT {
         }
       }
       if (maxSupport == 0) break;  // :807
-      chosenIdx[finalCount] = unsigned(selected);
+      if (lane == finalCount) chosenReg = unsigned(selected);
       alive &= ~(uint64_t(1) << unsigned(selected));
       if (lane < W) used |= cand_bits[size_t(selected) * 2 * W + lane];
       finalCount++;
     }
 
     // ---- reserve output space ----
-    uint64_t seqBytes = 0;
-    for (unsigned f = 0; f < finalCount; ++f) seqBytes += unsigned(cand_meta[chosenIdx[f] * 4 + 0]);
-    uint64_t pseudoBytes = 0;
-    for (unsigned p = 0; p < nPseudoFinal; ++p) pseudoBytes += pseudo_len[p];
+    // lane f holds the f-th chosen contig's numbers, lane p the p-th pseudo read's length: the loops below run on register
+    // exchanges instead of a chain of dependent slab loads per contig
+    const bool     isMine = lane < finalCount;
+    const unsigned myLen  = isMine ? unsigned(cand_meta[chosenReg * 4 + 0]) : 0u;
+    const int      myCb   = isMine ? cand_meta[chosenReg * 4 + 1] : 0;
+    const int      myCe   = isMine ? cand_meta[chosenReg * 4 + 2] : 0;
+    unsigned       lenScan = myLen;
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = wv::shfl(lenScan, int(lane) - off);
+      if (int(lane) >= off) lenScan += o;
+    }
+    const uint64_t seqBytes = wv::shfl(lenScan, 63);
+    uint64_t       pseudoBytes = 0;
+    for (unsigned p0 = 0; p0 < nPseudoFinal; p0 += 64) pseudoBytes += waveSum((p0 + lane < nPseudoFinal) ? pseudo_len[p0 + lane] : 0u);
     const uint64_t bitsWords = uint64_t(finalCount) * 2 * W + nPseudoFinal;
     unsigned long long seqBase = 0, bitsBase = 0;
     if (lane == 0) {
@@ -1565,23 +1575,23 @@ struct AssemblerT {
       if (lane == 0) P.loci[locus] = out;
       return;
     }
+    if (isMine) {  // every contig's record at once
+      AsmContigOut c;
+      c.seq_off    = seqBase + (lenScan - myLen);
+      c.bits_off   = bitsBase + uint64_t(lane) * 2 * W;
+      c.seq_len    = myLen;
+      c.cons_begin = myCb;
+      c.cons_end   = myCe;
+      c.reserved   = 0;
+      P.contigs[size_t(locus) * P.opt.maxAssemblyCount + lane] = c;
+    }
     uint64_t so = seqBase, bo = bitsBase;
     for (unsigned f = 0; f < finalCount; ++f) {
-      const unsigned ci  = chosenIdx[f];
-      const unsigned len = unsigned(cand_meta[ci * 4 + 0]);
+      const unsigned ci  = wv::readlane(chosenReg, int(f));
+      const unsigned len = wv::readlane(myLen, int(f));
       const uint8_t* src = cand_seq + size_t(ci) * P.max_contig_len;
       for (unsigned i = lane; i < len; i += 64) P.seq_arena[so + i] = src[i];
       if (lane < 2 * W) P.bits_arena[bo + lane] = cand_bits[size_t(ci) * 2 * W + lane];
-      if (lane == 0) {
-        AsmContigOut c;
-        c.seq_off    = so;
-        c.bits_off   = bo;
-        c.seq_len    = len;
-        c.cons_begin = cand_meta[ci * 4 + 1];
-        c.cons_end   = cand_meta[ci * 4 + 2];
-        c.reserved   = 0;
-        P.contigs[size_t(locus) * P.opt.maxAssemblyCount + f] = c;
-      }
       so += len;
       bo += 2 * W;
     }
