@@ -427,7 +427,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": int(dom_bytes / dom_launches), "avg_launch_ms": round(avg_launch_ms, 3),
-                         "launches": dom_launches, "note": dom_note},
+                         "launches": dom_launches, "note": dom_note,
+                         # extra (not the contract's fraction): the counter traffic against what this chip delivers to 64-byte
+                         # random accesses (tools/microbench/gather_ceiling.hip, DESIGN.md 5.1: 3.36 TB/s) -- the bound the kernel sits on
+                         "sector_traffic": None if not traffic or avg_launch_ms <= 0 else
+                                           {"achieved_GBps": round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1), "random_access_ceiling_GBps": 3360.0,
+                                            "frac": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / 3360.0, 3),
+                                            "traffic_over_algorithmic": round(traffic / max(1.0, dom_bytes / dom_launches), 1)}},
             "kernels_ms_per_step": {"assemble_kernel": round(asm_sum / steps, 3), "schedule_kernel": round(acc["schedule_ms"] / steps, 3),
                                     "align_kernels": round(align_sum / steps, 3),
                                     "note": "HIP events per block, summed; blocks overlap, so the sum exceeds ms_per_step"},
