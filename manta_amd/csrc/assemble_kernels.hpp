@@ -296,6 +296,7 @@ struct AssemblerT {
   // per-locus state (wave-uniform)
   unsigned nNormal, nReads, W, k, nNodes, nCodeWordsNormal, nMaskWordsNormal, nCand;
   unsigned codeWordsUsed, maskWordsUsed, slotMask;
+  const uint32_t* presentMap;  // see lookup4 (valid from the table pass to the end of the links pass)
   int      status;
   unsigned cyclicIters;
   uint64_t tPhase[8];
@@ -545,13 +546,27 @@ struct AssemblerT {
 
   /// four lookups with their memory round trips overlapped: all slot loads first, then all key fetches; only a
   /// collision (first probed slot holds another word) falls back to the serial probe loop
+  /// `present` (links pass only): one bit per table index, set if some word's probe sequence STARTS there (buildGraph) -- three of a
+  /// word's four possible successors usually do not exist, and two thirds of those are answered by this bitmap (a few hundred bytes,
+  /// cache resident) instead of a slot sector each
   template <int KW>
-  WV_DEV void lookup4(const Key<KW> (&keys)[4], unsigned (&out)[4]) const
+  WV_DEV void lookup4(const Key<KW> (&keys)[4], unsigned (&out)[4], const uint32_t* present = nullptr) const
   {
     const unsigned mask = slotMask;
     uint64_t       pr[4];
+    unsigned       h0[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pr[i] = slotPair(keyHash(keys[i]) & mask);
+    for (int i = 0; i < 4; ++i) h0[i] = keyHash(keys[i]) & mask;
+    if (present) {
+      uint32_t pw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pw[i] = present[h0[i] >> 5];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pr[i] = ((pw[i] >> (h0[i] & 31)) & 1u) ? slotPair(h0[i]) : ~uint64_t(0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pr[i] = slotPair(h0[i]);
+    }
     Key<KW> got[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -769,6 +784,10 @@ struct AssemblerT {
     while (true) {
       slotMask = tableSlots - 1;
       for (unsigned s = lane; s < tableSlots; s += 64) *reinterpret_cast<uint64_t*>(&slots[2 * size_t(s)]) = ~uint64_t(0);  // {no word, no id}
+      // which table indices start a probe sequence (lookup4 of the links pass); lives in the frontier region, idle until the cycle test
+      uint32_t* const present = (uint64_t(tableSlots) / 8 + 4 <= 8ull * P.cap_nodes + 256) ? frontier : nullptr;  // (always, for any sane capacity pair)
+      presentMap              = present;
+      for (unsigned s = lane; present && s < (tableSlots + 31) / 32; s += 64) present[s] = 0;
       wv::sync();
 
       // one fused pass over the k-mer instances (assembly/IterativeAssembler.cpp:516-548):
@@ -777,6 +796,12 @@ struct AssemblerT {
       //   word's support set.  Per-read de-dup is implicit (sets).
       const unsigned mask     = slotMask;
       const unsigned maxNodes = (tableSlots < P.cap_slots) ? unsigned((uint64_t(tableSlots) * 7) / 10) : tableSlots;
+      // Read sets are gathered in a DENSE array (W qwords per word, no links in between) and copied into the 64-byte
+      // records by the pass below: the words of a read have mostly consecutive ids, so the 64 atomics of a step fall into
+      // 64 * 8 W / 64 sectors (16 for W = 2) instead of one record sector each.  The array borrows the exact-search
+      // workspace (14 dwords per node, idle until the graph is complete); wider read sets keep the records.
+      const bool      denseSup = (2 * W <= 14);
+      uint64_t* const supBuild = reinterpret_cast<uint64_t*>(exact_ws + 16);
       bool           overflow = false;
       full                    = false;  // a lane can run out of slots while the table overflows; only the final pass counts
       nNodes                  = 0;
@@ -807,9 +832,14 @@ struct AssemblerT {
             unsigned       slot = ASM_NONE;
             bool           won  = false;
             unsigned       foundId = ASM_NONE;
-            if (j + k <= len && !(rdHasN && windowHasN(mwo, j))) {  // :531
-              const Key<KW> key = keyAt<KW>(pb);
+            unsigned       h0      = 0;  // first table index of the word's probe sequence
+            const bool     valid = (j + k <= len) && !(rdHasN && windowHasN(mwo, j));  // :531
+            Key<KW>        key;
+            if (valid) key = keyAt<KW>(pb);
+            // (guessing the ids of consecutive positions instead of probing the table was measured: no gain)
+            if (valid) {
               unsigned      s   = keyHash(key) & mask;
+              h0                = s;
               for (unsigned probe = 0; probe <= mask; ++probe) {
                 // one 8-byte load brings the word AND (for words claimed in an earlier step) its node id
                 const uint64_t pr  = wv::atomic_load(reinterpret_cast<const unsigned long long*>(&slots[2 * size_t(s)]));
@@ -847,16 +877,24 @@ struct AssemblerT {
             if (m) {  // some lane created a word in this step: publish the new nodes before anybody ORs into them
               if (won) {
                 slots[2 * size_t(slot) + 1] = id;
+                if (present) wv::atomic_or(&present[h0 >> 5], 1u << (h0 & 31));
                 node_key[id]                = pb;
-                for (unsigned w = 0; w < W; ++w) recSup(id)[w] = 0;
+                for (unsigned w = 0; w < W; ++w) (denseSup ? supBuild + size_t(id) * W : recSup(id))[w] = 0;
                 for (unsigned c = 0; c < 4; ++c) recPred(id)[c] = ASM_NONE;  // filled by the successors' scatter
               }
               wv::sync();
               if (slot != ASM_NONE && myId == ASM_NONE) myId = wv::atomic_load(&slots[2 * size_t(slot) + 1]);
             }
             if (slot != ASM_NONE) {
-              const unsigned long long before = wv::atomic_or(reinterpret_cast<unsigned long long*>(&recSup(myId)[r >> 6]), bit);
-              if (SMALL && (before & bit)) twice = true;  // the word is already in this read's word set (SmallAssembler.cpp:432)
+              uint64_t* const supAt = denseSup ? supBuild + size_t(myId) * W : recSup(myId);
+              if (SMALL) {
+                const unsigned long long before = wv::atomic_or(reinterpret_cast<unsigned long long*>(&supAt[r >> 6]), bit);
+                if (before & bit) twice = true;  // the word is already in this read's word set (SmallAssembler.cpp:432)
+              } else {
+                // No atomic needed: the slab belongs to this wave, every lane of the step adds the SAME bit (one read per step),
+                // and two lanes that meet in one word (the read holds it twice) store the same value.
+                supAt[r >> 6] |= bit;
+              }
             }
           }
           if (SMALL && wv::any(twice) && lane == 0) small_repeat[r >> 6] |= bit;
@@ -877,7 +915,13 @@ struct AssemblerT {
     for (unsigned nd = lane; nd < nNodes; nd += 64) {
       unsigned cnt = 0;
       for (unsigned w = 0; w < W; ++w) {
-        const uint64_t s = recSup(nd)[w];
+        uint64_t s;
+        if (2 * W <= 14) {  // (denseSup of the table pass: the read set moves into the record here)
+          s             = reinterpret_cast<const uint64_t*>(exact_ws + 16)[size_t(nd) * W + w];
+          recSup(nd)[w] = s;
+        } else {
+          s = recSup(nd)[w];
+        }
         cnt += unsigned(wv::popc(s & normalMask(w))) + P.opt.minCoverage * unsigned(wv::popc(s & ~normalMask(w)));
       }
       node_cnt[nd]  = cnt;
@@ -888,7 +932,7 @@ struct AssemblerT {
       {
         Key<KW> ks[4];
         for (unsigned c = 0; c < 4; ++c) ks[c] = keyShiftAppend<KW>(key, c);
-        lookup4<KW>(ks, sIds);
+        lookup4<KW>(ks, sIds, presentMap);
       }
       // Predecessor links are not looked up: nd is the predecessor of each of its successors through nd's own first
       // base, so the successor lookups scatter them (every (word, symbol) slot has exactly one writer).
