@@ -46,6 +46,11 @@ static const unsigned TENT_CAP     = 256;  // tentative-seed list capacity of on
 #define MANTA_ASM_LDS 10240
 #endif
 static const unsigned ASM_LDS_BYTES = MANTA_ASM_LDS;
+// first table size of a locus and word length: instances >> this, rounded up to a power of two (doubles when more than 70 % full).
+// Measured per 10 000 config-2 loci: >> 0: 11.17 ms, >> 1: 11.10, >> 2: 11.40 (collisions)
+#ifndef MANTA_ASM_TABLE_SHIFT
+#define MANTA_ASM_TABLE_SHIFT 1
+#endif
 #ifndef MANTA_ASM_STRETCH
 #define MANTA_ASM_STRETCH 96
 #endif
@@ -779,7 +784,7 @@ struct AssemblerT {
     // The table is sized for the DISTINCT words, which is usually a small fraction of the instances (reads overlap):
     // start at half the instance count and double on overflow (load factor > 0.7), which re-runs the pass.
     unsigned tableSlots = 64;
-    while (tableSlots < (inst >> 1) && tableSlots < P.cap_slots) tableSlots <<= 1;
+    while (tableSlots < (inst >> MANTA_ASM_TABLE_SHIFT) && tableSlots < P.cap_slots) tableSlots <<= 1;
     bool full = false;
     while (true) {
       slotMask = tableSlots - 1;
