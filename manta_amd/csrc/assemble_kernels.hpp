@@ -921,9 +921,8 @@ struct AssemblerT {
       unsigned cnt = 0;
       for (unsigned w = 0; w < W; ++w) {
         uint64_t s;
-        if (2 * W <= 14) {  // (denseSup of the table pass: the read set moves into the record here)
-          s             = reinterpret_cast<const uint64_t*>(exact_ws + 16)[size_t(nd) * W + w];
-          recSup(nd)[w] = s;
+        if (2 * W <= 14) {  // (denseSup of the table pass; the record is written once, whole, by the next pass)
+          s = reinterpret_cast<const uint64_t*>(exact_ws + 16)[size_t(nd) * W + w];
         } else {
           s = recSup(nd)[w];
         }
@@ -958,7 +957,7 @@ struct AssemblerT {
         // walk to the left takes them (:241-251), the successor graph of the cycle test / repeat search does not have them
         for (unsigned c = 0; c < 4; ++c) recPred(nd)[c] = lookup<KW>(keyShiftPrepend<KW>(key, c));
       }
-      packLinks(sIds, cnt, recPacked(nd, 0)[0], recPacked(nd, 0)[1]);
+      if (2 * W > 14) packLinks(sIds, cnt, recPacked(nd, 0)[0], recPacked(nd, 0)[1]);
       node_flag[nd] = (selfLoop ? NF_REPEAT : 0u) | (hasJunk ? NF_JUNK : 0u);
     }
     wv::sync();
@@ -971,6 +970,14 @@ struct AssemblerT {
         if (p != ASM_NONE && p != nd && !(SB == 8 && ((node_flag[nd] | node_flag[p]) & NF_JUNK))) indeg++;
       }
       packLinks(pIds, node_cnt[nd], recPacked(nd, 16)[0], recPacked(nd, 16)[1]);
+      if (2 * W <= 14) {
+        // the rest of the 64-byte record in the same go (one full-sector write per word instead of three partial ones at three
+        // different times): successors from the links array, read set from the dense array of the table pass
+        unsigned sIds[4];
+        for (unsigned c = 0; c < 4; ++c) sIds[c] = recSucc(nd)[c];
+        packLinks(sIds, node_cnt[nd], recPacked(nd, 0)[0], recPacked(nd, 0)[1]);
+        for (unsigned w = 0; w < W; ++w) recSup(nd)[w] = reinterpret_cast<const uint64_t*>(exact_ws + 16)[size_t(nd) * W + w];
+      }
       node_aux[nd] = indeg;
     }
     wv::sync();
