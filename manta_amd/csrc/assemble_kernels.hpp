@@ -346,9 +346,26 @@ struct AssemblerT {
   }
 
   /// optional per-phase shader-clock profile (compiled in with -DMANTA_ASM_PROFILE; costs registers)
-  WV_DEV void tick(const int phase)
+  WV_DEV void tick(int phase)
   {
 #ifdef MANTA_ASM_PROFILE
+#ifdef MANTA_ASM_PROFILE_EXACT  // developer build: the eight counters split the exact repeat search (tickExact), everything else is counter 7
+    phase = 7;
+#endif
+    const uint64_t now = wv::clock();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i == phase) tPhase[i] += now - tMark;
+    tMark = now;
+#else
+    (void)phase;
+#endif
+  }
+  /// sub-phases of exactRepeatSearch (0 insertion sequence + hashes, 1 rank inside the groups, 2 / 3 the two unordered_map orders,
+  /// 5 DFS set-up, 6 DFS) in a -DMANTA_ASM_PROFILE -DMANTA_ASM_PROFILE_EXACT build
+  WV_DEV void tickExact(const int phase)
+  {
+#if defined(MANTA_ASM_PROFILE) && defined(MANTA_ASM_PROFILE_EXACT)
     const uint64_t now = wv::clock();
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -1417,6 +1434,7 @@ struct AssemblerT {
     if (cyclic) {
       cyclicIters++;
       exactRepeatSearch();
+      tickExact(6);  // (developer build: the DFS; a no-op otherwise)
       tick(4);
       if (status != ASM_OK) return true;
 #ifdef MANTA_WAVE_EMU

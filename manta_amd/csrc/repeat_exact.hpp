@@ -197,6 +197,7 @@ WV_DEV_COLD void AssemblerT<SB>::exactRepeatSearch()
   }
 
   // ---- 1. insertion sequence -------------------------------------------------------------------
+  tickExact(7);
   for (unsigned r = lane; r <= nReads; r += 64) grpCnt[r] = 0;
   wv::sync();
   for (unsigned nd = lane; nd < n; nd += 64) {
@@ -232,6 +233,17 @@ WV_DEV_COLD void AssemblerT<SB>::exactRepeatSearch()
   wv::sync();
   wv::fence_acquire();
   // rank inside each group by lexicographic k-mer order (keys are distinct)
+  tickExact(0);
+  // (the first two key dwords of every member, by group position: the quadratic loop below then reads two consecutive arrays
+  // instead of chasing grp -> node_key -> pile for every pair; the full comparison is left for equal 32-symbol prefixes)
+  uint32_t* const pk0 = next;
+  uint32_t* const pk1 = frames;
+  for (unsigned i = lane; i < n; i += 64) {
+    const Key<KW> kx = keyAt<KW>(node_key[grp[i]]);
+    pk0[i]           = kx.w[0];
+    pk1[i]           = kx.w[1];
+  }
+  wv::sync();
   for (unsigned r = 0; r < nReads; ++r) {
     const unsigned g0 = tmp[r], g1 = tmp[r + 1];
     for (unsigned i = g0 + lane; i < g1; i += 64) {
@@ -240,13 +252,17 @@ WV_DEV_COLD void AssemblerT<SB>::exactRepeatSearch()
       unsigned       rank = 0;
       for (unsigned j = g0; j < g1; ++j) {
         if (j == i) continue;
-        if (keyLess(keyAt<KW>(node_key[grp[j]]), kx)) rank++;
+        const uint32_t b0 = pk0[j], b1 = pk1[j];
+        bool           less = (b0 < kx.w[0]) || (b0 == kx.w[0] && b1 < kx.w[1]);
+        if (b0 == kx.w[0] && b1 == kx.w[1]) less = keyLess(keyAt<KW>(node_key[grp[j]]), kx);
+        if (less) rank++;
       }
       seqA[g0 + rank] = x;
     }
   }
   wv::sync();
 
+  tickExact(1);
   // ---- 2./3. unordered_map order, twice ------------------------------------------------------------
   // scratch: next | tmp | idx | low | stack | frames | before  =  9n + 64 words, all free until the DFS
   const uint32_t* roots;
@@ -260,6 +276,7 @@ WV_DEV_COLD void AssemblerT<SB>::exactRepeatSearch()
     uint32_t*      bh    = bf + nbCap;              // 3n + 3n + 64 more words
     // iteration order of wordCount (insertion sequence seqA), then of wordIndices (filled by iterating wordCount)
     uint32_t* order1 = unorderedOrderWave(P, h, seqA, seqB, spare, chain, offs, bf, bh, n);
+    tickExact(2);
     uint32_t* s1     = (order1 == seqB) ? spare : seqB;
     uint32_t* order2 = unorderedOrderWave(P, h, order1, seqA, s1, chain, offs, bf, bh, n);
     // the DFS below reuses the pool: park the root order where it survives
@@ -271,6 +288,7 @@ WV_DEV_COLD void AssemblerT<SB>::exactRepeatSearch()
     roots = order2;
   }
 
+  tickExact(3);
   // ---- 4. DFS (:555-625) -------------------------------------------------------------------------------
   // The reference's recursion visits every node once; on these graphs almost every node has exactly one successor
   // ("run" nodes), so the traversal is mostly forced.  Lane 0 drives the Tarjan bookkeeping of the junction nodes;
@@ -308,6 +326,7 @@ WV_DEV_COLD void AssemblerT<SB>::exactRepeatSearch()
       runNext[nd] = (cnt == 1 && !self) ? only : ASM_NONE;
     }
     wv::sync();
+    tickExact(5);
 
     enum { REQ_NONE = 0, REQ_NEXTROOT = 1, REQ_DESCEND = 2, REQ_POP = 3 };
     unsigned fp = 0, sp = 0, nextIndex = 1, rootCursor = 0;
