@@ -152,6 +152,55 @@ def test_emulated_empty_and_degenerate_batches(emu):
     u.same(u.run_product(emu, b), u.run_oracle(b), 3)
 
 
+def test_emulated_read_piles_argument_and_capacity_errors(emu):
+    """the ABI's error behaviour: records that point outside their arenas are refused before anything runs; pile arrays that are
+    too small come back MANTA_E_CAPACITY with the sizes that would have been needed"""
+    import ctypes
+    from manta_amd._capi import MantaError
+    b = u.random_batch(5, n_loci=2, reads_per_scan=(20, 40))
+    loci, scans, reads, cigars, names, seqs, quals, refs = b.arrays()
+    good = u._call(emu, read_class_options(), b, loci, scans, reads, cigars, names, seqs, quals, refs, False)
+    assert len(good["pile_read"]) > 0
+    # search range: the breakend interval widened to 400 bases (SVCandidateAssembler.cpp:285-303), left alone when it is wider
+    sb, se = ctypes.c_int32(), ctypes.c_int32()
+    emu.lib.manta_read_search_range(1000, 1100, ctypes.byref(sb), ctypes.byref(se))
+    assert (sb.value, se.value) == (850, 1250)
+    emu.lib.manta_read_search_range(1000, 1500, ctypes.byref(sb), ctypes.byref(se))
+    assert (sb.value, se.value) == (1000, 1500)
+    # a record whose qualities lie outside the arena
+    keep = reads[0].qual_off
+    reads[0].qual_off = len(quals) + 5
+    with pytest.raises(MantaError) as e:
+        u._call(emu, read_class_options(), b, loci, scans, reads, cigars, names, seqs, quals, refs, True)
+    assert e.value.code == -1 and "outside the arenas" in str(e.value)
+    reads[0].qual_off = keep
+    # a region query that names records beyond the array
+    keep = scans[0].read_end
+    scans[0].read_end = len(b.reads) + 3
+    with pytest.raises(MantaError) as e:
+        u._call(emu, read_class_options(), b, loci, scans, reads, cigars, names, seqs, quals, refs, True)
+    assert e.value.code == -1
+    scans[0].read_end = keep
+    # pile arrays too small: MANTA_E_CAPACITY, *_used say what is needed
+    f = emu.lib.manta_read_piles_batch
+    n = len(b.reads)
+    dec, pidx = (ctypes.c_uint8 * n)(), (ctypes.c_uint32 * n)()
+    from manta_amd._capi import ReadLocusResult
+    res = (ReadLocusResult * 2)()
+    used = (ctypes.c_uint64 * 3)()
+    small = (ctypes.c_uint32 * 4)()
+    off = (ctypes.c_uint64 * (n + 2))()
+    begin = (ctypes.c_uint32 * 3)()
+    opt = read_class_options()
+    rc = f(emu.ctx, ctypes.byref(opt), 2, ctypes.cast(loci, ctypes.c_void_p), len(b.scans), ctypes.cast(scans, ctypes.c_void_p), n,
+           ctypes.cast(reads, ctypes.c_void_p), cigars.ctypes.data, len(cigars), names.ctypes.data, len(names), seqs.ctypes.data, len(seqs),
+           quals.ctypes.data, len(quals), refs.ctypes.data, len(refs), dec, pidx, ctypes.cast(res, ctypes.c_void_p), small, 1,
+           ctypes.byref(used, 0), small, 1, ctypes.byref(used, 8), small, off, off, small, 1, ctypes.byref(used, 16), begin)
+    assert rc == -6
+    assert used[2] == len(good["pile_read"]) and used[0] == len(good["piles"].codes) and used[1] == len(good["piles"].nmask)
+    assert bytes(dec) == good["decision"].tobytes()  # (decisions and per-candidate results are complete all the same)
+
+
 def check_piles_feed_the_pipeline(lib, oracle):
     """the piles the kernel builds from the demo's BAM records go straight into the small-SV pipeline (manta_smallsv_batch_piles)
     and give what the oracle gives on the reference's pile text"""
