@@ -265,12 +265,13 @@ struct Key {
 /// SB = bits per symbol of the packed pile.  2: the four bases as codes 0..3, 16 per dword (+ the N bitmap) -- the production
 /// form.  8: the reads' bytes as they are, 4 per dword -- the byte-generic form for piles that hold bytes outside {A,C,G,T,N}
 /// where masking them is not provably exact (the reference treats any byte as a symbol; only 'N' words are skipped and only
-/// A,C,G,T extend a contig); word lengths up to 4 x ASM_MAX_KW = 32 there.  Everything below a key is the same code.
+/// A,C,G,T extend a contig); keys of up to 32 dwords there (128 symbols, as in the 2-bit form).  Everything below a key is the same code.
 template <int SB>
 struct AssemblerT {
   static const unsigned SPD      = 32u / SB;          ///< symbols per code dword
   static const unsigned SYM_MASK = (1u << SB) - 1u;
-  static const unsigned MAX_K    = SPD * ASM_MAX_KW;  ///< longest word
+  static const int      GEN_KW   = (SB == 8) ? 32 : ASM_MAX_KW;  ///< key dwords of the longest word (128 symbols in either form)
+  static const unsigned MAX_K    = SPD * unsigned(GEN_KW);       ///< longest word
   /// code of alphabet symbol c (0..3 = A,C,G,T); alphabet index of a code (4: not in the alphabet); its character
   WV_DEV static unsigned symOfIndex(const unsigned c) { return (SB == 2) ? c : unsigned(uint8_t("ACGT"[c & 3u])); }
   WV_DEV static unsigned indexOfSym(const unsigned s)
@@ -1157,7 +1158,7 @@ struct AssemblerT {
   // ------------------------------------------------------------------------------------------------
   WV_DEV_COLD unsigned selectSeed()
   {
-    typedef Key<ASM_MAX_KW> GKey;
+    typedef Key<GEN_KW> GKey;
     const unsigned lane = unsigned(wv::lane());
     unsigned       best = 0;
     for (unsigned nd = lane; nd < nNodes; nd += 64) {
@@ -1175,10 +1176,10 @@ struct AssemblerT {
     minPre = ~waveMax(~minPre);
     unsigned mine = ASM_NONE;
     GKey     mineKey;
-    for (int i = 0; i < ASM_MAX_KW; ++i) mineKey.w[i] = 0xffffffffu;
+    for (int i = 0; i < GEN_KW; ++i) mineKey.w[i] = 0xffffffffu;
     for (unsigned nd = lane; nd < nNodes; nd += 64) {
       if (isUnused(nd) && node_cnt[nd] == best && node_k32[nd] == minPre) {
-        const GKey key = keyAt<ASM_MAX_KW>(node_key[nd]);
+        const GKey key = keyAt<GEN_KW>(node_key[nd]);
         if (mine == ASM_NONE || keyLess(key, mineKey)) {
           mine    = nd;
           mineKey = key;
@@ -1189,7 +1190,7 @@ struct AssemblerT {
       const int      src = wv::lane() ^ off;
       const unsigned on  = wv::shfl(mine, src);
       GKey           ok;
-      for (int i = 0; i < ASM_MAX_KW; ++i) ok.w[i] = wv::shfl(mineKey.w[i], src);
+      for (int i = 0; i < GEN_KW; ++i) ok.w[i] = wv::shfl(mineKey.w[i], src);
       if (on != ASM_NONE && (mine == ASM_NONE || keyLess(ok, mineKey))) {
         mine    = on;
         mineKey = ok;
@@ -1217,7 +1218,7 @@ struct AssemblerT {
 
   WV_DEV_COLD bool walk(const unsigned seed, const unsigned serial, const unsigned candIdx)
   {
-    static const int KW = ASM_MAX_KW;  // generic key width: this path is the wide-read-set fallback, not the hot one
+    static const int KW = GEN_KW;  // generic key width: this path is the wide-read-set fallback, not the hot one
     const unsigned lane = unsigned(wv::lane());
     uint64_t       S    = supWord(seed);  // contig.supportReads (:168)
     uint64_t       Rj   = 0;              // contig.rejectReads
@@ -1474,7 +1475,9 @@ struct AssemblerT {
     const unsigned kw = (k + SPD - 1) / SPD;
     if (kw <= 2) return buildContigs<2>();
     if (kw <= 4) return buildContigs<4>();
-    return buildContigs<8>();
+    if (SB != 8 || kw <= 8) return buildContigs<8>();
+    if (kw <= 16) return buildContigs<(SB == 8) ? 16 : 8>();  // (byte form only: 4 symbols per dword)
+    return buildContigs<(SB == 8) ? 32 : 8>();
   }
 
   // ------------------------------------------------------------------------------------------------

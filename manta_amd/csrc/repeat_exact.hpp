@@ -166,7 +166,7 @@ WV_DEV uint32_t* unorderedOrderWave(
 template <int SB>
 WV_DEV_COLD void AssemblerT<SB>::exactRepeatSearch()
 {
-  static const int KW = ASM_MAX_KW;
+  static const int KW = GEN_KW;
   const unsigned lane = unsigned(wv::lane());
   const unsigned n    = nNodes;
   // carve (u32 units) out of the `exact` workspace region: 14 * cap_nodes + 64 words

@@ -24,7 +24,7 @@ namespace manta_dev {
 template <int SB>
 WV_DEV unsigned AssemblerT<SB>::selectTentative(const unsigned T)
 {
-  static const int KW = ASM_MAX_KW;
+  static const int KW = GEN_KW;
   const unsigned lane = unsigned(wv::lane());
   if (T == 1) {
     const unsigned s = selectSeed();
@@ -234,7 +234,7 @@ template <int SB>
 template <int WQ>
 WV_DEV void AssemblerT<SB>::walkLanes(const unsigned nT)
 {
-  static const int KW = ASM_MAX_KW;
+  static const int KW = GEN_KW;
   const unsigned lane     = unsigned(wv::lane());
   const unsigned visWords = (P.cap_nodes + 31) / 32;
   const unsigned useWords = (nNodes + 31) / 32;

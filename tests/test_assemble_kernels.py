@@ -130,9 +130,14 @@ def test_junk_bytes_against_the_reference(emu, reflib):
 
 def random_junk_pile(seed):
     """a random pile (small-indel or repeat-rich) with a few bytes outside {A,C,G,T,N} sprinkled in, a possible all-digit read, a
-    possible duplicated read, and a random option block with word lengths up to 32 (the byte-generic kernel's limit)"""
+    possible duplicated read, and a random option block; every fourth seed with longer reads and word lengths of 33 .. 111 (keys of
+    up to 32 dwords in the byte-generic kernel)"""
     rng = random.Random(1000 + seed)
-    if rng.random() < 0.5:
+    long_words = (seed % 4 == 3)
+    if long_words:
+        reads = small_indel_locus(seed, n_reads=rng.choice([8, 16, 30]), read_len=rng.choice([90, 150]), ref_len=400,
+                                  sub_rate=rng.choice([0, 0.01]), n_rate=rng.choice([0, 0.005]))[0]
+    elif rng.random() < 0.5:
         reads = small_indel_locus(seed, n_reads=rng.choice([6, 12, 25]), read_len=rng.choice([30, 50]), ref_len=300,
                                   sub_rate=rng.choice([0, 0.02]), n_rate=rng.choice([0, 0.01]))[0]
     else:
@@ -146,8 +151,9 @@ def random_junk_pile(seed):
         reads.append(list("".join(rng.choice("0123456789") for _ in range(rng.randint(5, 20)))))
     if rng.random() < 0.3:
         reads.append(list(reads[rng.randrange(len(reads))]))
-    k0 = rng.choice([4, 6, 8, 12, 17, 25, 31])
-    o = asm_opts(minWordLength=k0, maxWordLength=min(32, k0 + rng.choice([0, 4, 9])), wordStepSize=rng.choice([1, 2, 3, 5]),
+    k0 = rng.choice([33, 41, 47, 60, 76]) if long_words else rng.choice([4, 6, 8, 12, 17, 25, 31])
+    kmax = min(128, k0 + rng.choice([0, 10, 35])) if long_words else min(32, k0 + rng.choice([0, 4, 9]))
+    o = asm_opts(minWordLength=k0, maxWordLength=kmax, wordStepSize=rng.choice([5, 7]) if long_words else rng.choice([1, 2, 3, 5]),
                  minCoverage=rng.choice([1, 1, 2]), minSupportReads=rng.choice([1, 2]), minUnusedReads=rng.choice([1, 3]),
                  maxAssemblyCount=rng.choice([2, 10]))
     return o, ["".join(r) for r in reads]
@@ -169,16 +175,24 @@ def test_gpu_random_junk_piles(gpu, oracle):
         assert assembly_text(r) == oracle.assemble(o, reads), (seed, o)
 
 
-def test_word_lengths_past_the_byte_generic_limit_are_reported(emu):
-    """a non-maskable junk byte together with a word length above 32: the one combination left outside the envelope"""
-    reads = ["ACGTACGTTGCATGCAAGGCTTAACCGGTTACGATCGATCGGATCGATTAGC=ATCGGCTA"] * 2 + ["ACGTACGTTGCATGCAAGGCTTAACCGGTTACGATCGATCGGATCGATTAGCGATCGGCTA"]
-    r = emu.assemble_batch(asm_opts(minWordLength=41, maxWordLength=41, minCoverage=1), [reads], strict=False)[0]
-    assert r["status"] == -5
+LONG_WORD_JUNK = (["ACGTACGTTGCATGCAAGGCTTAACCGGTTACGATCGATCGGATCGATTAGC=ATCGGCTA"] * 2 +
+                  ["ACGTACGTTGCATGCAAGGCTTAACCGGTTACGATCGATCGGATCGATTAGCGATCGGCTA"])
+
+
+def test_junk_with_the_default_word_lengths_equals_the_reference(emu, reflib):
+    """a non-maskable junk byte at Manta's default word lengths (41 .. 76): was the one combination outside the envelope (status -5)
+    while the byte-generic kernel's keys ended at 32 symbols; they hold 128 now, as the 2-bit kernel's do"""
+    for o in (asm_opts(minWordLength=41, maxWordLength=41, minCoverage=1), asm_opts(minCoverage=1), asm_opts(minWordLength=33, maxWordLength=128, wordStepSize=19)):
+        r = emu.assemble_batch(o, [LONG_WORD_JUNK])[0]
+        assert r["status"] == 0 and assembly_text(r) == reflib.assemble(o, LONG_WORD_JUNK)
 
 
 def test_restatement_matches_the_reference_on_junk_piles(oracle, reflib):
     for o, reads in junk_piles():
         assert oracle.assemble(asm_opts(**o), reads) == reflib.assemble(asm_opts(**o), reads), (o, reads)
+    for seed in range(200):  # (what test_gpu_random_junk_piles checks the device against)
+        o, reads = random_junk_pile(seed)
+        assert oracle.assemble(o, reads) == reflib.assemble(o, reads), (seed, o)
 
 
 def test_emulated_assembler_mid(emu, oracle):
