@@ -1902,6 +1902,7 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
       // Per device, process-wide: never two streamed assemblers on a device at once.
       std::unique_lock<std::mutex> streamedOnly(streamedAsmMu(ctx), std::defer_lock);
       if (as.streaming) streamedOnly.lock();
+      as.stageQueued = false;  // (a run that failed behind its queued staging must not leave the flag to the next one)
       b->evStart.record();
       as.launch();
       b->evAsm.record();
@@ -2450,6 +2451,7 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
       GateLock only(gates, &StageGates::asmMu);
       std::unique_lock<std::mutex> streamedOnly(streamedAsmMu(ctx), std::defer_lock);  // see smallsvRunImpl
       if (as.streaming) streamedOnly.lock();
+      as.stageQueued = false;  // (a run that failed behind its queued staging must not leave the flag to the next one)
       b->evStart.record();
       as.launch();
       b->evAsm.record();
