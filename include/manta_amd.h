@@ -491,7 +491,8 @@ typedef struct {
 
 /* one region query of getBreakendReads (:371-384): one breakend x one alignment file */
 typedef struct {
-  uint32_t read_begin, read_end; /* the query's records in file order */
+  uint32_t read_begin, read_end; /* the query's records in file order (coordinate-sorted, as a BAM region query returns them: the depth
+                                    estimate relies on it) */
   uint32_t bam_index;            /* alignment file: part of the read key (:110-111) */
   uint8_t  is_tumor;             /* _isAlignmentTumor[bamIndex] (:372): normal samples feed the depth estimate */
   uint8_t  is_locus_reversed;    /* getBreakendReads' isLocusReversed */
