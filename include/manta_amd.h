@@ -373,7 +373,11 @@ typedef struct {
                              and blocks are handed out through this counter instead of the call's own -- one work queue across the
                              node's GPUs for the one-process-per-GPU deployment.  A process fills the records and arenas of the
                              blocks it took; the loci of the others carry MANTA_E_NOT_TAKEN and the caller merges (block b covers
-                             loci [b * block_loci, ...): set block_loci explicitly so that every process cuts the same blocks) */
+                             loci [b * block_loci, ...): set block_loci explicitly so that every process cuts the same blocks).
+                             The library does not validate the counter: it must be ZERO before the first process calls and every
+                             process must pass the same batch and block_loci.  The caller verifies coverage when it merges -- every
+                             locus taken by exactly one process (a counter that was not reset, or a process that failed after taking
+                             blocks, shows up as loci nobody filled: status MANTA_E_NOT_TAKEN in every process' records) */
 } manta_batch_plan_t;
 
 typedef struct {
@@ -546,7 +550,9 @@ void manta_read_search_range(int32_t bp_begin, int32_t bp_end, int32_t* search_b
 
 /* Piles of n_loci candidates.  Outputs: decision / pile_index per record (pile_index: position inside the candidate's pile,
  * 0xffffffff when not inserted); the piles in manta_packed_piles_t layout in caller memory: codes_cap / mask_cap dwords,
- * reads_cap reads (MANTA_E_CAPACITY if exceeded; *_used report what is needed); pile_read[r] = record of pile read r. */
+ * reads_cap reads (MANTA_E_CAPACITY if exceeded; *_used report what is needed); pile_read[r] = record of pile read r.
+ * read_code_off / read_mask_off take reads_cap + 1 entries (the last one = one past the last read) and are required whenever
+ * n_loci > 0, also for a batch without a single record. */
 int manta_read_piles_batch(
     manta_ctx_t* ctx, const manta_read_class_options_t* opt, uint32_t n_loci, const manta_read_locus_t* loci, uint32_t n_scans,
     const manta_read_scan_t* scans, uint32_t n_reads, const manta_bam_read_t* reads, const uint32_t* cigars, uint64_t n_cigar_words,

@@ -23,6 +23,14 @@ class MantaError(RuntimeError):
 
 
 def default_library_path():
+    # MANTA_AMD_LIB: a developer build of the same HIP library (profile counters, register budgets) that tools/ put next to
+    # the product build -- only libraries under manta_amd/ are accepted; never a CPU path
+    alt = os.environ.get("MANTA_AMD_LIB")
+    if alt:
+        alt = os.path.abspath(alt)
+        if os.path.dirname(alt) not in (_HERE, os.path.join(_HERE, "variants")) or not os.path.basename(alt).startswith("libmanta_amd"):
+            raise MantaError(-2, "MANTA_AMD_LIB must name a libmanta_amd*.so under manta_amd/ (got %s)" % alt)
+        return alt
     return os.path.join(_HERE, "libmanta_amd.so")
 
 

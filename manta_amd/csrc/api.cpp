@@ -20,7 +20,7 @@
 
 #include "align_kernels.hpp"
 #include "assemble_kernels.hpp"
-#include "asm_fast.hpp"
+#include "asm_lds.hpp"
 #include "small_asm.hpp"
 #include "pipeline_kernels.hpp"
 #include "split_kernels.hpp"
@@ -392,21 +392,7 @@ int asmStatusToAbi(int st)
 }
 
 
-/// dynamic LDS per wave of assemble_kernel while it shares the CUs with assemble_fast_kernel (see AsmStage::plan)
-const unsigned kSharedAsmLds = 4608;
-
-/// One batch of loci through assemble_kernel: sizing, staging, launch, fetch.
-/// wavefronts per workgroup of assemble_fast_kernel.  Three workgroups fit a CU's LDS; at the kernel's ~200 VGPRs a SIMD holds
-/// two waves, so teams of two (6 waves per CU) keep all three workgroups resident -- measured 12.9 ms per 10 000 config-2 loci
-/// against 14.9 ms for teams of four (only two workgroups resident) and 17.2 ms for single waves.  MANTA_AMD_FAST_TEAM = 1..4
-/// overrides (experiments).
-static int fastTeam()
-{
-  const char* e = std::getenv("MANTA_AMD_FAST_TEAM");  // (read at every launch: the tests switch it)
-  const int   v = e ? std::atoi(e) : 2;
-  return (v >= 1 && v <= int(FA_TEAM)) ? v : 2;
-}
-
+/// One batch of loci through the assembler: sizing, staging, launch, fetch.
 struct AsmStage {
   manta_ctx_t* ctx;
   explicit AsmStage(manta_ctx_t* c) : ctx(c)
@@ -450,14 +436,14 @@ struct AsmStage {
   bool                  smallMode = false;  // small_assemble_kernel (SmallAssembler) instead of the iterative assembler
   uint32_t              smallMinSeedReads = 0, smallMaxIterations = 0;
   int                   wavesPerCuCap = 0;  // > 0: leave wave slots free for another block's aligners (pipelined batch calls)
-  bool                  useFast = false;  // assemble_fast_kernel (LDS-resident graph); what it does not cover goes to assemble_kernel
-  bool                  coSchedule = false;  // both kernels at once on one work queue (see launch())
-  int                   gridFast = 1, gridShare = 1;
-  rt::Stream            sideStream;  // the general kernel's stream while the two run side by side
-  rt::Event             evFork, evJoin;
-  std::vector<uint32_t> fastIds, genIds;  // cost-ordered work lists of the two kernels
-  DevBuf                bPunt;
-  uint32_t*             dPunt = nullptr;   // the general kernel's list: genIds, then the loci the fast kernel punted
+  bool                  useFast = false;  // the LDS pipeline (graph_kernel -> contig_kernel, asm_lds.hpp); what it does not cover goes to assemble_kernel
+  int                   gridFast = 1;      // graph_kernel workgroups
+  int                   gridContig[manta_dev::LG_CLASSES] = {0, 0, 0, 0};  // contig_kernel workgroups per LDS size class
+  uint32_t              classBytes[manta_dev::LG_CLASSES] = {0, 0, 0, 0};
+  uint64_t              lgArenaCap = 0, cwsStride = 0;
+  std::vector<uint32_t> fastIds, genIds;  // cost-ordered work lists of the two paths
+  DevBuf                bPunt, bLgArena, bLgOff, bLgClassIds, bLgCnt, bCws;
+  uint32_t*             dPunt = nullptr;   // the general kernel's list: genIds, then the loci the LDS pipeline punted
   // packed piles of the uploaded batch (manta_packed_piles_t), device side; dPlCodes == nullptr: 1 byte per base input
   DevBuf                bPlCodes, bPlMask, bPlLen, bPlCodeOff, bPlMaskOff;
   uint32_t *            dPlCodes = nullptr, *dPlMask = nullptr, *dPlLen = nullptr;
@@ -548,7 +534,7 @@ struct AsmStage {
           }
           p.maxReadLen = std::max<uint32_t>(p.maxReadLen, uint32_t(longest));
           cost[l] = b * uint64_t(re - rb);
-          if ((re - rb) + 2 * maxAsm <= FA_MAX_READS && w + 2 <= FA_MAX_PILE) {
+          if ((re - rb) + 2 * maxAsm <= manta_dev::LG_MAX_READS && w + 2 <= manta_dev::LG_MAX_PILE) {
             p.ldsFit++;
             cost[l] |= uint64_t(1) << 63;  // (marks the locus for the split below; reads x bases stays far below 2^63)
           }
@@ -580,16 +566,13 @@ struct AsmStage {
       order.resize(n_loci);
       for (uint32_t l = 0; l < n_loci; ++l) order[l] = keyed[l].second;
     }
-    // assemble_fast_kernel (asm_fast.hpp, LDS-resident graph) is opt-in: MANTA_AMD_ASM_PATH=fast runs it on the loci whose pile
-    // fits its envelope and hands the rest -- and whatever it punts: cycles, next word length, graphs that do not fit -- to the
-    // general kernel; =both runs the two side by side on one work queue.  Measured on MI355X: it moves
-    // ~3x the algorithmic bytes instead of 142x and does not spill, but one wave per 52 KB of LDS (3 per CU) is bound by the
-    // issue latency of a single wave: 16.7 ms per 10 k config-2 loci against 12.1 ms for the general kernel at 16 waves per
-    // CU, and side by side each workgroup displaces five general waves' worth of LDS for the throughput of 3.5 (11.9 ms).
+    // The LDS pipeline (asm_lds.hpp: graph_kernel -> contig_kernel) is the default for the loci whose pile fits its envelope;
+    // the rest -- and whatever it punts: cycles, next word length, graphs that do not fit -- goes to the general kernel.
+    // MANTA_AMD_ASM_PATH=general switches it off (A/B runs, the tests of the general kernel).
     {
       const char*       pathEnv = std::getenv("MANTA_AMD_ASM_PATH");
       const std::string path    = pathEnv ? pathEnv : "";
-      useFast                   = !smallMode && ldsFit > 0 && (path == "fast" || path == "both");
+      useFast                   = !smallMode && ldsFit > 0 && path != "general";
       fastIds.clear();
       genIds.clear();
       if (useFast) {
@@ -632,23 +615,40 @@ struct AsmStage {
     if (wavesPerCuCap > 0) wavesPerCu = std::min(wavesPerCu, wavesPerCuCap);
     grid                  = int(std::min<uint64_t>(n_loci, uint64_t(std::max(1, ctx->cuCount * wavesPerCu))));
     grid                  = rt::roundGrid(int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(grid), wsBudget / stride))));
-    // Side by side (MANTA_AMD_ASM_PATH=both): both kernels pull from ONE work queue, two fast workgroups per CU (104 KB of LDS)
-    // next to twelve general waves per CU with 4.5 KB of LDS each.
-    {
-      const char* pathEnv = std::getenv("MANTA_AMD_ASM_PATH");
-      coSchedule          = useFast && pathEnv && std::string(pathEnv) == "both";
-    }
-    const int fastPerCu = coSchedule ? 2 : int(163840 / FA_BUDGET);
-    gridFast            = int(std::max<uint64_t>(1, std::min<uint64_t>(fastIds.size(), uint64_t(ctx->cuCount) * fastPerCu)));
-    gridShare           = rt::roundGrid(int(std::max<uint64_t>(1, std::min<uint64_t>(fastIds.size(), uint64_t(ctx->cuCount) * 12))));
     if (useFast) {
-      // workspace slabs: the general kernel's waves first, the fast kernel's workgroups behind them
-      const uint64_t fit = std::max<uint64_t>(2, wsBudget / stride);
-      if (uint64_t(gridFast) + uint64_t(coSchedule ? gridShare : 0) > fit) {
-        gridFast  = int(std::max<uint64_t>(1, std::min<uint64_t>(gridFast, fit / 4)));
-        gridShare = rt::roundGrid(int(std::max<uint64_t>(1, std::min<uint64_t>(gridShare, fit - gridFast))));
+      using namespace manta_dev;
+      // graph_kernel: two workgroups of LG_WAVES wavefronts per CU (LG_BUDGET bytes of LDS each).  contig_kernel: one launch per
+      // LDS size class; a class of B bytes runs floor(160 KB / B) single-wave workgroups per CU (asked of the runtime).
+      gridFast = int(std::max<uint64_t>(1, std::min<uint64_t>(fastIds.size(), uint64_t(ctx->cuCount) * (163840 / LG_BUDGET))));
+      static const uint32_t kClassDefault[LG_CLASSES] = {27136, 32768, 40960, 54272};
+      for (unsigned c = 0; c < LG_CLASSES; ++c) classBytes[c] = kClassDefault[c];
+      if (const char* e = std::getenv("MANTA_AMD_LG_CLASSES")) {  // experiments: up to four ascending byte counts, comma separated
+        unsigned c = 0;
+        for (const char* q = e; *q && c < LG_CLASSES; ++c) {
+          classBytes[c] = uint32_t(std::strtoul(q, nullptr, 10)) & ~511u;
+          q             = std::strchr(q, ',');
+          if (!q) {
+            ++c;
+            break;
+          }
+          ++q;
+        }
+        for (; c < LG_CLASSES; ++c) classBytes[c] = 0;
       }
-      grid = std::max(grid, rt::roundGrid(gridFast) + (coSchedule ? gridShare : 0));
+      int maxGrid = 1;
+      for (unsigned c = 0; c < LG_CLASSES; ++c) {
+        gridContig[c] = 0;
+        if (!classBytes[c]) continue;
+        const int perCu = std::max(1, std::min(8, rt::blocksPerCu(contig_kernel, 64, classBytes[c], int(163840 / classBytes[c]))));
+        gridContig[c]   = int(std::max<uint64_t>(1, std::min<uint64_t>(fastIds.size(), uint64_t(ctx->cuCount) * perCu)));
+        maxGrid         = std::max(maxGrid, gridContig[c]);
+      }
+      if (std::getenv("MANTA_AMD_DEBUG"))
+        for (unsigned c = 0; c < LG_CLASSES; ++c)
+          if (classBytes[c]) std::fprintf(stderr, "manta_amd: contig_kernel class %u: %u bytes of LDS, %d workgroups (%d per CU by the runtime's count)\n", c, classBytes[c], gridContig[c], rt::blocksPerCu(contig_kernel, 64, classBytes[c], -1));
+      cwsStride  = ckWorkspaceLayout(maxContigLen).total;
+      lgArenaCap = std::min<uint64_t>(uint64_t(fastIds.size()) * lgSlabBytes(LG_MAX_NODES, LG_MAX_NODES, LG_MAX_PILE + 2), wsBudget / 2);
+      (void)maxGrid;
     }
     // contig + pseudo-read text one locus can emit at worst; the arena holds the typical case for every locus plus one
     // worst case, so a single-locus call (the runIterativeAssembler adapter) can never exhaust it
@@ -839,6 +839,13 @@ struct AsmStage {
       dPunt = bPunt.as<uint32_t>(nLoci);
       rt::h2d(dOrder, fastIds.data(), sizeof(uint32_t) * fastIds.size());
       rt::h2d(dPunt, genIds.data(), sizeof(uint32_t) * genIds.size());
+      int maxGrid = 1;
+      for (unsigned c = 0; c < manta_dev::LG_CLASSES; ++c) maxGrid = std::max(maxGrid, gridContig[c]);
+      (void)bLgArena.as<uint8_t>(lgArenaCap + 64);
+      (void)bLgOff.as<uint64_t>(nLoci);
+      (void)bLgClassIds.as<uint32_t>(uint64_t(manta_dev::LG_CLASSES) * fastIds.size());
+      (void)bLgCnt.as<uint64_t>(16);
+      (void)bCws.as<uint8_t>(cwsStride * uint64_t(maxGrid));
     } else {
       rt::h2d(dOrder, order.data(), sizeof(uint32_t) * nLoci);
     }
@@ -924,43 +931,52 @@ struct AsmStage {
     if (streaming && g >= ctx->cuCount * 16) g = rt::roundGrid(g - ctx->cuCount);
     P.lds_bytes = ASM_LDS_BYTES;
     if (useFast) {
-      // dCnt: [0] work counter of the fast kernel's list (shared with the general kernel when they run side by side),
-      // [14] length of the general kernel's own list (genIds + punts), [15] its work counter
+      using namespace manta_dev;
+      // dCnt: [0] work counter of graph_kernel's list, [14] length of the general kernel's own list (genIds + punts), [15] its
+      // work counter.  bLgCnt (qwords): [0] bytes of the slab arena in use, [1..2] loci per size class, [3..4] the class launches'
+      // work counters
       const uint32_t nGen = uint32_t(genIds.size());
       rt::h2d(reinterpret_cast<uint32_t*>(dCnt + 14), &nGen, sizeof(uint32_t));
-      AsmParams F  = P;
-      F.n_loci     = uint32_t(fastIds.size());
-      F.punt_ids   = dPunt;
-      F.punt_count = reinterpret_cast<uint32_t*>(dCnt + 14);
-      F.ws         = dWs + stride * uint64_t(coSchedule ? gridShare : 0);
-      if (coSchedule) {
-        AsmParams G = P;  // same list, same counter: whichever kernel has a free wave takes the next locus
-        G.n_loci    = uint32_t(fastIds.size());
-        G.lds_bytes = kSharedAsmLds;
-        {
-          // the end of the list belongs to the fast kernel (AsmParams::stop_before): about four loci per fast workgroup
-          const char*    e       = std::getenv("MANTA_AMD_ASM_RESERVE");
-          const uint32_t reserve = e ? uint32_t(std::max(0, std::atoi(e))) : 0u;  // (measured: any reserve loses, the fast kernel's aggregate rate is the lower one)
-          G.stop_before          = (G.n_loci > reserve) ? (G.n_loci - reserve) : 1u;
-        }
-        evFork.record();
-        rt::streamWaits(sideStream, evFork);
-        {
-          rt::ScopedStream onSide(sideStream);
-          rt::launch(assemble_kernel, gridShare, kSharedAsmLds, G);
-          evJoin.record();
-        }
-        rt::launchWG(assemble_fast_kernel, gridFast, fastTeam(), FA_BUDGET, F);
-        rt::curStreamWaits(evJoin);
-      } else {
-        rt::launchWG(assemble_fast_kernel, gridFast, fastTeam(), FA_BUDGET, F);
+      uint64_t* dLg = bLgCnt.as<uint64_t>(16);
+      rt::dzero(dLg, sizeof(uint64_t) * 16);
+      LgArgs A;
+      A.P            = P;
+      A.P.n_loci     = uint32_t(fastIds.size());
+      A.P.punt_ids   = dPunt;
+      A.P.punt_count = reinterpret_cast<uint32_t*>(dCnt + 14);
+      A.G.arena        = bLgArena.as<uint8_t>(lgArenaCap + 64);
+      A.G.arena_cap    = lgArenaCap;
+      A.G.arena_used   = reinterpret_cast<unsigned long long*>(dLg);
+      A.G.slab_off     = bLgOff.as<uint64_t>(nLoci);
+      A.G.class_ids    = bLgClassIds.as<uint32_t>(uint64_t(LG_CLASSES) * fastIds.size());
+      A.G.class_count  = reinterpret_cast<uint32_t*>(dLg + 1);
+      A.G.class_stride = uint32_t(fastIds.size());
+      for (unsigned c = 0; c < LG_CLASSES; ++c) A.G.class_bytes[c] = classBytes[c];
+      A.G.cls        = 0;
+      A.G.reserved   = 0;
+      int maxGrid = 1;
+      for (unsigned c = 0; c < LG_CLASSES; ++c) maxGrid = std::max(maxGrid, gridContig[c]);
+      A.G.cws        = bCws.as<uint8_t>(cwsStride * uint64_t(maxGrid));
+      A.G.cws_stride = cwsStride;
+      // streamed upload: a chunk the runtime moves with a shader copy needs a free workgroup slot (and, as far as this launch can
+      // know, LDS): graph_kernel's two workgroups per CU own all 160 KB, so a quarter of the CUs keep one slot free -- without it
+      // the copies never run and the persistent workgroups wait for their chunks forever (seen on hardware, round 4)
+      int gf = gridFast;
+      if (streaming && gf >= ctx->cuCount * 2) gf -= std::max(1, ctx->cuCount / 4);
+      rt::launchWG(graph_kernel, gf, int(LG_WAVES), LG_BUDGET, A);
+      for (unsigned c = 0; c < LG_CLASSES; ++c) {
+        if (!classBytes[c]) continue;
+        A.G.cls       = c;
+        A.P.counter   = reinterpret_cast<uint32_t*>(dLg + 3) + c;
+        A.P.lds_bytes = classBytes[c];
+        rt::launchSingle(contig_kernel, gridContig[c], classBytes[c], A);
       }
       P.locus_ids  = dPunt;
       P.n_loci     = nLoci;
       P.n_loci_dev = reinterpret_cast<uint32_t*>(dCnt + 14);
       P.counter    = reinterpret_cast<uint32_t*>(dCnt + 15);
-      // nothing for this launch unless the fast kernel handed something back: a small grid then (its waves find the list
-      // length in device memory); the full grid when the host already knows of loci outside the fast envelope
+      // nothing for this launch unless the pipeline handed something back: a small grid then (its waves find the list
+      // length in device memory); the full grid when the host already knows of loci outside the envelope
       if (nGen == 0) g = std::min(g, rt::roundGrid(std::max(1, ctx->cuCount * 4)));
       rt::launch(assemble_kernel, g, ASM_LDS_BYTES, P);
     } else {
@@ -1014,6 +1030,11 @@ struct AsmStage {
       rt::launch(assemble_kernel, g, ASM_LDS_BYTES, P);
       rt::sync();
       nRerun = uint32_t(ids.size());
+      // a locus that overflowed the typical-case workspace may only now reach the junk-byte tests (they run after the pack / after the
+      // graph is built): what reports ASM_E_ALPHABET on the worst-case workspace joins the byte-generic run below
+      rt::d2h(st.data(), dLoci, sizeof(AsmLocusOut) * nLoci);
+      for (const uint32_t l : ids)
+        if (st[l].status == ASM_E_ALPHABET) alphaIds.push_back(l);
       if (std::getenv("MANTA_AMD_DEBUG"))
         std::fprintf(stderr, "manta_amd: %zu of %u loci ran again on the worst-case workspace (%.1f MB per wave)\n", ids.size(), nLoci, double(stride2) / 1e6);
     }
@@ -1038,7 +1059,11 @@ struct AsmStage {
       P.n_loci    = uint32_t(alphaIds.size());
       P.locus_ids = dIds;
       P.counter   = reinterpret_cast<uint32_t*>(dCnt + 12);
+#ifndef MANTA_DEV_NO_GENERIC
       rt::launch(assemble_generic_kernel, g, ASM_LDS_BYTES, P);
+#else
+      throw rt::Error("developer build without the byte-generic kernel");
+#endif
       rt::sync();
       nRerun += uint32_t(alphaIds.size());
       if (std::getenv("MANTA_AMD_DEBUG"))
@@ -1110,12 +1135,18 @@ struct AsmStage {
     staged = true;
     ldsFallbacks = useFast ? uint32_t(hCnt[14] & 0xffffffffu) - uint32_t(genIds.size()) : 0u;
     if (std::getenv("MANTA_AMD_DEBUG") && useFast)
-      std::fprintf(stderr, "manta_amd: assemble_fast_kernel: %zu loci, %u handed to the general kernel (+ %zu outside its envelope)\n", fastIds.size(), ldsFallbacks, genIds.size());
+      std::fprintf(stderr, "manta_amd: LDS assembler pipeline: %zu loci, %u handed to the general kernel (+ %zu outside its envelope)\n", fastIds.size(), ldsFallbacks, genIds.size());
     if (std::getenv("MANTA_AMD_PROFILE")) {
-      static const char* names[8] = {"pack", "table", "links", "cycle-check", "exact", "seed", "walk", "select+emit"};
+      static const char* namesGeneral[8] = {"pack", "table", "links", "cycle-check", "exact", "seed", "walk", "select+emit"};
+#ifdef MANTA_LG_PROFILE_GRAPH
+      static const char* namesLds[8]     = {"pack", "table", "counts+list", "radix", "ties+ids", "slab+sets+init", "links+preds+sibs", "spec+write"};
+#else
+      static const char* namesLds[8]     = {"pack", "table", "sort+records", "cycle-check", "slab write/read", "seed+replay", "walk", "select+emit"};
+#endif
+      const char* const* names = useFast ? namesLds : namesGeneral;
       uint64_t           tot = 0;
       for (int i = 0; i < 8; ++i) tot += hCnt[4 + i];
-      std::fprintf(stderr, "manta_amd assemble_kernel phase share (shader clocks summed over %u loci, grid %d):", nLoci, grid);
+      std::fprintf(stderr, "manta_amd %s phase share (shader clocks summed over %u loci; graph_kernel: clocks of one wave of the workgroup):", useFast ? "graph_kernel + contig_kernel" : "assemble_kernel", nLoci);
       for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s=%.1f%%", names[i], tot ? 100.0 * double(hCnt[4 + i]) / double(tot) : 0.0);
       std::fprintf(stderr, " | avg clocks/locus=%.0f\n", double(tot) / nLoci);
     }
@@ -1597,7 +1628,7 @@ int manta_debug_repeat_words(
     AsmStage       st(ctx);
     int            rc = st.plan(o, 1, read_off, begin);
     if (rc != MANTA_OK) return rc;
-    st.useFast = st.coSchedule = false;  // the general kernel: its workspace slab is read back below
+    st.useFast = false;  // the general kernel: its workspace slab is read back below
     st.upload(bases, read_off, begin);
     rt::dzero(st.dWs, st.stride * uint64_t(st.grid));
     st.launch();
@@ -3472,8 +3503,10 @@ extern "C" int manta_read_piles_batch(
 {
   static const char* fn = "manta_read_piles_batch: ";
   if (!ctx) return MANTA_E_INVALID_ARG;
-  if (!opt || (n_loci && (!loci || !results || !locus_read_begin)) || (n_scans && !scans) ||
-      (n_reads && (!reads || !decision || !pile_index || !read_code_off || !read_mask_off)))
+  // (the two offset arrays take their "one past the last read" entry whenever there is a candidate, also with no read at all)
+  if (!opt || (n_loci && (!loci || !results || !locus_read_begin || !read_code_off || !read_mask_off)) || (n_scans && !scans) ||
+      (n_reads && (!reads || !decision || !pile_index)) || (n_cigar_words && !cigars) || (names_bytes && !names) || (seqs_bytes && !seqs) ||
+      (quals_bytes && !quals))
     return fail(ctx, MANTA_E_INVALID_ARG, std::string(fn) + "null argument");
   if (codes_used) *codes_used = 0;
   if (mask_used) *mask_used = 0;
@@ -3514,7 +3547,10 @@ extern "C" int manta_read_piles_batch(
     uint64_t tableCap = 64;
     while (tableCap < 2 * maxRecords) tableCap *= 2;
     const uint64_t stride = 2 * maxRange + 1 + tableCap;
-    const int      grid   = rt::roundGrid(int(std::min<uint64_t>(n_loci, uint64_t(std::max(1, ctx->cuCount * 8)))));
+    // one workspace per wave, sized for the widest breakend interval of the batch: a multi-megabase interval shrinks the grid instead
+    // of asking for (waves x that interval) bytes (the reference allocates searchRange.size() counters for the one candidate)
+    const uint64_t wsFit  = std::max<uint64_t>(1, workspaceBudget(size_t(16) << 30) / (stride * 4));
+    const int      grid   = rt::roundGrid(int(std::min<uint64_t>(std::min<uint64_t>(n_loci, wsFit), uint64_t(std::max(1, ctx->cuCount * 8)))));
     ReadClassParams P;
     std::memset(&P, 0, sizeof(P));
     P.opt    = *opt;

@@ -1803,6 +1803,7 @@ WV_KERNEL_OCC(MANTA_ASM_OCC) void assemble_kernel(const AsmParams P)
   }
 }
 
+#ifndef MANTA_DEV_NO_GENERIC  // (developer variants of the library leave the byte-generic kernel out: it is most of the compile time)
 /// the byte-generic form (AssemblerT<8>) for the loci assemble_kernel reports ASM_E_ALPHABET for: same launch contract; the
 /// workspace capacities count code dwords of 4 symbols.  Rare by construction (a byte outside {A,C,G,T,N} that cannot be
 /// masked exactly), so this kernel is about being right, not fast.
@@ -1831,5 +1832,6 @@ WV_KERNEL_OCC(MANTA_ASM_OCC) void assemble_generic_kernel(const AsmParams P)
     wv::sync();
   }
 }
+#endif
 
 }  // namespace manta_dev

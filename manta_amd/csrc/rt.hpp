@@ -37,6 +37,8 @@ inline void launchSingle(K kernel, int grid, size_t ldsBytes, const P& params) {
 template <typename K, typename P>
 inline void launchWG(K kernel, int grid, int nWaves, size_t ldsBytes, const P& params) { wv_emu::launchWG(grid, nWaves, ldsBytes, [&]() { kernel(params); }); }
 inline int roundGrid(int waves) { return waves; }
+template <typename K>
+inline int blocksPerCu(K, int, size_t, int fallback) { return fallback; }
 struct Stream {};
 inline void useStream(Stream*) {}
 struct ScopedStream { explicit ScopedStream(Stream&) {} };
@@ -163,6 +165,23 @@ inline void* hostAlloc(size_t n)
   return p;
 }
 inline void hostFree(void* p) { (void)hipHostFree(p); }
+/// kernels launched with more than the default 64 KB of dynamic LDS: the limit is raised to the whole CU's 160 KB once per
+/// kernel and thread (the same kernel is launched with different sizes: contig_kernel's size classes)
+inline void allowFullLds(const void* kernel)
+{
+  static thread_local const void* prepared[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  static thread_local int         devOf[8]    = {-1, -1, -1, -1, -1, -1, -1, -1};
+  const int dev = currentDevice();
+  for (int i = 0; i < 8; ++i)
+    if (prepared[i] == kernel && devOf[i] == dev) return;
+  check(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840), "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  for (int i = 0; i < 8; ++i)
+    if (prepared[i] == nullptr || i == 7) {
+      prepared[i] = kernel;
+      devOf[i]    = dev;
+      break;
+    }
+}
 template <typename K, typename P>
 inline void launch(K kernel, int grid, size_t ldsBytes, const P& params)
 {
@@ -174,12 +193,7 @@ inline void launch(K kernel, int grid, size_t ldsBytes, const P& params)
 template <typename K, typename P>
 inline void launchSingle(K kernel, int grid, size_t ldsBytes, const P& params)
 {
-  static thread_local const void* prepared = nullptr;
-  if (prepared != reinterpret_cast<const void*>(kernel)) {
-    check(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)),
-          "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    prepared = reinterpret_cast<const void*>(kernel);
-  }
+  allowFullLds(reinterpret_cast<const void*>(kernel));
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), ldsBytes, launchStream(), params);
   check(hipGetLastError(), "kernel launch");
 }
@@ -187,16 +201,23 @@ inline void launchSingle(K kernel, int grid, size_t ldsBytes, const P& params)
 template <typename K, typename P>
 inline void launchWG(K kernel, int grid, int nWaves, size_t ldsBytes, const P& params)
 {
-  static thread_local const void* prepared = nullptr;
-  if (prepared != reinterpret_cast<const void*>(kernel)) {
-    check(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)),
-          "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    prepared = reinterpret_cast<const void*>(kernel);
-  }
+  allowFullLds(reinterpret_cast<const void*>(kernel));
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * nWaves), ldsBytes, launchStream(), params);
   check(hipGetLastError(), "kernel launch");
 }
 inline int roundGrid(int waves) { return ((waves + WV_WAVES_PER_WG - 1) / WV_WAVES_PER_WG) * WV_WAVES_PER_WG; }
+/// workgroups of `threads` threads and `ldsBytes` of dynamic LDS the runtime places on one CU (`fallback` if it does not say)
+template <typename K>
+inline int blocksPerCu(K kernel, int threads, size_t ldsBytes, int fallback)
+{
+  allowFullLds(reinterpret_cast<const void*>(kernel));
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kernel), threads, ldsBytes) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fallback;
+  }
+  return n;
+}
 /// HIP event, recorded on the current stream
 struct Event {
   hipEvent_t e = nullptr;

@@ -15,6 +15,15 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ASM = json.load(open(os.path.join(GOLD, "assembler_reference_tests.json")))
 
 
+@pytest.fixture(autouse=True)
+def _general_kernel_unless_lds_test(request, monkeypatch):
+    """The LDS pipeline (asm_lds.hpp: graph_kernel -> contig_kernel) is the library's default for piles that fit its envelope.  The
+    tests of this module that were written for the general kernel keep exercising the general kernel (MANTA_AMD_ASM_PATH=general);
+    the *fast* / *lds* tests run the pipeline (with its punt list into the general kernel)."""
+    if not any(t in request.node.name for t in ("fast", "lds", "lane_order")):
+        monkeypatch.setenv("MANTA_AMD_ASM_PATH", "general")
+
+
 def _mid_cases(seeds):
     out = []
     for seed in seeds:
@@ -273,9 +282,9 @@ def test_emulated_serial_and_speculative_walks_agree(emu, oracle, monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# LDS-resident fast kernel (assemble_fast_kernel, asm_fast.hpp; MANTA_AMD_ASM_PATH=fast): same results as the oracle, and
-# everything it does not cover (cycles, next word length, wide read sets; N-masked piles are fine) goes to the general kernel
-# through the device-side punt list
+# The LDS pipeline (graph_kernel -> contig_kernel, asm_lds.hpp / asm_contig.hpp; the default, MANTA_AMD_ASM_PATH=general switches it
+# off): same results as the oracle, and everything it does not cover (cycles, next word length, wide read sets; N-masked piles are
+# fine) goes to the general kernel through the device-side punt list
 # ---------------------------------------------------------------------------------------------------------------
 def _lds_cases():
     cases = [(asm_opts(minWordLength=31), small_indel_locus(s)[0]) for s in range(3)]
@@ -300,12 +309,12 @@ def test_emulated_fast_kernel_matches_oracle(emu, oracle, monkeypatch):
     assert _check(emu, oracle, cases) == len(cases)
 
 
-@pytest.mark.parametrize("team", [1, 4])
-def test_emulated_fast_kernel_team_sizes(emu, oracle, monkeypatch, team):
-    """assemble_fast_kernel runs a locus on a team of cooperating wavefronts (default 2; the emulator interleaves the waves of
-    a workgroup at every rendezvous): single waves and teams of four must give the same results"""
+@pytest.mark.parametrize("classes", ["4096,8192,16384,54272", "12288", "54272"])
+def test_emulated_fast_kernel_lds_size_classes(emu, oracle, monkeypatch, classes):
+    """contig_kernel is launched once per LDS size class (graph_kernel sorts the loci into the smallest class their compact graph
+    fits); a graph that fits no class goes to the general kernel.  Whatever the classes are, the results are the same."""
     monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
-    monkeypatch.setenv("MANTA_AMD_FAST_TEAM", str(team))
+    monkeypatch.setenv("MANTA_AMD_LG_CLASSES", classes)
     cases = _lds_cases()[:24]
     assert _check(emu, oracle, cases) == len(cases)
 
@@ -365,7 +374,7 @@ def _fast_stats(emu):
 
 
 def test_emulated_fast_kernel_speculation_hits(emu, oracle, monkeypatch):
-    """the fast kernel's contig loop runs on speculation (asm_fast.hpp): config-2 loci must come out of (close to) ONE walk round
+    """the contig kernel's loop runs on speculation (asm_contig.hpp): config-2 loci must come out of (close to) ONE walk round
     each -- a regression guard for the seed prediction, which can only cost time, never results (those are checked as well)"""
     monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
     o = asm_opts(minWordLength=31)
@@ -377,13 +386,3 @@ def test_emulated_fast_kernel_speculation_hits(emu, oracle, monkeypatch):
         assert assembly_text(r) == oracle.assemble(o, reads)
     assert st["loci"] == 16 and st["cands"] == 16 * 20, st
     assert st["rounds"] <= 16 * 1.5, st
-
-
-@pytest.mark.gpu
-def test_gpu_side_by_side_kernels_match_oracle(gpu, oracle, monkeypatch):
-    """MANTA_AMD_ASM_PATH=both: the fast and the general kernel on one work queue"""
-    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "both")
-    o = asm_opts(minWordLength=31)
-    loci = [small_indel_locus(s, tandem=(s % 7 == 0), n_rate=(0.01 if s % 5 == 0 else 0.0))[0] for s in range(300)]
-    for reads, r in zip(loci, gpu.assemble_batch(o, loci)):
-        assert assembly_text(r) == oracle.assemble(o, reads)
