@@ -620,7 +620,7 @@ struct AsmStage {
       // graph_kernel: two workgroups of LG_WAVES wavefronts per CU (LG_BUDGET bytes of LDS each).  contig_kernel: one launch per
       // LDS size class; a class of B bytes runs floor(160 KB / B) single-wave workgroups per CU (asked of the runtime).
       gridFast = int(std::max<uint64_t>(1, std::min<uint64_t>(fastIds.size(), uint64_t(ctx->cuCount) * (163840 / LG_BUDGET))));
-      static const uint32_t kClassDefault[LG_CLASSES] = {27136, 32768, 40960, 54272};
+      static const uint32_t kClassDefault[LG_CLASSES] = {20480, 54272, 0, 0};  // 8 / 3 workgroups per CU (measured: every further class costs a launch tail)
       for (unsigned c = 0; c < LG_CLASSES; ++c) classBytes[c] = kClassDefault[c];
       if (const char* e = std::getenv("MANTA_AMD_LG_CLASSES")) {  // experiments: up to four ascending byte counts, comma separated
         unsigned c = 0;
@@ -646,7 +646,7 @@ struct AsmStage {
       if (std::getenv("MANTA_AMD_DEBUG"))
         for (unsigned c = 0; c < LG_CLASSES; ++c)
           if (classBytes[c]) std::fprintf(stderr, "manta_amd: contig_kernel class %u: %u bytes of LDS, %d workgroups (%d per CU by the runtime's count)\n", c, classBytes[c], gridContig[c], rt::blocksPerCu(contig_kernel, 64, classBytes[c], -1));
-      cwsStride  = ckWorkspaceLayout(maxContigLen).total;
+      cwsStride  = ckWorkspaceLayout().total;
       lgArenaCap = std::min<uint64_t>(uint64_t(fastIds.size()) * lgSlabBytes(LG_MAX_NODES, LG_MAX_NODES, LG_MAX_PILE + 2), wsBudget / 2);
       (void)maxGrid;
     }
@@ -824,7 +824,7 @@ struct AsmStage {
   {
     if (bases) dPlCodes = nullptr;
     streaming = streamingPiles = false;
-    dBases  = bBases.as<uint8_t>(nBases + 16);
+    dBases  = bBases.as<uint8_t>(nBases + 64);
     dOff    = bReadOff.as<uint64_t>(nReadsTotal + 1);
     dBegin  = bLocusBegin.as<uint32_t>(nLoci + 1);
     dLoci   = bLoci.as<AsmLocusOut>(nLoci);
@@ -953,7 +953,7 @@ struct AsmStage {
       A.G.class_stride = uint32_t(fastIds.size());
       for (unsigned c = 0; c < LG_CLASSES; ++c) A.G.class_bytes[c] = classBytes[c];
       A.G.cls        = 0;
-      A.G.reserved   = 0;
+      A.G.flags      = std::getenv("MANTA_AMD_LG_NO_PROOF") ? LG_FLAG_NO_PROOF : 0u;
       int maxGrid = 1;
       for (unsigned c = 0; c < LG_CLASSES; ++c) maxGrid = std::max(maxGrid, gridContig[c]);
       A.G.cws        = bCws.as<uint8_t>(cwsStride * uint64_t(maxGrid));

@@ -12,31 +12,34 @@
 //   selectContigs  :722-842, lane = candidate
 //
 // In an acyclic graph a walk cannot meet one of its own words again except through a self loop, so the per-walk visited set is
-// "chosen word == current word"; which walk touched which word is one 64-bit lane mask per word (no-return atomics into the
-// workgroup's workspace, L2 resident), which makes the replay a handful of register operations.
+// "chosen word == current word".  Every walk LOGS its words (16-bit ids, four per 8-byte store into the workgroup's workspace);
+// accepting a walk clears its words from the unused bitmap, so "was this seed consumed by an accepted contig" is one bit test.
+// (Round 4's first cut kept a 64-bit lane mask per word, updated by one L2 atomic per lane and step: 230 M atomics per 10 000
+// loci -- the L2's atomic rate, not the waves in flight, set the kernel's speed.)
 #pragma once
 #include "asm_lds.hpp"
 
 namespace manta_dev {
 
-static const unsigned CK_MAX_CONTIG = 4096;  // longer contigs (never seen on piles this small): general path
+#ifndef MANTA_CK_FAST_CAP
+#define MANTA_CK_FAST_CAP 6
+#endif
+static const unsigned CK_FAST_CAP = MANTA_CK_FAST_CAP;  // fast steps a lane may run ahead between two general steps of its wave
+static const unsigned CK_MAX_EXT = 1020;  // extension steps of one walk (both directions); longer contigs (never seen on piles this small): general path
 
 struct CkWsLayout {
-  uint64_t lane_seq, lane_bits, lane_meta, vis, total;
+  uint64_t lane_seq, lane_bits, lane_meta, lane_log, total;
 };
-WV_HD unsigned ckSeqWords(const unsigned max_contig_len)
-{
-  const unsigned m = (max_contig_len < CK_MAX_CONTIG) ? max_contig_len : CK_MAX_CONTIG;
-  return m / 16 + 2;
-}
-WV_HD CkWsLayout ckWorkspaceLayout(const unsigned max_contig_len)
+static const unsigned CK_SEQ_WORDS = CK_MAX_EXT / 16 + 2;   // per direction: 2-bit codes, 16 per dword
+static const unsigned CK_LOG_QW    = (CK_MAX_EXT + 4) / 4;  // per walk: 16-bit word ids, 4 per qword (entry 0 = the seed)
+WV_HD CkWsLayout ckWorkspaceLayout()
 {
   CkWsLayout L;
   uint64_t   o = 0;
-  L.lane_seq  = asmPut(o, 64ull * 2 * 4 * ckSeqWords(max_contig_len));
+  L.lane_seq  = asmPut(o, 64ull * 2 * 4 * CK_SEQ_WORDS);
   L.lane_bits = asmPut(o, 64ull * 4 * 8);
   L.lane_meta = asmPut(o, 64ull * 8 * 4);
-  L.vis       = asmPut(o, 8ull * (LG_MAX_NODES + 5));
+  L.lane_log  = asmPut(o, 64ull * 8 * CK_LOG_QW);
   L.total     = (o + 255) & ~uint64_t(255);
   return L;
 }
@@ -48,16 +51,18 @@ struct LdsContig {
   const LgParams&  G;
   char*            lds;
   const uint8_t*   slab;
-  FRec*            nodes;
+  FRec8*           nodes;
   FSet*            pool;
   uint32_t*        unused_bits;
-  uint16_t *       tent, *slotNode, *sib;
+  uint16_t *       tent, *slotNode, *sib, *sovf, *povf;
+  LgSlab           SL;
   uint8_t*         tbl;
   uint32_t*        lane_seq;
   uint64_t*        lane_bits;
   int32_t*         lane_meta;
-  unsigned long long* vm;
-  unsigned         lane, nNormal, W, k, nNodes, nFat, nEligible, nSpec, nSib, codeWords, nCand, maxLen, seqWords;
+  uint64_t*        lane_log;
+  unsigned         lane, nNormal, W, k, nNodes, nFat, nEligible, nSpec, nSib, nSovf, nPovf, codeWords, nCand, maxLen, seqWords;
+  bool             acyclic;
   unsigned         candSlotV;  // lane c: cache slot that holds candidate c's walk
   uint64_t         tMark;
 
@@ -69,15 +74,17 @@ struct LdsContig {
     slotNode    = reinterpret_cast<uint16_t*>(lds + CK_OFF_SLOTND);
     tbl         = reinterpret_cast<uint8_t*>(lds + CK_OFF_TBL);
     sib         = reinterpret_cast<uint16_t*>(lds + CK_OFF_SIB);
-    nodes       = reinterpret_cast<FRec*>(lds + CK_OFF_RECS);
+    sovf        = reinterpret_cast<uint16_t*>(lds + CK_OFF_SOVF);
+    povf        = reinterpret_cast<uint16_t*>(lds + CK_OFF_POVF);
+    nodes       = reinterpret_cast<FRec8*>(lds + CK_OFF_RECS);
     pool        = nullptr;
-    const CkWsLayout L = ckWorkspaceLayout(p.max_contig_len);
+    const CkWsLayout L = ckWorkspaceLayout();
     lane_seq  = reinterpret_cast<uint32_t*>(ws + L.lane_seq);
     lane_bits = reinterpret_cast<uint64_t*>(ws + L.lane_bits);
     lane_meta = reinterpret_cast<int32_t*>(ws + L.lane_meta);
-    vm        = reinterpret_cast<unsigned long long*>(ws + L.vis);
-    maxLen    = (p.max_contig_len < CK_MAX_CONTIG) ? p.max_contig_len : CK_MAX_CONTIG;
-    seqWords  = ckSeqWords(p.max_contig_len);
+    lane_log  = reinterpret_cast<uint64_t*>(ws + L.lane_log);
+    maxLen    = p.max_contig_len;
+    seqWords  = CK_SEQ_WORDS;
     candSlotV = 0;
     nCand     = 0;
   }
@@ -94,21 +101,24 @@ struct LdsContig {
   }
 
   WV_DEV bool isUnused(const unsigned nd) const { return (unused_bits[nd >> 5] >> (nd & 31)) & 1u; }
-  WV_DEV char*    scratch() const { return lds + CK_OFF_RECS + 16 * nNodes; }
+  WV_DEV char*    scratch() const { return lds + CK_OFF_RECS + ((8 * nNodes + 15) & ~15u); }
 
-  /// read support of a node as two set words
-  WV_DEV void supOf(const uint64_t w1, uint64_t& s0, uint64_t& s1) const
+  /// read support of word `nd` (record w) as two set words
+  WV_DEV void supOf(const unsigned nd, const FRec8 w, uint64_t& s0, uint64_t& s1) const
   {
-    const unsigned ref = lgSupRef(w1);
-    if (ref & LG_FAT) {
-      const FSet v = pool[ref & 0x7ffu];
+    if (nd < nFat) {
+      const FSet v = pool[nd];
       s0           = v.w[0];
       s1           = v.w[1];
     } else {
+      const unsigned ref = lg8Read(w);
       s0 = (ref < 64) ? (uint64_t(1) << ref) : 0;
       s1 = (ref >= 64) ? (uint64_t(1) << (ref - 64)) : 0;
     }
   }
+  /// successors / predecessors of word nd as 4 x 11 bits (id + 1)
+  WV_DEV uint64_t succOf(const unsigned nd, const FRec8 w) const { return lg8Links(w, nd, true, sovf, nSovf); }
+  WV_DEV uint64_t predOf(const unsigned nd, const FRec8 w) const { return lg8Links(w, nd, false, povf, nPovf); }
 
   // ------------------------------------------------------------------------------------------------
   // the slab -> LDS
@@ -124,13 +134,18 @@ struct LdsContig {
     nEligible       = wv::first(gh->nEligible);
     nSpec           = wv::first(gh->nSpec);
     nSib            = wv::first(gh->nSib);
+    nSovf           = wv::first(gh->nSovf);
+    nPovf           = wv::first(gh->nPovf);
     codeWords       = wv::first(gh->codeWords);
     W               = wv::first(gh->W);
+    acyclic         = wv::first(gh->acyclic) != 0;
     if (wv::first(gh->need) > P.lds_bytes || nNodes > LG_MAX_NODES) return false;
-    const FRec* gRec = reinterpret_cast<const FRec*>(slab + sizeof(LgHdr));
+    SL               = lgSlab(nNodes, nFat, codeWords);
+    const FRec8* gRec = reinterpret_cast<const FRec8*>(slab + SL.recs);
     for (unsigned i = lane; i < nNodes; i += 64) nodes[i] = gRec[i];
-    const uint16_t* gSib = gSpecList() + 64;
-    for (unsigned i = lane; i < 4 * nSib; i += 64) sib[i] = gSib[i];
+    // the three side tables lie back to back, in the slab and here
+    const uint16_t* gt = reinterpret_cast<const uint16_t*>(slab + SL.sib);
+    for (unsigned i = lane; i < 4 * (LG_SIB_CAP + 2 * LG_OVF_CAP); i += 64) sib[i] = gt[i];
     // seed eligibility (:679-682): ids in count order, so the seeds are the ids below nEligible
     {
       const unsigned lo = 32 * lane;
@@ -139,9 +154,10 @@ struct LdsContig {
     wv::sync();
     return true;
   }
-  WV_DEV const FSet*     gPool() const { return reinterpret_cast<const FSet*>(slab + sizeof(LgHdr) + 16ull * nNodes); }
-  WV_DEV const uint16_t* gSpecList() const { return reinterpret_cast<const uint16_t*>(slab + sizeof(LgHdr) + 16ull * nNodes + 16ull * nFat); }
-  WV_DEV const uint32_t* gCodes() const { return reinterpret_cast<const uint32_t*>(gSpecList() + 64 + 4 * LG_SIB_CAP); }
+  WV_DEV const FSet*     gPool() const { return reinterpret_cast<const FSet*>(slab + SL.pool); }
+  WV_DEV const uint16_t* gSpecList() const { return reinterpret_cast<const uint16_t*>(slab + SL.spec); }
+  WV_DEV const uint16_t* gPb() const { return reinterpret_cast<const uint16_t*>(slab + SL.pb); }
+  WV_DEV const uint32_t* gCodes() const { return reinterpret_cast<const uint32_t*>(slab + SL.codes); }
 
   WV_DEV void loadPool()
   {
@@ -170,10 +186,11 @@ struct LdsContig {
     for (unsigned nb = 0; nb < nNodes; nb += 64) {
       const unsigned nd = nb + lane;
       if (nd >= nNodes) continue;
-      const FRec rec = nodes[nd];
-      unsigned   id = 0, od = 0;
+      const FRec8    w  = nodes[nd];
+      const uint64_t sl = succOf(nd, w), pl = predOf(nd, w);
+      unsigned       id = 0, od = 0;
       for (unsigned c = 0; c < 4; ++c) {
-        const unsigned s = lgLinkId(rec.w0, c), p = lgLinkId(rec.w1, c);
+        const unsigned s = lgLinkId(sl, c), p = lgLinkId(pl, c);
         if (s != ASM_NONE && s != nd) od++;
         if (p != ASM_NONE && p != nd) id++;
       }
@@ -189,16 +206,17 @@ struct LdsContig {
       if (tail == head) break;
       removed += tail - head;
       for (unsigned i = head + lane; i < tail; i += 64) {
-        const unsigned nd  = queue[i];
-        const FRec     rec = nodes[nd];
+        const unsigned nd = queue[i];
+        const FRec8    w  = nodes[nd];
+        const uint64_t sl = succOf(nd, w), pl = predOf(nd, w);
         for (unsigned c = 0; c < 4; ++c) {
-          const unsigned s = lgLinkId(rec.w0, c);
+          const unsigned s = lgLinkId(sl, c);
           if (s != ASM_NONE && s != nd) {
             const unsigned sh  = 8 * (s & 3);
             const unsigned old = wv::atomic_sub(&st[s >> 2], 1u << sh) >> sh;
             if ((old & 0x7u) == 1u && !(wv::atomic_or(&st[s >> 2], 0x40u << sh) & (0x40u << sh))) queue[wv::atomic_add(qTail, 1u)] = uint16_t(s);
           }
-          const unsigned p = lgLinkId(rec.w1, c);
+          const unsigned p = lgLinkId(pl, c);
           if (p != ASM_NONE && p != nd) {
             const unsigned sh  = 8 * (p & 3);
             const unsigned old = wv::atomic_sub(&st[p >> 2], 8u << sh) >> sh;
@@ -239,24 +257,21 @@ struct LdsContig {
   // walks (:149-501), one lane per cache slot
   // ------------------------------------------------------------------------------------------------
   struct Cand {
-    uint64_t w0, w1, s0, s1;
+    FRec8    w;
+    uint64_t s0, s1;
   };
 
-  /// Fetching the word behind a link field `f` (id + 1; 0 = no word) takes two dependent LDS reads: its record, then --
-  /// if the word has one -- its bitset.  The walk issues the first reads of everything a step needs together, then the
-  /// second reads, then combines with mask arithmetic (no selects on loaded values: the compiler would turn those into
+  /// Fetching the word behind a link field `f` (id + 1; 0 = no word) takes two LDS reads: its record and -- if the word has
+  /// one (id < nFat) -- its bitset, both addressed by the id, so they go out together.  The walk issues the reads of everything a
+  /// step needs first, then combines with mask arithmetic (no selects on loaded values: the compiler would turn those into
   /// branches around the loads and serialise the round trips).  A word without a bitset reads pool entry 0 and masks it out.
-  WV_DEV FRec candRec(const unsigned f) const { return nodes[f ? f - 1 : 0]; }
-  WV_DEV FSet candPool(const uint64_t w1) const
+  WV_DEV FRec8 candRec(const unsigned f) const { return nodes[f ? f - 1 : 0]; }
+  WV_DEV FSet  candPool(const unsigned f) const { return pool[(f != 0 && f - 1 < nFat) ? f - 1 : 0u]; }
+  WV_DEV void  candSup(const unsigned f, const FRec8 w, const FSet& p, uint64_t& s0, uint64_t& s1) const
   {
-    const unsigned ref = lgSupRef(w1);
-    return pool[(ref & LG_FAT) ? (ref & 0x7ffu) : 0u];
-  }
-  WV_DEV static void candSup(const unsigned f, const uint64_t w1, const FSet& p, uint64_t& s0, uint64_t& s1)
-  {
-    const unsigned ref  = lgSupRef(w1);
-    const bool     fat  = (ref & LG_FAT) != 0;
-    const uint64_t useM = (f != 0 && fat) ? ~uint64_t(0) : 0;
+    const unsigned ref  = lg8Read(w);
+    const bool     fat  = f != 0 && f - 1 < nFat;
+    const uint64_t useM = fat ? ~uint64_t(0) : 0;
     const uint64_t bit  = uint64_t((f != 0 && !fat) ? 1u : 0u) << (ref & 63);
     const uint64_t hiM  = (ref & 64u) ? ~uint64_t(0) : 0;
     s0                  = (p.w[0] & useM) | (bit & ~hiM);
@@ -265,27 +280,19 @@ struct LdsContig {
   WV_DEV Cand loadCand(const unsigned f) const
   {
     Cand       c;
-    const FRec r = candRec(f);
-    const FSet p = candPool(r.w1);
-    c.w0         = r.w0;
-    c.w1         = r.w1;
-    candSup(f, r.w1, p, c.s0, c.s1);
+    const FSet p = candPool(f);
+    c.w          = candRec(f);
+    candSup(f, c.w, p, c.s0, c.s1);
     return c;
-  }
-  WV_DEV void loadSup(const unsigned f, uint64_t& s0, uint64_t& s1) const
-  {
-    const uint64_t w1 = nodes[f ? f - 1 : 0].w1;
-    const FSet     p  = candPool(w1);
-    candSup(f, w1, p, s0, s1);
   }
 
   /// the lanes of walkMask walk slotNode[lane]; results go to the slot's records in the workspace (lane_bits / lane_meta /
-  /// lane_seq) and bit `lane` of vm[word] for every word of the walk.
+  /// lane_seq) and the walk's words to its log (lane_log: entry 0 = the seed, then the chosen words in order).
   ///
   /// One lane executes the instruction stream of all 64, so the step is written for the union: the first two candidates
-  /// of a step (packed link lists: fields 0 and 1) are always fetched and compared branch-free, a third or fourth one
-  /// (three-way branches are rare) sits behind a wave vote; likewise the backward check (:377-427) fetches one "other"
-  /// neighbour of the chosen word branch-free and further ones behind a vote.  Appended bases come from the chosen
+  /// of a step (the record's own two links) are always fetched and compared branch-free, a third or fourth one
+  /// (three-way branches are rare: overflow table) sits behind a wave vote; likewise the backward check (:377-427) fetches one
+  /// "other" neighbour of the chosen word branch-free and further ones behind a vote.  Appended bases come from the chosen
   /// word's record (first / last base), not from the link position.
   WV_DEV void walkSlots(const uint64_t walkMask)
   {
@@ -293,7 +300,8 @@ struct LdsContig {
     LG_STAT(1, 1);
     LG_STAT(2, unsigned(wv::popc(walkMask)));
     const unsigned seed = has ? unsigned(slotNode[lane]) : 0u;
-    const unsigned long long laneBit = (unsigned long long)1 << lane;
+    uint64_t*      logBuf   = lane_log + size_t(lane) * CK_LOG_QW;
+    uint64_t       logAcc   = seed;
     uint32_t*      rightBuf = lane_seq + size_t(lane) * 2 * seqWords;
     uint32_t*      leftBuf  = rightBuf + seqWords;
     uint32_t       accR = 0, accL = 0;
@@ -301,25 +309,24 @@ struct LdsContig {
     bool           active = has, rep = false, tooLong = false;
     unsigned       mode = 0, cur = seed, consOffset = 0, nLeft = 0, nRight = 0;
     int            consEnd = 0, consBegin = 0;
-    FRec           seedRec = {0, 0};
+    FRec8          seedRec = 0;
     if (has) {
       seedRec = nodes[seed];
-      supOf(seedRec.w1, S0, S1);
-      wv::atomic_or(&vm[seed], laneBit);
-      if (lgSelfLoop(seedRec.w1)) {  // :172-179 (repeatWords of an acyclic graph = the self loops)
+      supOf(seed, seedRec, S0, S1);
+      if (lg8SelfLoop(seedRec)) {  // :172-179 (repeatWords of an acyclic graph = the self loops)
         rep    = true;
         active = false;
       } else {
         // unselected siblings of the seed reject the contig (:185-210).  The words that differ from the seed in the last base
         // only are the other successors of any predecessor of the seed; a seed without a predecessor has them in the side table.
-        const unsigned pf = unsigned(seedRec.w1) & 0x7ffu;
+        const unsigned pf = lg8Pred(seedRec, 0);
         if (pf) {
-          const uint64_t zw0 = nodes[pf - 1].w0;
+          const uint64_t zs = succOf(pf - 1, nodes[pf - 1]);
           for (unsigned c = 0; c < 4; ++c) {
-            const unsigned f = unsigned(zw0 >> (11 * c)) & 0x7ffu;
+            const unsigned f = unsigned(zs >> (11 * c)) & 0x7ffu;
             if (f && f - 1 != seed) {
               uint64_t a, b;
-              supOf(nodes[f - 1].w1, a, b);
+              supOf(f - 1, nodes[f - 1], a, b);
               R0 |= a;
               R1 |= b;
             }
@@ -331,7 +338,7 @@ struct LdsContig {
               const unsigned n = sib[4 * e + q];
               if (n == LG_NO_SLOT) continue;
               uint64_t a, b;
-              supOf(nodes[n].w1, a, b);
+              supOf(n, nodes[n], a, b);
               R0 |= a;
               R1 |= b;
             }
@@ -339,11 +346,64 @@ struct LdsContig {
         }
       }
     }
-    uint64_t link = active ? (seedRec.w0 & LG_M44) : 0;  // candidate list of the current word in walking direction
-    Cand     ca = loadCand(unsigned(link) & 0x7ffu), cb = loadCand(unsigned(link >> 11) & 0x7ffu);
+    FRec8 curRec = seedRec;  // record of `cur`
 
     while (wv::any(active)) {
-      const bool isEnd = (mode == 0);
+      // ---- fast steps.  Exactly one word ahead of the current one, and that word has exactly one word behind it (the current
+      // one): nothing to choose (:241-336 see one candidate), nobody to reject (:377-427 find no other neighbour).  If the word
+      // shares a read with the contig the general step below would do exactly this: take it, add its reads that do not reject
+      // the contig.  Four of five steps of a walk are of this kind, and they cost a tenth of the general step -- so every lane
+      // runs ahead through its unbranched stretch (up to CK_FAST_CAP words) before the wave takes one general step together.
+      for (unsigned it = 0; it < CK_FAST_CAP; ++it) {
+        const bool     fwd = (mode == 0);
+        const unsigned f   = unsigned(fwd ? curRec : (curRec >> 22)) & 0x7ffu;
+        const bool     one = active && f != 0 && (unsigned(fwd ? (curRec >> 11) : (curRec >> 33)) & 0x7ffu) == 0 &&
+                         !(fwd ? lg8SOvf(curRec) : lg8POvf(curRec));
+        const unsigned ff = one ? f : 0u;
+        const FRec8    w  = candRec(ff);
+        const FSet     p  = candPool(ff);
+        uint64_t       a0, a1;
+        candSup(ff, w, p, a0, a1);
+        const bool     backOne = (unsigned(fwd ? (w >> 33) : (w >> 11)) & 0x7ffu) == 0 && !(fwd ? lg8POvf(w) : lg8SOvf(w));
+        const unsigned shared  = unsigned(wv::popc(S0 & a0)) + unsigned(wv::popc(S1 & a1));
+        const unsigned wc      = lg8Cnt(w);
+        const bool     go = one && backOne && shared != 0 && wc >= P.opt.minCoverage && f - 1 != cur &&
+                        (k + nRight + nLeft + 1 < maxLen) && (nRight + nLeft < CK_MAX_EXT);
+        if (!wv::any(go)) break;
+        if (go) {
+          const unsigned pz = 1 + nRight + nLeft;
+          logAcc |= uint64_t(f - 1) << (16 * (pz & 3));
+          if ((pz & 3) == 3) {
+            logBuf[pz >> 2] = logAcc;
+            logAcc          = 0;
+          }
+          const unsigned sym = fwd ? lg8LastBase(w) : lg8FirstBase(w);
+          if (fwd) {
+            accR |= sym << (2 * (nRight & 15));
+            if ((nRight & 15) == 15) {
+              rightBuf[nRight >> 4] = accR;
+              accR                  = 0;
+            }
+            nRight++;
+          } else {
+            accL |= sym << (2 * (nLeft & 15));
+            if ((nLeft & 15) == 15) {
+              leftBuf[nLeft >> 4] = accL;
+              accL                = 0;
+            }
+            nLeft++;
+          }
+          if ((consOffset != 0) || (wc < P.opt.minConservativeCoverage)) consOffset += 1;
+          S0 |= a0 & ~R0;
+          S1 |= a1 & ~R1;
+          cur    = f - 1;
+          curRec = w;
+        }
+      }
+      // ---- the general step ----
+      const bool     isEnd = (mode == 0);
+      const uint64_t link  = active ? (isEnd ? succOf(cur, curRec) : predOf(cur, curRec)) : 0;  // candidates of the current word in walking direction
+      const Cand     ca = loadCand(unsigned(link) & 0x7ffu), cb = loadCand(unsigned(link >> 11) & 0x7ffu);
       // ---- choose the extension (:241-336): candidates a, b in alphabet order, strict '>' on the shared-read count ----
       const uint64_t A0 = S0 & ca.s0, A1 = S1 & ca.s1, B0 = S0 & cb.s0, B1 = S1 & cb.s1;
       const unsigned cntA = unsigned(wv::popc(A0)) + unsigned(wv::popc(A1)), cntB = unsigned(wv::popc(B0)) + unsigned(wv::popc(B1));
@@ -354,15 +414,13 @@ struct LdsContig {
       uint64_t       rm0  = (bWins ? A0 : B0) & ~SH0, rm1 = (bWins ? A1 : B1) & ~SH1;
       uint64_t       add0 = loserOn ? ((bWins ? ca.s0 : cb.s0) & ~SH0) : 0, add1 = loserOn ? ((bWins ? ca.s1 : cb.s1) & ~SH1) : 0;
       uint64_t       maxWR0 = bWins ? cb.s0 : ca.s0, maxWR1 = bWins ? cb.s1 : ca.s1;
-      uint64_t       maxCW0 = bWins ? B0 : A0, maxCW1 = bWins ? B1 : A1;
-      uint64_t       maxW0 = bWins ? cb.w0 : ca.w0, maxW1 = bWins ? cb.w1 : ca.w1;
+      uint64_t       maxCW0 = bWins ? B0 : A0, maxCW1 = bWins ? B1 : A1;  // (empty when neither candidate shares a read)
+      FRec8          maxW   = bWins ? cb.w : ca.w;
       unsigned       maxCnt = bWins ? cntB : cntA;
       unsigned       maxF   = bWins ? (unsigned(link >> 11) & 0x7ffu) : (unsigned(link) & 0x7ffu);  // id + 1 of the chosen word
-      if (maxCnt == 0) {
-        maxWR0 = maxWR1 = maxCW0 = maxCW1 = 0;
-        maxF = 0;
-      }
-      if (wv::any(active && ((link >> 22) & 0x7ffu) != 0)) {  // a third / fourth candidate somewhere in the wave (rare)
+      if (maxCnt == 0) maxF = 0;
+      if (wv::any(active && (link >> 22) != 0)) {  // a third / fourth candidate somewhere in the wave (rare)
+        if (maxCnt == 0) maxWR0 = maxWR1 = 0;  // (nothing chosen so far: nothing to lose to a later candidate)
         for (unsigned i = 2; i < 4; ++i) {
           const unsigned f = active ? (unsigned(link >> (11 * i)) & 0x7ffu) : 0u;
           if (!wv::any(f != 0)) continue;
@@ -382,8 +440,7 @@ struct LdsContig {
             maxCW1 = C1;
             maxCnt = cnt;
             maxF   = f;
-            maxW0  = c.w0;
-            maxW1  = c.w1;
+            maxW   = c.w;
           } else {  // :317-335
             rm0 |= C0 & ~T0;
             rm1 |= C1 & ~T1;
@@ -393,7 +450,7 @@ struct LdsContig {
         }
       }
       const unsigned maxNode      = maxF - 1;  // (ASM_NONE when nothing was chosen)
-      const unsigned maxBaseCount = maxF ? lgCnt(maxW0) : 0u;
+      const unsigned maxBaseCount = maxF ? lg8Cnt(maxW) : 0u;
       bool           stop = false, extend = false;
       if (active) {
         if (maxBaseCount < P.opt.minCoverage) {  // :343 (also "no candidate")
@@ -401,7 +458,7 @@ struct LdsContig {
         } else if (maxNode == cur) {  // :352-358: in an acyclic graph a walk meets its own words again only through a self loop
           rep  = true;
           stop = true;
-        } else if (k + nRight + nLeft + 1 >= maxLen) {
+        } else if (k + nRight + nLeft + 1 >= maxLen || nRight + nLeft >= CK_MAX_EXT) {
           tooLong = true;
           active  = false;
         } else {
@@ -409,7 +466,7 @@ struct LdsContig {
         }
       }
       // ---- requests: the neighbours of the chosen word against the walking direction (:377-427) ... ----
-      const uint64_t back = extend ? ((isEnd ? maxW1 : maxW0) & LG_M44) : 0;
+      const uint64_t back = extend ? (isEnd ? predOf(maxNode, maxW) : succOf(maxNode, maxW)) : 0;
       unsigned       o0 = 0, nOther = 0;
       for (unsigned c = 0; c < 4; ++c) {
         const unsigned f  = unsigned(back >> (11 * c)) & 0x7ffu;
@@ -417,22 +474,10 @@ struct LdsContig {
         if (ok && nOther == 0) o0 = f;
         nOther += ok ? 1u : 0u;
       }
-      // ---- ... and the next step's candidates (on a direction switch: the seed's predecessors) ----
-      const bool     toLeft = stop && (mode == 0);  // :488-491
-      const uint64_t next   = extend ? ((isEnd ? maxW0 : maxW1) & LG_M44) : (toLeft ? (seedRec.w1 & LG_M44) : 0);
-      const unsigned fa = unsigned(next) & 0x7ffu, fb = unsigned(next >> 11) & 0x7ffu;
-      const uint64_t ow1 = nodes[o0 ? o0 - 1 : 0].w1;  // first reads ...
-      const FRec     ra = candRec(fa), rb = candRec(fb);
-      const FSet     po = candPool(ow1), pa = candPool(ra.w1), pb = candPool(rb.w1);  // ... second reads
+      const FRec8    ow = candRec(o0);
+      const FSet     po = candPool(o0);
       uint64_t       b0, b1;
-      Cand           na, nb;
-      candSup(o0, ow1, po, b0, b1);
-      na.w0 = ra.w0;
-      na.w1 = ra.w1;
-      nb.w0 = rb.w0;
-      nb.w1 = rb.w1;
-      candSup(fa, ra.w1, pa, na.s0, na.s1);
-      candSup(fb, rb.w1, pb, nb.s0, nb.s1);
+      candSup(o0, ow, po, b0, b1);
       b0 &= ~maxCW0;  // :400-414
       b1 &= ~maxCW1;
       if (wv::any(nOther > 1)) {  // more than one other neighbour (rare)
@@ -443,16 +488,22 @@ struct LdsContig {
           const bool     want = ok && seen >= 1;
           seen += ok ? 1u : 0u;
           if (!wv::any(want)) continue;
-          uint64_t x0, x1;
-          loadSup(want ? f : 0u, x0, x1);
-          b0 |= x0 & ~maxCW0;
-          b1 |= x1 & ~maxCW1;
+          const Cand x = loadCand(want ? f : 0u);
+          b0 |= x.s0 & ~maxCW0;
+          b1 |= x.s1 & ~maxCW1;
         }
       }
       // ---- finish this step ----
       if (extend) {
-        wv::atomic_or(&vm[maxNode], laneBit);  // :482-484
-        const unsigned sym = isEnd ? lgLastBase(maxW1) : lgFirstBase(maxW1);
+        {  // :482-484: the word leaves unusedWords when this walk is accepted
+          const unsigned p = 1 + nRight + nLeft;
+          logAcc |= uint64_t(maxNode) << (16 * (p & 3));
+          if ((p & 3) == 3) {
+            logBuf[p >> 2] = logAcc;
+            logAcc         = 0;
+          }
+        }
+        const unsigned sym = isEnd ? lg8LastBase(maxW) : lg8FirstBase(maxW);
         if (isEnd) {  // :363
           accR |= sym << (2 * (nRight & 15));
           if ((nRight & 15) == 15) {
@@ -479,22 +530,21 @@ struct LdsContig {
         S1 |= maxWR1 & ~R1;
         S0 &= ~rm0;  // :471-473
         S1 &= ~rm1;
-        cur = maxNode;
+        cur    = maxNode;
+        curRec = maxW;
       }
       if (stop) {
-        if (mode == 0) {
+        if (mode == 0) {  // :488-491: on to the left, from the seed
           consEnd    = int(consOffset);
           mode       = 1;
           cur        = seed;
+          curRec     = seedRec;
           consOffset = 0;
         } else {
           consBegin = int(consOffset);
           active    = false;
         }
       }
-      link = next;
-      ca   = na;
-      cb   = nb;
     }
 
     if (has) {
@@ -505,6 +555,7 @@ struct LdsContig {
       lb[3]        = R1;
       if (nRight & 15) rightBuf[nRight >> 4] = accR;
       if (nLeft & 15) leftBuf[nLeft >> 4] = accL;
+      logBuf[(nRight + nLeft + 1) >> 2] = logAcc;  // (the last, partly filled qword; a full one was stored and this one is empty)
       int32_t* m = lane_meta + lane * 8;
       m[0]       = int(nLeft);
       m[1]       = int(nRight);
@@ -523,7 +574,6 @@ struct LdsContig {
     const unsigned capCand = 2 * P.opt.maxAssemblyCount;
     nCand                  = 0;
     if (nNodes == 0 || nEligible == 0) return 0;  // no word at this length (:522) / no seed: no contig, no repeat
-    for (unsigned i = lane; i < nNodes; i += 64) vm[i] = 0;
     slotNode[lane] = uint16_t(LG_NO_SLOT);
     uint64_t cached = 0;  // cache slots in use
     uint64_t accAll = 0;  // slots that hold accepted candidates (never evicted)
@@ -573,7 +623,6 @@ struct LdsContig {
           const unsigned sn   = unsigned(slotNode[lane]);
           const uint64_t dead = wv::ballot(((cached & ~accAll) >> lane) & 1u && sn != LG_NO_SLOT && !isUnused(sn));
           if (dead) {
-            for (unsigned i = lane; i < nNodes; i += 64) vm[i] = wv::atomic_load(&vm[i]) & ~dead;
             if ((dead >> lane) & 1u) slotNode[lane] = uint16_t(LG_NO_SLOT);
             cached &= ~dead;
             LG_STAT(5, unsigned(wv::popc(dead)));
@@ -582,7 +631,6 @@ struct LdsContig {
         }
         if (cached == ~uint64_t(0) && (miss & 1u)) {
           // still full and the very next seed has no walk: drop every cached walk that is not an accepted candidate
-          for (unsigned i = lane; i < nNodes; i += 64) vm[i] = wv::atomic_load(&vm[i]) & accAll;
           if (!((accAll >> lane) & 1u)) slotNode[lane] = uint16_t(LG_NO_SLOT);
           cached = accAll;
           LG_STAT(4, 1);
@@ -621,19 +669,19 @@ struct LdsContig {
           tick(6);
         }
       }
-      // replay: entry i is the reference's next seed iff no walk accepted before it in this round touched its word (every
-      // entry was unused when the list was made)
-      unsigned long long vmI = 0;
-      unsigned           flI = 0;
-      if (lane < nL) {
-        vmI = wv::atomic_load(&vm[node]);
-        if (slot != LG_NO_SLOT) flI = unsigned(lane_meta[slot * 8 + 4]);
+      // replay: entry i is the reference's next seed iff it is still unused when its turn comes (every entry was unused when the
+      // list was made; accepting a walk takes the walk's words out of unusedWords, :170,482)
+      unsigned flI = 0, lenI = 0;
+      if (lane < nL && slot != LG_NO_SLOT) {
+        const int32_t* m = lane_meta + slot * 8;
+        flI              = unsigned(m[4]);
+        lenI             = 1u + unsigned(m[0]) + unsigned(m[1]);
       }
       uint64_t acc = 0;
       bool     bad = false;
       for (unsigned i = 0; i < nL && nCand < capCand; ++i) {
-        const uint64_t v = wv::readlane(uint64_t(vmI), int(i));
-        if (v & acc) continue;  // consumed by an accepted walk: not a seed for the reference either
+        const unsigned nd = wv::readlane(node, int(i));
+        if (!isUnused(nd)) continue;  // consumed by an accepted walk: not a seed for the reference either
         const unsigned sl = wv::readlane(slot, int(i));
         if (sl == LG_NO_SLOT) break;  // the next seed has not been walked: next round
         if (wv::readlane(flI, int(i)) != 0) {  // repeat hit (the reference moves on to the next word length) or contig too long
@@ -643,16 +691,17 @@ struct LdsContig {
         acc |= uint64_t(1) << sl;
         if (lane == nCand) candSlotV = sl;
         nCand++;
+        // unusedWords.erase for every word of the accepted walk
+        const unsigned  n   = wv::readlane(lenI, int(i));
+        const uint16_t* log = reinterpret_cast<const uint16_t*>(lane_log + size_t(sl) * CK_LOG_QW);
+        for (unsigned j = lane; j < n; j += 64) {
+          const unsigned w = log[j];
+          wv::atomic_and(&unused_bits[w >> 5], ~(1u << (w & 31)));
+        }
+        wv::sync();
       }
       if (bad) return 1;
       accAll |= acc;
-      // unusedWords.erase for every word of the accepted walks (:170,482)
-      for (unsigned nb = 0; nb < ((nNodes + 63) & ~63u); nb += 64) {
-        const unsigned nd = nb + lane;
-        const uint64_t m  = wv::ballot(nd < nNodes && (wv::atomic_load(&vm[nd < nNodes ? nd : 0]) & acc) != 0);
-        if (lane < 2) unused_bits[(nb >> 5) + lane] &= ~uint32_t(m >> (32 * lane));
-      }
-      wv::sync();
       tick(7);
     }
     return 0;
@@ -737,12 +786,12 @@ struct LdsContig {
     }
     uint64_t        so = seqBase, bo = bitsBase;
     const uint32_t* gc = gCodes();
+    const uint16_t* gp = gPb();
     for (unsigned f = 0; f < finalCount; ++f) {
       const int      c   = int(chosenAt(f));
       const unsigned sl  = wv::readlane(candSlotV, c);
       const unsigned nL  = wv::readlane(nLeft, c), nR = wv::readlane(nRight, c), len = nL + k + nR;
-      const FRec     sr  = nodes[slotNode[sl]];
-      const unsigned seedPb = lgPb(sr.w0, sr.w1);
+      const unsigned seedPb = gp[slotNode[sl]];
       const uint32_t* rightBuf = lane_seq + size_t(sl) * 2 * seqWords;
       const uint32_t* leftBuf  = rightBuf + seqWords;
       for (unsigned i = lane; i < len; i += 64) {  // reverse(left) + seed + right
@@ -789,7 +838,7 @@ struct LdsContig {
     tMark = wv::clock();
     if (!load(locus)) return CK_PUNT;
     tick(4);
-    if (graphHasCycle()) return CK_PUNT;  // the exact repeat search is the general path's
+    if (!acyclic && graphHasCycle()) return CK_PUNT;  // the exact repeat search is the general path's
     tick(3);
     loadPool();
     tick(4);
@@ -798,6 +847,7 @@ struct LdsContig {
     tick(7);
     LG_STAT(0, 1);
     LG_STAT(3, nCand);
+    LG_STAT(6, acyclic ? 1u : 0u);
     return CK_DONE;
   }
 };

@@ -39,12 +39,13 @@ static const unsigned LG_FAT       = 0x800u; // support reference (12 bits): ind
 static const unsigned LG_NO_SLOT   = 0xffffu;
 static const unsigned LG_WAVES     = 8;      // wavefronts of a graph_kernel workgroup
 static const unsigned LG_BUDGET    = 81920;  // its LDS: two workgroups per CU
-static const unsigned LG_SIB_CAP   = 64;     // words without a predecessor that have siblings (side table)
+static const unsigned LG_SIB_CAP   = 32;     // words without a predecessor that have siblings (side table)
+static const unsigned LG_OVF_CAP   = 32;     // words with more than two successors / predecessors (side tables)
 static const unsigned LG_CLASSES   = 4;      // LDS size classes of contig_kernel (one launch each)
 
 // graph_kernel LDS map (bytes)
-static const unsigned LG_OFF_HDR   = 0;                          // u32[64]
-static const unsigned LG_OFF_RD    = 256;                        // u32[128] read descriptors {code dword offset : 11, length : 16, has N : 1}
+static const unsigned LG_OFF_HDR   = 0;                          // u32[64] header words, u16[128] byte offset of a read in the staged pile
+static const unsigned LG_OFF_RD    = 512;                        // u32[128] read descriptors {code dword offset : 11, length : 16, has N : 1}
 static const unsigned LG_OFF_RDM   = LG_OFF_RD + 512;            // u16[128] N-bitmap dword offset of a read
 static const unsigned LG_OFF_DBASE = LG_OFF_RDM + 256;           // u32[256] digit bases of a sort pass
 static const unsigned LG_OFF_WHIST = LG_OFF_DBASE + 1024;        // u32[LG_WAVES][256] per-wave digit counts / running offsets
@@ -55,10 +56,17 @@ static const unsigned LG_OFF_SORTB = LG_OFF_SORTA + 2 * LG_SLOTS;     // u16[204
 static const unsigned LG_OFF_KEYS  = LG_OFF_SORTB + 2 * LG_SLOTS;     // u32[2048] first 16 bases by slot; u16[2048] node id by slot after the sort
 static const unsigned LG_OFF_CNT   = LG_OFF_KEYS + 4 * LG_SLOTS;      // u8[2048] count by slot (0x80 | read: the word's only read)
 static const unsigned LG_OFF_DYN   = LG_OFF_CNT + LG_SLOTS;           // codes, N bitmap
-static_assert(LG_OFF_DYN + 12288 <= LG_BUDGET, "graph_kernel LDS map");
-// (dead after the sort: the per-wave histograms hold the sibling table and the chain labels of the speculation list)
+static_assert(LG_OFF_DYN + 12000 <= LG_BUDGET, "graph_kernel LDS map");
+static_assert(8 * (LG_SIB_CAP + 2 * LG_OVF_CAP) + 528 <= 1024 * LG_WAVES, "side tables inside the histogram region");
+// (dead after the sort: the per-wave histograms hold the side tables and the chain labels of the speculation list; sortB the
+// words' potentials; the digit bases hold the reads' anchors during the table pass)
 static const unsigned LG_OFF_SIB   = LG_OFF_WHIST;                    // u16[LG_SIB_CAP][4]
-static const unsigned LG_OFF_CHAIN = LG_OFF_WHIST + 8 * LG_SIB_CAP;   // u16[128] label, u16[128] distance
+static const unsigned LG_OFF_SOVF  = LG_OFF_SIB + 8 * LG_SIB_CAP;     // u16[LG_OVF_CAP][4]
+static const unsigned LG_OFF_POVF  = LG_OFF_SOVF + 8 * LG_OVF_CAP;    // u16[LG_OVF_CAP][4]
+static const unsigned LG_OFF_CHAIN = LG_OFF_POVF + 8 * LG_OVF_CAP;    // u16[128] label, u16[128] distance, u32[4] duplicate bits
+static const unsigned LG_OFF_PHI   = LG_OFF_SORTB;                    // i16[2048]
+static const unsigned LG_OFF_ANCH  = LG_OFF_DBASE;                    // u32[128] anchors, then i32[128] offsets
+static const unsigned LG_NO_ANCHOR = 0xffffffffu;
 
 // header words (graph_kernel LDS)
 enum {
@@ -66,16 +74,21 @@ enum {
   LG_H_FLAG = 1,   ///< pack: a byte outside the alphabet was seen; table: full
   LG_H_N    = 2,   ///< sort: number of words
   LG_H_NSIB = 3,
+  LG_H_NSOVF = 16, LG_H_NPOVF = 17,
+  LG_H_CYC  = 18,  ///< an edge against the potential: no proof of acyclicity
+  LG_H_PAR  = 32,  ///< [32] u8[128]: parent read of a read's anchor (offset resolution)
   LG_H_OFF_LO = 4, ///< slab offset of this locus in the arena (bytes)
   LG_H_OFF_HI = 5,
   LG_H_PUNT = 6,
   LG_H_TOT  = 8    ///< [4] scan: totals of the four digit quarters
 };
 
-struct alignas(16) FRec {
-  uint64_t w0;  ///< successor links 4 x 11 (id+1; packed from field 0 up in A,C,G,T order, 0 ends the list) | count << 44 (8 bit) | first occurrence, low 12 bits << 52
-  uint64_t w1;  ///< predecessor links 4 x 11 (same) | support reference << 44 (12 bit) | first base << 56 | last base << 58 | first occurrence, high 3 bits << 60 | self loop << 63
-};
+/// A word of the compact graph: 8 bytes.
+///   [0,11) [11,22)  successors 0, 1 (id + 1, 0 = none; A,C,G,T order)     [22,33) [33,44)  predecessors 0, 1 (same)
+///   [44,48) count, saturated at 15   [48,55) the word's only read (count 1; words with more reads are the ids below nFat and
+///   own bitset `id` of the pool)   [55,57) first base   [57,59) last base   59 self loop
+///   60 / 61: a third / fourth successor / predecessor in the overflow tables (three-way branches: a handful per locus)
+typedef uint64_t FRec8;
 struct alignas(16) FSet {
   uint64_t w[2];
 };
@@ -83,20 +96,48 @@ struct alignas(16) FBucket {
   uint32_t s[4];
 };
 
-/// what graph_kernel leaves in a locus' slab: this header, then FRec[nNodes], FSet[nFat], u16[64] speculation list,
-/// u16[LG_SIB_CAP][4] sibling table, u32[codeWords] 2-bit pile (for the seeds' text)
+/// what graph_kernel leaves in a locus' slab: this header, then (lgSlab) FRec8[nNodes], FSet[nFat], u16[64] speculation list,
+/// u16[LG_SIB_CAP][4] sibling table, u16[LG_OVF_CAP][4] x 2 overflow tables, u16[nNodes] first occurrences, u32[codeWords] 2-bit
+/// pile (the last two for the seeds' text)
 struct alignas(16) LgHdr {
   uint32_t nNodes, nFat, k, nNormal;
   uint32_t nEligible;     ///< ids below it are seeds (:678-682)
   uint32_t nSpec;         ///< entries of the round-0 walk list (entry 0 = the first seed)
   uint32_t nSib, codeWords;
-  uint32_t W, need, reserved0, reserved1;
-  uint32_t pad[4];
+  uint32_t W, need;
+  uint32_t nSovf, nPovf;
+  uint32_t acyclic;       ///< graph_kernel has a proof that the graph has no cycle (potential from the reads' offsets): no peel
+  uint32_t pad[3];
 };
-static const unsigned LG_SLAB_FIXED = sizeof(LgHdr) + 128 + 8 * LG_SIB_CAP;
+struct LgSlab {
+  uint32_t recs, pool, spec, sib, sovf, povf, pb, codes, total;
+};
+WV_HD LgSlab lgSlab(const unsigned nNodes, const unsigned nFat, const unsigned codeWords)
+{
+  LgSlab   L;
+  uint32_t o = uint32_t(sizeof(LgHdr));
+  L.recs  = o;
+  o += (8u * nNodes + 15u) & ~15u;
+  L.pool  = o;
+  o += 16u * nFat;
+  L.spec  = o;
+  o += 128u;
+  L.sib   = o;
+  o += 8u * LG_SIB_CAP;
+  L.sovf  = o;
+  o += 8u * LG_OVF_CAP;
+  L.povf  = o;
+  o += 8u * LG_OVF_CAP;
+  L.pb    = o;
+  o += (2u * nNodes + 15u) & ~15u;
+  L.codes = o;
+  o += (4u * codeWords + 15u) & ~15u;
+  L.total = o;
+  return L;
+}
 WV_HD uint64_t lgSlabBytes(const unsigned nNodes, const unsigned nFat, const unsigned codeWords)
 {
-  return LG_SLAB_FIXED + 16ull * nNodes + 16ull * nFat + 4ull * ((codeWords + 3) & ~3u);
+  return lgSlab(nNodes, nFat, codeWords).total;
 }
 
 // contig_kernel LDS map
@@ -106,13 +147,16 @@ static const unsigned CK_OFF_TENT   = 320;   // u16[128] seed list of the round
 static const unsigned CK_OFF_SLOTND = 576;   // u16[64] word walked by cache slot s
 static const unsigned CK_OFF_TBL    = 704;   // u8[64]
 static const unsigned CK_OFF_SIB    = 768;   // u16[LG_SIB_CAP][4]
-static const unsigned CK_OFF_RECS   = CK_OFF_SIB + 8 * LG_SIB_CAP;
-/// LDS the contig kernel needs for a graph: records + the larger of {bitset pool, cycle-test state}
-WV_HD unsigned ckNeed(const unsigned nNodes, const unsigned nFat)
+static const unsigned CK_OFF_SOVF   = CK_OFF_SIB + 8 * LG_SIB_CAP;
+static const unsigned CK_OFF_POVF   = CK_OFF_SOVF + 8 * LG_OVF_CAP;
+static const unsigned CK_OFF_RECS   = CK_OFF_POVF + 8 * LG_OVF_CAP;
+/// LDS the contig kernel needs for a graph: records + the larger of {bitset pool, cycle-test state (not for a graph that comes
+/// with a proof of acyclicity)}
+WV_HD unsigned ckNeed(const unsigned nNodes, const unsigned nFat, const bool acyclic)
 {
-  const unsigned kahn = 4 * ((nNodes + 3) / 4) + 2 * nNodes + 32;
-  const unsigned pool = 16 * nFat;
-  return CK_OFF_RECS + 16 * nNodes + ((pool > kahn) ? pool : ((kahn + 15) & ~15u));
+  const unsigned kahn = acyclic ? 0u : ((4 * ((nNodes + 3) / 4) + 2 * nNodes + 32 + 15) & ~15u);
+  const unsigned pool = 16 * (nFat ? nFat : 1u);
+  return CK_OFF_RECS + ((8 * nNodes + 15) & ~15u) + ((pool > kahn) ? pool : kahn);
 }
 
 /// parameters of the pipeline beyond AsmParams (both kernels take the pair)
@@ -128,10 +172,12 @@ struct LgParams {
   uint32_t            class_stride;
   uint32_t            class_bytes[LG_CLASSES];  ///< ascending LDS budgets; 0 = unused class
   uint32_t            cls;         ///< contig_kernel: the class this launch runs
-  uint32_t            reserved;
+  uint32_t            flags;       ///< LG_FLAG_*
   uint8_t*            cws;         ///< contig_kernel workspaces
   uint64_t            cws_stride;
 };
+
+static const uint32_t LG_FLAG_NO_PROOF = 1u;  ///< tests / A-B runs: never skip contig_kernel's cycle test
 
 /// one kernel argument: the assembler's parameters and the pipeline's
 struct LgArgs {
@@ -152,18 +198,33 @@ inline unsigned long long* fastStats()
 #endif
 
 // record fields
-WV_DEV unsigned lgCnt(const uint64_t w0) { return unsigned(w0 >> 44) & 0xffu; }
-WV_DEV unsigned lgPb(const uint64_t w0, const uint64_t w1) { return (unsigned(w0 >> 52) & 0xfffu) | ((unsigned(w1 >> 60) & 7u) << 12); }
-WV_DEV unsigned lgSupRef(const uint64_t w1) { return unsigned(w1 >> 44) & 0xfffu; }
-WV_DEV unsigned lgFirstBase(const uint64_t w1) { return unsigned(w1 >> 56) & 3u; }
-WV_DEV unsigned lgLastBase(const uint64_t w1) { return unsigned(w1 >> 58) & 3u; }
-WV_DEV bool     lgSelfLoop(const uint64_t w1) { return (w1 >> 63) != 0; }
+WV_DEV unsigned lg8Succ(const FRec8 w, const unsigned i) { return unsigned(w >> (11 * i)) & 0x7ffu; }         // id + 1
+WV_DEV unsigned lg8Pred(const FRec8 w, const unsigned i) { return unsigned(w >> (22 + 11 * i)) & 0x7ffu; }    // id + 1
+WV_DEV unsigned lg8Cnt(const FRec8 w) { return unsigned(w >> 44) & 15u; }
+WV_DEV unsigned lg8Read(const FRec8 w) { return unsigned(w >> 48) & 0x7fu; }
+WV_DEV unsigned lg8FirstBase(const FRec8 w) { return unsigned(w >> 55) & 3u; }
+WV_DEV unsigned lg8LastBase(const FRec8 w) { return unsigned(w >> 57) & 3u; }
+WV_DEV bool     lg8SelfLoop(const FRec8 w) { return (w >> 59) & 1u; }
+WV_DEV bool     lg8SOvf(const FRec8 w) { return (w >> 60) & 1u; }
+WV_DEV bool     lg8POvf(const FRec8 w) { return (w >> 61) & 1u; }
+static const uint64_t LG_M22 = (uint64_t(1) << 22) - 1;
+static const uint64_t LG_M44 = (uint64_t(1) << 44) - 1;
+/// the (up to four) neighbours of word `nd` as 4 x 11 bits: the two of the record, the rest from the overflow table `ovf`
+/// (u16 {word, third, fourth, -}, `nOvf` entries; searched only for the flagged words)
+WV_DEV uint64_t lg8Links(const FRec8 w, const unsigned nd, const bool succ, const uint16_t* ovf, const unsigned nOvf)
+{
+  uint64_t l = (succ ? w : (w >> 22)) & LG_M22;
+  if (succ ? lg8SOvf(w) : lg8POvf(w)) {
+    for (unsigned e = 0; e < nOvf; ++e)
+      if (unsigned(ovf[4 * e]) == nd) l |= (uint64_t(ovf[4 * e + 1]) << 22) | (uint64_t(ovf[4 * e + 2]) << 33);
+  }
+  return l;
+}
 WV_DEV unsigned lgLinkId(const uint64_t w, const unsigned c)
 {
   const unsigned f = unsigned(w >> (11 * c)) & 0x7ffu;
   return f ? f - 1 : ASM_NONE;
 }
-static const uint64_t LG_M44 = (uint64_t(1) << 44) - 1;
 
 // ====================================================================================================================
 // graph_kernel
@@ -177,7 +238,10 @@ struct LdsGraph {
   uint16_t *       rdm, *sortA, *sortB, *slotId;
   uint8_t*         cntArr;
   FSet*            sets;
-  FRec*            nodes;
+  FRec8*           nodes;   // records (the sets' bytes, after the bitsets have left for the slab)
+  uint64_t*        pred4;   // predecessors by symbol while the links are scattered (4 x 11 bits)
+  int16_t*         phi;     // potential of a word (id): offset of its first read + position in it
+  int16_t*         roff;    // offset of a read (overlays rdm after the table pass)
   unsigned         nNormal, W, k, nNodes, nFat, nEligible, lowTier, codeWords;
   uint64_t         tMark;
 
@@ -193,7 +257,10 @@ struct LdsGraph {
     whist  = reinterpret_cast<uint32_t*>(lds + LG_OFF_WHIST);
     slots  = reinterpret_cast<uint32_t*>(lds + LG_OFF_SLOTS);
     sets   = reinterpret_cast<FSet*>(lds + LG_OFF_SETS);
-    nodes  = reinterpret_cast<FRec*>(lds + LG_OFF_SETS);
+    nodes  = reinterpret_cast<FRec8*>(lds + LG_OFF_SETS);
+    pred4  = reinterpret_cast<uint64_t*>(lds + LG_OFF_SETS) + LG_SLOTS;
+    phi    = reinterpret_cast<int16_t*>(lds + LG_OFF_PHI);
+    roff   = reinterpret_cast<int16_t*>(lds + LG_OFF_RDM);
     sortA  = reinterpret_cast<uint16_t*>(lds + LG_OFF_SORTA);
     sortB  = reinterpret_cast<uint16_t*>(lds + LG_OFF_SORTB);
     keyArr = reinterpret_cast<uint32_t*>(lds + LG_OFF_KEYS);
@@ -339,6 +406,61 @@ struct LdsGraph {
     return ASM_NONE;
   }
 
+  /// four lookups with their LDS round trips overlapped: the buckets of all keys that are still open are read together, then the
+  /// keys behind matching tags; a key whose bucket is full without a match goes on to the next bucket in the next round
+  template <int KW>
+  WV_DEV void lookupSlots4(const Key<KW> (&keys)[4], unsigned (&out)[4]) const
+  {
+    unsigned b[4], tag[4], skip[4], probes[4];
+    bool     open[4];
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t h = keyHash(keys[i]);
+      tag[i]           = h >> 15;
+      b[i]             = h & (LG_BUCKETS - 1);
+      skip[i]          = 0;
+      probes[i]        = 0;
+      open[i]          = true;
+      out[i]           = ASM_NONE;
+    }
+    while (open[0] || open[1] || open[2] || open[3]) {
+      FBucket bk[4];
+      for (int i = 0; i < 4; ++i) bk[i] = *reinterpret_cast<const FBucket*>(slots + 4 * b[i]);
+      unsigned at[4];
+      uint32_t sv[4];
+      for (int i = 0; i < 4; ++i) {
+        at[i] = 4;
+        sv[i] = LG_EMPTY;
+        for (int j = 3; j >= 0; --j)
+          if (unsigned(j) >= skip[i] && (bk[i].s[j] == LG_EMPTY || (bk[i].s[j] >> 15) == tag[i])) {
+            at[i] = unsigned(j);
+            sv[i] = bk[i].s[j];
+          }
+      }
+      Key<KW> got[4];
+      for (int i = 0; i < 4; ++i) got[i] = keyAt<KW>((open[i] && at[i] < 4 && sv[i] != LG_EMPTY) ? (sv[i] & 0x7fffu) : 0u);
+      for (int i = 0; i < 4; ++i) {
+        if (!open[i]) continue;
+        if (at[i] == 4) {  // bucket full, no match: next bucket
+          b[i]    = (b[i] + 1) & (LG_BUCKETS - 1);
+          skip[i] = 0;
+          if (++probes[i] >= LG_BUCKETS) open[i] = false;
+        } else if (sv[i] == LG_EMPTY) {  // an empty slot ends the search
+          open[i] = false;
+        } else if (keyEq(got[i], keys[i])) {
+          out[i]  = 4 * b[i] + at[i];
+          open[i] = false;
+        } else {  // a tag collision: on with the next slot of this bucket
+          skip[i] = at[i] + 1;
+          if (skip[i] == 4) {
+            b[i]    = (b[i] + 1) & (LG_BUCKETS - 1);
+            skip[i] = 0;
+            if (++probes[i] >= LG_BUCKETS) open[i] = false;
+          }
+        }
+      }
+    }
+  }
+
   WV_DEV uint64_t plShift(const unsigned locus, const unsigned i) const
   {
     return P.pl_chunk_shift ? P.pl_chunk_shift[3 * size_t(locus / P.chunk_loci) + i] : uint64_t(0);
@@ -357,7 +479,8 @@ struct LdsGraph {
     W = (nNormal + 2 * P.opt.maxAssemblyCount + 63) / 64;
     if (W == 0) W = 1;
     const uint64_t plR = plShift(locus, 0), plC = plShift(locus, 1), plM = plShift(locus, 2);
-    unsigned       cw = 0, mw = 0;
+    unsigned       cw = 0, mw = 0, nb = 0;  // code dwords, N-bitmap dwords, bases so far
+    uint16_t*      rstart  = reinterpret_cast<uint16_t*>(hdr + 64);
     bool           tooLong = false;
     for (unsigned base = 0; base < nNormal; base += 64) {
       const unsigned r   = base + lane;
@@ -366,21 +489,24 @@ struct LdsGraph {
       if (len > 0xffffu) tooLong = true;
       const unsigned myC = (r < nNormal) ? (len + 15) / 16 + 1 : 0u;  // +1 padding dword so key fetches may read one past
       const unsigned myM = (r < nNormal) ? (len + 31) / 32 + 1 : 0u;
-      unsigned       sc = myC, sm = myM;
+      unsigned       sc = myC, sm = myM, sb = (r < nNormal) ? len : 0u;
       for (int off = 1; off < 64; off <<= 1) {
-        const unsigned oc = wv::shfl(sc, wv::lane() - off), om = wv::shfl(sm, wv::lane() - off);
+        const unsigned oc = wv::shfl(sc, wv::lane() - off), om = wv::shfl(sm, wv::lane() - off), ob = wv::shfl(sb, wv::lane() - off);
         if (wv::lane() >= off) {
           sc += oc;
           sm += om;
+          sb += ob;
         }
       }
       const unsigned cwo = cw + sc - myC, mwo = mw + sm - myM;
       if (tw == 0 && r < nNormal && cwo <= 0x7ffu) {
-        rd[r]  = cwo | ((len & 0xffffu) << 11);
-        rdm[r] = uint16_t(mwo);
+        rd[r]     = cwo | ((len & 0xffffu) << 11);
+        rdm[r]    = uint16_t(mwo);
+        rstart[r] = uint16_t(nb + sb - len);
       }
       cw += wv::readlane(sc, 63);
       mw += wv::readlane(sm, 63);
+      nb += wv::readlane(sb, 63);
     }
     if (wv::any(tooLong) || cw + 2 > LG_MAX_PILE) return false;
     const unsigned cwPad = (cw + 2 + 3) & ~3u, mwPad = (mw + 2 + 3) & ~3u;
@@ -413,18 +539,31 @@ struct LdsGraph {
     }
     bool           bad   = false;
     const uint32_t shift = P.chunk_shift ? P.chunk_shift[locus / P.chunk_loci] : 0u;
+    // The locus' bases are one contiguous run of the input arena: every thread fetches 16-byte pieces of it into LDS (the sets'
+    // bytes, unused until the table pass) -- all loads in flight at once, one memory latency for the whole pile -- and the
+    // conversion below reads its bytes from there.
+    char* const stage = lds + LG_OFF_SETS;
+    unsigned    lead  = 0;
+    {
+      const uintptr_t g0 = reinterpret_cast<uintptr_t>(P.bases + P.read_off[rBegin] + shift);
+      lead               = unsigned(g0 & 15);
+      const u32x4*   gsrc    = reinterpret_cast<const u32x4*>(g0 - lead);
+      const unsigned nChunks = (lead + nb + 15) / 16 + 1;  // (+1: the byte funnel reads up to four bytes past a read's last dword; the arena is padded)
+      for (unsigned c = tid(); c < nChunks; c += nThreads()) reinterpret_cast<u32x4*>(stage)[c] = gsrc[c];
+    }
+    teamSync();
     // 8 lanes per read, 8 reads per pass: lane (g, i) converts code dwords i, i+8, ... of read (base + g)
     for (unsigned base = 8 * tw; base < nNormal; base += 8 * tn) {
       const unsigned r = base + (lane >> 3);
       if (r >= nNormal) continue;
-      const uint8_t* src = P.bases + P.read_off[rBegin + r] + shift;
+      const char*    src = stage + lead + rstart[r];
       const unsigned d = rd[r], cwo = d & 0x7ffu, len = (d >> 11) & 0xffffu, mwo = rdm[r];
       const unsigned nCw = (len + 15) / 16 + 1;
       bool           sawN = false;
       for (unsigned wi = (lane & 7); wi < nCw; wi += 8) {
         uint32_t code = 0, nbits = 0;
         if (wi * 16 < len) {
-          // 16 bases = five aligned dword loads + a byte funnel (the input arena is padded)
+          // 16 bases = five aligned dword reads + a byte funnel
           const uintptr_t addr = reinterpret_cast<uintptr_t>(src + wi * 16);
           const uint32_t* ap   = reinterpret_cast<const uint32_t*>(addr & ~uintptr_t(3));
           const unsigned  sh   = unsigned(addr & 3) * 8;
@@ -470,6 +609,7 @@ struct LdsGraph {
   template <int KW>
   WV_DEV bool tablePass()
   {
+    if (tid() < LG_MAX_READS) reinterpret_cast<uint32_t*>(lds + LG_OFF_ANCH)[tid()] = LG_NO_ANCHOR;
     for (unsigned s = tid(); s < LG_SLOTS; s += nThreads()) {
       slots[s]      = LG_EMPTY;
       sets[s].w[0] = 0;
@@ -492,13 +632,14 @@ struct LdsGraph {
         const unsigned mwo    = wv::readlane(mV, int(ri));
         unsigned long long* const setWord = reinterpret_cast<unsigned long long*>(&sets[0].w[r >> 6]);
         const unsigned long long  setBit  = (unsigned long long)1 << (r & 63);
+        bool                      haveAnchor = false;  // (see readOffsets)
         for (unsigned j0 = 0; j0 + k <= len; j0 += 64) {
           const unsigned j  = j0 + lane;
           const unsigned pb = cwo * 16 + j;
           bool           todo = (j + k <= len) && !(rdHasN && windowHasN(mwo, j));  // :531
           Key<KW>        key;
           uint32_t       mine = 0;
-          unsigned       tag = 0, b = 0, slot = 0, skip = 0;
+          unsigned       tag = 0, b = 0, slot = 0, skip = 0, foundPb = 0x8000u;
           if (todo) {
             key              = keyAt<KW>(pb);
             const uint32_t h = keyHash(key);
@@ -530,8 +671,9 @@ struct LdsGraph {
                   slot = 4 * b + at;
                   todo = false;
                 } else if ((s >> 15) == tag && keyEq(keyAt<KW>(s & 0x7fffu), key)) {
-                  slot = 4 * b + at;
-                  todo = false;
+                  slot    = 4 * b + at;
+                  foundPb = s & 0x7fffu;
+                  todo    = false;
                 } else {
                   skip = at + 1;  // another word (taken under this lane's eyes, or a tag collision): next slot of the bucket
                   if (skip == 4) {
@@ -547,6 +689,19 @@ struct LdsGraph {
             }
           }
           if ((j + k <= len) && !fail && !(rdHasN && windowHasN(mwo, j))) wv::atomic_or(setWord + 2 * slot, setBit);
+          if (!haveAnchor) {
+            // the read's anchor: its first word that another read had brought before (position here, first occurrence there)
+            // (only words of EARLIER reads -- their codes lie below this read's -- so that the anchors form a forest: reads are
+            // inserted concurrently, and two of them anchoring at each other would leave both without an offset)
+            const bool     cand = foundPb < cwo * 16;
+            const uint64_t mc   = wv::ballot(cand);
+            if (mc) {
+              const int      l   = wv::ctz(mc);
+              const unsigned apb = wv::readlane(foundPb, l);
+              if (lane == 0) reinterpret_cast<uint32_t*>(lds + LG_OFF_ANCH)[r] = apb | ((j0 + unsigned(l)) << 15);
+              haveAnchor = true;
+            }
+          }
         }
       }
     }
@@ -557,8 +712,8 @@ struct LdsGraph {
 
   // ------------------------------------------------------------------------------------------------
   // the words in seed order (:686-696: count descending, k-mer ascending).  Stable LSD radix sort of the occupied slots over
-  // {first 16 bases (four passes), 255 - count}; what still ties (same count, same first 16 bases) is ranked by full key compares
-  // inside its (short) run.  Result: sortA[id] = slot, slotId[slot] = id, nFat / nEligible / lowTier from the count digits.
+  // {first 8 bases (two passes), 255 - count}; what still ties (same count, same first 8 bases: a word or two) is ranked by full
+  // key compares inside its run.  Result: sortA[id] = slot, slotId[slot] = id, nFat / nEligible / lowTier from the count digits.
   // ------------------------------------------------------------------------------------------------
   WV_DEV unsigned cntOf(const unsigned slot) const
   {
@@ -605,11 +760,12 @@ struct LdsGraph {
     const unsigned c0 = chunk * tw, c1 = (c0 + chunk < n) ? (c0 + chunk) : n;
     uint16_t *     src = sortA, *dst = sortB;
     uint32_t*      myHist = whist + 256 * tw;
-    for (int pass = 0; pass < 5; ++pass) {
+    // three passes: bits 16..23 and 24..31 of the first 16 bases, then the count
+    for (int pass = 0; pass < 3; ++pass) {
       for (unsigned i = tid(); i < 256 * tn; i += nThreads()) whist[i] = 0;
       teamSync();
       auto digitOf = [&](const unsigned slot) -> unsigned {
-        return (pass < 4) ? ((keyArr[slot] >> (8 * pass)) & 255u) : (255u - cntOf(slot));
+        return (pass < 2) ? ((keyArr[slot] >> (16 + 8 * pass)) & 255u) : (255u - cntOf(slot));
       };
       for (unsigned i0 = c0; i0 < c1; i0 += 64) {
         const unsigned i = i0 + lane;
@@ -661,7 +817,7 @@ struct LdsGraph {
         wv::sync();
       }
       teamSync();
-      if (pass == 4 && tid() == 0) {
+      if (pass == 2 && tid() == 0) {
         // ids below dbase[d] have counts above 255 - d
         const unsigned minCov = P.opt.minCoverage;
         hdr[LG_H_TOT + 4] = dbase[254];                                                      // count >= 2
@@ -677,19 +833,19 @@ struct LdsGraph {
     nFat      = hdr[LG_H_TOT + 4];
     nEligible = hdr[LG_H_TOT + 5];
     lowTier   = hdr[LG_H_TOT + 6];
-    // five passes: the sorted list sits in sortB (= src); runs of equal {count, first 16 bases} -> exact order into sortA
+    // three passes: the sorted list sits in sortB (= src); runs of equal {count, first 8 bases} -> exact order into sortA
     for (unsigned i = tid(); i < n; i += nThreads()) {
       const unsigned slot = src[i];
-      const unsigned c = cntOf(slot), p = keyArr[slot];
+      const unsigned c = cntOf(slot), p = keyArr[slot] >> 16;
       unsigned       lo = i, hi = i;
       while (lo > 0) {
         const unsigned o = src[lo - 1];
-        if (cntOf(o) != c || keyArr[o] != p) break;
+        if (cntOf(o) != c || (keyArr[o] >> 16) != p) break;
         lo--;
       }
       while (hi + 1 < n) {
         const unsigned o = src[hi + 1];
-        if (cntOf(o) != c || keyArr[o] != p) break;
+        if (cntOf(o) != c || (keyArr[o] >> 16) != p) break;
         hi++;
       }
       unsigned rank = 0;
@@ -711,75 +867,211 @@ struct LdsGraph {
   }
 
   // ------------------------------------------------------------------------------------------------
-  // node records in the new numbering, links (8 table lookups per word), sibling table, speculation list; see FRec
+  // A proof that the graph has no cycle, for free in the common case.  Reads that come from one haplotype and differ by
+  // substitutions only agree on a coordinate: read r sits at offset off[r] such that a word at position j of r has the
+  // coordinate off[r] + j in every read that holds it.  The table pass notes one ANCHOR per read (its first word that another
+  // read had brought before: position here, position there), the offsets follow by pointer doubling over the anchor forest, and
+  // a word's potential phi = coordinate of its first occurrence.  If phi rises along EVERY edge the graph is acyclic -- that is
+  // checked edge by edge in the links pass, so a wrong or inconsistent offset (indel haplotypes, an anchor cycle between reads
+  // inserted at the same time) costs nothing but the proof: contig_kernel then runs its peel.
+  // ------------------------------------------------------------------------------------------------
+  /// read that owns packed base index pb (the reads' code offsets ascend)
+  WV_DEV unsigned readOfPb(const unsigned pb) const
+  {
+    const unsigned cwd = pb >> 4;
+    unsigned       lo = 0, hi = nNormal;  // rd[lo].cwo <= cwd < rd[hi].cwo
+    while (hi - lo > 1) {
+      const unsigned mid = (lo + hi) >> 1;
+      if ((rd[mid] & 0x7ffu) <= cwd) lo = mid; else hi = mid;
+    }
+    return lo;
+  }
+  WV_DEV void readOffsets()
+  {
+    if (tw == 0) {
+      const uint32_t* anch = reinterpret_cast<const uint32_t*>(lds + LG_OFF_ANCH);
+      int32_t*        off  = reinterpret_cast<int32_t*>(lds + LG_OFF_ANCH) + LG_MAX_READS;
+      uint8_t*        par  = reinterpret_cast<uint8_t*>(hdr + LG_H_PAR);
+      int32_t         myOff[2];
+      unsigned        myPar[2];
+      for (unsigned h = 0; h < 2; ++h) {
+        const unsigned r = lane + 64 * h;
+        myOff[h] = 0;
+        myPar[h] = r;
+        if (r < nNormal) {
+          const uint32_t a = anch[r];
+          if (a != LG_NO_ANCHOR) {
+            const unsigned apb = a & 0x7fffu, j = a >> 15;
+            const unsigned r0  = readOfPb(apb);
+            myPar[h] = r0;
+            myOff[h] = int32_t(apb - 16u * (rd[r0] & 0x7ffu)) - int32_t(j);
+          }
+        }
+      }
+      wv::sync();  // (every anchor has been read: the offsets take the second half of the same array... and rdm's bytes below)
+      for (unsigned h = 0; h < 2; ++h) {
+        off[lane + 64 * h] = myOff[h];
+        par[lane + 64 * h] = uint8_t(myPar[h]);
+      }
+      wv::sync();
+      for (int round = 0; round < 7; ++round) {
+        int32_t  po[2];
+        unsigned pp[2];
+        for (unsigned h = 0; h < 2; ++h) {
+          po[h] = off[myPar[h]];
+          pp[h] = par[myPar[h]];
+        }
+        wv::sync();
+        for (unsigned h = 0; h < 2; ++h) {
+          const unsigned r = lane + 64 * h;
+          if (myPar[h] != r) {  // (a root keeps its offset)
+            myOff[h] += po[h];
+            if (pp[h] == myPar[h]) {  // the parent is a root: done after this addition
+              off[r] = myOff[h];
+              par[r] = uint8_t(r);
+              myPar[h] = r;
+            } else {
+              off[r]   = myOff[h];
+              par[r]   = uint8_t(pp[h]);
+              myPar[h] = pp[h];
+            }
+          }
+        }
+        wv::sync();
+      }
+#ifdef MANTA_WAVE_EMU
+      if (std::getenv("MANTA_EMU_PROOF_TRACE"))
+        for (unsigned h = 0; h < 2; ++h)
+          if (lane + 64 * h < nNormal) std::fprintf(stderr, "  read %u: anchor %08x off %d par %u\n", lane + 64 * h, anch[lane + 64 * h], myOff[h], myPar[h]);
+#endif
+      // (rdm is dead after the table pass: its bytes take the offsets; one that does not fit 16 bits only loses the proof)
+      for (unsigned h = 0; h < 2; ++h) {
+        const int32_t v = myOff[h];
+        roff[lane + 64 * h] = int16_t((v > 30000) ? 30000 : ((v < -30000) ? -30000 : v));
+      }
+    }
+    teamSync();
+  }
+
+  // ------------------------------------------------------------------------------------------------
+  // node records in the new numbering (FRec8), links (8 table lookups per word), side tables
   // ------------------------------------------------------------------------------------------------
   template <int KW>
-  WV_DEV bool buildRecords(uint8_t* slab)
+  WV_DEV bool buildRecords(uint8_t* slab, const LgSlab& SL)
   {
-    // bitsets of the words with more than one read: ids below nFat, straight into the slab
-    FSet* gPool = reinterpret_cast<FSet*>(slab + sizeof(LgHdr) + 16ull * nNodes);
+    // bitsets of the words with more than one read: ids below nFat, straight into the slab; first occurrences likewise
+    FSet*     gPool = reinterpret_cast<FSet*>(slab + SL.pool);
+    uint16_t* gPb   = reinterpret_cast<uint16_t*>(slab + SL.pb);
     for (unsigned i = tid(); i < nFat; i += nThreads()) gPool[i] = sets[sortA[i]];
     teamSync();  // (the sets are dead: the records take their place)
     for (unsigned i = tid(); i < nNodes; i += nThreads()) {
       const unsigned slot = sortA[i], pb = slots[slot] & 0x7fffu, enc = cntArr[slot];
       const unsigned cnt = (enc & 0x80u) ? 1u : enc;
-      const unsigned sup = (enc & 0x80u) ? (enc & 0x7fu) : (LG_FAT | i);
+      const unsigned sup = (enc & 0x80u) ? (enc & 0x7fu) : 0u;
       const Key<KW>  key = keyAt<KW>(pb);
       unsigned       last = 0;
       for (int w = 0; w < KW; ++w)
         if (unsigned(w) == ((k - 1) >> 4)) last = (key.w[w] >> (30 - 2 * ((k - 1) & 15))) & 3u;
-      FRec rec;
-      rec.w0   = (uint64_t(pb & 0xfffu) << 52) | (uint64_t(cnt) << 44);
-      rec.w1   = (uint64_t(sup) << 44) | (uint64_t(key.w[0] >> 30) << 56) | (uint64_t(last) << 58) | (uint64_t(pb >> 12) << 60);
-      nodes[i] = rec;
+      nodes[i] = (uint64_t(cnt > 15 ? 15 : cnt) << 44) | (uint64_t(sup) << 48) | (uint64_t(key.w[0] >> 30) << 55) | (uint64_t(last) << 57);
+      pred4[i] = 0;
+      gPb[i]   = uint16_t(pb);
+      const unsigned r = readOfPb(pb);
+      phi[i]           = int16_t(int(roff[r]) + int(pb - 16u * (rd[r] & 0x7ffu)));
     }
-    if (tid() == 0) hdr[LG_H_NSIB] = 0;
+    if (tid() == 0) {
+      hdr[LG_H_NSIB]  = 0;
+      hdr[LG_H_NSOVF] = 0;
+      hdr[LG_H_NPOVF] = 0;
+      hdr[LG_H_CYC]   = 0;
+    }
     teamSync();
     tick(2, 5);
-    // successor lookups, predecessor scatter (by symbol position; packed below)
+    // successor lookups, predecessor scatter (by symbol position; packed below), the potential along every edge
+    uint16_t* sovf = reinterpret_cast<uint16_t*>(lds + LG_OFF_SOVF);
+    uint16_t* povf = reinterpret_cast<uint16_t*>(lds + LG_OFF_POVF);
+    bool      against = false;
     for (unsigned nb = 64 * tw; nb < nNodes; nb += 64 * tn) {
       const unsigned nd = nb + lane;
       if (nd < nNodes) {
-        const uint64_t w0in = nodes[nd].w0;
         const unsigned pb   = slots[sortA[nd]] & 0x7fffu;
         const Key<KW>  key  = keyAt<KW>(pb);
         const unsigned firstBase = key.w[0] >> 30;
-        uint64_t       w0 = w0in;
-        bool           selfLoop = false;
+        const int      myPhi = phi[nd];
+        unsigned       found[4];
         unsigned       m = 0;
+        bool           selfLoop = false;
+        Key<KW>        sk[4];
+        unsigned       sslot[4];
+        for (unsigned c = 0; c < 4; ++c) sk[c] = keyShiftAppend<KW>(key, c);
+        lookupSlots4<KW>(sk, sslot);
         for (unsigned c = 0; c < 4; ++c) {
-          const unsigned ss = lookupSlot<KW>(keyShiftAppend<KW>(key, c));
+          const unsigned ss = sslot[c];
           if (ss == ASM_NONE) continue;
           const unsigned s = slotId[ss];
-          w0 |= uint64_t(s + 1) << (11 * m);
-          m++;
-          if (s == nd) selfLoop = true;
-          wv::atomic_or(reinterpret_cast<unsigned long long*>(&nodes[s].w1), (unsigned long long)(uint64_t(nd + 1) << (11 * firstBase)));
+          found[m++]       = s + 1;
+          if (s == nd) {
+            selfLoop = true;
+          } else if (int(phi[s]) <= myPhi) {
+            against = true;
+#ifdef MANTA_WAVE_EMU
+            if (std::getenv("MANTA_EMU_PROOF_TRACE")) {
+              const unsigned pbs = slots[sortA[s]] & 0x7fffu;
+              std::fprintf(stderr, "  against: word %u (read %u pos %u phi %d) -> word %u (read %u pos %u phi %d)\n", nd, readOfPb(pb), pb - 16 * (rd[readOfPb(pb)] & 0x7ffu), myPhi,
+                           s, readOfPb(pbs), pbs - 16 * (rd[readOfPb(pbs)] & 0x7ffu), int(phi[s]));
+            }
+#endif
+          }
+          wv::atomic_or(reinterpret_cast<unsigned long long*>(&pred4[s]), (unsigned long long)(uint64_t(nd + 1) << (11 * firstBase)));
         }
-        nodes[nd].w0 = w0;
-        if (selfLoop) wv::atomic_or(reinterpret_cast<unsigned long long*>(&nodes[nd].w1), (unsigned long long)(uint64_t(1) << 63));
+        uint64_t w = nodes[nd];
+        if (m > 0) w |= uint64_t(found[0]);
+        if (m > 1) w |= uint64_t(found[1]) << 11;
+        if (selfLoop) w |= uint64_t(1) << 59;
+        if (m > 2) {
+          w |= uint64_t(1) << 60;
+          const unsigned at = wv::atomic_add(&hdr[LG_H_NSOVF], 1u);
+          if (at < LG_OVF_CAP) {
+            sovf[4 * at + 0] = uint16_t(nd);
+            sovf[4 * at + 1] = uint16_t(found[2]);
+            sovf[4 * at + 2] = uint16_t(m > 3 ? found[3] : 0u);
+            sovf[4 * at + 3] = 0;
+          }
+        }
+        nodes[nd] = w;
       }
     }
+    if (wv::any(against) && lane == 0) wv::atomic_or(&hdr[LG_H_CYC], 1u);
     teamSync();
-    // predecessor lists packed like the successor lists; words without a predecessor: their siblings (the words that differ in
-    // the last base only, :185-210) cannot be found through a predecessor's successor list -> side table
+    // predecessors: the first two into the record, further ones into the overflow table; words without a predecessor: their
+    // siblings (the words that differ in the last base only, :185-210) cannot be found through a predecessor's successor
+    // list -> side table
     uint16_t* sib = reinterpret_cast<uint16_t*>(lds + LG_OFF_SIB);
     for (unsigned nd = tid(); nd < nNodes; nd += nThreads()) {
-      const uint64_t w1 = nodes[nd].w1;
-      uint64_t       pk = 0;
-      unsigned       m  = 0;
+      const uint64_t p4 = pred4[nd];
+      unsigned       pf[4];
+      unsigned       m = 0;
       for (unsigned c = 0; c < 4; ++c) {
-        const uint64_t f = (w1 >> (11 * c)) & 0x7ffu;
-        if (f == 0) continue;
-        pk |= f << (11 * m);
-        m++;
+        const unsigned f = unsigned(p4 >> (11 * c)) & 0x7ffu;
+        if (f) pf[m++] = f;
       }
-      nodes[nd].w1 = (w1 & ~LG_M44) | pk;
+      uint64_t w = nodes[nd];
+      if (m > 0) w |= uint64_t(pf[0]) << 22;
+      if (m > 1) w |= uint64_t(pf[1]) << 33;
+      if (m > 2) {
+        w |= uint64_t(1) << 61;
+        const unsigned at = wv::atomic_add(&hdr[LG_H_NPOVF], 1u);
+        if (at < LG_OVF_CAP) {
+          povf[4 * at + 0] = uint16_t(nd);
+          povf[4 * at + 1] = uint16_t(pf[2]);
+          povf[4 * at + 2] = uint16_t(m > 3 ? pf[3] : 0u);
+          povf[4 * at + 3] = 0;
+        }
+      }
+      nodes[nd] = w;
       if (m == 0) {
-        const uint64_t w0  = nodes[nd].w0;
-        const unsigned pb  = lgPb(w0, w1);
+        const unsigned pb  = slots[sortA[nd]] & 0x7fffu;
         const Key<KW>  key = keyAt<KW>(pb);
-        const unsigned lastBase = lgLastBase(w1);
+        const unsigned lastBase = lg8LastBase(w);
         unsigned       found[3] = {LG_NO_SLOT, LG_NO_SLOT, LG_NO_SLOT};
         unsigned       nf = 0;
         for (unsigned c = 0; c < 4; ++c) {
@@ -802,7 +1094,9 @@ struct LdsGraph {
     }
     teamSync();
     tick(2, 6);
-    if (wv::atomic_load(&hdr[LG_H_NSIB]) > LG_SIB_CAP) return false;
+    if (wv::atomic_load(&hdr[LG_H_NSIB]) > LG_SIB_CAP || wv::atomic_load(&hdr[LG_H_NSOVF]) > LG_OVF_CAP ||
+        wv::atomic_load(&hdr[LG_H_NPOVF]) > LG_OVF_CAP)
+      return false;
     return true;
   }
 
@@ -815,28 +1109,31 @@ struct LdsGraph {
   {
     uint16_t* label = reinterpret_cast<uint16_t*>(lds + LG_OFF_CHAIN);
     uint16_t* dist  = label + 128;
+    uint32_t* dupW  = reinterpret_cast<uint32_t*>(dist + 128);  // [4] duplicate bits of the 128 entries
     const unsigned e0 = lowTier, e1 = (nEligible < lowTier + 128) ? nEligible : (lowTier + 128);
     const unsigned nE = (e1 > e0) ? (e1 - e0) : 0u;
-    auto outOnly = [&](const FRec& rec, const unsigned nd, unsigned& od) -> unsigned {
+    // a word's only successor / number of predecessors, self loops aside (a word with an overflow entry has three or more)
+    auto outOnly = [&](const FRec8 w, const unsigned nd, unsigned& od) -> unsigned {
       unsigned only = ASM_NONE;
-      od            = 0;
-      for (unsigned c = 0; c < 4; ++c) {
-        const unsigned s = lgLinkId(rec.w0, c);
-        if (s != ASM_NONE && s != nd) {
+      od            = lg8SOvf(w) ? 3u : 0u;
+      for (unsigned c = 0; c < 2; ++c) {
+        const unsigned f = lg8Succ(w, c);
+        if (f && f - 1 != nd) {
           od++;
-          only = s;
+          only = f - 1;
         }
       }
       return only;
     };
-    auto inDeg = [&](const FRec& rec, const unsigned nd) -> unsigned {
-      unsigned id = 0;
-      for (unsigned c = 0; c < 4; ++c) {
-        const unsigned p = lgLinkId(rec.w1, c);
-        if (p != ASM_NONE && p != nd) id++;
+    auto inDeg = [&](const FRec8 w, const unsigned nd) -> unsigned {
+      unsigned id = lg8POvf(w) ? 3u : 0u;
+      for (unsigned c = 0; c < 2; ++c) {
+        const unsigned f = lg8Pred(w, c);
+        if (f && f - 1 != nd) id++;
       }
       return id;
     };
+    if (tid() < 4) dupW[tid()] = 0;
     if (tid() < nE) {
       unsigned cur = e0 + tid(), steps = 0;
       while (steps < 192) {
@@ -850,25 +1147,38 @@ struct LdsGraph {
       dist[tid()]  = uint16_t(steps);
     }
     teamSync();
+    // entry e is dropped if an earlier entry of its stretch lies upstream (more steps to the stretch's end); the earlier
+    // entries are dealt out to the waves
+    if (nE > 0) {
+      unsigned eL[2], eD[2];
+      bool     dup[2] = {false, false};
+      for (unsigned h = 0; h < 2; ++h) {
+        const unsigned i = lane + 64 * h;
+        eL[h]            = (i < nE) ? unsigned(label[i]) : ASM_NONE;
+        eD[h]            = (i < nE) ? unsigned(dist[i]) : 0u;
+      }
+      for (unsigned j = tw; j < nE; j += tn) {
+        const unsigned lj = label[j], dj = dist[j];
+        for (unsigned h = 0; h < 2; ++h)
+          if (j < lane + 64 * h && lj == eL[h] && dj > eD[h]) dup[h] = true;
+      }
+      for (unsigned h = 0; h < 2; ++h) {
+        const uint64_t m = wv::ballot(dup[h]);
+        if (lane == 0 && m) {
+          wv::atomic_or(&dupW[2 * h], uint32_t(m));
+          wv::atomic_or(&dupW[2 * h + 1], uint32_t(m >> 32));
+        }
+      }
+    }
+    teamSync();
     unsigned n0 = 0;
     if (tw == 0) {
       if (nEligible > 0) {
-        bool     dup[2] = {false, false};
-        unsigned eL[2], eD[2];
-        for (unsigned h = 0; h < 2; ++h) {
-          const unsigned i = lane + 64 * h;
-          eL[h]            = (i < nE) ? unsigned(label[i]) : ASM_NONE;
-          eD[h]            = (i < nE) ? unsigned(dist[i]) : 0u;
-        }
-        for (unsigned j = 0; j < nE; ++j) {
-          const unsigned lj = label[j], dj = dist[j];
-          for (unsigned h = 0; h < 2; ++h)
-            if (j < lane + 64 * h && lj == eL[h] && dj > eD[h]) dup[h] = true;
-        }
         n0 = 1;
         for (unsigned h = 0; h < 2; ++h) {
           const unsigned i    = lane + 64 * h;
-          const bool     keep = (i < nE) && !dup[h] && (e0 + i) != 0u;
+          const bool     dup  = (dupW[2 * h + (lane >> 5)] >> (lane & 31)) & 1u;
+          const bool     keep = (i < nE) && !dup && (e0 + i) != 0u;
           const uint64_t mk   = wv::ballot(keep);
           const unsigned pos  = n0 + unsigned(wv::popc(mk & ((uint64_t(1) << lane) - 1)));
           if (keep && pos < 64) spec[pos] = uint16_t(e0 + i);
@@ -887,10 +1197,12 @@ struct LdsGraph {
   WV_DEV bool runK(const unsigned locus)
   {
     if (!tablePass<KW>()) return false;
+    readOffsets();
     tick(1, 1);
     if (!sortWords<KW>()) return false;
     // slab for this locus
-    const uint64_t bytes = lgSlabBytes(nNodes, nFat, codeWords);
+    const LgSlab   SL    = lgSlab(nNodes, nFat, codeWords);
+    const uint64_t bytes = SL.total;
     if (tid() == 0) {
       const unsigned long long off = wv::atomic_add(G.arena_used, (unsigned long long)bytes);
       hdr[LG_H_OFF_LO] = uint32_t(off);
@@ -899,23 +1211,27 @@ struct LdsGraph {
     teamSync();
     const uint64_t off = (uint64_t(wv::atomic_load(&hdr[LG_H_OFF_HI])) << 32) | wv::atomic_load(&hdr[LG_H_OFF_LO]);
     if (off + bytes > G.arena_cap) return false;
-    const unsigned need = ckNeed(nNodes, nFat);
-    unsigned       cls  = LG_CLASSES;
+    uint8_t* slab = G.arena + off;
+    if (!buildRecords<KW>(slab, SL)) return false;
+    const bool     acyclic = wv::atomic_load(&hdr[LG_H_CYC]) == 0 && !(G.flags & LG_FLAG_NO_PROOF);
+    const unsigned need    = ckNeed(nNodes, nFat, acyclic);
+    unsigned       cls     = LG_CLASSES;
     for (unsigned c = LG_CLASSES; c-- > 0;)
       if (G.class_bytes[c] && need <= G.class_bytes[c]) cls = c;
     if (cls == LG_CLASSES) return false;
-    uint8_t* slab = G.arena + off;
-    if (!buildRecords<KW>(slab)) return false;
-    uint16_t*      gSpec = reinterpret_cast<uint16_t*>(slab + sizeof(LgHdr) + 16ull * nNodes + 16ull * nFat);
+    uint16_t*      gSpec = reinterpret_cast<uint16_t*>(slab + SL.spec);
     const unsigned nSpec = speculationList(gSpec);
     // the rest of the slab
-    FRec* gRec = reinterpret_cast<FRec*>(slab + sizeof(LgHdr));
+    FRec8* gRec = reinterpret_cast<FRec8*>(slab + SL.recs);
     for (unsigned i = tid(); i < nNodes; i += nThreads()) gRec[i] = nodes[i];
-    uint16_t*       gSib  = gSpec + 64;
-    const uint16_t* sib   = reinterpret_cast<const uint16_t*>(lds + LG_OFF_SIB);
-    const unsigned  nSib  = wv::atomic_load(&hdr[LG_H_NSIB]);
-    for (unsigned i = tid(); i < 4 * nSib; i += nThreads()) gSib[i] = sib[i];
-    uint32_t* gCodes = reinterpret_cast<uint32_t*>(gSib + 4 * LG_SIB_CAP);
+    const unsigned nSib = wv::atomic_load(&hdr[LG_H_NSIB]), nSovf = wv::atomic_load(&hdr[LG_H_NSOVF]), nPovf = wv::atomic_load(&hdr[LG_H_NPOVF]);
+    {
+      // the three side tables lie back to back in LDS and in the slab (fixed capacities)
+      const uint16_t* tsrc = reinterpret_cast<const uint16_t*>(lds + LG_OFF_SIB);
+      uint16_t*       tdst = reinterpret_cast<uint16_t*>(slab + SL.sib);
+      for (unsigned i = tid(); i < 4 * (LG_SIB_CAP + 2 * LG_OVF_CAP); i += nThreads()) tdst[i] = tsrc[i];
+    }
+    uint32_t* gCodes = reinterpret_cast<uint32_t*>(slab + SL.codes);
     for (unsigned i = tid(); i < codeWords; i += nThreads()) gCodes[i] = codes[i];
     if (tid() == 0) {
       LgHdr h;
@@ -929,8 +1245,10 @@ struct LdsGraph {
       h.codeWords = codeWords;
       h.W         = W;
       h.need      = need;
-      h.reserved0 = h.reserved1 = 0;
-      for (int i = 0; i < 4; ++i) h.pad[i] = 0;
+      h.nSovf     = nSovf;
+      h.nPovf     = nPovf;
+      h.acyclic   = acyclic ? 1u : 0u;
+      for (int i = 0; i < 3; ++i) h.pad[i] = 0;
       *reinterpret_cast<LgHdr*>(slab) = h;
       G.slab_off[locus]               = off;
       G.class_ids[size_t(cls) * G.class_stride + wv::atomic_add(&G.class_count[cls], 1u)] = locus;
@@ -945,7 +1263,7 @@ struct LdsGraph {
     const unsigned minWL = P.locus_min_wl ? P.locus_min_wl[locus] : P.opt.minWordLength;
     const unsigned maxWL = P.locus_max_wl ? P.locus_max_wl[locus] : P.opt.maxWordLength;
     if (minWL == 0 || maxWL > 16u * ASM_MAX_KW || minWL > maxWL || 2 * P.opt.maxAssemblyCount > ASM_MAX_CAND) return false;
-    if (P.opt.minCoverage > 250 || P.opt.maxAssemblyCount > 20) return false;
+    if (P.opt.minCoverage > 15 || P.opt.minConservativeCoverage > 15 || P.opt.maxAssemblyCount > 20) return false;  // (records keep counts up to 15)
     k     = minWL;
     tMark = wv::clock();
     if (!pack(locus)) return false;

@@ -93,6 +93,7 @@ WV_DEV unsigned atomic_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 WV_DEV unsigned atomic_cas(unsigned* p, unsigned cmp, unsigned v) { return atomicCAS(p, cmp, v); }
 WV_DEV unsigned atomic_or(unsigned* p, unsigned v) { return atomicOr(p, v); }
 WV_DEV unsigned atomic_sub(unsigned* p, unsigned v) { return atomicSub(p, v); }
+WV_DEV unsigned atomic_and(unsigned* p, unsigned v) { return atomicAnd(p, v); }
 WV_DEV unsigned atomic_exch(unsigned* p, unsigned v) { return atomicExch(p, v); }
 WV_DEV unsigned atomic_min(unsigned* p, unsigned v) { return atomicMin(p, v); }
 WV_DEV unsigned atomic_max(unsigned* p, unsigned v) { return atomicMax(p, v); }

@@ -296,6 +296,7 @@ inline void sync() { wv_emu::yieldLane("sync"); }
 
 inline unsigned atomic_add(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
 inline unsigned atomic_sub(unsigned* p, unsigned v) { const unsigned o = *p; *p = o - v; return o; }
+inline unsigned atomic_and(unsigned* p, unsigned v) { const unsigned o = *p; *p = o & v; return o; }
 inline unsigned atomic_exch(unsigned* p, unsigned v) { const unsigned o = *p; *p = v; return o; }
 inline unsigned atomic_min(unsigned* p, unsigned v) { const unsigned o = *p; if (v < o) *p = v; return o; }
 inline unsigned atomic_max(unsigned* p, unsigned v) { const unsigned o = *p; if (v > o) *p = v; return o; }

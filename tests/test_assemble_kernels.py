@@ -370,7 +370,7 @@ def _fast_stats(emu):
     import ctypes
     st = (ctypes.c_ulonglong * 8)()
     emu.lib.manta_emu_fast_stats(st)
-    return dict(loci=st[0], rounds=st[1], walks=st[2], cands=st[3], evictions=st[4], reclaimed=st[5])
+    return dict(loci=st[0], rounds=st[1], walks=st[2], cands=st[3], evictions=st[4], reclaimed=st[5], proofs=st[6])
 
 
 def test_emulated_fast_kernel_speculation_hits(emu, oracle, monkeypatch):
@@ -386,3 +386,17 @@ def test_emulated_fast_kernel_speculation_hits(emu, oracle, monkeypatch):
         assert assembly_text(r) == oracle.assemble(o, reads)
     assert st["loci"] == 16 and st["cands"] == 16 * 20, st
     assert st["rounds"] <= 16 * 1.5, st
+    # reads of one haplotype that differ by substitutions only: graph_kernel proves the graph acyclic from the reads' offsets
+    # (a potential that rises along every edge) and contig_kernel skips its peel -- unless a read of the first, concurrently
+    # inserted batch found no word of an earlier read to anchor at (then the peel runs: same result)
+    assert st["proofs"] >= 12, st
+
+
+def test_emulated_fast_kernel_without_the_acyclicity_proof(emu, oracle, monkeypatch):
+    """MANTA_AMD_LG_NO_PROOF: contig_kernel runs its own cycle test (the two-sided peel) on every locus -- same results"""
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
+    monkeypatch.setenv("MANTA_AMD_LG_NO_PROOF", "1")
+    cases = _lds_cases()[:16]
+    _fast_stats(emu)
+    assert _check(emu, oracle, cases) == len(cases)
+    assert _fast_stats(emu)["proofs"] == 0
