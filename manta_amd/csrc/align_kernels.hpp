@@ -129,7 +129,8 @@ WV_DEV void waveArgmaxFirst(bool& have, int& val, unsigned& idx)
   }
 }
 
-template <int KIND, int E>
+/// PAIR: the back-pointer cells of two alignments interleave in one slab (align_pair.hpp); this alignment reads every second word
+template <int KIND, int E, bool PAIR = false>
 struct Aligner {
   typedef KindTraits<KIND>          KT;
   typedef typename KT::cell_t       cell_t;
@@ -167,7 +168,7 @@ struct Aligner {
     const unsigned strip = MULTI ? (q - 1) / STRIPW : 0u, qs = MULTI ? (q - 1) % STRIPW : (q - 1);
     const unsigned l = qs / E, e = qs % E;
     const uint64_t idx = uint64_t(strip) * stripCells + (uint64_t(g + l) * E + e) * 64 + l;
-    return (7 - ((int(ptr[idx]) >> (state * BITS)) & FMASK)) & FMASK;
+    return (7 - ((int(ptr[PAIR ? 2 * idx : idx]) >> (state * BITS)) & FMASK)) & FMASK;
   }
 
   // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,295 @@
+// GlobalLargeIndelAligner (alignment/GlobalLargeIndelAlignerImpl.hpp:35-225), TWO alignments per wavefront in packed 16-bit
+// arithmetic.
+//
+// align_kernel<1,E> spends ~50 VALU instructions per DP cell: five states, each an arg-max over up to five candidates, every
+// candidate packed as value*8 + (7 - state) so that one integer max carries the reference's strict-'>' tie order
+// (GlobalLargeIndelAligner.hpp:124-151).  The contigs of small-SV loci are short (a few hundred bases), so those values are
+// small: a cell of such an alignment fits 13 bits + the 3 index bits = one int16.  This kernel runs the same recurrence on
+// v_pk_add_i16 / v_pk_max_i16 with the low half of every register belonging to task A and the high half to task B: the same
+// instruction stream, half the instructions per cell.
+//
+// Exactness.  States live in the x8 domain (value * 8, index bits clear).  The reference's finite sentinel badVal = -10000
+// becomes INT16_MIN = -4096 * 8, and every addition SATURATES, so sentinel-derived cells stay at or just above it.  A cell
+// whose value derives from the boundary row / column without the sentinel ("real") is bounded below by
+//     Q * min(mismatch, offEdge, 0) + open + extend + largeIndel   (the all-mismatch diagonal; a gap state always has the
+//                                                                   fresh-open candidate of its neighbour)
+// and sentinel-derived cells are bounded above by  -4096 + Q * max(match, 0).  pairEligible() admits an E bucket only when the
+// first bound clears the second with a margin for every query the bucket can hold: then every arg-max among candidates that
+// include a real one picks the same winner as the reference's int arithmetic, and the traceback (which starts at a real cell
+// and follows winners) only ever reads such cells.  Pointers of sentinel-only cells may differ from the reference's; nothing
+// reads them.  The '='/'X' expansion and the traceback are align_kernel's own (Aligner<1, E, true>: the two tasks' cells
+// interleave in one slab, a task reads every second 16-bit word).
+//
+// Rows.  Both tasks sweep max(G_A, G_B) reference rows; the shorter one computes rows past its reference against base 0 (never a
+// match), its start candidates stop at its own last row.  Start candidates are tracked as in align_kernel (AlignerUtil.hpp:53-67).
+#pragma once
+#include "align_kernels.hpp"
+
+namespace manta_dev {
+
+static const int PAIR_BAD8 = -32768;  // the sentinel in the x8 domain
+
+/// may a bucket of E columns per lane (queries up to 64 E bases) run on the packed kernel with these scores ?
+WV_HD bool pairEligible(const int E, const int match, const int mismatch, const int open, const int extend, const int offEdge,
+                        const int largeIndel, const int allowEdgeIns)
+{
+  if (E > 6 || allowEdgeIns) return false;
+  const long q      = 64L * E;
+  const long perCol = -long((mismatch < offEdge) ? ((mismatch < 0) ? mismatch : 0) : ((offEdge < 0) ? offEdge : 0));
+  const long gaps   = -long((open < 0) ? open : 0) - long((extend < 0) ? extend : 0) - long((largeIndel < 0) ? largeIndel : 0);
+  const long up     = q * long((match > 0) ? match : 0);
+  // (also: open / largeIndel must not be positive beyond the margin, and every per-step addend must fit the packed constants)
+  if (open > 0 || extend > 0 || largeIndel > 0 || match < 0 || match > 64 || mismatch < -512 || offEdge < -512 || open < -2048 || largeIndel < -2048 || extend < -512)
+    return false;
+  return q * perCol + gaps + up + 64 < 4096;
+}
+
+template <int E>
+struct PairAligner {
+  static const int   NS = 5;
+  const AlignParams& P;
+
+  WV_DEV PairAligner(const AlignParams& p) : P(p) {}
+
+  WV_DEV static uint32_t pk(const int lo, const int hi) { return (uint32_t(lo) & 0xffffu) | (uint32_t(hi) << 16); }
+  WV_DEV static uint32_t pk2(const int v) { return pk(v, v); }
+  WV_DEV static int      half(const uint32_t v, const int h) { return h ? (int(v) >> 16) : int(int16_t(v & 0xffffu)); }
+
+  /// both tasks' sweeps; returns their traceback starts.  ptr32: cell pairs, layout ptr32[(t * E + e) * 64 + lane]
+  WV_DEV void sweep(const AlignTaskDev& TA, const AlignTaskDev& TB, uint32_t* ptr32, StartCand& outA, StartCand& outB)
+  {
+    const int      lane = wv::lane();
+    const unsigned QA = TA.query_len, QB = TB.query_len, GA = TA.ref1_len, GB = TB.ref1_len;
+    const unsigned G  = (GA > GB) ? GA : GB;
+    const int      open = P.open, extend = P.extend, L = P.extra, offEdge = P.off_edge;
+    // packed constants (x8 domain; the index bits of candidate i are 7 - i)
+    const uint32_t cM0 = pk2(7), cD1 = pk2(6), cI2 = pk2(5), cJ3 = pk2(4), cJI4 = pk2(3);
+    const uint32_t cOpen0   = pk2(open * 8 + 7);        // match + open, candidate 0
+    const uint32_t cL0      = pk2(L * 8 + 7);           // match + L, candidate 0
+    const uint32_t cLmOpen2 = pk2((L - open) * 8 + 5);  // insert + L - open, candidate 2
+    const uint32_t cL4      = pk2(L * 8 + 3);           // jumpIns + L, candidate 4
+    const uint32_t cBad1 = pk2(PAIR_BAD8 + 6), cBad3 = pk2(PAIR_BAD8 + 4);
+    const uint32_t cExt     = pk2(extend * 8);
+    const uint32_t cMatch   = pk2(P.match * 8);
+    const uint32_t cMisDiff = pk2((P.mismatch - P.match) * 8);
+    const uint32_t clrIdx = 0xfff8fff8u, idxBits = 0x00070007u, bad = pk2(PAIR_BAD8);
+
+    // traceback start candidates per task (rows at q == Q; off-edge candidates of the last row)
+    StartCand candRows[2] = {{0, 0, 0, ST_MATCH, false}, {0, 0, 0, ST_MATCH, false}};
+    bool      haveOff[2]  = {false, false};
+    int       offVal[2]   = {0, 0};
+    unsigned  offQ[2]     = {0, 0};
+    const unsigned Qs[2] = {QA, QB}, Gs[2] = {GA, GB};
+    unsigned       lQ[2], eQ[2];
+    for (int h = 0; h < 2; ++h) {
+      lQ[h] = (Qs[h] - 1) / E;
+      eQ[h] = (Qs[h] - 1) % E;
+    }
+
+    uint32_t st[NS][E], lcur[NS], lprev[NS], qc[E];
+    for (int e = 0; e < E; ++e) {
+      const unsigned q0 = unsigned(lane) * E + e;
+      const unsigned a = (q0 < QA) ? TA.query[q0] : 0u, b = (q0 < QB) ? TB.query[q0] : 0u;
+      qc[e]            = a | (b << 16);
+      const int row0   = int((q0 + 1) * unsigned(offEdge)) * 8;  // row 0 (GlobalAlignerImpl.hpp:66-80); beyond a task's query: unused columns
+      for (int s = 0; s < NS; ++s) st[s][e] = bad;
+      st[ST_MATCH][e] = pk2(row0 < PAIR_BAD8 ? PAIR_BAD8 : row0);
+    }
+    for (int s = 0; s < NS; ++s) lcur[s] = lprev[s] = bad;
+    lcur[ST_MATCH] = lprev[ST_MATCH] = 0;  // column 0, row 0
+
+    unsigned curA = 0, curB = 0, nextA = 0, nextB = 0;
+    {
+      const unsigned i0 = unsigned(lane);
+      nextA             = (i0 < GA) ? TA.ref1[i0] : 0u;
+      nextB             = (i0 < GB) ? TB.ref1[i0] : 0u;
+    }
+    uint32_t rc = 0;  // this lane's reference symbols for its current row (A | B << 16)
+
+    const unsigned nSteps = G + 63;
+    for (unsigned t = 1; t <= nSteps; ++t) {
+      if (((t - 1) & 63) == 0) {
+        curA              = nextA;
+        curB              = nextB;
+        const unsigned i0 = t - 1 + 64 + unsigned(lane);
+        nextA             = (i0 < GA) ? TA.ref1[i0] : 0u;
+        nextB             = (i0 < GB) ? TB.ref1[i0] : 0u;
+      }
+      const unsigned c0 = wv::readlane(curA, int((t - 1) & 63)) | (wv::readlane(curB, int((t - 1) & 63)) << 16);
+      rc                = wv::shr1(rc, c0);
+      uint32_t incoming[NS];
+      for (int s = 0; s < NS; ++s) incoming[s] = wv::shr1(st[s][E - 1], bad);
+      const int g = int(t) - lane;  // this lane's row
+      for (int s = 0; s < NS; ++s) {
+        lprev[s] = lcur[s];
+        lcur[s]  = incoming[s];
+      }
+      if (lane == 0) {  // column 0: rows >= 1 are (0, bad, bad, ..); row 0 handled by the initial lprev (GlobalAlignerImpl.hpp:98-107)
+        if (g >= 2) {
+          for (int s = 0; s < NS; ++s) lprev[s] = bad;
+          lprev[ST_MATCH] = 0;
+        }
+        for (int s = 0; s < NS; ++s) lcur[s] = bad;
+        lcur[ST_MATCH] = 0;
+      }
+      const bool active = (g >= 1) && (unsigned(g) <= G);
+      if (!active) continue;
+
+      uint32_t diag[NS], left[NS];
+      for (int s = 0; s < NS; ++s) {
+        diag[s] = lprev[s];
+        left[s] = lcur[s];
+      }
+      uint32_t cells[E];
+      for (int e = 0; e < E; ++e) {
+        uint32_t up[NS];
+        for (int s = 0; s < NS; ++s) up[s] = st[s][e];
+        const bool     firstCol = (e == 0) && (lane == 0);
+        // substitution score per half: match where the symbols agree
+        const uint32_t differ = wv::pk_min_u16(qc[e] ^ rc, 0x00010001u);
+        const uint32_t sub8   = wv::pk_mad_u16(differ, cMisDiff, cMatch);
+        uint32_t       nv[NS], code;
+        {  // match: max5 over the diagonal cell's states
+          uint32_t m = wv::pk_max_i16(wv::pk_max_i16(wv::pk_add_sat_i16(diag[ST_MATCH], cM0), wv::pk_add_sat_i16(diag[ST_DELETE], cD1)), wv::pk_add_sat_i16(diag[ST_INSERT], cI2));
+          m          = wv::pk_max_i16(wv::pk_max_i16(m, wv::pk_add_sat_i16(diag[ST_JUMP], cJ3)), wv::pk_add_sat_i16(diag[ST_JUMPINS], cJI4));
+          nv[ST_MATCH] = wv::pk_add_sat_i16(m & clrIdx, sub8);
+          code         = m & idxBits;
+        }
+        {  // delete (:121-135)
+          uint32_t m = wv::pk_max_i16(wv::pk_max_i16(wv::pk_add_sat_i16(up[ST_MATCH], cOpen0), wv::pk_add_sat_i16(up[ST_DELETE], cD1)), wv::pk_add_sat_i16(up[ST_INSERT], cI2));
+          m          = wv::pk_max_i16(wv::pk_max_i16(m, cBad3), wv::pk_add_sat_i16(up[ST_JUMPINS], cJI4));
+          uint32_t b = wv::pk_add_sat_i16(m & clrIdx, cExt);
+          if (firstCol) b = bad;
+          nv[ST_DELETE] = b;
+          code |= (m & idxBits) << 3;
+        }
+        {  // insert (:137-146)
+          uint32_t m = wv::pk_max_i16(wv::pk_max_i16(wv::pk_add_sat_i16(left[ST_MATCH], cOpen0), cBad1), wv::pk_add_sat_i16(left[ST_INSERT], cI2));
+          uint32_t b = wv::pk_add_sat_i16(m & clrIdx, cExt);
+          if (firstCol) b = bad;
+          nv[ST_INSERT] = b;
+          code |= (m & idxBits) << 6;
+        }
+        {  // jumpDel (:148-166)
+          uint32_t m = wv::pk_max_i16(wv::pk_max_i16(wv::pk_add_sat_i16(up[ST_MATCH], cL0), cBad1), wv::pk_add_sat_i16(up[ST_INSERT], cLmOpen2));
+          m          = wv::pk_max_i16(wv::pk_max_i16(m, wv::pk_add_sat_i16(up[ST_JUMP], cJ3)), wv::pk_add_sat_i16(up[ST_JUMPINS], cL4));
+          uint32_t b = m & clrIdx;
+          if (firstCol) b = bad;
+          nv[ST_JUMP] = b;
+          code |= (m & idxBits) << 9;
+        }
+        {  // jumpIns (:169-176)
+          uint32_t m = wv::pk_max_i16(wv::pk_max_i16(wv::pk_add_sat_i16(left[ST_MATCH], cL0), cBad1), wv::pk_add_sat_i16(left[ST_JUMPINS], cJI4));
+          uint32_t b = m & clrIdx;
+          if (firstCol) b = bad;
+          nv[ST_JUMPINS] = b;
+          code |= (m & idxBits) << 12;
+        }
+        for (int s = 0; s < NS; ++s) {
+          diag[s]  = up[s];
+          left[s]  = nv[s];
+          st[s][e] = nv[s];
+        }
+        cells[e] = code;
+      }
+      for (int e = 0; e < E; ++e) ptr32[(uint64_t(t) * E + e) * 64 + unsigned(lane)] = cells[e];
+
+      // traceback start candidates, per task
+      for (int h = 0; h < 2; ++h) {
+        if (unsigned(g) > Gs[h]) continue;
+        if (unsigned(lane) == lQ[h]) {
+          uint32_t vM = 0;
+          for (int e = 0; e < E; ++e)
+            if (unsigned(e) == eQ[h]) vM = st[ST_MATCH][e];
+          candUpdate(candRows[h], half(vM, h) >> 3, unsigned(g), Qs[h], ST_MATCH);
+        }
+        if (unsigned(g) == Gs[h]) {
+          // off-edge candidates of the last row (q < Q; the reference's extra q == Q term can never win the strict '>')
+          for (int e = 0; e < E; ++e) {
+            const unsigned q = unsigned(lane) * E + e + 1;
+            if (q < Qs[h]) {
+              const int v = (half(st[ST_MATCH][e], h) >> 3) + int((Qs[h] - q) * unsigned(offEdge));
+              if (!haveOff[h] || v > offVal[h]) {
+                haveOff[h] = true;
+                offVal[h]  = v;
+                offQ[h]    = q;
+              }
+            }
+          }
+        }
+      }
+    }
+    for (int h = 0; h < 2; ++h) {
+      // q == 0 off-edge candidate (column 0 holds match == 0 on every row >= 1); it precedes every other q in scan order
+      if (lane == 0) {
+        const int v0 = int(Qs[h] * unsigned(offEdge));
+        if (!haveOff[h] || v0 >= offVal[h]) {
+          haveOff[h] = true;
+          offVal[h]  = v0;
+          offQ[h]    = 0;
+        }
+      }
+      waveArgmaxFirst(haveOff[h], offVal[h], offQ[h]);
+      StartCand best;
+      best.val   = wv::readlane(candRows[h].val, int(lQ[h]));
+      best.ref   = wv::readlane(candRows[h].ref, int(lQ[h]));
+      best.query = Qs[h];
+      best.state = ST_MATCH;
+      best.init  = true;
+      candUpdate(best, offVal[h], Gs[h], offQ[h], ST_MATCH);
+      if (h == 0)
+        outA = best;
+      else
+        outB = best;
+    }
+  }
+
+  WV_DEV void run(const AlignTaskDev& TA, const AlignTaskDev& TB, AlignResultDev& resA, AlignResultDev& resB, const bool haveB, uint8_t* slab)
+  {
+    StartCand sa, sb;
+    sweep(TA, TB, reinterpret_cast<uint32_t*>(slab), sa, sb);
+    wv::sync();  // back-pointers written by all lanes are read by all lanes below
+    for (int h = 0; h < (haveB ? 2 : 1); ++h) {
+      const AlignTaskDev& T = h ? TB : TA;
+      Aligner<1, E, true> al(P);
+      al.query      = T.query;
+      al.ref1       = T.ref1;
+      al.ref2       = nullptr;
+      al.Q          = T.query_len;
+      al.R1         = T.ref1_len;
+      al.R2         = 0;
+      al.G          = T.ref1_len;
+      al.ptr        = reinterpret_cast<uint16_t*>(slab) + h;
+      al.nStrips    = 1;
+      al.stripCells = 0;
+      AlignResultDev r;
+      al.tracebackSingle(h ? sb : sa, T, r);
+      if (wv::lane() == 0) (h ? resB : resA) = r;
+      wv::sync();
+    }
+  }
+};
+
+/// the work unit is a PAIR of tasks of one E bucket (task_ids[2 i], task_ids[2 i + 1]; an odd last task runs against itself).
+/// Launched with HALF the waves align_kernel<1,E> would get for the same bucket: a wave's cell pairs take two of that kernel's
+/// slabs (P.ptr_ws_stride is the single-alignment stride).
+template <int E>
+WV_KERNEL void align_pair_kernel(const AlignParams P)
+{
+  uint8_t*       slab   = P.ptr_ws + uint64_t(wv::block()) * 2 * P.ptr_ws_stride;
+  const unsigned nTasks = P.n_tasks_dev ? *P.n_tasks_dev : P.n_tasks;
+  const unsigned nPairs = (nTasks + 1) / 2;
+  while (true) {
+    unsigned slot = 0;
+    if (wv::lane() == 0) slot = wv::atomic_add(P.counter, 1u);
+    slot = wv::first(slot);
+    if (slot >= nPairs) break;
+    const unsigned ia = 2 * slot, ib = (2 * slot + 1 < nTasks) ? 2 * slot + 1 : 2 * slot;
+    const unsigned ta = P.task_ids ? P.task_ids[ia] : ia, tb = P.task_ids ? P.task_ids[ib] : ib;
+    PairAligner<E> al(P);
+    al.run(P.tasks[ta], P.tasks[tb], P.results[ta], P.results[tb], ib != ia, slab);
+    wv::sync();
+  }
+}
+
+}  // namespace manta_dev

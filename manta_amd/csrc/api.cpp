@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "align_kernels.hpp"
+#include "align_pair.hpp"
 #include "assemble_kernels.hpp"
 #include "asm_lds.hpp"
 #include "small_asm.hpp"
@@ -180,13 +181,34 @@ void launchAlignE(int eIdx, int grid, const AlignParams& P)
   }
 }
 
+/// GlobalLargeIndelAligner buckets of short queries run two alignments per wave in packed 16-bit arithmetic (align_pair.hpp) when
+/// the scores leave the margin pairEligible() asks for: half the waves, each with two of the single kernel's slabs
+bool launchAlignPair(int eIdx, int grid, const AlignParams& P)
+{
+  static const bool off = std::getenv("MANTA_AMD_NO_ALIGN_PAIRS") != nullptr;  // A/B knob
+  const int E = kESet[eIdx];
+  if (off || grid < 8 || !pairEligible(E, P.match, P.mismatch, P.open, P.extend, P.off_edge, P.extra, P.allow_edge_ins)) return false;
+  const int g2 = (grid / 2) & ~(WV_WAVES_PER_WG - 1);
+  if (std::getenv("MANTA_AMD_DEBUG")) std::fprintf(stderr, "manta_amd: align_pair_kernel<%d>: %d waves (two alignments each)\n", E, g2);
+  switch (E) {
+  case 1: rt::launch(align_pair_kernel<1>, g2, 0, P); break;
+  case 2: rt::launch(align_pair_kernel<2>, g2, 0, P); break;
+  case 3: rt::launch(align_pair_kernel<3>, g2, 0, P); break;
+  case 4: rt::launch(align_pair_kernel<4>, g2, 0, P); break;
+  case 5: rt::launch(align_pair_kernel<5>, g2, 0, P); break;
+  case 6: rt::launch(align_pair_kernel<6>, g2, 0, P); break;
+  default: return false;
+  }
+  return true;
+}
+
 void launchAlignKind(int kind, int eIdx, int grid, const AlignParams& P)
 {
   if (kind == MANTA_ALIGNER_GLOBAL)
     launchAlignE<0>(eIdx, grid, P);
-  else if (kind == MANTA_ALIGNER_LARGE_INDEL)
-    launchAlignE<1>(eIdx, grid, P);
-  else
+  else if (kind == MANTA_ALIGNER_LARGE_INDEL) {
+    if (!launchAlignPair(eIdx, grid, P)) launchAlignE<1>(eIdx, grid, P);
+  } else
     launchAlignE<2>(eIdx, grid, P);
 }
 
@@ -963,7 +985,16 @@ struct AsmStage {
       // the copies never run and the persistent workgroups wait for their chunks forever (seen on hardware, round 4)
       int gf = gridFast;
       if (streaming && gf >= ctx->cuCount * 2) gf -= std::max(1, ctx->cuCount / 4);
-      rt::launchWG(graph_kernel, gf, int(LG_WAVES), LG_BUDGET, A);
+      // (the instantiation by the longest first word length among the loci of this launch: keys of 2 / 4 / 8 dwords)
+      uint32_t firstWl = opt.min_word_length;
+      if (!locusMinWl.empty())
+        for (const uint32_t l : fastIds) firstWl = std::max(firstWl, locusMinWl[l]);
+      if (firstWl <= 32)
+        rt::launchWG(graph_kernel<2>, gf, int(LG_WAVES), LG_BUDGET, A);
+      else if (firstWl <= 64)
+        rt::launchWG(graph_kernel<4>, gf, int(LG_WAVES), LG_BUDGET, A);
+      else
+        rt::launchWG(graph_kernel<8>, gf, int(LG_WAVES), LG_BUDGET, A);
       for (unsigned c = 0; c < LG_CLASSES; ++c) {
         if (!classBytes[c]) continue;
         A.G.cls       = c;
@@ -1139,7 +1170,7 @@ struct AsmStage {
     if (std::getenv("MANTA_AMD_PROFILE")) {
       static const char* namesGeneral[8] = {"pack", "table", "links", "cycle-check", "exact", "seed", "walk", "select+emit"};
 #ifdef MANTA_LG_PROFILE_GRAPH
-      static const char* namesLds[8]     = {"pack", "table", "counts+list", "radix", "ties+ids", "slab+sets+init", "links+preds+sibs", "spec+write"};
+      static const char* namesLds[8]     = {"pack", "table", "links", "counts+radix", "ties+ids", "slab+sets+init", "preds+sibs", "spec+write"};
 #else
       static const char* namesLds[8]     = {"pack", "table", "sort+records", "cycle-check", "slab write/read", "seed+replay", "walk", "select+emit"};
 #endif

@@ -22,7 +22,7 @@
 namespace manta_dev {
 
 #ifndef MANTA_CK_FAST_CAP
-#define MANTA_CK_FAST_CAP 6
+#define MANTA_CK_FAST_CAP 3
 #endif
 static const unsigned CK_FAST_CAP = MANTA_CK_FAST_CAP;  // fast steps a lane may run ahead between two general steps of its wave
 static const unsigned CK_MAX_EXT = 1020;  // extension steps of one walk (both directions); longer contigs (never seen on piles this small): general path

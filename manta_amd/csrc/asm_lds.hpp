@@ -64,6 +64,8 @@ static const unsigned LG_OFF_SIB   = LG_OFF_WHIST;                    // u16[LG_
 static const unsigned LG_OFF_SOVF  = LG_OFF_SIB + 8 * LG_SIB_CAP;     // u16[LG_OVF_CAP][4]
 static const unsigned LG_OFF_POVF  = LG_OFF_SOVF + 8 * LG_OVF_CAP;    // u16[LG_OVF_CAP][4]
 static const unsigned LG_OFF_CHAIN = LG_OFF_POVF + 8 * LG_OVF_CAP;    // u16[128] label, u16[128] distance, u32[4] duplicate bits
+static const unsigned LG_FILTER_BITS = 16384;
+static const unsigned LG_OFF_FILTER = LG_OFF_WHIST + 4096;            // u32[512] presence filter over the hash tags
 static const unsigned LG_OFF_PHI   = LG_OFF_SORTB;                    // i16[2048]
 static const unsigned LG_OFF_ANCH  = LG_OFF_DBASE;                    // u32[128] anchors, then i32[128] offsets
 static const unsigned LG_NO_ANCHOR = 0xffffffffu;
@@ -242,6 +244,7 @@ struct LdsGraph {
   uint64_t*        pred4;   // predecessors by symbol while the links are scattered (4 x 11 bits)
   int16_t*         phi;     // potential of a word (id): offset of its first read + position in it
   int16_t*         roff;    // offset of a read (overlays rdm after the table pass)
+  uint32_t*        filter;  // presence filter (maybePresent)
   unsigned         nNormal, W, k, nNodes, nFat, nEligible, lowTier, codeWords;
   uint64_t         tMark;
 
@@ -261,6 +264,7 @@ struct LdsGraph {
     pred4  = reinterpret_cast<uint64_t*>(lds + LG_OFF_SETS) + LG_SLOTS;
     phi    = reinterpret_cast<int16_t*>(lds + LG_OFF_PHI);
     roff   = reinterpret_cast<int16_t*>(lds + LG_OFF_RDM);
+    filter = reinterpret_cast<uint32_t*>(lds + LG_OFF_FILTER);
     sortA  = reinterpret_cast<uint16_t*>(lds + LG_OFF_SORTA);
     sortB  = reinterpret_cast<uint16_t*>(lds + LG_OFF_SORTB);
     keyArr = reinterpret_cast<uint32_t*>(lds + LG_OFF_KEYS);
@@ -271,8 +275,8 @@ struct LdsGraph {
   }
 
   /// per-phase shader clocks of the workgroup's first wave (-DMANTA_ASM_PROFILE).  -DMANTA_LG_PROFILE_GRAPH: the eight counters
-  /// split graph_kernel alone (`fine`: 0 pack, 1 table, 2 counts + slot list, 3 radix passes, 4 ties + ids, 5 slab + bitsets +
-  /// record init, 6 links + predecessors + siblings, 7 speculation list + slab write); contig_kernel counts nothing then
+  /// split graph_kernel alone (`fine`: 0 pack, 1 table, 2 successor links, 3 counts + radix passes, 4 ties + ids, 5 slab + bitsets +
+  /// record init, 6 predecessors + siblings, 7 speculation list + slab write); contig_kernel counts nothing then
   WV_DEV void tick(const int phase, const int fine)
   {
 #ifdef MANTA_ASM_PROFILE
@@ -406,59 +410,32 @@ struct LdsGraph {
     return ASM_NONE;
   }
 
-  /// four lookups with their LDS round trips overlapped: the buckets of all keys that are still open are read together, then the
-  /// keys behind matching tags; a key whose bucket is full without a match goes on to the next bucket in the next round
-  template <int KW>
-  WV_DEV void lookupSlots4(const Key<KW> (&keys)[4], unsigned (&out)[4]) const
+  /// Presence filter over the words' hash tags (16 K bits, built after the table pass): three of a word's four possible successors
+  /// usually do not exist, and 93 % of those are answered by one bit test instead of a bucket probe.
+  WV_DEV bool maybePresent(const uint32_t h) const
   {
-    unsigned b[4], tag[4], skip[4], probes[4];
-    bool     open[4];
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t h = keyHash(keys[i]);
-      tag[i]           = h >> 15;
-      b[i]             = h & (LG_BUCKETS - 1);
-      skip[i]          = 0;
-      probes[i]        = 0;
-      open[i]          = true;
-      out[i]           = ASM_NONE;
-    }
-    while (open[0] || open[1] || open[2] || open[3]) {
-      FBucket bk[4];
-      for (int i = 0; i < 4; ++i) bk[i] = *reinterpret_cast<const FBucket*>(slots + 4 * b[i]);
-      unsigned at[4];
-      uint32_t sv[4];
-      for (int i = 0; i < 4; ++i) {
-        at[i] = 4;
-        sv[i] = LG_EMPTY;
-        for (int j = 3; j >= 0; --j)
-          if (unsigned(j) >= skip[i] && (bk[i].s[j] == LG_EMPTY || (bk[i].s[j] >> 15) == tag[i])) {
-            at[i] = unsigned(j);
-            sv[i] = bk[i].s[j];
-          }
-      }
-      Key<KW> got[4];
-      for (int i = 0; i < 4; ++i) got[i] = keyAt<KW>((open[i] && at[i] < 4 && sv[i] != LG_EMPTY) ? (sv[i] & 0x7fffu) : 0u);
-      for (int i = 0; i < 4; ++i) {
-        if (!open[i]) continue;
-        if (at[i] == 4) {  // bucket full, no match: next bucket
-          b[i]    = (b[i] + 1) & (LG_BUCKETS - 1);
-          skip[i] = 0;
-          if (++probes[i] >= LG_BUCKETS) open[i] = false;
-        } else if (sv[i] == LG_EMPTY) {  // an empty slot ends the search
-          open[i] = false;
-        } else if (keyEq(got[i], keys[i])) {
-          out[i]  = 4 * b[i] + at[i];
-          open[i] = false;
-        } else {  // a tag collision: on with the next slot of this bucket
-          skip[i] = at[i] + 1;
-          if (skip[i] == 4) {
-            b[i]    = (b[i] + 1) & (LG_BUCKETS - 1);
-            skip[i] = 0;
-            if (++probes[i] >= LG_BUCKETS) open[i] = false;
-          }
-        }
+    const unsigned t = (h >> 15) & (LG_FILTER_BITS - 1);
+    return (filter[t >> 5] >> (t & 31)) & 1u;
+  }
+  /// lookupSlot behind the filter
+  template <int KW>
+  WV_DEV unsigned lookupFiltered(const Key<KW>& key) const
+  {
+    if (!maybePresent(keyHash(key))) return ASM_NONE;
+    return lookupSlot<KW>(key);
+  }
+  WV_DEV void buildFilter()
+  {
+    for (unsigned i = tid(); i < LG_FILTER_BITS / 32; i += nThreads()) filter[i] = 0;
+    teamSync();
+    for (unsigned s = tid(); s < LG_SLOTS; s += nThreads()) {
+      const uint32_t v = slots[s];
+      if (v != LG_EMPTY) {
+        const unsigned t = (v >> 15) & (LG_FILTER_BITS - 1);
+        wv::atomic_or(&filter[t >> 5], 1u << (t & 31));
       }
     }
+    teamSync();
   }
 
   WV_DEV uint64_t plShift(const unsigned locus, const unsigned i) const
@@ -650,40 +627,42 @@ struct LdsGraph {
             for (int w = 0; w < KW; ++w) key.w[w] = 0;
           }
           unsigned probes = 0;
+          // One probe round: read the bucket; the first slot (past `skip`) that is empty or carries the tag decides -- an empty
+          // slot is claimed with a compare-and-swap, a tagged one has its word fetched and compared, both in the same LDS round
+          // trip.  A lane that loses the swap simply goes round again: the bucket then shows who took the slot.
           while (wv::any(todo)) {
-            if (todo) {
-              const FBucket bk = *reinterpret_cast<const FBucket*>(slots + 4 * b);
-              // first slot of the bucket (past `skip`) that is empty or carries the tag
-              unsigned at = 4;
-              for (int i = 3; i >= 0; --i)
-                if (unsigned(i) >= skip && (bk.s[i] == LG_EMPTY || (bk.s[i] >> 15) == tag)) at = unsigned(i);
-              if (at == 4) {
+            const FBucket bk = *reinterpret_cast<const FBucket*>(slots + 4 * b);
+            unsigned      at = 4;
+            uint32_t      sv = LG_EMPTY;
+            for (int i = 3; i >= 0; --i) {
+              const bool hit = unsigned(i) >= skip && (bk.s[i] == LG_EMPTY || (bk.s[i] >> 15) == tag);
+              at             = hit ? unsigned(i) : at;
+              sv             = hit ? bk.s[i] : sv;
+            }
+            const bool tryClaim = todo && at < 4 && sv == LG_EMPTY;
+            const bool tryMatch = todo && at < 4 && sv != LG_EMPTY;
+            uint32_t   casOld   = 0;
+            if (tryClaim) casOld = wv::atomic_cas(&slots[4 * b + at], LG_EMPTY, mine);
+            const Key<KW> got  = keyAt<KW>(tryMatch ? (sv & 0x7fffu) : 0u);
+            const bool    same = keyEq(got, key);
+            if (tryClaim) {
+              if (casOld == LG_EMPTY) {
+                slot = 4 * b + at;
+                todo = false;
+              }
+            } else if (tryMatch && same) {
+              slot    = 4 * b + at;
+              foundPb = sv & 0x7fffu;
+              todo    = false;
+            } else if (todo) {
+              // another word under the tag (17 bits: rare): next slot of the bucket; a full bucket without the word: next bucket
+              skip = tryMatch ? at + 1 : 4u;
+              if (skip == 4) {
                 b    = (b + 1) & (LG_BUCKETS - 1);
                 skip = 0;
                 if (++probes >= LG_BUCKETS) {
                   fail = true;
                   todo = false;
-                }
-              } else {
-                uint32_t s = (at == 0) ? bk.s[0] : (at == 1) ? bk.s[1] : (at == 2) ? bk.s[2] : bk.s[3];
-                if (s == LG_EMPTY) s = wv::atomic_cas(&slots[4 * b + at], LG_EMPTY, mine);
-                if (s == LG_EMPTY) {  // claimed
-                  slot = 4 * b + at;
-                  todo = false;
-                } else if ((s >> 15) == tag && keyEq(keyAt<KW>(s & 0x7fffu), key)) {
-                  slot    = 4 * b + at;
-                  foundPb = s & 0x7fffu;
-                  todo    = false;
-                } else {
-                  skip = at + 1;  // another word (taken under this lane's eyes, or a tag collision): next slot of the bucket
-                  if (skip == 4) {
-                    b    = (b + 1) & (LG_BUCKETS - 1);
-                    skip = 0;
-                    if (++probes >= LG_BUCKETS) {
-                      fail = true;
-                      todo = false;
-                    }
-                  }
                 }
               }
             }
@@ -755,7 +734,6 @@ struct LdsGraph {
       nFat = nEligible = lowTier = 0;
       return true;
     }
-    tick(2, 2);
     const unsigned chunk = (((n + tn - 1) / tn) + 63) & ~63u;  // elements of one wave, in order
     const unsigned c0 = chunk * tw, c1 = (c0 + chunk < n) ? (c0 + chunk) : n;
     uint16_t *     src = sortA, *dst = sortB;
@@ -963,7 +941,7 @@ struct LdsGraph {
     FSet*     gPool = reinterpret_cast<FSet*>(slab + SL.pool);
     uint16_t* gPb   = reinterpret_cast<uint16_t*>(slab + SL.pb);
     for (unsigned i = tid(); i < nFat; i += nThreads()) gPool[i] = sets[sortA[i]];
-    teamSync();  // (the sets are dead: the records take their place)
+    buildFilter();  // (its barriers also end the sets' life: the records take their place)
     for (unsigned i = tid(); i < nNodes; i += nThreads()) {
       const unsigned slot = sortA[i], pb = slots[slot] & 0x7fffu, enc = cntArr[slot];
       const unsigned cnt = (enc & 0x80u) ? 1u : enc;
@@ -1000,10 +978,8 @@ struct LdsGraph {
         unsigned       found[4];
         unsigned       m = 0;
         bool           selfLoop = false;
-        Key<KW>        sk[4];
         unsigned       sslot[4];
-        for (unsigned c = 0; c < 4; ++c) sk[c] = keyShiftAppend<KW>(key, c);
-        lookupSlots4<KW>(sk, sslot);
+        for (unsigned c = 0; c < 4; ++c) sslot[c] = lookupFiltered<KW>(keyShiftAppend<KW>(key, c));
         for (unsigned c = 0; c < 4; ++c) {
           const unsigned ss = sslot[c];
           if (ss == ASM_NONE) continue;
@@ -1042,6 +1018,7 @@ struct LdsGraph {
     }
     if (wv::any(against) && lane == 0) wv::atomic_or(&hdr[LG_H_CYC], 1u);
     teamSync();
+    tick(2, 2);
     // predecessors: the first two into the record, further ones into the overflow table; words without a predecessor: their
     // siblings (the words that differ in the last base only, :185-210) cannot be found through a predecessor's successor
     // list -> side table
@@ -1078,7 +1055,7 @@ struct LdsGraph {
           if (c == lastBase) continue;
           Key<KW> s2 = key;
           keySetBase(s2, k - 1, c);
-          const unsigned ss = lookupSlot<KW>(s2);
+          const unsigned ss = lookupFiltered<KW>(s2);
           if (ss != ASM_NONE) found[nf++] = slotId[ss];
         }
         if (nf) {
@@ -1257,7 +1234,8 @@ struct LdsGraph {
     return true;
   }
 
-  /// false: the general path takes the locus
+  /// false: the general path takes the locus.  MAXKW: the widest key (dwords) this instantiation carries code for
+  template <int MAXKW>
   WV_DEV bool run(const unsigned locus)
   {
     const unsigned minWL = P.locus_min_wl ? P.locus_min_wl[locus] : P.opt.minWordLength;
@@ -1269,17 +1247,21 @@ struct LdsGraph {
     if (!pack(locus)) return false;
     tick(0, 0);
     const unsigned kw = (k + 15) >> 4;
+    if (kw > unsigned(MAXKW)) return false;
     if (kw <= 2) return runK<2>(locus);
-    if (kw <= 4) return runK<4>(locus);
-    return runK<8>(locus);
+    if (MAXKW >= 4 && kw <= 4) return runK<(MAXKW >= 4 ? 4 : 2)>(locus);
+    return runK<MAXKW>(locus);
   }
 };
 
 /// persistent workgroups of LG_WAVES wavefronts, LG_BUDGET bytes of dynamic LDS each; params as assemble_kernel plus the
 /// pipeline's own.  Loci this path does not cover are appended to P.punt_ids (P.punt_count counts them).
+/// One instantiation per key width (word lengths up to 32 / 64 / 128): the register allocation of a kernel is that of its widest
+/// path, and the 32-dword keys of the longest words would cost the ordinary word lengths their spill-free build.
 #ifndef MANTA_LG_WAVES_PER_SIMD
 #define MANTA_LG_WAVES_PER_SIMD 4
 #endif
+template <int MAXKW>
 WV_KERNEL_WG(LG_WAVES) WV_WAVES_PER_SIMD(MANTA_LG_WAVES_PER_SIMD) void graph_kernel(const LgArgs A)
 {
   const AsmParams& P = A.P;
@@ -1298,7 +1280,7 @@ WV_KERNEL_WG(LG_WAVES) WV_WAVES_PER_SIMD(MANTA_LG_WAVES_PER_SIMD) void graph_ker
     bool           ok      = false;
     if (arrived) {
       LdsGraph g(P, G, lds);
-      ok = g.run(locus);
+      ok = g.template run<MAXKW>(locus);
     }
     wv::sync();
     if (tw == 0 && !ok && wv::lane() == 0) P.punt_ids[wv::atomic_add(P.punt_count, 1u)] = locus;

@@ -112,6 +112,26 @@ WV_DEV void fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 /// shader-clock timestamp (s_memtime) for the optional per-phase profile
 WV_DEV uint64_t clock() { return uint64_t(__builtin_readcyclecounter()); }
 
+// packed 16-bit arithmetic: two int16 / uint16 per register (v_pk_add_i16 clamp, v_pk_max_i16, v_pk_min_u16, v_pk_mad_u16)
+typedef short          pk_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short pk_u2 __attribute__((ext_vector_type(2)));
+WV_DEV uint32_t pk_add_sat_i16(uint32_t a, uint32_t b)
+{
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(pk_s2, a), __builtin_bit_cast(pk_s2, b)));
+}
+WV_DEV uint32_t pk_max_i16(uint32_t a, uint32_t b)
+{
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pk_s2, a), __builtin_bit_cast(pk_s2, b)));
+}
+WV_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(pk_u2, a), __builtin_bit_cast(pk_u2, b)));
+}
+WV_DEV uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c)
+{
+  return __builtin_bit_cast(uint32_t, pk_u2(__builtin_bit_cast(pk_u2, a) * __builtin_bit_cast(pk_u2, b) + __builtin_bit_cast(pk_u2, c)));
+}
+
 WV_DEV int popc(unsigned v) { return __popc(v); }
 WV_DEV int popc(uint64_t v) { return __popcll(v); }
 WV_DEV int ctz(uint64_t v) { return __builtin_ctzll(v); }  // v != 0

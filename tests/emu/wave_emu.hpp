@@ -310,6 +310,45 @@ inline unsigned atomic_load_system(const unsigned* p) { return *p; }
 inline void sleep() {}
 inline void fence_acquire() {}
 
+// packed 16-bit arithmetic (two lanes of 16 bits per 32-bit value), as the hardware's v_pk_* instructions compute it
+inline uint32_t pk_add_sat_i16(uint32_t a, uint32_t b)
+{
+  uint32_t r = 0;
+  for (int h = 0; h < 2; ++h) {
+    int v = int(int16_t(a >> (16 * h))) + int(int16_t(b >> (16 * h)));
+    v     = (v > 32767) ? 32767 : ((v < -32768) ? -32768 : v);
+    r |= (uint32_t(v) & 0xffffu) << (16 * h);
+  }
+  return r;
+}
+inline uint32_t pk_max_i16(uint32_t a, uint32_t b)
+{
+  uint32_t r = 0;
+  for (int h = 0; h < 2; ++h) {
+    const int x = int16_t(a >> (16 * h)), y = int16_t(b >> (16 * h));
+    r |= (uint32_t(x > y ? x : y) & 0xffffu) << (16 * h);
+  }
+  return r;
+}
+inline uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+  uint32_t r = 0;
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t x = (a >> (16 * h)) & 0xffffu, y = (b >> (16 * h)) & 0xffffu;
+    r |= (x < y ? x : y) << (16 * h);
+  }
+  return r;
+}
+inline uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c)
+{
+  uint32_t r = 0;
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t x = (a >> (16 * h)) & 0xffffu, y = (b >> (16 * h)) & 0xffffu, z = (c >> (16 * h)) & 0xffffu;
+    r |= ((x * y + z) & 0xffffu) << (16 * h);
+  }
+  return r;
+}
+
 inline uint64_t clock() { return 0; }
 inline int popc(unsigned v) { return __builtin_popcount(v); }
 inline int popc(uint64_t v) { return __builtin_popcountll(v); }
