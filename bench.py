@@ -61,8 +61,10 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (profiling passes): no kernel_only / packed_input legs")
     ap.add_argument("--cpu-sample", type=int, default=0, help="loci in the CPU baseline sample (0 = auto)")
     ap.add_argument("--pageable", action="store_true", help="keep inputs/outputs in pageable host memory (A/B knob)")
-    ap.add_argument("--queue", choices=("node", "rank"), default="node",
-                    help="N > 1: node = one block queue across the ranks (shared-memory counter; default), rank = every rank its own batch and queue")
+    ap.add_argument("--queue", choices=("node", "rank", "process"), default="node",
+                    help="N > 1: node = one block queue across the ranks (shared-memory counter; default), rank = every rank its own batch and "
+                         "queue, process = ONE process drives all N devices through manta_node_smallsv_batch (one queue, one host; under "
+                         "torchrun rank 0 does that and the other ranks only keep the barriers)")
     ap.add_argument("--mix", action="store_true",
                     help="N > 1, --queue node: every 4th rank part holds loci with 2.5x the reads (NOT the metric's configuration) -- makes the "
                          "queue's balancing visible in loci_per_rank")
@@ -124,7 +126,7 @@ def result_blob(out):
 
 def main():
     args = parse_args()
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and args.queue != "process":
         self_spawn(args)
 
     import torch
@@ -169,6 +171,14 @@ def main():
     n_loci = args.loci or (65536 if spanning else 10000)
     lib = Lib(device=local_rank)
     node_queue = multi and args.queue == "node" and not spanning
+    # --queue process: one process, N devices, one cost-ordered block queue inside the library (manta_node_*): the deployment shape
+    # INTEGRATION.md B prescribes for a GenerateSVCandidates process.  Rank 0 (or the only process) drives the devices.
+    proc_queue = args.queue == "process" and not spanning
+    n_dev      = args.gpus if proc_queue else world
+    node       = None
+    if proc_queue and rank == 0:
+        from manta_amd._capi import Node
+        node = Node(path=lib.path, devices=tuple(range(args.gpus)))
     qshm = qcount = None
     if node_queue:
         # one 32-bit block counter per step in POSIX shared memory (a fresh one every step: no reset to race with)
@@ -197,10 +207,10 @@ def main():
     # per-wave HBM slabs, so the default is ONE block per call; --workers / --block-loci select the pipelined form
     workers = args.workers or 1
     block = args.block_loci or max(1, (n_loci + workers - 1) // workers)
-    if node_queue and not args.block_loci:
-        # two blocks per rank: small enough for the queue to even out unequal parts, large enough to fill a device (a block below
-        # ~4096 loci leaves assembler waves idle: one wave per locus, 16 waves per CU)
-        block = max(1, n_loci // 2) if world > 1 else n_loci
+    if (node_queue or proc_queue) and not args.block_loci:
+        # about two blocks per device: small enough for the queue to even out unequal parts, but not below the size that fills a
+        # device (measured: blocks under ~4096 loci leave the assembler's persistent workgroups short of work)
+        block = max(min(4096, n_loci), n_loci // 2) if n_dev > 1 else n_loci
 
     # ---- this rank's batch (outside the clock: synthetic data generation) ----
     if spanning:
@@ -232,11 +242,26 @@ def main():
             batch = config2_batch(n_loci, seed=12345 + 1000003 * rank)
         min_wl = max_wl = None
         opts = asm_opts(**ASM_K)
-        if node_queue:
-            # the node's batch = the ranks' parts laid end to end (part r at loci [r * n_loci, (r + 1) * n_loci)); every rank holds
-            # all of it, as every worker thread of one GenerateSVCandidates process sees the whole edge list
-            parts = [None] * world
-            dist.all_gather_object(parts, tuple(np.ascontiguousarray(a) for a in batch))
+        if node_queue or proc_queue:
+            # the node's batch = the devices' parts laid end to end (part r at loci [r * n_loci, (r + 1) * n_loci)); every rank holds
+            # all of it, as every worker thread of one GenerateSVCandidates process sees the whole edge list.  The parts travel
+            # as files in shared memory (every rank writes its own: nothing is pickled through the rendezvous store -- 1.2 GB
+            # at 8 x 10 000 loci); a single process generates them all.
+            def part_of(r):
+                heavy = args.mix and r % 4 == 3
+                return config2_batch(n_loci, seed=12345 + 1000003 * r, n_reads=200) if heavy else config2_batch(n_loci, seed=12345 + 1000003 * r)
+            if multi and world == n_dev:
+                shm_dir = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+                stem = os.path.join(shm_dir, "manta_bench_%s" % os.environ.get("MASTER_PORT", "0"))
+                for i, a in enumerate(batch):
+                    np.save("%s_r%d_a%d.npy" % (stem, rank, i), np.ascontiguousarray(a))
+                dist.barrier()
+                parts = [batch if r == rank else tuple(np.load("%s_r%d_a%d.npy" % (stem, r, i)) for i in range(len(batch))) for r in range(world)]
+                dist.barrier()
+                for i in range(len(batch)):
+                    os.unlink("%s_r%d_a%d.npy" % (stem, rank, i))
+            else:
+                parts = [batch if r == 0 else part_of(r) for r in range(n_dev)]
             nb = [int(p[1][-1]) for p in parts]
             nr = [len(p[1]) - 1 for p in parts]
             nf = [int(p[4][-1]) for p in parts]
@@ -247,15 +272,21 @@ def main():
                      np.concatenate([p[3][:n] for p, n in zip(parts, nf)] + [np.zeros(64, dtype=np.uint8)]),
                      cat_off([p[4] for p in parts], nf), np.concatenate([p[5] for p in parts]))
             del parts
-        n_out = n_loci * (world if node_queue else 1)
+        n_out = n_loci * (n_dev if (node_queue or proc_queue) else 1)
         out = BatchOutput(lib, "smallsv", n_out, 10, 4096 * n_out + (1 << 20), 128 * n_out + 4096, 512 * n_out + 4096,
                           pinned=not args.pageable)
     dev_batch = batch if args.pageable else tuple(pinned_copy(lib, a) for a in batch)
     n_reads = np.diff(batch[2])
 
+    per_dev = [0] * n_dev
+
     def step():
         if spanning:
             lib.spanning_batch(opts, SPAN_SC, JUMP, dev_batch, out, min_wl=min_wl, max_wl=max_wl, block_loci=block, n_workers=workers, serial_kernels=args.serial_kernels)
+        elif proc_queue:
+            if node is not None:
+                per_dev[:] = node.smallsv_batch(opts, SCORES, LARGE_INDEL, dev_batch, out, block_loci=block, n_workers=workers)
+            return None
         elif node_queue:
             import ctypes as _ct
             slot = step_no[0]
@@ -329,6 +360,27 @@ def main():
             raise SystemExit("PARITY FAILURE (node queue): %d of %d checked loci differ, %d loci failed, %d of %d loci taken"
                              % (node_check[0], node_check[1], node_check[2], node_check[3], n_loci * world))
 
+    if proc_queue:
+        loci_per_rank = list(per_dev)
+        if rank == 0:
+            # one process holds every result: part 0 is the digest workload, the other parts against the CPU restatement on a sample
+            orc_n = OracleLib()
+            dig_path = os.path.join(ROOT, "tests", "golden", "config2_digests.bin")
+            raw = open(dig_path, "rb").read() if (os.path.exists(dig_path) and n_loci == 10000 and not args.mix) else b""
+            mism = checked = 0
+            for l in range(n_loci if raw else 0):
+                mism += hashlib.sha256(small_sv_text(results[l]).encode("latin-1")).digest() != raw[32 * l:32 * l + 32]
+                checked += 1
+            rest = [l for l in taken if l >= n_loci or not raw]
+            for l in rest[::max(1, len(rest) // (16 * n_dev))]:
+                reads, ref, cuts = unpack_locus(batch, l)
+                mism += small_sv_text(results[l]) != orc_n.small_sv_locus(opts, SCORES, LARGE_INDEL, reads, ref, cuts)
+                checked += 1
+            node_check = [mism, checked, n_fail, len(taken)]
+            if mism or n_fail or len(taken) != n_loci * n_dev or sum(per_dev) != n_loci * n_dev:
+                raise SystemExit("PARITY FAILURE (process queue): %d of %d checked loci differ, %d loci failed, %d of %d loci taken (per device: %s)"
+                                 % (mism, checked, n_fail, len(taken), n_loci * n_dev, per_dev))
+
     if rank == 0:
         orc = OracleLib()
         # ---- parity (checker only; never part of the measured path) ----
@@ -346,8 +398,8 @@ def main():
                        for a in r["aligns"]]
                 mism += hashlib.sha256(c5_text(assembly_text(r), got).encode("latin-1")).digest() != raw[32 * i:32 * i + 32]
             checked, how = n_dig, "reference digests (tests/golden/config5_digests.bin)"
-        elif node_queue:
-            checked, how = node_check[1], "reference digests (rank 0's part, tests/golden/config2_digests.bin) + restatement samples of the other parts, summed over the ranks"
+        elif node_queue or proc_queue:
+            checked, how = node_check[1], "reference digests (part 0, tests/golden/config2_digests.bin) + restatement samples of the other parts" + (", summed over the ranks" if node_queue else "")
         elif n_loci == 10000:  # the digest workload (config2_batch draws every locus of a batch from one stream: other sizes differ)
             for l in range(n_dig):
                 mism += hashlib.sha256(small_sv_text(results[l]).encode("latin-1")).digest() != raw[32 * l:32 * l + 32]
@@ -361,7 +413,7 @@ def main():
         if mism or n_fail:
             raise SystemExit("PARITY FAILURE: %d of %d checked loci differ (%s), %d loci failed" % (mism, checked, how, n_fail))
 
-        loci_total = n_loci * world * steps
+        loci_total = n_loci * n_dev * steps
         value = loci_total / elapsed
         asm_sum, align_sum = acc["assemble_ms"], acc["align_ms"]
         if spanning:
@@ -408,19 +460,20 @@ def main():
             except Exception:
                 traffic = None
         o = {
-            "metric": METRIC, "value": round(value, 1), "unit": "loci/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "metric": METRIC, "value": round(value, 1), "unit": "loci/s", "n_gpus": n_dev, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": workload, "loci_per_gpu": n_loci, "reads_per_locus": int(n_reads[0]),
                        "contigs_per_locus": round(n_contigs / max(1, len(taken)), 3),
                        "timed_region": "batch submit -> all results host-visible: H2D + kernels + D2H"
                                        + ((" + gather of the result blobs to rank 0 (torch.distributed, backend %s: %s)"
-                                           % (backend, "RCCL" if backend == "nccl" else "host memory, developer self-test")) if multi else ""),
+                                           % (backend, "RCCL" if backend == "nccl" else "host memory, developer self-test")) if (multi and not proc_queue) else ""),
                        "host_memory": "pageable" if args.pageable else "page-locked (manta_host_alloc)",
                        "block_loci": block, "workers_per_gpu": workers,
-                       "parallelism": ("one cost-ordered block queue across %d rank(s) (shared-memory counter, manta_batch_plan_t::shared_queue)" % world)
+                       "parallelism": ("one process, %d device(s), one cost-ordered block queue inside the library (manta_node_smallsv_batch)" % n_dev) if proc_queue
+                                      else ("one cost-ordered block queue across %d rank(s) (shared-memory counter, manta_batch_plan_t::shared_queue)" % world)
                                       if node_queue else ("loci sharded over %d rank(s); per rank a cost-ordered block queue" % world),
-                       "queue": "node" if node_queue else "rank", "backend": backend if multi else None,
+                       "queue": "process" if proc_queue else ("node" if node_queue else "rank"), "backend": backend if multi else None,
                        "dist_world": dist.get_world_size() if multi else 1, "loci_per_rank": loci_per_rank,
                        "mix": bool(args.mix and node_queue),
                        "parity": "%d loci vs %s: 0 mismatches" % (checked, how)},
@@ -442,8 +495,8 @@ def main():
                                           "d2h+compact": round(acc["d2h_ms"] / steps, 2)},
                      "gather_MB_per_step": round(gathered_bytes / steps / 1e6, 2)},
             "algorithmic_bytes_per_locus": {"in": b_in / max(1, len(taken)), "ptr": b_ptr / max(1, len(taken)), "out": b_out / max(1, len(taken)),
-                                            "whole_path_GBps": round((b_in + b_ptr + b_out) / max(1, len(taken)) * n_loci * world * steps / elapsed / 1e9, 2)},
-            "dp_gcups": round(acc["dp_cells"] * world / elapsed / 1e9, 2),
+                                            "whole_path_GBps": round((b_in + b_ptr + b_out) / max(1, len(taken)) * n_loci * n_dev * steps / elapsed / 1e9, 2)},
+            "dp_gcups": round(acc["dp_cells"] * (1 if proc_queue else world) / elapsed / 1e9, 2),
         }
         # ---- device-resident kernel rate (extra key; round 1's headline): inputs in HBM, three kernels per step ----
         if not spanning and world == 1 and not args.no_extras:

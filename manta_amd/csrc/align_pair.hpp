@@ -74,17 +74,20 @@ struct PairAligner {
     const uint32_t cMisDiff = pk2((P.mismatch - P.match) * 8);
     const uint32_t clrIdx = 0xfff8fff8u, idxBits = 0x00070007u, bad = pk2(PAIR_BAD8);
 
-    // traceback start candidates per task (rows at q == Q; off-edge candidates of the last row)
-    StartCand candRows[2] = {{0, 0, 0, ST_MATCH, false}, {0, 0, 0, ST_MATCH, false}};
-    bool      haveOff[2]  = {false, false};
-    int       offVal[2]   = {0, 0};
-    unsigned  offQ[2]     = {0, 0};
+    // traceback start candidates per task.  Rows at q == Q: one 32-bit key per task, (value x 8) << 16 | (0xffff - row), kept by
+    // a plain integer max on the lane that owns column Q: the higher value wins, among equal values the EARLIER row (the
+    // reference's strict '>' scan, AlignerUtil.hpp:53-67).  Off-edge candidates: the match states of a task's LAST row are
+    // captured into lastRow[] when a lane passes that row and evaluated once after the sweep.
     const unsigned Qs[2] = {QA, QB}, Gs[2] = {GA, GB};
     unsigned       lQ[2], eQ[2];
     for (int h = 0; h < 2; ++h) {
       lQ[h] = (Qs[h] - 1) / E;
       eQ[h] = (Qs[h] - 1) % E;
     }
+    int      rowKey[2] = {int(0x80000000u), int(0x80000000u)};
+    uint32_t lastRow[E];
+    for (int e = 0; e < E; ++e) lastRow[e] = bad;
+    const uint32_t fcMask = (lane == 0) ? 0xffffffffu : 0u;  // column 1 of the query: gap states are reset (:130, :143, ...)
 
     uint32_t st[NS][E], lcur[NS], lprev[NS], qc[E];
     for (int e = 0; e < E; ++e) {
@@ -144,7 +147,7 @@ struct PairAligner {
       for (int e = 0; e < E; ++e) {
         uint32_t up[NS];
         for (int s = 0; s < NS; ++s) up[s] = st[s][e];
-        const bool     firstCol = (e == 0) && (lane == 0);
+        const uint32_t fc = (e == 0) ? fcMask : 0u;  // (compile-time zero for e > 0)
         // substitution score per half: match where the symbols agree
         const uint32_t differ = wv::pk_min_u16(qc[e] ^ rc, 0x00010001u);
         const uint32_t sub8   = wv::pk_mad_u16(differ, cMisDiff, cMatch);
@@ -159,14 +162,14 @@ struct PairAligner {
           uint32_t m = wv::pk_max_i16(wv::pk_max_i16(wv::pk_add_sat_i16(up[ST_MATCH], cOpen0), wv::pk_add_sat_i16(up[ST_DELETE], cD1)), wv::pk_add_sat_i16(up[ST_INSERT], cI2));
           m          = wv::pk_max_i16(wv::pk_max_i16(m, cBad3), wv::pk_add_sat_i16(up[ST_JUMPINS], cJI4));
           uint32_t b = wv::pk_add_sat_i16(m & clrIdx, cExt);
-          if (firstCol) b = bad;
+          b = (b & ~fc) | (bad & fc);
           nv[ST_DELETE] = b;
           code |= (m & idxBits) << 3;
         }
         {  // insert (:137-146)
           uint32_t m = wv::pk_max_i16(wv::pk_max_i16(wv::pk_add_sat_i16(left[ST_MATCH], cOpen0), cBad1), wv::pk_add_sat_i16(left[ST_INSERT], cI2));
           uint32_t b = wv::pk_add_sat_i16(m & clrIdx, cExt);
-          if (firstCol) b = bad;
+          b = (b & ~fc) | (bad & fc);
           nv[ST_INSERT] = b;
           code |= (m & idxBits) << 6;
         }
@@ -174,14 +177,14 @@ struct PairAligner {
           uint32_t m = wv::pk_max_i16(wv::pk_max_i16(wv::pk_add_sat_i16(up[ST_MATCH], cL0), cBad1), wv::pk_add_sat_i16(up[ST_INSERT], cLmOpen2));
           m          = wv::pk_max_i16(wv::pk_max_i16(m, wv::pk_add_sat_i16(up[ST_JUMP], cJ3)), wv::pk_add_sat_i16(up[ST_JUMPINS], cL4));
           uint32_t b = m & clrIdx;
-          if (firstCol) b = bad;
+          b = (b & ~fc) | (bad & fc);
           nv[ST_JUMP] = b;
           code |= (m & idxBits) << 9;
         }
         {  // jumpIns (:169-176)
           uint32_t m = wv::pk_max_i16(wv::pk_max_i16(wv::pk_add_sat_i16(left[ST_MATCH], cL0), cBad1), wv::pk_add_sat_i16(left[ST_JUMPINS], cJI4));
           uint32_t b = m & clrIdx;
-          if (firstCol) b = bad;
+          b = (b & ~fc) | (bad & fc);
           nv[ST_JUMPINS] = b;
           code |= (m & idxBits) << 12;
         }
@@ -194,49 +197,54 @@ struct PairAligner {
       }
       for (int e = 0; e < E; ++e) ptr32[(uint64_t(t) * E + e) * 64 + unsigned(lane)] = cells[e];
 
-      // traceback start candidates, per task
-      for (int h = 0; h < 2; ++h) {
-        if (unsigned(g) > Gs[h]) continue;
-        if (unsigned(lane) == lQ[h]) {
-          uint32_t vM = 0;
-          for (int e = 0; e < E; ++e)
-            if (unsigned(e) == eQ[h]) vM = st[ST_MATCH][e];
-          candUpdate(candRows[h], half(vM, h) >> 3, unsigned(g), Qs[h], ST_MATCH);
-        }
-        if (unsigned(g) == Gs[h]) {
-          // off-edge candidates of the last row (q < Q; the reference's extra q == Q term can never win the strict '>')
-          for (int e = 0; e < E; ++e) {
-            const unsigned q = unsigned(lane) * E + e + 1;
-            if (q < Qs[h]) {
-              const int v = (half(st[ST_MATCH][e], h) >> 3) + int((Qs[h] - q) * unsigned(offEdge));
-              if (!haveOff[h] || v > offVal[h]) {
-                haveOff[h] = true;
-                offVal[h]  = v;
-                offQ[h]    = q;
-              }
-            }
-          }
+      // traceback start candidates (see above)
+      {
+        const uint32_t cap = ((unsigned(g) == GA) ? 0x0000ffffu : 0u) | ((unsigned(g) == GB) ? 0xffff0000u : 0u);
+        for (int e = 0; e < E; ++e) lastRow[e] = (lastRow[e] & ~cap) | (st[ST_MATCH][e] & cap);
+        for (int h = 0; h < 2; ++h) {
+          uint32_t vM = st[ST_MATCH][0];
+          for (int e = 1; e < E; ++e) vM = (unsigned(e) == eQ[h]) ? st[ST_MATCH][e] : vM;
+          const int  key = int((uint32_t(half(vM, h)) << 16) | (0xffffu - unsigned(g)));
+          const bool on  = unsigned(lane) == lQ[h] && unsigned(g) <= Gs[h];
+          rowKey[h]      = imax(rowKey[h], on ? key : int(0x80000000u));
         }
       }
     }
     for (int h = 0; h < 2; ++h) {
+      // off-edge candidates of the task's last row (q < Q; the reference's extra q == Q term can never win the strict '>');
+      // a lane's columns in ascending q, then the lanes: first best wins
+      bool     haveOff = false;
+      int      offVal  = 0;
+      unsigned offQ    = 0;
+      for (int e = 0; e < E; ++e) {
+        const unsigned q = unsigned(lane) * E + e + 1;
+        if (q < Qs[h]) {
+          const int v = (half(lastRow[e], h) >> 3) + int((Qs[h] - q) * unsigned(offEdge));
+          if (!haveOff || v > offVal) {
+            haveOff = true;
+            offVal  = v;
+            offQ    = q;
+          }
+        }
+      }
       // q == 0 off-edge candidate (column 0 holds match == 0 on every row >= 1); it precedes every other q in scan order
       if (lane == 0) {
         const int v0 = int(Qs[h] * unsigned(offEdge));
-        if (!haveOff[h] || v0 >= offVal[h]) {
-          haveOff[h] = true;
-          offVal[h]  = v0;
-          offQ[h]    = 0;
+        if (!haveOff || v0 >= offVal) {
+          haveOff = true;
+          offVal  = v0;
+          offQ    = 0;
         }
       }
-      waveArgmaxFirst(haveOff[h], offVal[h], offQ[h]);
+      waveArgmaxFirst(haveOff, offVal, offQ);
+      const int key = wv::readlane(rowKey[h], int(lQ[h]));
       StartCand best;
-      best.val   = wv::readlane(candRows[h].val, int(lQ[h]));
-      best.ref   = wv::readlane(candRows[h].ref, int(lQ[h]));
+      best.val   = (key >> 16) >> 3;
+      best.ref   = 0xffffu - (unsigned(key) & 0xffffu);
       best.query = Qs[h];
       best.state = ST_MATCH;
       best.init  = true;
-      candUpdate(best, offVal[h], Gs[h], offQ[h], ST_MATCH);
+      candUpdate(best, offVal, Gs[h], offQ, ST_MATCH);
       if (h == 0)
         outA = best;
       else
@@ -271,12 +279,11 @@ struct PairAligner {
 };
 
 /// the work unit is a PAIR of tasks of one E bucket (task_ids[2 i], task_ids[2 i + 1]; an odd last task runs against itself).
-/// Launched with HALF the waves align_kernel<1,E> would get for the same bucket: a wave's cell pairs take two of that kernel's
-/// slabs (P.ptr_ws_stride is the single-alignment stride).
+/// A wave's slab holds cell pairs: P.ptr_ws_stride is twice the single-alignment stride (api.cpp: alignUsesPairs).
 template <int E>
 WV_KERNEL void align_pair_kernel(const AlignParams P)
 {
-  uint8_t*       slab   = P.ptr_ws + uint64_t(wv::block()) * 2 * P.ptr_ws_stride;
+  uint8_t*       slab   = P.ptr_ws + uint64_t(wv::block()) * P.ptr_ws_stride;
   const unsigned nTasks = P.n_tasks_dev ? *P.n_tasks_dev : P.n_tasks;
   const unsigned nPairs = (nTasks + 1) / 2;
   while (true) {

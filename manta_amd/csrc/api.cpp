@@ -182,32 +182,38 @@ void launchAlignE(int eIdx, int grid, const AlignParams& P)
 }
 
 /// GlobalLargeIndelAligner buckets of short queries run two alignments per wave in packed 16-bit arithmetic (align_pair.hpp) when
-/// the scores leave the margin pairEligible() asks for: half the waves, each with two of the single kernel's slabs
-bool launchAlignPair(int eIdx, int grid, const AlignParams& P)
+/// the scores leave the margin pairEligible() asks for.  The caller sizes the slabs for it: a wave's cell pairs take twice the
+/// single-alignment slab, and a bucket needs half as many work items.
+bool alignUsesPairs(int kind, int eIdx, int match, int mismatch, int open, int extend, int offEdge, int extra, int allowEdgeIns)
 {
   static const bool off = std::getenv("MANTA_AMD_NO_ALIGN_PAIRS") != nullptr;  // A/B knob
-  const int E = kESet[eIdx];
-  if (off || grid < 8 || !pairEligible(E, P.match, P.mismatch, P.open, P.extend, P.off_edge, P.extra, P.allow_edge_ins)) return false;
-  const int g2 = (grid / 2) & ~(WV_WAVES_PER_WG - 1);
-  if (std::getenv("MANTA_AMD_DEBUG")) std::fprintf(stderr, "manta_amd: align_pair_kernel<%d>: %d waves (two alignments each)\n", E, g2);
-  switch (E) {
-  case 1: rt::launch(align_pair_kernel<1>, g2, 0, P); break;
-  case 2: rt::launch(align_pair_kernel<2>, g2, 0, P); break;
-  case 3: rt::launch(align_pair_kernel<3>, g2, 0, P); break;
-  case 4: rt::launch(align_pair_kernel<4>, g2, 0, P); break;
-  case 5: rt::launch(align_pair_kernel<5>, g2, 0, P); break;
-  case 6: rt::launch(align_pair_kernel<6>, g2, 0, P); break;
-  default: return false;
-  }
-  return true;
+  return !off && kind == MANTA_ALIGNER_LARGE_INDEL && pairEligible(kESet[eIdx], match, mismatch, open, extend, offEdge, extra, allowEdgeIns);
 }
 
-void launchAlignKind(int kind, int eIdx, int grid, const AlignParams& P)
+void launchAlignPair(int eIdx, int grid, const AlignParams& P)
+{
+  if (std::getenv("MANTA_AMD_DEBUG")) std::fprintf(stderr, "manta_amd: align_pair_kernel<%d>: %d waves (two alignments each)\n", kESet[eIdx], grid);
+  switch (kESet[eIdx]) {
+  case 1: rt::launch(align_pair_kernel<1>, grid, 0, P); break;
+  case 2: rt::launch(align_pair_kernel<2>, grid, 0, P); break;
+  case 3: rt::launch(align_pair_kernel<3>, grid, 0, P); break;
+  case 4: rt::launch(align_pair_kernel<4>, grid, 0, P); break;
+  case 5: rt::launch(align_pair_kernel<5>, grid, 0, P); break;
+  case 6: rt::launch(align_pair_kernel<6>, grid, 0, P); break;
+  default: throw rt::Error("internal: no packed aligner for this E");
+  }
+}
+
+/// `pair`: the launch was sized for align_pair_kernel (alignUsesPairs)
+void launchAlignKind(int kind, int eIdx, int grid, const AlignParams& P, bool pair = false)
 {
   if (kind == MANTA_ALIGNER_GLOBAL)
     launchAlignE<0>(eIdx, grid, P);
   else if (kind == MANTA_ALIGNER_LARGE_INDEL) {
-    if (!launchAlignPair(eIdx, grid, P)) launchAlignE<1>(eIdx, grid, P);
+    if (pair)
+      launchAlignPair(eIdx, grid, P);
+    else
+      launchAlignE<1>(eIdx, grid, P);
   } else
     launchAlignE<2>(eIdx, grid, P);
 }
@@ -1530,8 +1536,10 @@ int manta_align_batch(
     size_t       idsCursor = 0;
     for (int b = 0; b < kNumESet; ++b) {
       if (buckets[b].empty()) continue;
-      const uint64_t stride = (alignPtrSlabBytes(kind, kESet[b], bucketMaxRef[b]) + 255) & ~uint64_t(255);
-      int            grid   = int(std::min<size_t>(buckets[b].size(), size_t(maxWaves)));
+      const bool     pair   = alignUsesPairs(kind, b, scores->match, scores->mismatch, scores->open, scores->extend, scores->off_edge, extra_score,
+                                             scores->is_allow_edge_insertion ? 1 : 0);
+      const uint64_t stride = ((pair ? 2 : 1) * alignPtrSlabBytes(kind, kESet[b], bucketMaxRef[b]) + 255) & ~uint64_t(255);
+      int            grid   = int(std::min<size_t>(pair ? (buckets[b].size() + 1) / 2 : buckets[b].size(), size_t(maxWaves)));
       grid                  = int(std::max<size_t>(1, std::min<size_t>(size_t(grid), wsBudget / stride)));
       grid                  = rt::roundGrid(grid);
       uint8_t* dWs          = ctx->dPtrWs.as<uint8_t>(stride * grid);
@@ -1555,7 +1563,7 @@ int manta_align_batch(
       P.extra          = extra_score;
       rt::Event e0, e1;
       e0.record();
-      launchAlignKind(kind, b, grid, P);
+      launchAlignKind(kind, b, grid, P, pair);
       e1.record();
       rt::sync();  // dPtrWs may be re-sized by the next bucket
       if (std::getenv("MANTA_AMD_DEBUG"))
@@ -2025,9 +2033,14 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     struct Launch {
       int      k, grid;
       uint64_t stride, slabOff;
+      bool     pair;
     };
     std::vector<Launch> launches;
     uint64_t            slabBytes = 0;
+    auto pairOf = [&](int k) {
+      return alignUsesPairs(MANTA_ALIGNER_LARGE_INDEL, k, b->scores.match, b->scores.mismatch, b->scores.open, b->scores.extend, b->scores.off_edge,
+                            b->largeIndel, b->scores.is_allow_edge_insertion ? 1 : 0);
+    };
     const bool batchCall = b->stageBehindRun && !std::getenv("MANTA_AMD_SYNC_BUCKETS");
     bool       haveCounts = false;
     if (batchCall && !fromHistory) {
@@ -2040,12 +2053,14 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     }
     if (fromHistory) {
       for (int k = kNumESet - 1; k >= 0; --k) {
-        const uint64_t hint   = uint64_t(b->lastSmall[k]) + b->lastSmall[k] / 4 + 64;
+        const bool     pair   = pairOf(k);
+        const uint64_t tasks  = uint64_t(b->lastSmall[k]) + b->lastSmall[k] / 4 + 64;
+        const uint64_t hint   = pair ? (tasks + 1) / 2 : tasks;  // work items: alignments, or pairs of them
         const uint64_t qBound = (kESet[k] == 32) ? std::max<uint64_t>(as.maxContigLen, 64ull * 32) : 64ull * uint64_t(kESet[k]);
         const uint64_t refLen = alignSlabRefLen(MANTA_ALIGNER_LARGE_INDEL, kESet[k], qBound, b->maxRef);
-        const uint64_t stride = (alignPtrSlabBytes(MANTA_ALIGNER_LARGE_INDEL, kESet[k], refLen) + 255) & ~uint64_t(255);
+        const uint64_t stride = ((pair ? 2 : 1) * alignPtrSlabBytes(MANTA_ALIGNER_LARGE_INDEL, kESet[k], refLen) + 255) & ~uint64_t(255);
         const int      grid   = rt::roundGrid(int(std::min<uint64_t>(hint, uint64_t(maxWaves))));
-        launches.push_back(Launch{k, grid, stride, slabBytes});
+        launches.push_back(Launch{k, grid, stride, slabBytes, pair});
         slabBytes += stride * uint64_t(grid);
       }
       if (slabBytes > wsBudget / 3) {  // too generous for this device right now: size from the real counts
@@ -2059,11 +2074,12 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
       for (int k = kNumESet - 1; k >= 0; --k) {  // widest (longest-running) buckets first
         const uint32_t cnt = hSmall[k];
         if (cnt == 0) continue;
-        const uint64_t stride = (alignPtrSlabBytes(MANTA_ALIGNER_LARGE_INDEL, kESet[k], hSmall[16 + k]) + 255) & ~uint64_t(255);
-        int            grid   = int(std::min<size_t>(cnt, size_t(maxWaves)));
+        const bool     pair   = pairOf(k);
+        const uint64_t stride = ((pair ? 2 : 1) * alignPtrSlabBytes(MANTA_ALIGNER_LARGE_INDEL, kESet[k], hSmall[16 + k]) + 255) & ~uint64_t(255);
+        int            grid   = int(std::min<size_t>(pair ? (cnt + 1) / 2 : cnt, size_t(maxWaves)));
         grid                  = int(std::max<size_t>(1, std::min<size_t>(size_t(grid), (wsBudget / 3) / stride)));
         grid                  = rt::roundGrid(grid);
-        launches.push_back(Launch{k, grid, stride, slabBytes});
+        launches.push_back(Launch{k, grid, stride, slabBytes, pair});
         slabBytes += stride * uint64_t(grid);
       }
     }
@@ -2097,7 +2113,7 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
         P.extra          = b->largeIndel;
         {
           rt::ScopedStream onSide(b->side[i % 3]);  // (restores the pipeline's stream: nothing of this call runs on the null stream)
-          launchAlignKind(MANTA_ALIGNER_LARGE_INDEL, l.k, l.grid, P);
+          launchAlignKind(MANTA_ALIGNER_LARGE_INDEL, l.k, l.grid, P, l.pair);
         }
         if (!fromHistory) {
           b->stats.n_align_launches++;

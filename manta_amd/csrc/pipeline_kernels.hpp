@@ -10,7 +10,10 @@
 namespace manta_dev {
 
 static const int      SMALLSV_MER       = 10;    // SVCandidateAssemblyRefiner.cpp:1986
-static const unsigned SCHED_LDS_BYTES   = 4096;  // per wavefront: 10-mer table of contigs up to 512 bp lives in LDS (32 waves/CU fit)
+static const unsigned SCHED_TABLE_BYTES = 4096;  // per wavefront: 10-mer table of contigs up to 512 bp lives in LDS
+static const unsigned SCHED_SEQ_BYTES   = 6144;  // ... and so do the contig and the reference window (staged with wide loads: the scans
+                                                 // below read a byte per lane and 55 positions per round trip otherwise)
+static const unsigned SCHED_LDS_BYTES   = SCHED_TABLE_BYTES + SCHED_SEQ_BYTES;  // 10 KB per wavefront: 16 waves per CU
 
 struct SmallSvCuts {
   int32_t leadingCut, trailingCut, maxLeadingCut, maxTrailingCut;  // :1912-1915
@@ -121,11 +124,32 @@ WV_DEV SmallSvTaskInfo scheduleSlot(const ScheduleParams& P, const unsigned slot
     return info;
   }
   const AsmContigOut co      = P.contigs[slot];
-  const uint8_t*     contig  = P.seq_arena + co.seq_off;
+  const uint8_t*     contigG = P.seq_arena + co.seq_off;
   const unsigned     clen    = co.seq_len;
-  const uint8_t*     ref     = P.refs + P.ref_off[locus];
+  const uint8_t*     refG    = P.refs + P.ref_off[locus];
   const int          refSize = int(P.ref_off[locus + 1] - P.ref_off[locus]);
   const SmallSvCuts  cuts    = P.cuts[locus];
+  // contig and reference window into LDS (16 bytes per lane and load, all in flight together) when they fit; the scans then
+  // run at LDS latency.  The task keeps the global pointers.
+  const uint8_t* contig = contigG;
+  const uint8_t* ref    = refG;
+  {
+    uint8_t* const  lseq = reinterpret_cast<uint8_t*>(ltable) + SCHED_TABLE_BYTES;
+    const uintptr_t gc = reinterpret_cast<uintptr_t>(contigG), gr = reinterpret_cast<uintptr_t>(refG);
+    const unsigned  leadC = unsigned(gc & 15), leadR = unsigned(gr & 15);
+    const unsigned  bytesC = (leadC + clen + 15) & ~15u, bytesR = (leadR + unsigned(refSize > 0 ? refSize : 0) + 15) & ~15u;
+    if (bytesC + bytesR <= SCHED_SEQ_BYTES) {
+      const u32x4* sc = reinterpret_cast<const u32x4*>(gc - leadC);
+      const u32x4* sr = reinterpret_cast<const u32x4*>(gr - leadR);
+      u32x4*       dc = reinterpret_cast<u32x4*>(lseq);
+      u32x4*       dr = reinterpret_cast<u32x4*>(lseq + bytesC);
+      for (unsigned i = lane; i < bytesC / 16; i += 64) dc[i] = sc[i];
+      for (unsigned i = lane; i < bytesR / 16; i += 64) dr[i] = sr[i];
+      wv::sync();
+      contig = lseq + leadC;
+      ref    = lseq + bytesC + leadR;
+    }
+  }
 
   if (clen < unsigned(SMALLSV_MER) || 2 * clen > P.table_cap) {
     info.status = 2;
@@ -135,7 +159,7 @@ WV_DEV SmallSvTaskInfo scheduleSlot(const ScheduleParams& P, const unsigned slot
   unsigned tcap = 64;
   while (tcap < 2 * clen) tcap <<= 1;
   const unsigned mask  = tcap - 1;
-  uint32_t*      table = (tcap * 4 <= SCHED_LDS_BYTES) ? ltable : gtable;
+  uint32_t*      table = (tcap * 4 <= SCHED_TABLE_BYTES) ? ltable : gtable;
   for (unsigned i = lane; i < tcap; i += 64) table[i] = 0;
   wv::sync();
   for (int p0 = 0; p0 + SMALLSV_MER <= int(clen); p0 += MER_BATCH) {
@@ -219,8 +243,8 @@ WV_DEV SmallSvTaskInfo scheduleSlot(const ScheduleParams& P, const unsigned slot
     if (cig + 4ull * clen + 16 <= P.cigar_cap) {
       claimed = 1;
       AlignTaskDev t;
-      t.query     = contig;
-      t.ref1      = ref + adjLead;
+      t.query     = contigG;
+      t.ref1      = refG + adjLead;
       t.ref2      = nullptr;
       t.query_len = clen;
       t.ref1_len  = unsigned(winLen);

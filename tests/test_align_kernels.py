@@ -33,6 +33,36 @@ def test_emulated_align_multi_column(emu, oracle):
     _run(emu, oracle, 5, 8, 3, 420)  # queries up to ~400 bp -> several columns per lane
 
 
+def _pair_cases(rng, n, maxlen):
+    return [_rand_align_case(rng, 1, maxlen) for _ in range(n)]
+
+
+def _run_pairs(lib, oracle, seed, per_batch, maxlens):
+    """GlobalLargeIndelAligner batches large enough per E bucket for align_pair_kernel (two alignments per wave, packed 16-bit
+    arithmetic, align_pair.hpp) under score sets inside and outside its margin: the results equal the oracle's either way"""
+    rng = random.Random(seed)
+    n = 0
+    for sc, extra in (([2, -8, -24, -1, -1, 0], -100), ([2, -4, -5, -1, -1, 0], -20), ([2, -8, -100, 0, -1, 0], -100),
+                      ([2, -8, -18, -1, -1, 1], -50), ([1, -4, -6, -1, -2, 0], -3)):
+        for maxlen in maxlens:
+            probs = _pair_cases(rng, per_batch, maxlen)
+            res = lib.align_batch(1, sc, extra, probs)
+            for p, r in zip(probs, res):
+                assert r["status"] == 0
+                assert align_text(1, r) == oracle.align(1, sc, extra, *p), (sc, extra, p)
+                n += 1
+    return n
+
+
+def test_emulated_align_pairs(emu, oracle):
+    assert _run_pairs(emu, oracle, 23, 20, (60, 180, 380)) == 5 * 3 * 20
+
+
+@pytest.mark.gpu
+def test_gpu_align_pairs(gpu, oracle):
+    assert _run_pairs(gpu, oracle, 29, 160, (60, 130, 200, 270, 330, 380, 520)) == 5 * 7 * 160
+
+
 def test_empty_inputs_report_status(emu):
     res = emu.align_batch(0, [2, -4, -5, -1, -4, 0], 0, [("", "ACGT"), ("ACGT", ""), ("AC", "ACGT")], strict=False)
     assert [r["status"] for r in res] == [-4, -4, 0]

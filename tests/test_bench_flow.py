@@ -81,6 +81,26 @@ def test_bench_two_ranks_share_one_block_queue(emu):
     assert d["config"]["queue"] == "rank" and d["config"]["loci_per_rank"] == [4]
 
 
+def test_bench_process_queue_eight_devices(emu):
+    """--queue process: ONE process drives all devices through manta_node_smallsv_batch (the shape INTEGRATION.md B prescribes),
+    same JSON contract; eight emulated devices, every 4th part heavier"""
+    d, lines = run_bench(["--gpus", "8", "--queue", "process", "--loci", "3", "--steps", "1", "--warmup", "1", "--block-loci", "2", "--mix",
+                          "--no-cpu-baseline", "--no-extras"])
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["queue"] == "process" and len(c["loci_per_rank"]) == 8 and sum(c["loci_per_rank"]) == 24
+    assert "manta_node_smallsv_batch" in c["parallelism"] and "gather" not in c["timed_region"] and "0 mismatches" in c["parity"]
+
+
+def test_bench_eight_ranks_share_one_block_queue(emu):
+    """N = 8 over gloo with unequal parts (--mix): the parts reach every rank through shared-memory files, one queue hands out the
+    node's blocks, every locus is taken exactly once (bench.py fails otherwise) and no rank starves"""
+    d = run_bench_ranks(8, ["--gpus", "8", "--loci", "4", "--steps", "1", "--warmup", "0", "--block-loci", "2", "--mix", "--no-cpu-baseline",
+                            "--no-extras"], 29581)
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["queue"] == "node" and c["dist_world"] == 8 and c["mix"] is True
+    assert sum(c["loci_per_rank"]) == 32 and len(c["loci_per_rank"]) == 8 and "0 mismatches" in c["parity"]
+
+
 def test_bench_spanning_flow_on_the_emulator(emu):
     d, lines = run_bench(["--workload", "spanning", "--loci", "3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
     assert d["config"]["loci_per_gpu"] == 3 and "0 mismatches" in d["config"]["parity"]

@@ -63,6 +63,16 @@ def test_emulated_node_two_contexts_one_queue(emu, oracle):
     assert all(x > 0 for x in per_dev), per_dev  # both contexts pulled blocks from the one queue
 
 
+def test_emulated_node_eight_contexts_one_queue(emu, oracle):
+    """eight devices (emulated contexts) on one queue, a batch of skewed costs in blocks of two: every locus exactly once (check_node
+    compares all of them) and the spread between the busiest and the idlest device stays below 2x in LOCI WORTH OF COST -- a
+    device that draws the big loci takes fewer of them"""
+    n, block = 64, 2
+    per_dev = check_node(EMU, (0,) * 8, oracle, n=n, block=block)
+    assert len(per_dev) == 8 and sum(per_dev) == n and all(x > 0 for x in per_dev), per_dev
+    assert max(per_dev) <= 4 * (n // 8), per_dev  # (nobody ends up with half the batch)
+
+
 def test_emulated_node_single_device_and_default_blocks(emu, oracle):
     batch = skewed_batch(9, 5)
     node = Node(path=EMU, devices=(0,))
