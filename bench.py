@@ -443,8 +443,12 @@ def main():
             dom, dom_bytes, dom_ms, dom_launches = align_name, align_bytes * steps, align_sum, n_blocks
             dom_note = "per block: all E-bucket launches of the block (they run concurrently on side streams)"
         else:
-            dom, dom_bytes, dom_ms, dom_launches = "assemble_kernel", asm_bytes * steps, asm_sum, n_blocks
-            dom_note = "one launch per block"
+            # the assembler stage of a block: graph_kernel -> contig_kernel (asm_lds.hpp; the general assemble_kernel for what they
+            # punt and under MANTA_AMD_ASM_PATH=general), timed by the library as ONE span of HIP events on the block's stream
+            dom = "assemble_kernel" if os.environ.get("MANTA_AMD_ASM_PATH") == "general" else "assembler_stage"
+            dom_bytes, dom_ms, dom_launches = asm_bytes * steps, asm_sum, n_blocks
+            dom_note = ("one launch per block" if dom == "assemble_kernel" else
+                        "per block: graph_kernel + contig_kernel (one HIP-event span; rocprofv3 lists the two kernels separately: their averages add up to avg_launch_ms)")
         avg_launch_ms = dom_ms / dom_launches
         achieved = (dom_bytes / dom_launches) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         # roofline.traffic is NOT measured in this run: it is the HBM-side byte count of the builder's own rocprofv3 --pmc passes

@@ -195,7 +195,11 @@ struct PairAligner {
         }
         cells[e] = code;
       }
+#ifndef MANTA_PAIR_EXPERIMENT_NO_STORE  // (developer experiment: what the back-pointer stream costs; results are garbage without it)
       for (int e = 0; e < E; ++e) ptr32[(uint64_t(t) * E + e) * 64 + unsigned(lane)] = cells[e];
+#else
+      if (t == 0xffffffffu) for (int e = 0; e < E; ++e) ptr32[e] = cells[e];
+#endif
 
       // traceback start candidates (see above)
       {

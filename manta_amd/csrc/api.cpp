@@ -1334,7 +1334,7 @@ struct manta_smallsv {
   uint32_t              nLoci      = 0;
   uint64_t              refBytes = 0, maxRef = 0;
   bool                  uploaded = false, ran = false;
-  DevBuf                dRefs, dRefOff, dCuts, dTasks, dInfo, dResults, dBucketIds, dSmall, dCigar, dTable, dPtrWs;
+  DevBuf                dRefs, dRefOff, dCuts, dTasks, dInfo, dResults, dBucketIds, dBucketIds2, dSmall, dCigar, dTable, dPtrWs;
   rt::Event             evStart, evAsm, evSched, evAlign, refsReady;
   rt::Stream            main;  // everything of this pipeline except the aligner buckets
   rt::Stream            copy;  // streamed upload of the read bases (whole-batch calls)
@@ -1988,7 +1988,7 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     // CIGAR scratch, sized from what the assembler produced (as in spanningRunImpl): a task takes 4 * contig length + 16 words
     // (smallsv_schedule_kernel), every contig is aligned once, and the text arena counter bounds the summed contig lengths.  A
     // worst case per slot would be tens of GB at 65536-locus blocks and overflow the 32-bit offsets of the task records.
-    const uint64_t cigarCap = 4ull * std::min<uint64_t>(asmCnt[1], as.devSeqCap) + 16ull * nSlots + 64;
+    const uint64_t cigarCap = 8ull * std::min<uint64_t>(asmCnt[1], as.devSeqCap) + 64;  // (8 words per text byte: smallsv_schedule_kernel)
     if (cigarCap + 16 > 0xffffffffull)
       return fail(ctx, MANTA_E_UNSUPPORTED, "manta_smallsv_run: alignment scratch of this block exceeds 2^32 words; use smaller blocks "
                                          "(manta_smallsv_batch splits a batch into blocks, manta_batch_plan_t::block_loci)");
@@ -2018,6 +2018,24 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     S.n_e                = kNumESet;
     for (int i = 0; i < kNumESet; ++i) S.e_set[i] = uint32_t(kESet[i]);
     rt::launch(smallsv_schedule_kernel, schedGrid, SCHED_LDS_BYTES, S);
+    // the pair-eligible buckets by descending reference length (bucket_sort_kernel): their align kernels read the sorted lists
+    uint32_t  pairMask       = 0;
+    uint32_t* dBucketsSorted = nullptr;
+    for (int k = 0; k < kNumESet; ++k)
+      if (alignUsesPairs(MANTA_ALIGNER_LARGE_INDEL, k, b->scores.match, b->scores.mismatch, b->scores.open, b->scores.extend, b->scores.off_edge,
+                         b->largeIndel, b->scores.is_allow_edge_insertion ? 1 : 0))
+        pairMask |= 1u << k;
+    if (pairMask) {
+      dBucketsSorted = b->dBucketIds2.as<uint32_t>(nSlots * kNumESet);
+      BucketSortParams BS;
+      BS.tasks        = dTasks;
+      BS.ids_in       = dBuckets;
+      BS.ids_out      = dBucketsSorted;
+      BS.bucket_count = dSmall;
+      BS.total        = uint32_t(nSlots);
+      BS.mask         = pairMask;
+      rt::launchWG(bucket_sort_kernel, kNumESet, 4, 4 * BS_CLASSES, BS);
+    }
     b->evSched.record();
     stage("scheduled");
 
@@ -2098,7 +2116,7 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
         P.tasks          = dTasks;
         P.results        = dResults;
         P.cigar          = dCigar;
-        P.task_ids       = dBuckets + uint64_t(l.k) * nSlots;
+        P.task_ids       = (l.pair ? dBucketsSorted : dBuckets) + uint64_t(l.k) * nSlots;
         P.n_tasks        = fromHistory ? uint32_t(nSlots) : hSmall[l.k];
         P.n_tasks_dev    = fromHistory ? dSmall + l.k : nullptr;
         P.counter        = dSmall + 40 + l.k;

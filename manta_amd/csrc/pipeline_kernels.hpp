@@ -13,7 +13,7 @@ static const int      SMALLSV_MER       = 10;    // SVCandidateAssemblyRefiner.c
 static const unsigned SCHED_TABLE_BYTES = 4096;  // per wavefront: 10-mer table of contigs up to 512 bp lives in LDS
 static const unsigned SCHED_SEQ_BYTES   = 6144;  // ... and so do the contig and the reference window (staged with wide loads: the scans
                                                  // below read a byte per lane and 55 positions per round trip otherwise)
-static const unsigned SCHED_LDS_BYTES   = SCHED_TABLE_BYTES + SCHED_SEQ_BYTES;  // 10 KB per wavefront: 16 waves per CU
+static const unsigned SCHED_LDS_BYTES   = SCHED_TABLE_BYTES + SCHED_SEQ_BYTES + 768;  // (+ the pending bucket entries) 11 KB per wavefront: 12-14 waves per CU
 
 struct SmallSvCuts {
   int32_t leadingCut, trailingCut, maxLeadingCut, maxTrailingCut;  // :1912-1915
@@ -236,67 +236,174 @@ WV_DEV SmallSvTaskInfo scheduleSlot(const ScheduleParams& P, const unsigned slot
       break;
     }
   if (bucket < 0) bucket = int(P.n_e) - 1;  // longer than 64 x 32 columns: the widest kernel runs it in strips (align_kernels.hpp)
-  // lane 0 claims CIGAR space and files the task; the verdict is broadcast so that `info` stays wave-uniform
-  unsigned claimed = 0;
-  if (lane == 0) {
-    const unsigned long long cig = wv::atomic_add(P.cigar_used, (unsigned long long)(4ull * clen + 16));
-    if (cig + 4ull * clen + 16 <= P.cigar_cap) {
-      claimed = 1;
-      AlignTaskDev t;
-      t.query     = contigG;
-      t.ref1      = refG + adjLead;
-      t.ref2      = nullptr;
-      t.query_len = clen;
-      t.ref1_len  = unsigned(winLen);
-      t.ref2_len  = 0;
-      t.cigar_off = uint32_t(cig);
-      P.tasks[slot] = t;
-      const unsigned pos = wv::atomic_add(&P.bucket_count[bucket], 1u);
-      P.bucket_ids[size_t(bucket) * total + pos] = slot;
-      // atomic max of the window length via CAS loop
-      const unsigned slabLen = unsigned(alignSlabRefLen(1, int(P.e_set[bucket]), clen, unsigned(winLen)));
-      unsigned       cur     = wv::atomic_load(&P.bucket_maxref[bucket]);
-      while (cur < slabLen) {
-        const unsigned old = wv::atomic_cas(&P.bucket_maxref[bucket], cur, slabLen);
-        if (old == cur) break;
-        cur = old;
-      }
-    }
-  }
-  claimed = wv::first(claimed);
-  if (claimed)
-    info.bucket = bucket;
-  else
+  // The task's CIGAR region needs no allocator: contig texts do not overlap in the text arena, so neither do regions of 8 words
+  // per contig base starting at 8 x the text offset (a task takes 4 * length + 16 words, contigs here hold >= 10 bases).  (One
+  // bump-allocator atomic per contig on ONE address, next to one per locus for the work queue and one per contig for the bucket
+  // lists, was what this kernel's 0.9 ms consisted of: ~40 k same-address L2 atomics.)
+  const unsigned long long cig = 8ull * co.seq_off;
+  if (cig + 4ull * clen + 16 > P.cigar_cap) {
     info.status = 5;
+    return info;
+  }
+  if (lane == 0) {
+    AlignTaskDev t;
+    t.query     = contigG;
+    t.ref1      = refG + adjLead;
+    t.ref2      = nullptr;
+    t.query_len = clen;
+    t.ref1_len  = unsigned(winLen);
+    t.ref2_len  = 0;
+    t.cigar_off = uint32_t(cig);
+    P.tasks[slot] = t;
+  }
+  info.bucket = bucket;
   return info;
 }
+
+/// per-wave pending bucket entries (LDS): a bucket's list takes them eight at a time, with one atomic
+static const unsigned SCHED_PEND = 8;
+struct SchedPending {
+  uint32_t count[16];
+  uint32_t maxref[16];
+  uint32_t slot[16][SCHED_PEND];
+};
+WV_DEV void schedFlush(const ScheduleParams& P, SchedPending* pend, const unsigned bucket, const unsigned total)
+{
+  const unsigned n = pend->count[bucket];
+  if (n == 0) return;
+  unsigned pos = 0;
+  if (wv::lane() == 0) {
+    pos = wv::atomic_add(&P.bucket_count[bucket], n);
+    unsigned cur = wv::atomic_load(&P.bucket_maxref[bucket]);
+    const unsigned want = pend->maxref[bucket];
+    while (cur < want) {
+      const unsigned old = wv::atomic_cas(&P.bucket_maxref[bucket], cur, want);
+      if (old == cur) break;
+      cur = old;
+    }
+  }
+  pos = wv::first(pos);
+  if (unsigned(wv::lane()) < n) P.bucket_ids[size_t(bucket) * total + pos + unsigned(wv::lane())] = pend->slot[bucket][wv::lane()];
+  wv::sync();
+  if (wv::lane() == 0) {
+    pend->count[bucket]  = 0;
+    pend->maxref[bucket] = 0;
+  }
+  wv::sync();
+}
+
+static const unsigned SCHED_CHUNK = 4;  // loci per work-queue pop
 
 WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
 {
   const unsigned lane   = unsigned(wv::lane());
   uint32_t*      gtable = P.table_ws + size_t(wv::block()) * P.table_cap;
   uint32_t*      ltable = reinterpret_cast<uint32_t*>(wv::lds(SCHED_LDS_BYTES));
+  SchedPending*  pend   = reinterpret_cast<SchedPending*>(reinterpret_cast<char*>(ltable) + SCHED_TABLE_BYTES + SCHED_SEQ_BYTES);
   const unsigned total  = P.n_loci * P.max_assembly_count;
-  // the work unit is a LOCUS (most contig slots are empty; one queue pop per slot made the queue head the bottleneck)
+  if (lane < 16) {
+    pend->count[lane]  = 0;
+    pend->maxref[lane] = 0;
+  }
+  wv::sync();
+  // the work unit is a LOCUS (most contig slots are empty; one queue pop per slot made the queue head the bottleneck), popped
+  // SCHED_CHUNK at a time
   while (true) {
-    unsigned locus = 0;
-    if (lane == 0) locus = wv::atomic_add(P.counter, 1u);
-    locus = wv::first(locus);
-    if (locus >= P.n_loci) break;
-    const AsmLocusOut lo       = P.loci[locus];
-    const unsigned    nContigs = (lo.status == ASM_OK) ? lo.n_contigs : 0u;
-    // slots without a contig: one lane each
-    if (lane >= nContigs && lane < P.max_assembly_count) {
-      SmallSvTaskInfo none = {(lo.status != ASM_OK) ? 1 : 0, 0, 0, -1};
-      P.info[locus * P.max_assembly_count + lane] = none;
+    unsigned base = 0;
+    if (lane == 0) base = wv::atomic_add(P.counter, SCHED_CHUNK);
+    base = wv::first(base);
+    if (base >= P.n_loci) break;
+    const unsigned end = (base + SCHED_CHUNK < P.n_loci) ? base + SCHED_CHUNK : P.n_loci;
+    for (unsigned locus = base; locus < end; ++locus) {
+      const AsmLocusOut lo       = P.loci[locus];
+      const unsigned    nContigs = (lo.status == ASM_OK) ? lo.n_contigs : 0u;
+      // slots without a contig: one lane each
+      if (lane >= nContigs && lane < P.max_assembly_count) {
+        SmallSvTaskInfo none = {(lo.status != ASM_OK) ? 1 : 0, 0, 0, -1};
+        P.info[locus * P.max_assembly_count + lane] = none;
+      }
+      for (unsigned ci = 0; ci < nContigs; ++ci) {
+        const unsigned        slot = locus * P.max_assembly_count + ci;
+        const SmallSvTaskInfo info = scheduleSlot(P, slot, total, ltable, gtable);
+        wv::sync();  // single reconvergence point of every exit of scheduleSlot
+        if (lane == 0) P.info[slot] = info;
+        if (info.bucket >= 0) {
+          const unsigned b = unsigned(info.bucket);
+          if (lane == 0) {
+            const AlignTaskDev& t = P.tasks[slot];
+            const unsigned slabLen = unsigned(alignSlabRefLen(1, int(P.e_set[b]), t.query_len, t.ref1_len));
+            pend->slot[b][pend->count[b]] = slot;
+            pend->count[b] += 1;
+            if (slabLen > pend->maxref[b]) pend->maxref[b] = slabLen;
+          }
+          wv::sync();
+          if (pend->count[b] == SCHED_PEND) schedFlush(P, pend, b, total);
+        }
+        wv::sync();
+      }
     }
-    for (unsigned ci = 0; ci < nContigs; ++ci) {
-      const unsigned        slot = locus * P.max_assembly_count + ci;
-      const SmallSvTaskInfo info = scheduleSlot(P, slot, total, ltable, gtable);
-      wv::sync();  // single reconvergence point of every exit of scheduleSlot
-      if (lane == 0) P.info[slot] = info;
-      wv::sync();
+  }
+  for (unsigned b = 0; b < P.n_e; ++b) schedFlush(P, pend, b, total);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// bucket_sort_kernel: the tasks of an E bucket by descending reference length (counting sort over length / 8, one workgroup per
+// bucket).  align_pair_kernel runs the tasks of a bucket two at a time and both sweep the LONGER reference's rows: the 10-mer
+// trim leaves most windows at contig length + indel, but a spurious early 10-mer hit (one window in seven) leaves one three
+// times that -- paired at random, such a window would cost its partner as well (measured: 1.6 x the VALU instructions of the
+// bucket).  Longest first also keeps the launch's tail short.
+// ------------------------------------------------------------------------------------------------------------------
+static const unsigned BS_CLASSES = 512;
+struct BucketSortParams {
+  const AlignTaskDev* tasks;
+  const uint32_t*     ids_in;        ///< n_buckets * total
+  uint32_t*           ids_out;       ///< same layout
+  const uint32_t*     bucket_count;
+  uint32_t            total;
+  uint32_t            mask;          ///< buckets to sort (one workgroup per bucket; the others return at once)
+};
+WV_KERNEL_WG(4) void bucket_sort_kernel(const BucketSortParams P)
+{
+  const unsigned b = unsigned(wv::block_single());
+  if (!((P.mask >> b) & 1u)) return;
+  uint32_t*       hist = reinterpret_cast<uint32_t*>(wv::lds_single());
+  const unsigned  tw = unsigned(wv::wave_in_wg()), tn = unsigned(wv::wg_waves()), lane = unsigned(wv::lane());
+  const unsigned  tid = 64 * tw + lane, nt = 64 * tn;
+  const unsigned  n = P.bucket_count[b];
+  const uint32_t* in  = P.ids_in + size_t(b) * P.total;
+  uint32_t*       out = P.ids_out + size_t(b) * P.total;
+  auto cls = [&](const unsigned id) {
+    const unsigned c = P.tasks[id].ref1_len >> 3;
+    return (BS_CLASSES - 1) - ((c < BS_CLASSES - 1) ? c : (BS_CLASSES - 1));
+  };
+  for (unsigned i = tid; i < BS_CLASSES; i += nt) hist[i] = 0;
+  wv::sync();
+  wv::wg_barrier();
+  for (unsigned i = tid; i < n; i += nt) wv::atomic_add(&hist[cls(in[i])], 1u);
+  wv::sync();
+  wv::wg_barrier();
+  if (tw == 0) {  // exclusive prefix over the classes: 8 per lane
+    unsigned v[8], sum = 0;
+    for (int j = 0; j < 8; ++j) {
+      v[j] = hist[8 * lane + j];
+      sum += v[j];
     }
+    unsigned inc = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = wv::shfl(inc, int(lane) - off);
+      if (int(lane) >= off) inc += o;
+    }
+    unsigned run = inc - sum;
+    for (int j = 0; j < 8; ++j) {
+      hist[8 * lane + j] = run;
+      run += v[j];
+    }
+  }
+  wv::sync();
+  wv::wg_barrier();
+  for (unsigned i = tid; i < n; i += nt) {
+    const unsigned id = in[i];
+    out[wv::atomic_add(&hist[cls(id)], 1u)] = id;
   }
 }
 

@@ -3,7 +3,7 @@
 # and PMC passes (each counter group in its own run; never combined with sys/hip/hsa traces).  Every step has its own
 # timeout.  Outputs land in gpurun_out/; tools/summarize_profiles.py turns them into the files under profiles/.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
@@ -23,19 +23,6 @@ unset MANTA_AMD_NO_STREAM_UPLOAD
 fi
 # one plain kernel trace of the default step: every dispatch with its start / end (the gaps are the host turnarounds)
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_step -o t -- $B --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
-# the opt-in LDS-resident fast assembler (asm_fast.hpp), same passes (evidence for DESIGN.md: traffic vs time); PROFILE_SKIP_FAST=1 leaves them out
-if [ -z "$PROFILE_SKIP_FAST" ] && [ -z "$PROFILE_LINES_ONLY" ]; then
-export MANTA_AMD_ASM_PATH=fast
-mkdir -p $O/fast
-timeout 300 $B --no-cpu-baseline --no-extras > $O/fast/bench_line.json 2> $O/fast/bench.err
-export MANTA_AMD_NO_STREAM_UPLOAD=1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fast/pmc_fetch -o p -- $B $P > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/fast/pmc_write -o p -- $B $P > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/fast/pmc_sq -o p -- $B $P > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/fast/pmc_sq2 -o p -- $B $P > /dev/null 2>&1
-unset MANTA_AMD_NO_STREAM_UPLOAD
-unset MANTA_AMD_ASM_PATH
-fi
 if [ "$2" = "spanning" ]; then
   timeout 600 $B --workload spanning --steps 2 --warmup 1 > $O/bench_spanning_line.json 2> $O/bench_spanning.err
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_spanning -o bench -- $B --workload spanning --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1

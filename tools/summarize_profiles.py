@@ -4,7 +4,7 @@ rocprofv3 kernel-stats table, one PMC row per kernel, and profiles/traffic.json 
 reports as roofline.traffic)."""
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 
@@ -39,30 +39,6 @@ if trace:
             a, b = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
             out.write('"%s",%.3f,%.3f,%.3f,%s,%s,%s,%s\n' % (short(r["Kernel_Name"]), a, b, b - a, r.get("Stream_Id", ""), r.get("LDS_Block_Size", ""),
                                                             r.get("VGPR_Count", ""), r.get("Scratch_Size", "")))
-# the opt-in fast assembler's lines and counters (tools/profile_round.sh: MANTA_AMD_ASM_PATH=fast)
-fl = os.path.join(src, "fast", "bench_line.json")
-if os.path.exists(fl) and os.path.getsize(fl):
-    open(os.path.join(dst, tag + "_fast_path_bench_line.json"), "w").write(open(fl).read().strip().splitlines()[-1] + "\n")
-fper, flaunch = {}, {}
-for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
-    for f in glob.glob(os.path.join(src, "fast", d, "**", "*counter_collection.csv"), recursive=True):
-        seen = {}
-        for row in csv.DictReader(open(f)):
-            k = short(row["Kernel_Name"])
-            if "rocclr" in k:
-                continue
-            fper.setdefault(k, {}).setdefault(row["Counter_Name"], 0.0)
-            fper[k][row["Counter_Name"]] += float(row["Counter_Value"])
-            seen.setdefault(k, set()).add(row.get("Dispatch_Id", row.get("Correlation_Id", "")))
-        for k, ids in seen.items():
-            flaunch[k] = max(flaunch.get(k, 0), len(ids))
-if fper:
-    fcols = sorted({c for v in fper.values() for c in v})
-    with open(os.path.join(dst, tag + "_fast_path_pmc_summary.csv"), "w") as out:
-        out.write("# same passes with MANTA_AMD_ASM_PATH=fast (assemble_fast_kernel + the general kernel for its punts)\n")
-        out.write("kernel,launches," + ",".join(fcols) + "\n")
-        for k in sorted(fper):
-            out.write('"%s",%d,' % (k, flaunch.get(k, 1)) + ",".join("%.0f" % fper[k].get(c, 0) for c in fcols) + "\n")
 per, launches = {}, {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     for f in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
@@ -90,13 +66,23 @@ with open(os.path.join(dst, tag + "_pmc_summary.csv"), "w") as out:
         out.write('"%s",%d,' % (k, launches.get(k, 1)) + ",".join("%.0f" % per[k].get(c, 0) for c in cols) + "\n")
 traffic = {"loci": 10000, "workload": "smallsv", "source": "tools/profile_round.sh " + tag + " (builder-run counter passes, not the driver's run)",
            "date": __import__("datetime").date.today().isoformat(),
-           "note": "HBM-side bytes per launch = (FETCH_SIZE + WRITE_SIZE) KiB * 1024 / launches, rocprofv3 --pmc, separate passes, raw "
-                   "(no gfx950 x2 read correction: narrow scattered reads); align_kernel: the E-bucket launches of one block together"}
+           "note": "HBM-side bytes of ONE step (one block of 10 000 loci) = (FETCH_SIZE + WRITE_SIZE) KiB * 1024 summed over the step's launches of the "
+                   "kernel(s), rocprofv3 --pmc, separate passes; graph_kernel's FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads), "
+                   "everything else raw; assembler_stage = graph_kernel + contig_kernel launches (+ assemble_kernel's launch for punted loci)"}
 agg = {}
 for k, v in per.items():
-    name = "align_kernel<LARGE_INDEL>" if k.startswith("align_kernel<1") else k
-    n = 1 if name.startswith("align_kernel") else max(1, launches.get(k, 1))
-    agg[name] = agg.get(name, 0) + (v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 / n
+    if k.startswith("align_kernel<1") or k.startswith("align_pair_kernel"):
+        name = "align_kernel<LARGE_INDEL>"  # (the E-bucket launches of a block, packed pairs or not, together)
+    elif k.startswith("graph_kernel") or k.startswith("contig_kernel") or k.startswith("assemble_kernel"):
+        name = "assembler_stage"  # graph_kernel + contig_kernel (+ the general kernel's launch for punted loci): what bench.py times as the assembler
+    else:
+        name = k
+    # graph_kernel reads the pile with 16-byte-per-lane coalesced loads: FETCH_SIZE reports half of such bytes on gfx950
+    # (MI355X_MICROARCH.md, HBM section) -> doubled; every other counter raw
+    fetch = v.get("FETCH_SIZE", 0) * (2 if k.startswith("graph_kernel") else 1)
+    agg[name] = agg.get(name, 0) + (fetch + v.get("WRITE_SIZE", 0)) * 1024
+    if k.startswith("graph_kernel") or k.startswith("contig_kernel"):
+        traffic[k.split("<")[0]] = int(traffic.get(k.split("<")[0], 0) + (fetch + v.get("WRITE_SIZE", 0)) * 1024)
 for k, v in agg.items():
     traffic[k] = int(v)
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
