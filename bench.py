@@ -547,6 +547,21 @@ def main():
                                  "note": "read piles as 2-bit codes + N bitmap (manta_packed_piles_t, 0.375 B/base) instead of 1 B/base; "
                                          "same timed region; results identical to the default run"}
         # ---- CPU baseline: the reference's own sources (oracle/_ref) on this box's host cores ----
+        # ---- the candidate-level rate (extra key): SVCandidateAssemblyRefiner::getCandidateAssemblyDataBatch, the C++ host adapter a
+        # GenerateSVCandidates process would call, on 10 000 config-2 shaped complex candidates: reference and read
+        # callbacks, packing, the device batch, the per-candidate host glue (tools/cpp/perf_refiner.cpp, built by __graft_entry__.build())
+        exe = os.path.join(ROOT, "tools", "cpp", "perf_refiner")
+        if (not spanning and world == 1 and not args.no_extras and os.path.exists(exe)
+                and os.path.abspath(lib.path) == os.path.join(ROOT, "manta_amd", "libmanta_amd.so")):
+            try:
+                pr = subprocess.run([exe, "10000", "0"], capture_output=True, text=True, timeout=600)
+                rows = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+                if pr.returncode == 0 and rows:
+                    o["refiner_batch"] = json.loads(rows[-1])
+                else:
+                    o["refiner_batch"] = {"error": (pr.stderr or pr.stdout)[-300:]}
+            except Exception as e:  # (an extra leg never takes the line down)
+                o["refiner_batch"] = {"error": str(e)[-300:]}
         if world == 1 and not args.no_cpu_baseline:
             cores = cores_available()
             kind, cpu = ("reference", RefLib()) if have_ref() else ("port", orc)

@@ -1951,7 +1951,9 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     uint32_t*        dBuckets = b->dBucketIds.as<uint32_t>(nSlots * kNumESet);
     uint32_t*        dSmall   = b->dSmall.as<uint32_t>(64);  // [0..11] counts, [16..27] maxref, [32] sched counter, [34..35] cigar_used, [40..51] align counters
     const uint32_t   tableCap = nextPow2(2ull * as.maxContigLen);
-    const int        schedGrid = rt::roundGrid(int(std::min<uint64_t>(nLoci, uint64_t(std::max(1, ctx->cuCount * 32)))));
+    const int        schedWaves = std::getenv("MANTA_AMD_SCHED_WAVES_PER_CU") ? std::max(1, std::atoi(std::getenv("MANTA_AMD_SCHED_WAVES_PER_CU"))) : 12;
+    const uint32_t   schedChunk = std::getenv("MANTA_AMD_SCHED_CHUNK") ? uint32_t(std::max(1, std::atoi(std::getenv("MANTA_AMD_SCHED_CHUNK")))) : 2u;
+    const int        schedGrid = rt::roundGrid(int(std::min<uint64_t>((nLoci + schedChunk - 1) / schedChunk, uint64_t(std::max(1, ctx->cuCount * schedWaves)))));
     uint32_t*        dTable   = b->dTable.as<uint32_t>(uint64_t(tableCap) * schedGrid);
     rt::dzero(dSmall, sizeof(uint32_t) * 64);
     rt::dzero(dResults, sizeof(AlignResultDev) * nSlots);
@@ -2016,6 +2018,7 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     S.table_ws           = dTable;
     S.table_cap          = tableCap;
     S.n_e                = kNumESet;
+    S.chunk              = schedChunk;
     for (int i = 0; i < kNumESet; ++i) S.e_set[i] = uint32_t(kESet[i]);
     rt::launch(smallsv_schedule_kernel, schedGrid, SCHED_LDS_BYTES, S);
     // the pair-eligible buckets by descending reference length (bucket_sort_kernel): their align kernels read the sorted lists

@@ -13,7 +13,7 @@ static const int      SMALLSV_MER       = 10;    // SVCandidateAssemblyRefiner.c
 static const unsigned SCHED_TABLE_BYTES = 4096;  // per wavefront: 10-mer table of contigs up to 512 bp lives in LDS
 static const unsigned SCHED_SEQ_BYTES   = 6144;  // ... and so do the contig and the reference window (staged with wide loads: the scans
                                                  // below read a byte per lane and 55 positions per round trip otherwise)
-static const unsigned SCHED_LDS_BYTES   = SCHED_TABLE_BYTES + SCHED_SEQ_BYTES + 768;  // (+ the pending bucket entries) 11 KB per wavefront: 12-14 waves per CU
+static const unsigned SCHED_LDS_BYTES   = SCHED_TABLE_BYTES + SCHED_SEQ_BYTES + 1024;  // (+ the pending bucket entries) 11 KB per wavefront: 12-14 waves per CU
 
 struct SmallSvCuts {
   int32_t leadingCut, trailingCut, maxLeadingCut, maxTrailingCut;  // :1912-1915
@@ -51,6 +51,7 @@ struct ScheduleParams {
   // E set
   uint32_t e_set[16];
   uint32_t n_e;
+  uint32_t chunk;  // loci per work-queue pop (smallsv_schedule_kernel)
 };
 
 WV_DEV unsigned merCode(const uint8_t* p, bool& valid)
@@ -179,44 +180,42 @@ WV_DEV SmallSvTaskInfo scheduleSlot(const ScheduleParams& P, const unsigned slot
   const int minRefIndex    = cuts.leadingCut;
   const int maxRefIndex    = refSize - (cuts.trailingCut + SMALLSV_MER);
   const int maxFwdRefIndex = (cuts.maxLeadingCut < maxRefIndex) ? cuts.maxLeadingCut : maxRefIndex;
-  // first hit scanning forward (:1997-2001)
+  // first hit scanning forward (:1997-2001) and last hit scanning backward (:2004-2008, windows of 55 start positions, highest
+  // window first), one window of each per round: the two scans are independent, so their lane shuffles and table probes overlap
   int adjLead = maxFwdRefIndex + 1;
   if (adjLead < minRefIndex) adjLead = minRefIndex;  // empty scan range: the loop variable keeps its initial value
-  {
-    // the next batch's bases are requested before this batch is looked up (one memory round trip per batch otherwise)
-    unsigned cNext = merLoadBase(ref, refSize, minRefIndex);
-    for (int base = minRefIndex; base <= maxFwdRefIndex; base += MER_BATCH) {
-      const unsigned c = cNext;
-      cNext            = merLoadBase(ref, refSize, base + MER_BATCH);
-      bool           valid;
-      const unsigned code = merCodesFromBase(c, valid);
-      const int      i    = base + int(lane);
-      const bool     hit  = valid && i <= maxFwdRefIndex && merLookup(table, mask, code);
-      const uint64_t m    = wv::ballot(hit);
-      if (m) {
-        adjLead = base + wv::ctz(m);
-        break;
-      }
-    }
-  }
-  // last hit scanning backward (:2004-2008): windows of 55 start positions, highest window first
   const int minRevRefIndex = (minRefIndex > refSize - cuts.maxTrailingCut) ? minRefIndex : (refSize - cuts.maxTrailingCut);
   int       revIndex       = minRevRefIndex - 1;
   if (revIndex > maxRefIndex) revIndex = maxRefIndex;  // empty scan range
   {
-    unsigned cNext = merLoadBase(ref, refSize, maxRefIndex - (MER_BATCH - 1));
-    for (int top = maxRefIndex; top >= minRevRefIndex; top -= MER_BATCH) {
-      const int      base = top - (MER_BATCH - 1);
-      const unsigned c    = cNext;
-      cNext               = merLoadBase(ref, refSize, base - MER_BATCH);
-      bool           valid;
-      const unsigned code = merCodesFromBase(c, valid);
-      const int      i    = base + int(lane);
-      const bool     hit  = valid && i >= minRevRefIndex && i <= top && merLookup(table, mask, code);
-      const uint64_t m    = wv::ballot(hit);
-      if (m) {
-        revIndex = base + (63 - wv::clz(m));
-        break;
+    int  fBase = minRefIndex, bTop = maxRefIndex;
+    bool fDone = fBase > maxFwdRefIndex, bDone = bTop < minRevRefIndex;
+    while (!fDone || !bDone) {
+      const int      bBase = bTop - (MER_BATCH - 1);
+      const unsigned cf = merLoadBase(ref, refSize, fDone ? -1000 : fBase), cb = merLoadBase(ref, refSize, bDone ? -1000 : bBase);
+      bool           vf, vb;
+      const unsigned codeF = merCodesFromBase(cf, vf), codeB = merCodesFromBase(cb, vb);
+      const int      iF = fBase + int(lane), iB = bBase + int(lane);
+      const bool     hitF = !fDone && vf && iF <= maxFwdRefIndex && merLookup(table, mask, codeF);
+      const bool     hitB = !bDone && vb && iB >= minRevRefIndex && iB <= bTop && merLookup(table, mask, codeB);
+      const uint64_t mF = wv::ballot(hitF), mB = wv::ballot(hitB);
+      if (!fDone) {
+        if (mF) {
+          adjLead = fBase + wv::ctz(mF);
+          fDone   = true;
+        } else {
+          fBase += MER_BATCH;
+          fDone = fBase > maxFwdRefIndex;
+        }
+      }
+      if (!bDone) {
+        if (mB) {
+          revIndex = bBase + (63 - wv::clz(mB));
+          bDone    = true;
+        } else {
+          bTop -= MER_BATCH;
+          bDone = bTop < minRevRefIndex;
+        }
       }
     }
   }
@@ -266,6 +265,7 @@ struct SchedPending {
   uint32_t count[16];
   uint32_t maxref[16];
   uint32_t slot[16][SCHED_PEND];
+  uint32_t cigarWords;  ///< upper bound of the CIGAR words of this wave's tasks (manta_smallsv_output_sizes reports the kernel's total)
 };
 WV_DEV void schedFlush(const ScheduleParams& P, SchedPending* pend, const unsigned bucket, const unsigned total)
 {
@@ -292,8 +292,6 @@ WV_DEV void schedFlush(const ScheduleParams& P, SchedPending* pend, const unsign
   wv::sync();
 }
 
-static const unsigned SCHED_CHUNK = 4;  // loci per work-queue pop
-
 WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
 {
   const unsigned lane   = unsigned(wv::lane());
@@ -305,15 +303,16 @@ WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
     pend->count[lane]  = 0;
     pend->maxref[lane] = 0;
   }
+  if (lane == 0) pend->cigarWords = 0;
   wv::sync();
   // the work unit is a LOCUS (most contig slots are empty; one queue pop per slot made the queue head the bottleneck), popped
-  // SCHED_CHUNK at a time
+  // P.chunk at a time
   while (true) {
     unsigned base = 0;
-    if (lane == 0) base = wv::atomic_add(P.counter, SCHED_CHUNK);
+    if (lane == 0) base = wv::atomic_add(P.counter, P.chunk);
     base = wv::first(base);
     if (base >= P.n_loci) break;
-    const unsigned end = (base + SCHED_CHUNK < P.n_loci) ? base + SCHED_CHUNK : P.n_loci;
+    const unsigned end = (base + P.chunk < P.n_loci) ? base + P.chunk : P.n_loci;
     for (unsigned locus = base; locus < end; ++locus) {
       const AsmLocusOut lo       = P.loci[locus];
       const unsigned    nContigs = (lo.status == ASM_OK) ? lo.n_contigs : 0u;
@@ -334,6 +333,7 @@ WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
             const unsigned slabLen = unsigned(alignSlabRefLen(1, int(P.e_set[b]), t.query_len, t.ref1_len));
             pend->slot[b][pend->count[b]] = slot;
             pend->count[b] += 1;
+            pend->cigarWords += 4 * t.query_len + 16;
             if (slabLen > pend->maxref[b]) pend->maxref[b] = slabLen;
           }
           wv::sync();
@@ -344,6 +344,7 @@ WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
     }
   }
   for (unsigned b = 0; b < P.n_e; ++b) schedFlush(P, pend, b, total);
+  if (lane == 0 && pend->cigarWords) wv::atomic_add(P.cigar_used, (unsigned long long)pend->cigarWords);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

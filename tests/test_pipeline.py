@@ -23,6 +23,14 @@ def test_emulated_pipeline_small(emu, oracle):
     _run(emu, oracle, loci, asm_opts(minWordLength=21, maxWordLength=41), (40, 40, 200, 200))
 
 
+def test_emulated_pipeline_output_sizes_cover_many_contigs(emu, oracle):
+    """the staged download sizes the caller's arenas from manta_smallsv_output_sizes: the CIGAR bound must hold for batches whose
+    CIGARs add up to more than a handful of words (round 4: the schedule kernel's allocator went away, its total must not)"""
+    loci = [small_indel_locus(100 + s, n_reads=20, read_len=50, ref_len=400, sub_rate=0.02) for s in range(40)]
+    st = _run(emu, oracle, loci, asm_opts(minWordLength=15, maxWordLength=25), (20, 20, 150, 150))
+    assert st["n_alignments"] >= 40
+
+
 def test_emulated_pipeline_no_trim_hit_and_edges(emu, oracle):
     """reference windows unrelated to the reads (no 10-mer hit): the trim falls back to its loop bounds"""
     loci = [(small_indel_locus(1, n_reads=20, read_len=50, ref_len=400)[0], small_indel_locus(2, ref_len=400)[1]),
