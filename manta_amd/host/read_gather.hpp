@@ -14,17 +14,56 @@
 //         bamStream.resetRegion(tid, batch.searchBegin(), batch.searchEnd());
 //         while (bamStream.next()) batch.addRecord(*bamStream.get_record_ptr()->get_data(), isSASplit, mateCigarOrNull);
 //     batch.run(ctx, options);   // -> piles() in manta_packed_piles_t layout, decisions(), results()
+//     batch.retrieveRemoteReads(fetcher, options);   // complex candidates searched with isSearchRemoteInsertionReads (:570-655)
 //
 // addRecord takes the htslib bam1_t fields as plain values so that this header does not depend on htslib.
+//
+// Remote mates (retrieveRemoteReads, :141-256).  The kernel flags the records whose mates the reference would look up
+// (MANTA_READ_REMOTE_MATE) and reports isRetrieveRemoteReads per candidate; the look-ups are BAM seeks, i.e. the caller's
+// bam_streamer, reached through RemoteMateFetcher.  Everything between the flags and the final pile is here: the target list per
+// file (RemoteMateReadUtil.hpp:39-71), its sort and the merge into region queries (:154-185), the scan of a region with the
+// (read number, name) match, the MAPQ-0 rule, the orientation rule and insertAssemblyRead's read index (:205-250) -- the mates go
+// behind the candidate's local reads exactly as the reference appends them.
 #pragma once
+#include <algorithm>
 #include <cctype>
 #include <cstring>
+#include <functional>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "manta_amd.hpp"
+#include "read_pile.hpp"
 
 namespace manta_amd {
+
+/// one record of a remote region query, as addRecord takes them
+struct RemoteRecord {
+  int32_t        pos  = 0;  ///< bam1_core_t::pos (0-based)
+  uint16_t       flag = 0;
+  uint8_t        mapq = 0;
+  const char*    qname = nullptr;
+  const uint8_t* seq4  = nullptr;
+  const uint8_t* qual  = nullptr;
+  uint32_t       lQseq = 0;
+  bool           hasSA = false;  ///< bam_record::isSASplit
+};
+
+/// the caller's BAM layer: `bamStream.resetRegion(tid, begin, end); while (bamStream.next()) ...` on file `bamIndex`
+/// (SVCandidateAssembler.cpp:205-207).  Hands the records to `sink` in file order and stops when it returns false.
+struct RemoteMateFetcher {
+  virtual ~RemoteMateFetcher() {}
+  virtual void scanRegion(uint32_t bamIndex, int32_t tid, int32_t begin, int32_t end, const std::function<bool(const RemoteRecord&)>& sink) = 0;
+};
+
+/// what the reference keeps in its RemoteReadCache for PE scoring (:241)
+struct RemoteReadCacheEntry {
+  uint32_t    candidate;
+  std::string qname;
+  int         readNo;
+  uint64_t    pileRead;  ///< index into finalPiles()
+};
 
 struct ReadGatherBatch {
   std::vector<manta_read_locus_t>        loci;
@@ -181,7 +220,124 @@ struct ReadGatherBatch {
         pileRead.data(), n, &readsUsed, locusReadBegin.data());
     if (rc != MANTA_OK && rc != MANTA_E_UNSUPPORTED) throw GeneralException(std::string("manta_amd read gathering: ") + manta_last_error(ctx), rc);
     _nPileReads = readsUsed;
+    _haveFinal  = false;
   }
+
+  /// The reference's tail of getBreakendReads (:570-655) for every candidate added with isSearchRemote whose result says
+  /// retrieve_remote.  Afterwards finalPiles() / finalPileReadText() / finalLocusReadBegin() describe the piles with the mates
+  /// appended (identical to piles() when nothing was fetched); a candidate whose mate holds the BAM code '=' gets status
+  /// MANTA_E_UNSUPPORTED like a local read would.
+  void retrieveRemoteReads(RemoteMateFetcher& fetcher, const manta_read_class_options_t& opt)
+  {
+    const unsigned maxNumReads = opt.max_reads ? opt.max_reads : 1000u;  // :342
+    _final.clear();
+    remoteCache.clear();
+    nRemoteTargets = nRemoteInserted = 0;
+    struct Target {  // RemoteReadInfo
+      std::string qname;
+      int         readNo, tid, pos, readSize;
+      bool        isFound;
+    };
+    for (size_t l = 0; l < loci.size(); ++l) {
+      // the candidate's local reads, as the device packed them
+      for (uint32_t r = locusReadBegin[l]; r < locusReadBegin[l + 1]; ++r) copyPileRead(r);
+      if (loci[l].search_remote && results[l].retrieve_remote && results[l].status == MANTA_OK) {
+        uint32_t nBam = 0;
+        for (uint32_t s = loci[l].scan_begin; s < loci[l].scan_end; ++s) nBam = std::max(nBam, scans[s].bam_index + 1);
+        std::unordered_set<std::string> readIndex;  // insertAssemblyRead's keys of what is in the pile (:108-119)
+        bool                            haveIndex = false;
+        for (uint32_t bamIndex = 0; bamIndex < nBam; ++bamIndex) {  // :620
+          std::vector<Target> remotes;
+          bool                isLocusReversed = false;
+          for (uint32_t s = loci[l].scan_begin; s < loci[l].scan_end; ++s) {
+            if (scans[s].bam_index != bamIndex) continue;
+            isLocusReversed = scans[s].is_locus_reversed != 0;
+            for (uint32_t i = scans[s].read_begin; i < scans[s].read_end; ++i) {
+              if (!(decision[i] & MANTA_READ_REMOTE_MATE)) continue;
+              const manta_bam_read_t& r(reads[i]);
+              remotes.push_back(Target{std::string(reinterpret_cast<const char*>(names.data()) + r.qname_off, r.qname_len),
+                                       (recordReadNo(r.flag) == 1) ? 2 : 1, r.mate_tid, r.mate_pos, int(r.read_len), false});
+            }
+          }
+          if (remotes.empty()) continue;
+          nRemoteTargets += remotes.size();
+          if (!haveIndex) {
+            for (uint32_t s = loci[l].scan_begin; s < loci[l].scan_end; ++s)
+              for (uint32_t i = scans[s].read_begin; i < scans[s].read_end; ++i)
+                if (decision[i] & MANTA_READ_IN_PILE) readIndex.insert(readKey(reads[i], scans[s].bam_index));
+            haveIndex = true;
+          }
+          std::sort(remotes.begin(), remotes.end(), [](const Target& a, const Target& b) {  // RemoteMateReadUtil.hpp:53-60
+            if (a.tid < b.tid) return true;
+            if (a.tid == b.tid) return a.pos < b.pos;
+            return false;
+          });
+          struct Region {
+            int    tid, begin, end;
+            size_t first, last;  // targets [first, last)
+          };
+          std::vector<Region> regions;
+          int                 lastTid = -1, lastPos = -1;
+          for (size_t t = 0; t < remotes.size(); ++t) {  // :162-185
+            if (lastTid == remotes[t].tid && lastPos + remotes[t].readSize >= remotes[t].pos) {
+              regions.back().end  = remotes[t].pos;
+              regions.back().last = t + 1;
+            } else {
+              regions.push_back(Region{remotes[t].tid, remotes[t].pos, remotes[t].pos, t, t + 1});
+            }
+            lastTid = remotes[t].tid;
+            lastPos = remotes[t].pos;
+          }
+          for (const Region& g : regions) {
+            const int lastTargetPos = remotes[g.last - 1].pos;
+            fetcher.scanRegion(bamIndex, g.tid, g.begin, g.end + 1, [&](const RemoteRecord& rec) -> bool {
+              if (_final.nReads() - _final.locusBegin.back() >= maxNumReads) return false;  // :208
+              if (rec.pos + 1 > lastTargetPos + 1) return false;                           // :219 (bam_record::pos() is 1-based)
+              if ((rec.flag & 0x800u) || ((rec.flag & 0x100u) && rec.hasSA)) return true;  // isNonStrictSupplement
+              for (size_t t = g.first; t < g.last; ++t) {
+                Target& remote(remotes[t]);
+                if (remote.isFound) continue;
+                if (recordReadNo(rec.flag) != remote.readNo) continue;
+                if (std::strcmp(rec.qname, remote.qname.c_str()) != 0) continue;
+                remote.isFound = true;
+                if (rec.mapq != 0) break;
+                bool isReversed = isLocusReversed;
+                if (!(rec.flag & 0x10u) == !(rec.flag & 0x20u)) isReversed = !isReversed;  // :231-234
+                const std::string key = std::string(rec.qname) + "_" + ((rec.flag & 0x80u) ? '2' : '1') + "_" + std::to_string(bamIndex);
+                if (!readIndex.insert(key).second) break;  // name collision (:112-119)
+                if (!_final.addBamRead(rec.seq4, rec.qual, rec.lQseq, uint8_t(opt.min_qval), isReversed)) {
+                  results[l].status = MANTA_E_UNSUPPORTED;
+                  break;
+                }
+                remoteCache.push_back(RemoteReadCacheEntry{uint32_t(l), remote.qname, recordReadNo(rec.flag), uint64_t(_final.nReads() - 1)});
+                ++nRemoteInserted;
+                break;
+              }
+              return true;
+            });
+          }
+        }
+      }
+      _final.endLocus();
+    }
+    _haveFinal = true;
+  }
+
+  /// piles with the remote mates appended (retrieveRemoteReads), else the device piles
+  manta_packed_piles_t finalPiles() const { return _haveFinal ? _final.view() : piles(); }
+  uint64_t             nFinalPileReads() const { return _haveFinal ? _final.nReads() : _nPileReads; }
+  uint32_t             finalLocusReadBegin(const size_t l) const { return _haveFinal ? _final.locusBegin[l] : locusReadBegin[l]; }
+  std::string          finalPileReadText(const uint64_t r) const
+  {
+    if (!_haveFinal) return pileReadText(r);
+    std::string s(_final.readLen[r], 'N');
+    for (uint32_t i = 0; i < _final.readLen[r]; ++i)
+      if (!((_final.nmask[_final.maskOff[r] + (i >> 5)] >> (i & 31)) & 1u))
+        s[i] = "ACGT"[(_final.codes[_final.codeOff[r] + (i >> 4)] >> (30 - 2 * (i & 15))) & 3u];
+    return s;
+  }
+  std::vector<RemoteReadCacheEntry> remoteCache;
+  uint64_t                          nRemoteTargets = 0, nRemoteInserted = 0;
 
   manta_packed_piles_t piles() const
   {
@@ -206,8 +362,24 @@ struct ReadGatherBatch {
   }
 
 private:
-  int32_t  _searchBegin = 0, _searchEnd = 0;
-  uint64_t _nPileReads  = 0;
+  static int recordReadNo(const uint16_t flag) { return ((flag & 0x80u) && !(flag & 0x40u)) ? 2 : 1; }  // bam_record::read_no
+  std::string readKey(const manta_bam_read_t& r, const uint32_t bamIndex) const
+  {
+    return std::string(reinterpret_cast<const char*>(names.data()) + r.qname_off, r.qname_len) + "_" + ((r.flag & 0x80u) ? '2' : '1') + "_" +
+           std::to_string(bamIndex);
+  }
+  void copyPileRead(const uint64_t r)
+  {
+    _final.codes.insert(_final.codes.end(), codes.begin() + long(codeOff[r]), codes.begin() + long(codeOff[r] + (readLen[r] + 15) / 16));
+    _final.nmask.insert(_final.nmask.end(), nmask.begin() + long(maskOff[r]), nmask.begin() + long(maskOff[r] + (readLen[r] + 31) / 32));
+    _final.readLen.push_back(readLen[r]);
+    _final.codeOff.push_back(_final.codes.size());
+    _final.maskOff.push_back(_final.nmask.size());
+  }
+  int32_t         _searchBegin = 0, _searchEnd = 0;
+  uint64_t        _nPileReads  = 0;
+  ReadPileBuilder _final;
+  bool            _haveFinal = false;
 };
 
 }  // namespace manta_amd

@@ -7,6 +7,7 @@
 //     other _ref libraries),
 //   * SVLocusScanner's constructor (alignment statistics file, boost serialization) -> empty object; getBreakendReads never
 //     consults it (grep _readScanner manta/SVCandidateAssembler.cpp).
+#include <algorithm>
 #include <map>
 #include <set>
 
@@ -255,6 +256,7 @@ REF_EXPORT int ref_breakend_pile(
     g_captured = &pile;
     Assembly                 as;
     reference_contig_segment r1, r2;
+    RemoteReadCache          remote;
     if (state2 >= 0) {
       bp2.interval = GenomeInterval(tid2, begin2, end2);
       bp2.state    = static_cast<SVBreakendState::index_t>(state2);
@@ -275,12 +277,17 @@ REF_EXPORT int ref_breakend_pile(
     } else {
       static const pos_t extraRefEdgeSize(700);
       getIntervalReferenceSegment(fastaPath, header, extraRefEdgeSize, bp1.interval, r1);
-      RemoteReadCache remote;
       assembler.assembleComplexSVCandidate(bp1, r1, isSearchRemote != 0, remote, as);
     }
     g_captured = nullptr;
     os << "reads " << pile.size() << "\n";
     for (const std::string& r : pile) os << r << "\n";
+    {  // the RemoteReadCache retrieveRemoteReads filled (SVCandidateAssembler.cpp:241), by name
+      std::vector<std::string> keys;
+      for (const auto& kv : remote) keys.push_back(kv.first);
+      std::sort(keys.begin(), keys.end());
+      for (const std::string& k : keys) os << "remote " << k << " " << int(remote[k].readNo) << " " << remote[k].readSeq << "\n";
+    }
     os << "ref1 " << r1.get_offset() << " " << r1.seq() << "\n";
     os << "ref2 " << r2.get_offset() << " " << r2.seq() << "\n";
     os << "maxdepth " << (scanOpt.maxDepthFactor) << " " << scanOpt.maxLocalDepthFactorForRemoteReadRetrieval << "\n";

@@ -351,12 +351,73 @@ class RefBam:
         lines = self.buf.value.decode().splitlines()
         assert lines and lines[0].startswith("reads "), lines[:1]
         n_reads = int(lines[0].split()[1])
-        out = dict(reads=lines[1:1 + n_reads])
+        out = dict(reads=lines[1:1 + n_reads], remote=[])
         for l in lines[1 + n_reads:]:
             f = l.split(" ")
             if f[0] in ("ref1", "ref2"):
                 out[f[0]] = (int(f[1]), f[2] if len(f) > 2 else "")
+            elif f[0] == "remote":  # the RemoteReadCache, by name: qname, read number, read
+                out["remote"].append(" ".join(f[1:]))
         return out
+
+
+class GatherLib:
+    """tests/cpp/host_gather_capi.cpp: manta_amd/host/read_gather.hpp (ReadGatherBatch + remote-mate retrieval) for Python"""
+    SCAN_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32)
+
+    def __init__(self, lib_dir, lib_name, tag):
+        import subprocess
+        cpp = os.path.join(ROOT, "tests", "cpp")
+        so = os.path.join(cpp, "libhost_gather_%s.so" % tag)
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "manta_amd", "host"), os.path.join(cpp, "host_gather_capi.cpp"), "-o", so,
+                               "-L" + lib_dir, "-l" + lib_name, "-Wl,-rpath," + lib_dir])
+        self.lib = ctypes.CDLL(so)
+        self.lib.rg_new.restype = ctypes.c_void_p
+        self.lib.rg_counts.restype = ctypes.c_ulonglong
+        self.buf = ctypes.create_string_buffer(1 << 24)
+
+    def gather(self, candidates, opt, fetch):
+        """candidates: [dict(scans, is_max_depth, search_remote, max_depth, max_local)] with scans as Batch.add_locus takes them;
+        fetch(bam_index, tid, begin, end) -> records of that region query.  -> [dict(status, pile, cache)], dict(queries, targets, inserted)"""
+        L, c = self.lib, ctypes
+        h = c.c_void_p(L.rg_new())
+        try:
+            for cand in candidates:
+                L.rg_begin_candidate(h, int(cand["is_max_depth"]), c.c_float(cand["max_depth"]), c.c_float(cand["max_local"]), int(cand["search_remote"]))
+                for s in cand["scans"]:
+                    L.rg_begin_query(h, s["bp_begin"], s["bp_end"], s["bp_state"], int(s["is_locus_reversed"]), s["bam_index"], int(s["is_tumor"]),
+                                     int(s["first_of_breakend"]), s["ref_begin"], s["ref_seq"].encode())
+                    for r in s["records"]:
+                        cw = cigar_words(r["cigar"])
+                        L.rg_add_record(h, r["tid"], r["pos"], r["mtid"], r["mpos"], r["flag"], r["mapq"], (c.c_uint32 * max(1, len(cw)))(*cw), len(cw),
+                                        r["qname"].encode(), bytes(r["seq4"]) + b"\0", bytes(r["qual"]) + b"\0", r["read_len"], int(r["sa"]),
+                                        None if r["mc"] == "*" else r["mc"].encode())
+            assert L.rg_run(h, c.byref(opt)) == 0, self._err(h)
+
+            def on_scan(_user, bam_index, tid, begin, end):
+                for r in fetch(bam_index, tid, begin, end):
+                    if not L.rg_remote_record(h, r["pos"], r["flag"], r["mapq"], r["qname"].encode(), bytes(r["seq4"]) + b"\0", bytes(r["qual"]) + b"\0",
+                                              r["read_len"], int(r["sa"])):
+                        break
+            cb = self.SCAN_CB(on_scan)
+            nq = L.rg_retrieve_remote(h, c.byref(opt), cb, None)
+            assert nq >= 0, self._err(h)
+            out = []
+            for l in range(len(candidates)):
+                assert L.rg_pile_text(h, l, self.buf, len(self.buf)) >= 0
+                lines = self.buf.value.decode().splitlines()
+                head = lines[0].split()
+                assert int(head[3]) == len(lines) - 1
+                assert L.rg_remote_cache(h, l, self.buf, len(self.buf)) >= 0
+                out.append(dict(status=int(head[1]), pile=lines[1:], cache=self.buf.value.decode().splitlines()))
+            return out, dict(queries=nq, targets=L.rg_counts(h, 0), inserted=L.rg_counts(h, 1))
+        finally:
+            L.rg_free(h)
+
+    def _err(self, h):
+        self.lib.rg_error(h, self.buf, len(self.buf))
+        return self.buf.value.decode()
 
 
 def write_fasta(path, chroms):

@@ -11,6 +11,9 @@ import numpy as np
 import pytest
 
 from manta_amd._capi import pack_piles
+import read_class_util as rcu
+from manta_amd._capi import read_class_options
+from test_read_class import G as RC_DEMO, demo_batch
 from test_read_pile import pack_records, pile_lib  # noqa: F401  (fixture)
 from test_refiner import mine_emu, mine_gpu  # noqa: F401  (fixtures)
 
@@ -32,6 +35,36 @@ def check_cases(lib):
                 assert int(r[1]) + c["window_begin"][i] == c["expect_pos"][i], (c["name"], r[:5])
             n_sv += 1
     return n_sv
+
+
+def check_chain(lib, refiner):
+    """Product only, end to end: the decoded records of the demo BAMs' region queries (tests/golden/read_class_demo.json.gz) ->
+    manta_read_piles_batch (read gathering on the device) -> those piles into the product refiner (device assemble + align through
+    manta_smallsv_* / manta_spanning_*) -> candidateSV.vcf records; against the unmodified reference's refiner text and VCF records
+    for the same candidates (tests/golden/demo_cases.json) and the published demo breakends.  Nothing of oracle/ in between."""
+    n_sv = 0
+    for i, c in enumerate(G["cases"]):
+        rc = RC_DEMO["cases"][i]
+        assert rc["pile"] == c["case"]["reads"]  # (the two golden files describe the same candidate)
+        p = rcu.run_product(lib, demo_batch([rc]), read_class_options(min_candidate_variant_size=rc["min_variant"]), strict=True)
+        case = dict(c["case"], reads=p["piles_text"][0])
+        assert refiner.run(case) == c["ref_text"], c["name"]
+        vcf = refiner.vcf(case)
+        assert vcf == c["ref_vcf"], c["name"]
+        if c["expect_pos"]:
+            for k, r in enumerate(l.split("\t") for l in vcf.splitlines()):
+                assert int(r[1]) + c["window_begin"][k] == c["expect_pos"][k], (c["name"], r[:5])
+            n_sv += 1
+    return n_sv
+
+
+def test_emulated_chain_from_bam_records_to_vcf_records(emu, mine_emu):
+    assert check_chain(emu, mine_emu) == 3
+
+
+@pytest.mark.gpu
+def test_gpu_chain_from_bam_records_to_vcf_records(gpu, mine_gpu):
+    assert check_chain(gpu, mine_gpu) == 3
 
 
 def test_published_demo_records_are_reproduced_by_the_stored_reference_output():

@@ -115,6 +115,100 @@ def test_restatement_matches_the_reference_on_synthetic_bam_files():
     assert n_reads > 100
 
 
+def remote_mate_case(rb, tmp, seed):
+    """A complex candidate with chimeric pairs whose mates lie elsewhere (a second chromosome, or > 10 kb away), written as BAM files:
+    the unmodified reference (assembleComplexSVCandidate with isSearchRemoteInsertionReads: getBreakendReads + retrieveRemoteReads,
+    SVCandidateAssembler.cpp:141-256,570-655) against kernel flags + manta_amd/host/read_gather.hpp's retrieval, with the
+    reference's own BAM layer answering the region queries of both."""
+    rng = random.Random(7000 + seed)
+    chrom_a = "".join(rng.choice("ACGT") for _ in range(30000))
+    chrom_b = "".join(rng.choice("ACGT") for _ in range(100000))
+    chroms = [("chrA", chrom_a), ("chrB", chrom_b)]
+    fa = os.path.join(tmp, "rg%d.fa" % seed)
+    u.write_fasta(fa, chroms)
+    n_bam = rng.choice([1, 2, 2, 3])
+    centre, half = rng.randrange(12500, 17500), rng.choice([10, 60, 150])
+    state = rng.choice([u.COMPLEX, u.COMPLEX, u.UNKNOWN, u.RIGHT_OPEN, u.LEFT_OPEN])
+    bp = (0, centre - half, centre + half, state)
+    sb, se = ctypes.c_int32(), ctypes.c_int32()
+    u._oracle_lib().oracle_read_search_range(bp[1], bp[2], ctypes.byref(sb), ctypes.byref(se))
+    clusters = [(1, rng.randrange(2000, 95000)) for _ in range(rng.choice([1, 2, 3]))]
+    clusters.append((0, centre + rng.choice([-1, 1]) * rng.randrange(10300, 11500)))
+    pool = ["shared%d" % k for k in range(12)]
+    bams, tumor = [], []
+    for bi in range(n_bam):
+        recs = u.random_scan(rng, rng.randrange(5, 70), bp[1], bp[2], bp[3], 0, chrom_a, bi, False, True, False, pool)["records"]
+        for k in range(rng.randrange(3, 45)):  # chimeric pairs: the local read
+            rl, pos = rng.choice([50, 75, 100]), rng.randrange(sb.value - 60, se.value + 20)
+            ctid, cpos = rng.choice(clusters)
+            flag = 0x1 | rng.choice([0x40, 0x80]) | rng.choice([0, 0x10]) | rng.choice([0, 0x20])
+            a = rng.randrange(0, 25)
+            cigar = "%dM" % rl if a == 0 else rng.choice(["%dS%dM" % (a, rl - a), "%dM%dS" % (rl - a, a)])
+            bases = "".join(chrom_a[pos + i] if rng.random() > 0.03 else rng.choice("ACGTN") for i in range(rl))
+            name = rng.choice(pool) if rng.random() < 0.1 else "chim%d_%d" % (bi, k)
+            recs.append(u.record_from_bases(name, flag, 0, pos, rng.choice([0, 14, 15, 20, 60, 60]), ctid, cpos + rng.randrange(0, 350), cigar, bases,
+                                            [rng.choice([2, 4, 5, 20, 30, 38]) for _ in range(rl)], 1 if rng.random() < 0.1 else 0))
+        mates = []
+        for r in recs:  # ... and, mostly, the mate where the local read says it is
+            far = (r["flag"] & 0x1) and not (r["flag"] & 0x8) and (r["mtid"] != 0 or abs(r["pos"] - r["mpos"]) >= 9000)
+            if not far or rng.random() < 0.12:
+                continue
+            rl = rng.choice([50, 75, 100])
+            other = 0x40 if (r["flag"] & 0x80) and not (r["flag"] & 0x40) else 0x80
+            if rng.random() < 0.08:
+                other ^= 0xc0  # a record of the same name and the WRONG read number
+            flag = 0x1 | other | rng.choice([0, 0x10]) | rng.choice([0, 0x20])
+            src = chroms[r["mtid"]][1]
+            bases = "".join(src[r["mpos"] + i] if rng.random() > 0.05 else rng.choice("ACGTN") for i in range(rl))
+            quals = [rng.choice([2, 4, 5, 20, 30, 38]) for _ in range(rl)]
+            mapq = 0 if rng.random() < 0.75 else rng.choice([0, 1, 30])
+            mpos = r["mpos"] + (rng.choice([-3, 1, 2]) if rng.random() < 0.06 else 0)  # (a wrong mate position: before / behind the query)
+            m = u.record_from_bases(r["qname"], flag, r["mtid"], mpos, mapq, 0, r["pos"], "%dM" % rl, bases, quals)
+            if rng.random() < 0.1:  # a supplementary / secondary copy in front of it
+                mates.append(dict(m, flag=flag | rng.choice([0x800, 0x100]), sa=1))
+            mates.append(m)
+            if rng.random() < 0.1:  # the same read twice: only the first is taken
+                mates.append(dict(m, mapq=0))
+        for ctid, cpos in clusters:  # bystanders in the remote regions
+            for _ in range(rng.randrange(0, 12)):
+                pos = cpos + rng.randrange(-80, 420)
+                mates.append(u.record_from_bases("by%d" % rng.randrange(10 ** 6), 0x1 | 0x40, ctid, pos, rng.choice([0, 30]), ctid, pos + 200, "50M",
+                                                 chroms[ctid][1][pos:pos + 50], [30] * 50))
+        recs = [r for r in recs + mates if r["pos"] >= 0 and r["mpos"] >= 0]
+        recs = [recs[i] for i in sorted(range(len(recs)), key=lambda i: (recs[i]["tid"], recs[i]["pos"], i))]
+        sam = os.path.join(tmp, "rg%d_%d.sam" % (seed, bi))
+        u.write_sam(sam, chroms, recs)
+        rb.sam_to_bam(sam, sam[:-3] + "bam")
+        bams.append(sam[:-3] + "bam")
+        tumor.append(bi >= max(1, n_bam - 1) and n_bam > 1)
+    depth, chrom_depth, cd = rng.random() < 0.6, rng.choice([0.4, 3.0, 3.0, 20.0]), ""
+    if depth:
+        cd = os.path.join(tmp, "rgcd%d.txt" % seed)
+        open(cd, "w").write("chrA\t%g\nchrB\t%g\n" % (chrom_depth, chrom_depth))
+    ref = rb.pile(bams, tumor, fa, cd, 10, True, bp)
+    roff, rseq = ref["ref1"]
+    scans = [dict(records=rb.region_records(bams[bi], fa, 0, sb.value, se.value), bam_index=bi, is_tumor=tumor[bi], is_locus_reversed=False,
+                  first_of_breakend=(bi == 0), bp_begin=bp[1], bp_end=bp[2], bp_state=bp[3], ref_begin=roff, ref_seq=rseq) for bi in range(n_bam)]
+    f = np.float32(chrom_depth)
+    cand = dict(scans=scans, is_max_depth=depth, search_remote=True, max_depth=float(f * np.float32(12)), max_local=float(f * np.float32(7)))
+    return cand, ref, (lambda bam_index, tid, begin, end: rb.region_records(bams[bam_index], fa, tid, begin, end))
+
+
+def check_remote_mates(gather, n_cases):
+    rb = u.RefBam()
+    fetched, tripped = 0, 0
+    with tempfile.TemporaryDirectory(prefix="manta_rg_") as tmp:
+        for seed in range(n_cases):
+            cand, ref, fetch = remote_mate_case(rb, tmp, seed)
+            out, stats = gather.gather([cand], read_class_options(), fetch)
+            assert out[0]["status"] == 0 and out[0]["pile"] == ref["reads"], seed
+            assert out[0]["cache"] == ref["remote"], seed
+            assert stats["inserted"] >= len(ref["remote"])
+            fetched += stats["inserted"]
+            tripped += stats["targets"] == 0
+    return fetched, tripped
+
+
 def check_random(lib, seeds, n_loci=4, reads_per_scan=(5, 160)):
     n = 0
     for seed in seeds:
@@ -131,6 +225,52 @@ def check_demo(lib):
         p = u.run_product(lib, demo_batch(cases), read_class_options(min_candidate_variant_size=minvar), strict=True)
         for l, c in enumerate(cases):
             assert p["piles_text"][l] == c["pile"], c["name"]
+
+
+@pytest.fixture(scope="module")
+def gather_emu(emu):
+    return u.GatherLib(os.path.join(ROOT, "tests", "emu"), "manta_amd_emu", "emu")
+
+
+@pytest.fixture(scope="module")
+def gather_gpu(gpu):
+    return u.GatherLib(os.path.join(ROOT, "manta_amd"), "manta_amd", "gpu")
+
+
+@pytest.mark.skipif(not u.have_ref_bam(), reason="oracle/_ref/libmanta_ref_bam.so not built (reference sources unavailable)")
+def test_emulated_remote_mates_match_the_reference(gather_emu):
+    fetched, tripped = check_remote_mates(gather_emu, 16)
+    assert fetched > 60 and tripped < 10
+
+
+def check_remote_mate_goldens(gather):
+    """tests/golden/remote_mate_cases.json.gz (make_remote_mate_golden.py): the same candidates with the stored answers of the region
+    queries; piles and RemoteReadCache of the unmodified reference"""
+    RG = json.loads(gzip.open(os.path.join(ROOT, "tests", "golden", "remote_mate_cases.json.gz")).read())
+    n = 0
+    for c in RG["cases"]:
+        scans = [dict({k: v for k, v in s.items() if k != "lines"}, records=[u.parse_record(l) for l in s["lines"]]) for s in c["scans"]]
+        cand = dict(scans=scans, is_max_depth=c["is_max_depth"], search_remote=True, max_depth=c["max_depth"], max_local=c["max_local"])
+        asked = []
+
+        def fetch(bam_index, tid, begin, end):
+            key = "%d:%d:%d-%d" % (bam_index, tid, begin, end)
+            asked.append(key)
+            return [u.parse_record(l) for l in c["remote_regions"][key]]  # (a query the reference would not make is a KeyError)
+        out, stats = gather.gather([cand], read_class_options(), fetch)
+        assert out[0]["status"] == 0 and out[0]["pile"] == c["ref_pile"] and out[0]["cache"] == c["ref_cache"], c["seed"]
+        assert asked == list(c["remote_regions"]) or sorted(asked) == sorted(c["remote_regions"]), c["seed"]
+        n += stats["inserted"]
+    return n
+
+
+def test_emulated_remote_mate_goldens(gather_emu):
+    assert check_remote_mate_goldens(gather_emu) == 104
+
+
+@pytest.mark.gpu
+def test_gpu_remote_mate_goldens(gather_gpu):
+    assert check_remote_mate_goldens(gather_gpu) == 104
 
 
 def test_emulated_kernel_matches_restatement_on_random_records(emu):
