@@ -121,19 +121,13 @@ struct PairAligner {
       const unsigned c0 = wv::readlane(curA, int((t - 1) & 63)) | (wv::readlane(curB, int((t - 1) & 63)) << 16);
       rc                = wv::shr1(rc, c0);
       uint32_t incoming[NS];
-      for (int s = 0; s < NS; ++s) incoming[s] = wv::shr1(st[s][E - 1], bad);
+      // lane 0 receives column 0 from the shift's fill value: rows >= 1 are (0, bad, bad, ..) (GlobalAlignerImpl.hpp:98-107); row 0 is
+      // the initial lprev, and from row 2 on lprev is the previous step's lcur, i.e. the same fill
+      for (int s = 0; s < NS; ++s) incoming[s] = wv::shr1(st[s][E - 1], (s == ST_MATCH) ? 0u : bad);
       const int g = int(t) - lane;  // this lane's row
       for (int s = 0; s < NS; ++s) {
         lprev[s] = lcur[s];
         lcur[s]  = incoming[s];
-      }
-      if (lane == 0) {  // column 0: rows >= 1 are (0, bad, bad, ..); row 0 handled by the initial lprev (GlobalAlignerImpl.hpp:98-107)
-        if (g >= 2) {
-          for (int s = 0; s < NS; ++s) lprev[s] = bad;
-          lprev[ST_MATCH] = 0;
-        }
-        for (int s = 0; s < NS; ++s) lcur[s] = bad;
-        lcur[ST_MATCH] = 0;
       }
       const bool active = (g >= 1) && (unsigned(g) <= G);
       if (!active) continue;
@@ -299,6 +293,60 @@ WV_KERNEL void align_pair_kernel(const AlignParams P)
     const unsigned ta = P.task_ids ? P.task_ids[ia] : ia, tb = P.task_ids ? P.task_ids[ib] : ib;
     PairAligner<E> al(P);
     al.run(P.tasks[ta], P.tasks[tb], P.results[ta], P.results[tb], ib != ia, slab);
+    wv::sync();
+  }
+}
+
+/// Every packed bucket of a block in ONE persistent launch.  Per-bucket launches on side streams do not share the device well:
+/// the widest bucket's grid fills the wave slots and the narrow buckets -- few pairs, long dependent chains (short contigs against
+/// whole reference windows) -- either wait behind it or crawl beside it (measured: 1.9 ms at 79 % of the VALU issue rate, then
+/// 1.1 ms at 28 %).  Here one queue covers the buckets in the order the host gives (fewest tasks first: the long chains start at
+/// once, the bulk of the widest bucket fills in behind), and a wave runs whichever width its pair needs.
+struct PairMultiParams {
+  AlignParams     A;           ///< tasks, results, cigar, scores, counter; ptr_ws / ptr_ws_stride sized for the widest bucket
+  const uint32_t* bucket_ids;  ///< [bucket][n_slots]: the buckets' task ids, reference length descending (bucket_sort_kernel)
+  const uint32_t* counts;      ///< device: tasks per bucket
+  uint32_t        n_slots;
+  uint32_t        n_order;     ///< <= 6
+  uint8_t         order[8];    ///< bucket indices in queue order
+  uint8_t         e_of[8];     ///< their E
+};
+
+WV_KERNEL void align_pair_multi_kernel(const PairMultiParams M)
+{
+  uint8_t* slab = M.A.ptr_ws + uint64_t(wv::block()) * M.A.ptr_ws_stride;
+  unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0, n4 = 0, n5 = 0;  // tasks per queue position
+  if (M.n_order > 0) n0 = M.counts[M.order[0]];
+  if (M.n_order > 1) n1 = M.counts[M.order[1]];
+  if (M.n_order > 2) n2 = M.counts[M.order[2]];
+  if (M.n_order > 3) n3 = M.counts[M.order[3]];
+  if (M.n_order > 4) n4 = M.counts[M.order[4]];
+  if (M.n_order > 5) n5 = M.counts[M.order[5]];
+  const unsigned f1 = (n0 + 1) / 2, f2 = f1 + (n1 + 1) / 2, f3 = f2 + (n2 + 1) / 2, f4 = f3 + (n3 + 1) / 2, f5 = f4 + (n4 + 1) / 2,
+                 f6 = f5 + (n5 + 1) / 2;
+  while (true) {
+    unsigned slot = 0;
+    if (wv::lane() == 0) slot = wv::atomic_add(M.A.counter, 1u);
+    slot = wv::first(slot);
+    if (slot >= f6) break;
+    unsigned j = 0, base = 0, n = n0;
+    if (slot >= f1) { j = 1; base = f1; n = n1; }
+    if (slot >= f2) { j = 2; base = f2; n = n2; }
+    if (slot >= f3) { j = 3; base = f3; n = n3; }
+    if (slot >= f4) { j = 4; base = f4; n = n4; }
+    if (slot >= f5) { j = 5; base = f5; n = n5; }
+    const unsigned  p   = slot - base;
+    const uint32_t* ids = M.bucket_ids + uint64_t(M.order[j]) * M.n_slots;
+    const unsigned  ia = 2 * p, ib = (2 * p + 1 < n) ? 2 * p + 1 : 2 * p;
+    const unsigned  ta = ids[ia], tb = ids[ib];
+    switch (M.e_of[j]) {
+    case 1: PairAligner<1>(M.A).run(M.A.tasks[ta], M.A.tasks[tb], M.A.results[ta], M.A.results[tb], ib != ia, slab); break;
+    case 2: PairAligner<2>(M.A).run(M.A.tasks[ta], M.A.tasks[tb], M.A.results[ta], M.A.results[tb], ib != ia, slab); break;
+    case 3: PairAligner<3>(M.A).run(M.A.tasks[ta], M.A.tasks[tb], M.A.results[ta], M.A.results[tb], ib != ia, slab); break;
+    case 4: PairAligner<4>(M.A).run(M.A.tasks[ta], M.A.tasks[tb], M.A.results[ta], M.A.results[tb], ib != ia, slab); break;
+    case 5: PairAligner<5>(M.A).run(M.A.tasks[ta], M.A.tasks[tb], M.A.results[ta], M.A.results[tb], ib != ia, slab); break;
+    default: PairAligner<6>(M.A).run(M.A.tasks[ta], M.A.tasks[tb], M.A.results[ta], M.A.results[tb], ib != ia, slab); break;
+    }
     wv::sync();
   }
 }

@@ -2075,7 +2075,8 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     if (fromHistory) {
       for (int k = kNumESet - 1; k >= 0; --k) {
         const bool     pair   = pairOf(k);
-        const uint64_t tasks  = uint64_t(b->lastSmall[k]) + b->lastSmall[k] / 4 + 64;
+        // (a bucket that was empty last time gets a token grid: tasks that do turn up are still aligned, just by few waves)
+        const uint64_t tasks  = b->lastSmall[k] ? uint64_t(b->lastSmall[k]) + b->lastSmall[k] / 4 + 64 : 4;
         const uint64_t hint   = pair ? (tasks + 1) / 2 : tasks;  // work items: alignments, or pairs of them
         const uint64_t qBound = (kESet[k] == 32) ? std::max<uint64_t>(as.maxContigLen, 64ull * 32) : 64ull * uint64_t(kESet[k]);
         const uint64_t refLen = alignSlabRefLen(MANTA_ALIGNER_LARGE_INDEL, kESet[k], qBound, b->maxRef);
@@ -2110,21 +2111,51 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     // The E buckets are independent launches: they run on side streams so that the tail of one overlaps the others
     // (a launch's last alignments leave most of the device idle otherwise).  Each bucket gets its own slab region.
     {
+      // The packed buckets share ONE launch and one queue (align_pair_multi_kernel: buckets with the fewest tasks first, so the
+      // few long alignments of narrow buckets start at once and the bulk of the widest fills in behind them); every other
+      // bucket is its own launch on a side stream.
+      static const bool   noMerge = std::getenv("MANTA_AMD_NO_ALIGN_MERGE") != nullptr;  // A/B knob: one launch per packed bucket
+      std::vector<Launch> merged;
+      if (!noMerge) {
+        std::vector<Launch> rest;
+        for (const Launch& l : launches) (l.pair ? merged : rest).push_back(l);
+        if (merged.size() < 2 || merged.size() > 6) {
+          merged.clear();
+        } else {
+          launches.swap(rest);
+          slabBytes = 0;
+          for (Launch& l : launches) {
+            l.slabOff = slabBytes;
+            slabBytes += l.stride * uint64_t(l.grid);
+          }
+        }
+      }
+      uint64_t mergedStride = 0, mergedWaves = 0, mergedOff = slabBytes;
+      const uint32_t* counts = fromHistory ? b->lastSmall : hSmall;
+      if (!merged.empty()) {
+        std::stable_sort(merged.begin(), merged.end(), [&](const Launch& x, const Launch& y) { return counts[x.k] < counts[y.k]; });
+        for (const Launch& l : merged) {
+          mergedStride = std::max(mergedStride, l.stride);
+          mergedWaves += uint64_t(l.grid);
+        }
+        mergedWaves = uint64_t(rt::roundGrid(int(std::min<uint64_t>(mergedWaves, uint64_t(maxWaves)))));
+        mergedWaves = std::max<uint64_t>(1, std::min<uint64_t>(mergedWaves, (wsBudget / 3) / mergedStride));
+        slabBytes += mergedStride * mergedWaves;
+      }
       uint8_t* dWsAll = b->dPtrWs.as<uint8_t>(slabBytes + 256);
       // (without the host read in between nothing else orders the side streams behind the schedule kernel)
       for (int i = 0; i < 3; ++i) rt::streamWaits(b->side[i], b->evSched);
-      for (size_t i = 0; i < launches.size(); ++i) {
-        const Launch& l(launches[i]);
-        AlignParams   P;
+      auto baseParams = [&]() {
+        AlignParams P;
         P.tasks          = dTasks;
         P.results        = dResults;
         P.cigar          = dCigar;
-        P.task_ids       = (l.pair ? dBucketsSorted : dBuckets) + uint64_t(l.k) * nSlots;
-        P.n_tasks        = fromHistory ? uint32_t(nSlots) : hSmall[l.k];
-        P.n_tasks_dev    = fromHistory ? dSmall + l.k : nullptr;
-        P.counter        = dSmall + 40 + l.k;
-        P.ptr_ws         = dWsAll + l.slabOff;
-        P.ptr_ws_stride  = l.stride;
+        P.task_ids       = nullptr;
+        P.n_tasks        = 0;
+        P.n_tasks_dev    = nullptr;
+        P.counter        = nullptr;
+        P.ptr_ws         = nullptr;
+        P.ptr_ws_stride  = 0;
         P.match          = b->scores.match;
         P.mismatch       = b->scores.mismatch;
         P.open           = b->scores.open;
@@ -2132,6 +2163,40 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
         P.off_edge       = b->scores.off_edge;
         P.allow_edge_ins = b->scores.is_allow_edge_insertion ? 1 : 0;
         P.extra          = b->largeIndel;
+        return P;
+      };
+      if (!merged.empty()) {
+        PairMultiParams M;
+        M.A               = baseParams();
+        M.A.counter       = dSmall + 40 + merged[0].k;  // (the queue head of the first bucket serves the shared queue)
+        M.A.ptr_ws        = dWsAll + mergedOff;
+        M.A.ptr_ws_stride = mergedStride;
+        M.bucket_ids      = dBucketsSorted;
+        M.counts          = dSmall;
+        M.n_slots         = uint32_t(nSlots);
+        M.n_order         = uint32_t(merged.size());
+        for (size_t i = 0; i < 8; ++i) {
+          M.order[i] = uint8_t(i < merged.size() ? merged[i].k : 0);
+          M.e_of[i]  = uint8_t(i < merged.size() ? kESet[merged[i].k] : 0);
+        }
+        if (std::getenv("MANTA_AMD_DEBUG"))
+          std::fprintf(stderr, "manta_amd: align_pair_multi_kernel: %llu waves over %zu packed buckets, slab stride %llu\n",
+                       (unsigned long long)mergedWaves, merged.size(), (unsigned long long)mergedStride);
+        rt::launch(align_pair_multi_kernel, int(mergedWaves), 0, M);  // on the pipeline's own stream
+        if (!fromHistory) {
+          b->stats.n_align_launches++;
+          for (const Launch& l : merged) b->stats.n_alignments += hSmall[l.k];
+        }
+      }
+      for (size_t i = 0; i < launches.size(); ++i) {
+        const Launch& l(launches[i]);
+        AlignParams   P  = baseParams();
+        P.task_ids       = (l.pair ? dBucketsSorted : dBuckets) + uint64_t(l.k) * nSlots;
+        P.n_tasks        = fromHistory ? uint32_t(nSlots) : hSmall[l.k];
+        P.n_tasks_dev    = fromHistory ? dSmall + l.k : nullptr;
+        P.counter        = dSmall + 40 + l.k;
+        P.ptr_ws         = dWsAll + l.slabOff;
+        P.ptr_ws_stride  = l.stride;
         {
           rt::ScopedStream onSide(b->side[i % 3]);  // (restores the pipeline's stream: nothing of this call runs on the null stream)
           launchAlignKind(MANTA_ALIGNER_LARGE_INDEL, l.k, l.grid, P, l.pair);
@@ -3582,6 +3647,8 @@ extern "C" int manta_read_piles_batch(
   if (n_loci == 0) return MANTA_OK;
   // what the kernels index with must lie inside what was handed over
   uint64_t maxRange = 1, maxRecords = 1, codeBound = 0, maskBound = 0;
+  std::vector<uint32_t> chunks;  // read_test_kernel's work list: 64 records of one query each (scan, first record, candidate)
+  chunks.reserve(3 * (size_t(n_reads) / 64 + n_scans + 1));
   for (uint32_t l = 0; l < n_loci; ++l) {
     if (loci[l].scan_begin > loci[l].scan_end || loci[l].scan_end > n_scans)
       return fail(ctx, MANTA_E_INVALID_ARG, std::string(fn) + "candidate " + std::to_string(l) + ": scans outside the scan array");
@@ -3595,6 +3662,11 @@ extern "C" int manta_read_piles_batch(
       ReadClass::searchRange(sc, sb, se);
       maxRange = std::max<uint64_t>(maxRange, uint64_t(se > sb ? se - sb : 0) + 2);
       recs += sc.read_end - sc.read_begin;
+      for (uint32_t base = sc.read_begin; base < sc.read_end; base += 64) {
+        chunks.push_back(s);
+        chunks.push_back(base);
+        chunks.push_back(l);
+      }
     }
     maxRecords = std::max(maxRecords, recs);
   }
@@ -3637,7 +3709,7 @@ extern "C" int manta_read_piles_batch(
     P.quals  = up(ctx->dRc[6], quals, quals_bytes);
     P.refs   = up(ctx->dRc[7], refs, refs_bytes);
     // outputs and workspace in one allocation each
-    uint8_t* dOut = ctx->dRc[8].as<uint8_t>(uint64_t(n_reads) * 12 + uint64_t(n_loci) * (sizeof(manta_read_locus_result_t) + 16 + 32) + 256 +
+    uint8_t* dOut = ctx->dRc[8].as<uint8_t>(uint64_t(n_reads) * 13 + uint64_t(n_loci) * (sizeof(manta_read_locus_result_t) + 16 + 32) + 256 +
                                             4 * (uint64_t(n_loci) + 1));
     P.pile_index   = reinterpret_cast<uint32_t*>(dOut);
     P.tmp          = P.pile_index + n_reads;
@@ -3645,8 +3717,11 @@ extern "C" int manta_read_piles_batch(
     P.locus_counts = reinterpret_cast<uint32_t*>(P.results + n_loci);
     P.locus_base   = reinterpret_cast<unsigned long long*>(P.locus_counts + 4 * uint64_t(n_loci));
     P.locus_read_begin = reinterpret_cast<uint32_t*>(P.locus_base + 4 * (uint64_t(n_loci) + 1));
-    P.counter      = P.locus_read_begin + n_loci + 1;
-    P.decision     = reinterpret_cast<uint8_t*>(P.counter + 2);
+    P.counter      = P.locus_read_begin + n_loci + 1;  // four queue heads
+    P.decision     = reinterpret_cast<uint8_t*>(P.counter + 4);
+    P.pre          = P.decision + n_reads;
+    P.chunks       = reinterpret_cast<const uint32_t*>(up(ctx->dRc[14], chunks.data(), 4 * chunks.size()));
+    P.n_chunks     = uint32_t(chunks.size() / 3);
     P.ws           = ctx->dRc[9].as<uint32_t>(stride * uint64_t(grid));
     P.ws_stride    = stride;
     P.range_cap    = uint32_t(maxRange);
@@ -3657,10 +3732,14 @@ extern "C" int manta_read_piles_batch(
     P.pile_read    = P.read_len + n_reads + 1;
     P.read_code_off = ctx->dRc[13].as<unsigned long long>(2 * (uint64_t(n_reads) + 2));
     P.read_mask_off = P.read_code_off + n_reads + 1;
-    rt::dzero(P.counter, 2 * sizeof(uint32_t));
+    rt::dzero(P.counter, 4 * sizeof(uint32_t));
+    const int wide    = rt::roundGrid(std::max(1, ctx->cuCount * 16));
+    auto      gridFor = [&](uint64_t items) { return std::min(wide, rt::roundGrid(int(std::max<uint64_t>(1, std::min<uint64_t>(items, 1u << 20))))); };
+    rt::launch(read_test_kernel, gridFor(P.n_chunks), 0, P);
     rt::launch(read_class_kernel, grid, 0, P);
     rt::launch(read_pile_offsets_kernel, rt::roundGrid(1), 0, P);
     rt::launch(read_pile_pack_kernel, grid, 0, P);
+    rt::launch(read_pile_bases_kernel, gridFor(uint64_t(n_reads) / 8 + 1), 0, P);
     unsigned long long totals[4] = {0, 0, 0, 0};
     rt::d2h(totals, P.locus_base + 4 * uint64_t(n_loci), sizeof(totals));  // (synchronizes)
     if (reads_used) *reads_used = totals[0];

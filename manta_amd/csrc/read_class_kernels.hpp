@@ -18,8 +18,12 @@
 //      first of its key iff it is that index
 //   F  ordered count of the firsts -> pile positions; the cap cuts everything behind the 1000th insertion (those records are
 //      never looked at by the reference: their decisions are cleared, their depth trips do not count)
-// Then one wave scans the per-candidate totals into offsets, and a wave per candidate converts the inserted reads (4 bit ->
-// 2 bit + N bitmap, Q mask, reverse complement), 32 bases per lane step.
+// What in C depends on the record alone -- the expensive part: cigar walks, the semi-aligned base comparison, quality sums -- runs
+// first and RECORD-PARALLEL over the whole batch (read_test_kernel: a wave per 64 records of a query, one byte of verdicts per
+// record); the candidate-serial passes above then only combine those bits with the state they carry.
+// Then one wave scans the per-candidate totals into offsets, a wave per candidate lays out its pile reads' rows, and the inserted
+// reads are converted PILE-READ-PARALLEL (4 bit -> 2 bit + N bitmap, Q mask, reverse complement; eight lanes per read, 32 bases per
+// lane step).  Five launches, no host turnaround.
 #pragma once
 #include "../../include/manta_amd.h"
 #include "wave.hpp"
@@ -37,6 +41,8 @@ enum {
   RC_MATEREV = 64u  // shadow keeper whose mate is on the forward strand: orientation flips (:558-563)
 };
 static const unsigned RC_EMPTY = 0xffffffffu;
+// read_test_kernel's byte per record
+enum { PRE_REMOTE = 1u, PRE_INDEL = 2u, PRE_SEMI = 4u, PRE_ANCHOR = 8u, PRE_GOOD = 16u };
 
 struct ReadClassParams {
   manta_read_class_options_t       opt;
@@ -49,7 +55,10 @@ struct ReadClassParams {
   uint8_t*                         decision;
   uint32_t*                        pile_index;
   manta_read_locus_result_t*       results;
-  uint32_t*                        tmp;        // [n_reads]
+  uint32_t*                        tmp;        // [n_reads]; after read_class_kernel: the candidate of pile read r
+  uint8_t*                         pre;        // [n_reads] PRE_* (read_test_kernel)
+  const uint32_t*                  chunks;     // [n_chunks][3]: scan, first record, candidate -- 64 records of one query each
+  uint32_t                         n_chunks;
   uint32_t*                        ws;         // per wave: cov_prev[range_cap] | cov_cur[range_cap + 1] | table[table_cap]
   uint64_t                         ws_stride;  // dwords
   uint32_t                         range_cap, table_cap;
@@ -306,6 +315,65 @@ struct ReadClass {
     }
   }
 
+  /// The tests of the scan loop's body that read nothing but the record, its query and the options (:443-509 and the shadow
+  /// finder's predicates, ShadowReadFinder.cpp:33-100): run record-parallel over the whole batch by read_test_kernel, before the
+  /// candidate-serial passes, which only combine the bits with the state they carry.
+  WV_DEV unsigned recordTests(const manta_read_locus_t& loc, const manta_read_scan_t& sc, const manta_bam_read_t& r) const
+  {
+    int sb, se;
+    searchRange(sc, sb, se);
+    const unsigned minIndel  = P.opt.min_candidate_variant_size / 2;  // :317
+    const bool     rightOpen = (sc.bp_state != 2), leftOpen = (sc.bp_state != 1);  // :320-329
+    unsigned       pre       = 0;
+    const PathView path = pathOf(r);
+    if (loc.search_remote) {  // :443-470, RemoteMateReadUtil.cpp:29-55
+      bool cand = paired(r) && !unmapped(r) && !mateUnmapped(r) && r.mapq >= P.opt.min_mapq && r.tid >= 0 && r.mate_tid >= 0;
+      if (cand && r.tid == r.mate_tid) {
+        const int dd = r.pos - r.mate_pos;
+        cand         = (dd < 0 ? -dd : dd) >= 10000;
+      }
+      if (cand) {  // matchifyEdgeSoftClipRefRange (SimpleAlignment.cpp:77-108) against the flanks (:302-303)
+        int      rb = r.pos, re = r.pos;
+        unsigned first, last;
+        matchEdges(path, first, last);
+        for (unsigned k = 0; k < path.size(); ++k) {
+          const unsigned op = path.op(k), len = path.length(k);
+          if (k < first) {
+            if (opReadLen(op)) rb -= int(len);
+          } else if (k > last) {
+            if (opReadLen(op)) re += int(len);
+          } else if (opRefLen(op)) {
+            re += int(len);
+          }
+        }
+        const bool hitsLeft = (re > sb) && (rb < sc.bp_begin), hitsRight = (re > sc.bp_end) && (rb < se);
+        const bool leftMate = leftOpen && !hitsLeft, rightMate = rightOpen && !hitsRight;
+        if (!((!leftMate && !fwd(r)) || (!rightMate && fwd(r)))) pre |= PRE_REMOTE;
+      }
+    }
+    if (!unmapped(r)) {
+      for (unsigned k = 0; k < path.size(); ++k)  // :473-483: the FIRST indel segment decides
+        if (opIndel(path.op(k))) {
+          if (path.length(k) >= minIndel) pre |= PRE_INDEL;
+          break;
+        }
+      unsigned lead, trail;  // :486-509
+      semiAligned(r, sc, lead, trail);
+      if ((rightOpen && trail >= 4) || (leftOpen && lead >= 4)) pre |= PRE_SEMI;
+    }
+    // shadow finder predicates (ShadowReadFinder.cpp:33-100)
+    if (paired(r) && !unmapped(r) && mateUnmapped(r) && !(!leftOpen && !fwd(r)) && !(!rightOpen && fwd(r)) &&
+        r.mapq >= P.opt.min_singleton_mapq_candidates)
+      pre |= PRE_ANCHOR;
+    if (paired(r) && unmapped(r) && !mateUnmapped(r)) {
+      unsigned       sum = 0;
+      const uint8_t* q   = P.quals + r.qual_off;
+      for (unsigned p = 0; p < r.read_len; ++p) sum += q[p];
+      if ((r.read_len ? sum / r.read_len : 0u) >= 25u) pre |= PRE_GOOD;  // get_avg_quality (bam_record_util.cpp:110-122)
+    }
+    return pre;
+  }
+
   /// passes A-D over one region query.  Returns false if the search range does not fit the workspace.
   WV_DEV bool scanQuery(const manta_read_locus_t& loc, const manta_read_scan_t& sc, uint32_t* covPrev, uint32_t* covCur)
   {
@@ -369,8 +437,6 @@ struct ReadClass {
       wv::sync();
     }
     // C
-    const unsigned minIndel  = P.opt.min_candidate_variant_size / 2;  // :317
-    const bool     rightOpen = (sc.bp_state != 2), leftOpen = (sc.bp_state != 1);  // :320-329
     for (unsigned base = sc.read_begin; base < firstBeyond; base += 64) {
       const unsigned i = base + lane;
       if (i >= firstBeyond) continue;
@@ -398,52 +464,12 @@ struct ReadClass {
         }
       }
       t |= RC_REACH;
-      const PathView path = pathOf(r);
-      if (loc.search_remote) {  // :443-470, RemoteMateReadUtil.cpp:29-55
-        bool cand = paired(r) && !unmapped(r) && !mateUnmapped(r) && r.mapq >= P.opt.min_mapq && r.tid >= 0 && r.mate_tid >= 0;
-        if (cand && r.tid == r.mate_tid) {
-          const int dd = r.pos - r.mate_pos;
-          cand         = (dd < 0 ? -dd : dd) >= 10000;
-        }
-        if (cand) {  // matchifyEdgeSoftClipRefRange (SimpleAlignment.cpp:77-108) against the flanks (:302-303)
-          int      rb = r.pos, re = r.pos;
-          unsigned first, last;
-          matchEdges(path, first, last);
-          for (unsigned k = 0; k < path.size(); ++k) {
-            const unsigned op = path.op(k), len = path.length(k);
-            if (k < first) {
-              if (opReadLen(op)) rb -= int(len);
-            } else if (k > last) {
-              if (opReadLen(op)) re += int(len);
-            } else if (opRefLen(op)) {
-              re += int(len);
-            }
-          }
-          const bool hitsLeft = (re > sb) && (rb < sc.bp_begin), hitsRight = (re > sc.bp_end) && (rb < se);
-          const bool leftMate = leftOpen && !hitsLeft, rightMate = rightOpen && !hitsRight;
-          if (!((!leftMate && !fwd(r)) || (!rightMate && fwd(r)))) d |= MANTA_READ_REMOTE_MATE;
-        }
-      }
-      if (!unmapped(r)) {
-        for (unsigned k = 0; k < path.size(); ++k)  // :473-483: the FIRST indel segment decides
-          if (opIndel(path.op(k))) {
-            if (path.length(k) >= minIndel) d |= MANTA_READ_INDEL;
-            break;
-          }
-        unsigned lead, trail;  // :486-509
-        semiAligned(r, sc, lead, trail);
-        if ((rightOpen && trail >= 4) || (leftOpen && lead >= 4)) d |= MANTA_READ_SEMI_ALIGNED;
-      }
-      // shadow finder predicates (ShadowReadFinder.cpp:33-100)
-      if (paired(r) && !unmapped(r) && mateUnmapped(r) && !(!leftOpen && !fwd(r)) && !(!rightOpen && fwd(r)) &&
-          r.mapq >= P.opt.min_singleton_mapq_candidates)
-        t |= RC_ANCHOR;
-      if (paired(r) && unmapped(r) && !mateUnmapped(r)) {
-        unsigned       sum = 0;
-        const uint8_t* q   = P.quals + r.qual_off;
-        for (unsigned p = 0; p < r.read_len; ++p) sum += q[p];
-        if ((r.read_len ? sum / r.read_len : 0u) >= 25u) t |= RC_GOOD;  // get_avg_quality (bam_record_util.cpp:110-122)
-      }
+      const unsigned pre = P.pre[i];  // read_test_kernel: what depends on the record alone
+      if (pre & PRE_REMOTE) d |= MANTA_READ_REMOTE_MATE;
+      if (pre & PRE_INDEL) d |= MANTA_READ_INDEL;
+      if (pre & PRE_SEMI) d |= MANTA_READ_SEMI_ALIGNED;
+      if (pre & PRE_ANCHOR) t |= RC_ANCHOR;
+      if (pre & PRE_GOOD) t |= RC_GOOD;
       P.tmp[i]      = t;
       P.decision[i] = uint8_t(d);
     }
@@ -592,8 +618,8 @@ struct ReadClass {
     }
   }
 
-  /// pile reads of one candidate into the packed layout: offsets from the candidate's bases, then the bases themselves
-  WV_DEV void packLocus(const unsigned l)
+  /// pile reads of one candidate: their rows of the packed layout (length, record, code / mask offsets) from the candidate's bases
+  WV_DEV void packOffsets(const unsigned l)
   {
     const unsigned           lane = unsigned(wv::lane());
     const manta_read_locus_t loc  = P.loci[l];
@@ -620,19 +646,23 @@ struct ReadClass {
           P.pile_read[r]             = i;
           P.read_code_off[r]         = cb + cRun + ci - c;
           P.read_mask_off[r]         = mb + mRun + mi - mk;
+          P.tmp[r]                   = l;  // (the per-record words are done with: pile read -> candidate, for packBases)
         }
         cRun += wv::shfl(ci, 63);
         mRun += wv::shfl(mi, 63);
       }
     }
-    wv::sync();
-    // insertAssemblyRead (:121-135): text of the 4-bit codes, Q mask, reverse complement -- 32 output bases per lane step
-    const unsigned nPile   = P.locus_counts[4 * size_t(l)];
-    bool           equals  = false;
-    for (unsigned p0 = 0; p0 < nPile; p0 += 8) {
-      const unsigned p = p0 + (lane >> 3);
-      if (p >= nPile) continue;
-      const unsigned long long r   = rb + p;
+  }
+
+  /// insertAssemblyRead (:121-135) for eight pile reads [8 g, 8 g + 8) of the batch: text of the 4-bit codes, Q mask, reverse
+  /// complement -- eight lanes per read, 32 output bases per lane step
+  WV_DEV void packBases(const unsigned g, const unsigned long long nPileAll)
+  {
+    const unsigned lane = unsigned(wv::lane());
+    bool           equals = false;
+    {
+      const unsigned long long r = 8ull * g + (lane >> 3);
+      if (r >= nPileAll) return;
       const unsigned           i   = P.pile_read[r];
       const manta_bam_read_t   rec = P.reads[i];
       const bool               rev = (P.decision[i] & MANTA_READ_REVERSED) != 0;
@@ -664,10 +694,26 @@ struct ReadClass {
         co[2 * w] = c0;
         if (2 * w + 1 < (len + 15) / 16) co[2 * w + 1] = c1;
       }
+      if (equals) P.results[P.tmp[r]].status = MANTA_E_UNSUPPORTED;
     }
-    if (wv::any(equals) && lane == 0) P.results[l].status = MANTA_E_UNSUPPORTED;
   }
 };
+
+/// record-parallel: the per-record tests of every record of the batch (a wave per 64 records of one query)
+WV_KERNEL void read_test_kernel(const ReadClassParams P)
+{
+  ReadClass rc(P);
+  while (true) {
+    unsigned c = 0;
+    if (wv::lane() == 0) c = wv::atomic_add(&P.counter[2], 1u);
+    c = wv::first(c);
+    if (c >= P.n_chunks) break;
+    const manta_read_scan_t sc = P.scans[P.chunks[3 * size_t(c)]];
+    const unsigned          i  = P.chunks[3 * size_t(c) + 1] + unsigned(wv::lane());
+    if (i < sc.read_end) P.pre[i] = uint8_t(rc.recordTests(P.loci[P.chunks[3 * size_t(c) + 2]], sc, P.reads[i]));
+    wv::sync();
+  }
+}
 
 /// persistent waves: one candidate at a time
 WV_KERNEL void read_class_kernel(const ReadClassParams P)
@@ -720,7 +766,22 @@ WV_KERNEL void read_pile_pack_kernel(const ReadClassParams P)
     if (wv::lane() == 0) l = wv::atomic_add(&P.counter[1], 1u);
     l = wv::first(l);
     if (l >= P.n_loci) break;
-    rc.packLocus(l);
+    rc.packOffsets(l);
+    wv::sync();
+  }
+}
+
+/// pile-read-parallel: eight reads per wave step
+WV_KERNEL void read_pile_bases_kernel(const ReadClassParams P)
+{
+  ReadClass                rc(P);
+  const unsigned long long nPileAll = P.locus_base[4 * size_t(P.n_loci)];
+  while (true) {
+    unsigned g = 0;
+    if (wv::lane() == 0) g = wv::atomic_add(&P.counter[3], 1u);
+    g = wv::first(g);
+    if (8ull * g >= nPileAll) break;
+    rc.packBases(g, nPileAll);
     wv::sync();
   }
 }

@@ -123,13 +123,19 @@ WV_DEV uint32_t pk_max_i16(uint32_t a, uint32_t b)
 {
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pk_s2, a), __builtin_bit_cast(pk_s2, b)));
 }
+// (these two as the instruction itself: from the vector builtins the compiler rewrites min(x, 1) * c + d into compares and selects
+// per half -- six instructions where two do)
 WV_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b)
 {
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(pk_u2, a), __builtin_bit_cast(pk_u2, b)));
+  uint32_t r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 WV_DEV uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c)
 {
-  return __builtin_bit_cast(uint32_t, pk_u2(__builtin_bit_cast(pk_u2, a) * __builtin_bit_cast(pk_u2, b) + __builtin_bit_cast(pk_u2, c)));
+  uint32_t r;
+  asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
 }
 
 WV_DEV int popc(unsigned v) { return __popc(v); }
