@@ -312,7 +312,13 @@ struct PairMultiParams {
   uint8_t         e_of[8];     ///< their E
 };
 
-WV_KERNEL void align_pair_multi_kernel(const PairMultiParams M)
+template <int E>
+WV_DEV void runPairWidth(const AlignParams& A, const unsigned ta, const unsigned tb, const bool haveB, uint8_t* slab)
+{
+  PairAligner<E>(A).run(A.tasks[ta], A.tasks[tb], A.results[ta], A.results[tb], haveB, slab);
+}
+
+WV_KERNEL_OCC(4) void align_pair_multi_kernel(const PairMultiParams M)
 {
   uint8_t* slab = M.A.ptr_ws + uint64_t(wv::block()) * M.A.ptr_ws_stride;
   unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0, n4 = 0, n5 = 0;  // tasks per queue position
@@ -340,12 +346,12 @@ WV_KERNEL void align_pair_multi_kernel(const PairMultiParams M)
     const unsigned  ia = 2 * p, ib = (2 * p + 1 < n) ? 2 * p + 1 : 2 * p;
     const unsigned  ta = ids[ia], tb = ids[ib];
     switch (M.e_of[j]) {
-    case 1: PairAligner<1>(M.A).run(M.A.tasks[ta], M.A.tasks[tb], M.A.results[ta], M.A.results[tb], ib != ia, slab); break;
-    case 2: PairAligner<2>(M.A).run(M.A.tasks[ta], M.A.tasks[tb], M.A.results[ta], M.A.results[tb], ib != ia, slab); break;
-    case 3: PairAligner<3>(M.A).run(M.A.tasks[ta], M.A.tasks[tb], M.A.results[ta], M.A.results[tb], ib != ia, slab); break;
-    case 4: PairAligner<4>(M.A).run(M.A.tasks[ta], M.A.tasks[tb], M.A.results[ta], M.A.results[tb], ib != ia, slab); break;
-    case 5: PairAligner<5>(M.A).run(M.A.tasks[ta], M.A.tasks[tb], M.A.results[ta], M.A.results[tb], ib != ia, slab); break;
-    default: PairAligner<6>(M.A).run(M.A.tasks[ta], M.A.tasks[tb], M.A.results[ta], M.A.results[tb], ib != ia, slab); break;
+    case 1: runPairWidth<1>(M.A, ta, tb, ib != ia, slab); break;
+    case 2: runPairWidth<2>(M.A, ta, tb, ib != ia, slab); break;
+    case 3: runPairWidth<3>(M.A, ta, tb, ib != ia, slab); break;
+    case 4: runPairWidth<4>(M.A, ta, tb, ib != ia, slab); break;
+    case 5: runPairWidth<5>(M.A, ta, tb, ib != ia, slab); break;
+    default: runPairWidth<6>(M.A, ta, tb, ib != ia, slab); break;
     }
     wv::sync();
   }

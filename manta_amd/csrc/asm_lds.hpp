@@ -2,27 +2,28 @@
 // length of a locus whose k-mer graph is acyclic and small enough):
 //
 //   graph_kernel   one workgroup of LG_WAVES wavefronts per locus, LG_BUDGET bytes of LDS (two workgroups per CU).  Everything
-//                  that is parallel over k-mer instances or over words: pack -> table pass (getKmerCounts :506-550) -> counts ->
-//                  SORT of the words into the reference's seed order (:686-696: count descending, k-mer ascending) -> node
-//                  records with successor / predecessor links in that numbering -> the compact graph (16 bytes per word + 16 per
-//                  word with more than one read) goes to a per-locus slab in global memory.
-//   contig_kernel  one single-wave workgroup per locus, only the compact graph in LDS (~22 KB for a config-2 locus: six per CU
-//                  instead of three): cycle test, the contig loop (:685-713) on speculative lane-per-seed walks (:149-501),
-//                  selectContigs (:722-842), output.
+//                  that is parallel over k-mer instances or over words: pack -> table pass (getKmerCounts :506-550; the slot of a
+//                  word IS its identity: claim + one ds_or into the slot's read set) -> counts -> SORT of the words into the
+//                  reference's seed order (:686-696: count descending, k-mer ascending) -> 8-byte node records with successor /
+//                  predecessor links in that numbering -> proof of acyclicity from the reads' offsets -> the compact graph (8 bytes
+//                  per word + 16 per word with more than one read) goes to a per-locus slab in global memory.
+//   contig_kernel  (asm_contig.hpp) one single-wave workgroup per locus, only the compact graph in LDS (12-19 KB for a config-2
+//                  locus: eight per CU): cycle test where there is no proof, the contig loop (:685-713) on speculative lane-per-seed
+//                  walks (:149-501), selectContigs (:722-842), output.
 //
 // Why two kernels.  The fused predecessor of this file (assemble_fast_kernel, rounds 2-3) held a locus' 52 KB of LDS from the
 // first byte to the last contig: three loci per CU, and for two thirds of a locus' time only one wave of the workgroup had work
 // (the walks are one dependent chain per lane).  The parallel half wants many waves and room for simple dense structures; the
 // serial half wants as many loci in flight as possible and needs neither the pile nor the hash table.  Splitting at the graph
-// gives each half its own occupancy, register budget and LDS map; the hand-over costs ~20 KB per locus, written and read once,
+// gives each half its own occupancy, register budget and LDS map; the hand-over costs ~16 KB per locus, written and read once,
 // coalesced.
 //
 // What the sort buys: with node ids in seed order, "the next unused seed" is the lowest set bit of a bitmap, the two lowest
 // count tiers are an id range, the words with more than one read are the ids below nFat (their bitsets need no reference), and
 // the contig kernel never looks at a key -- no pile, no table, no key compares in LDS.
 //
-// Anything this path does not cover -- a cycle, a repeat hit that asks for the next word length, > 108 reads, a graph that does
-// not fit, bytes outside {A,C,G,T,N} -- goes onto the punt list; assemble_kernel, launched behind, picks it up from device
+// Anything this path does not cover -- a cycle, a repeat hit that asks for the next word length, > LG_MAX_READS reads, a graph that
+// does not fit, bytes outside {A,C,G,T,N} -- goes onto the punt list; assemble_kernel, launched behind, picks it up from device
 // memory.  Nothing is approximated.
 #pragma once
 #include "assemble_kernels.hpp"

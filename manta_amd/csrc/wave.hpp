@@ -29,6 +29,8 @@
 #define WV_HD __host__ __device__ inline
 // cold paths (measured: real out-of-line calls cost more than they save on gfx950, so this is still inline)
 #define WV_DEV_COLD __device__ __forceinline__
+// a real call (once per work item, never per step): keeps the caller's register budget at the callee's own
+#define WV_DEV_CALL __device__ __attribute__((noinline))
 
 extern __shared__ __attribute__((aligned(16))) char wv_dyn_lds[];
 

@@ -24,6 +24,7 @@
 #define WV_WAVES_PER_WG 1
 #define WV_HD inline
 #define WV_DEV_COLD inline
+#define WV_DEV_CALL inline
 
 namespace wv_emu {
 

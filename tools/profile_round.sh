@@ -29,6 +29,16 @@ if [ "$2" = "spanning" ]; then
   timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/spanning_pmc_fetch -o p -- $B --workload spanning --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
   timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/spanning_pmc_write -o p -- $B --workload spanning --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
 fi
+if [ "$2" = "spanning" ] || [ "$3" = "read_class" ] || [ "$2" = "read_class" ]; then
+  # read gathering (manta_read_piles_batch) as a measured component: its line, kernel stats, counters in separate passes
+  RC="python $R/tools/bench_read_class.py 150"
+  timeout 200 $RC > $O/read_class.log 2>&1
+  tail -1 $O/read_class.log > $O/read_class_line.json
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rc_stats -o rc -- $RC > /dev/null 2>&1
+  timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/rc_pmc_fetch -o p -- $RC > /dev/null 2>&1
+  timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/rc_pmc_write -o p -- $RC > /dev/null 2>&1
+  timeout 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $O/rc_pmc_sq -o p -- $RC > /dev/null 2>&1
+fi
 # keep only the small files (gpurun_out merges back <= 64 MiB)
 find $O -name "*_kernel_trace.csv" -size +8M -delete
 find $O -name "*.rocpd" -delete

@@ -71,7 +71,7 @@ traffic = {"loci": 10000, "workload": "smallsv", "source": "tools/profile_round.
                    "everything else raw; assembler_stage = graph_kernel + contig_kernel launches (+ assemble_kernel's launch for punted loci)"}
 agg = {}
 for k, v in per.items():
-    if k.startswith("align_kernel<1") or k.startswith("align_pair_kernel"):
+    if k.startswith("align_kernel<1") or k.startswith("align_pair"):
         name = "align_kernel<LARGE_INDEL>"  # (the E-bucket launches of a block, packed pairs or not, together)
     elif k.startswith("graph_kernel") or k.startswith("contig_kernel") or k.startswith("assemble_kernel"):
         name = "assembler_stage"  # graph_kernel + contig_kernel (+ the general kernel's launch for punted loci): what bench.py times as the assembler
@@ -104,6 +104,9 @@ if sper:
     span_loci = 65536
     if os.path.exists(sp) and os.path.getsize(sp):
         span_loci = json.loads(open(sp).read().strip().splitlines()[-1])["config"]["loci_per_gpu"]
+    marker = os.path.join(src, "spanning_pmc_loci.txt")  # (counter passes on fewer loci than the bench line: tools/gpu_r4_q.sh)
+    if os.path.exists(marker):
+        span_loci = int(open(marker).read().split()[0])
     st = {"loci": span_loci, "workload": "spanning", "source": traffic["source"], "date": traffic["date"], "note": traffic["note"]}
     for k, v in sper.items():
         name = "align_kernel<JUMP>" if k.startswith("align_kernel<2") else k
@@ -111,5 +114,35 @@ if sper:
         st[name] = int(st.get(name, 0) + (v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 / n)
     json.dump(st, open(os.path.join(dst, "traffic_spanning.json"), "w"), indent=1)
     print(json.dumps(st, indent=1))
+# read gathering (tools/profile_round.sh <tag> ... read_class): line, kernel stats, one counter row per kernel (launches of the whole
+# bench_read_class.py run: 6 timed calls + the checked one)
+rcl = os.path.join(src, "read_class_line.json")
+if os.path.exists(rcl) and os.path.getsize(rcl):
+    json.loads(open(rcl).read())
+    open(os.path.join(dst, tag + "_read_class_line.json"), "w").write(open(rcl).read())
+    rcs = glob.glob(os.path.join(src, "rc_stats", "**", "*kernel_stats.csv"), recursive=True)
+    if rcs:
+        open(os.path.join(dst, tag + "_read_class_kernel_stats.csv"), "w").write(open(rcs[0]).read())
+    rper, rlaunch = {}, {}
+    for d in ("rc_pmc_fetch", "rc_pmc_write", "rc_pmc_sq"):
+        for f in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
+            seen = {}
+            for row in csv.DictReader(open(f)):
+                k = short(row["Kernel_Name"])
+                if "rocclr" in k:
+                    continue
+                rper.setdefault(k, {}).setdefault(row["Counter_Name"], 0.0)
+                rper[k][row["Counter_Name"]] += float(row["Counter_Value"])
+                seen.setdefault(k, set()).add(row.get("Dispatch_Id", row.get("Correlation_Id", "")))
+            for k, ids in seen.items():
+                rlaunch[k] = max(rlaunch.get(k, 0), len(ids))
+    if rper:
+        rcols = sorted({c for v in rper.values() for c in v})
+        with open(os.path.join(dst, tag + "_read_class_pmc.csv"), "w") as out:
+            out.write("# rocprofv3 --pmc passes over `python tools/bench_read_class.py 150` (315 541 records, 150 candidates), summed per kernel over the\n")
+            out.write("# run's launches (column 2); FETCH_SIZE / WRITE_SIZE in KiB, separate passes\n")
+            out.write("kernel,launches," + ",".join(rcols) + "\n")
+            for k in sorted(rper):
+                out.write('"%s",%d,' % (k, rlaunch.get(k, 1)) + ",".join("%.0f" % rper[k].get(c, 0) for c in rcols) + "\n")
 print(json.dumps(traffic, indent=1))
 print(line[:300])
