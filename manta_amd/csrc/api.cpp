@@ -667,7 +667,8 @@ struct AsmStage {
       for (unsigned c = 0; c < LG_CLASSES; ++c) {
         gridContig[c] = 0;
         if (!classBytes[c]) continue;
-        const int perCu = std::max(1, std::min(8, rt::blocksPerCu(contig_kernel, 64, classBytes[c], int(163840 / classBytes[c]))));
+        static const int wgCap = std::getenv("MANTA_AMD_CONTIG_WG_CAP") ? std::atoi(std::getenv("MANTA_AMD_CONTIG_WG_CAP")) : 8;  // experiments
+        const int perCu = std::max(1, std::min(wgCap, rt::blocksPerCu(contig_kernel, 64, classBytes[c], int(163840 / classBytes[c]))));
         gridContig[c]   = int(std::max<uint64_t>(1, std::min<uint64_t>(fastIds.size(), uint64_t(ctx->cuCount) * perCu)));
         maxGrid         = std::max(maxGrid, gridContig[c]);
       }
@@ -3087,6 +3088,9 @@ int smallsvBatchImpl(
     manta_smallsv* b   = ctx->smallPool[w / nCtx];
     try {
       rt::setDevice(ctx->deviceId);
+      // a pooled pipeline that served other options or scores: its bucket counts say nothing about this call's contigs
+      if (std::memcmp(&b->opt, opt, sizeof(*opt)) != 0 || std::memcmp(&b->scores, scores, sizeof(*scores)) != 0 || b->largeIndel != large_indel_score)
+        b->bucketHistory = false;
       b->opt           = *opt;
       b->scores        = *scores;
       b->largeIndel    = large_indel_score;

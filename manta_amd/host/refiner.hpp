@@ -346,8 +346,37 @@ inline void toResult(const AlignJob& j, JumpAlignmentResult<int>& result)
   toPath(j.cigar.data() + j.res.cigar2_off, j.res.cigar2_len, result.align2.apath);
 }
 
+/// page-locked staging memory kept by a refiner object across calls (manta_host_alloc: the upload is a plain DMA, and the buffer is
+/// not zero-filled and re-faulted on every batch as a std::vector would be); falls back to pageable memory if the driver says no
+struct PinnedArena {
+  uint8_t* p   = nullptr;
+  size_t   cap = 0;
+  PinnedArena() = default;
+  PinnedArena(const PinnedArena&) = delete;
+  PinnedArena& operator=(const PinnedArena&) = delete;
+  ~PinnedArena()
+  {
+    if (p) manta_host_free(p);
+  }
+  /// at least `n` bytes, or nullptr
+  uint8_t* ensure(const size_t n)
+  {
+    if (n <= cap) return p;
+    if (p) manta_host_free(p);
+    p   = nullptr;
+    cap = 0;
+    const size_t want = n + n / 4 + 4096;
+    void*        q    = nullptr;
+    if (manta_host_alloc(want, &q) != MANTA_OK || !q) return nullptr;
+    p   = static_cast<uint8_t*>(q);
+    cap = want;
+    return p;
+  }
+};
+
 struct PackedReads {
   std::vector<uint8_t>  bases;
+  const uint8_t*        basesPtr = nullptr;  ///< the flattened piles + one pad byte (finish())
   std::vector<uint64_t> readOff{0};
   std::vector<uint32_t> locusBegin{0};
   std::vector<uint64_t> bitsBound;  ///< per locus
@@ -364,14 +393,21 @@ struct PackedReads {
     const uint64_t W = (reads.size() + 2ull * maxAssemblyCount + 63) / 64;
     bitsBound.push_back(uint64_t(maxAssemblyCount) * 2 * W + 2ull * maxAssemblyCount + 8);
   }
-  /// flatten the piles into `bases` (the copy is spread over host threads)
-  void finish(const unsigned threads)
+  /// flatten the piles (the copy is spread over host threads) into `stage` if it can hold them, else into `bases`; the kernels
+  /// read input arenas in aligned dwords: one pad byte behind the last base
+  void finish(const unsigned threads, PinnedArena* stage = nullptr)
   {
-    bases.resize(readOff.back());
+    uint8_t* dst = stage ? stage->ensure(readOff.back() + 16) : nullptr;
+    if (!dst) {
+      bases.resize(readOff.back() + 1);
+      dst = bases.data();
+    }
+    dst[readOff.back()] = 0;
+    basesPtr            = dst;
     parallelFor(piles.size(), threads, [&](const size_t l) {
       size_t r = locusBegin[l];
       for (const std::string& rd : *piles[l]) {
-        std::copy(rd.begin(), rd.end(), bases.begin() + readOff[r]);
+        std::copy(rd.begin(), rd.end(), dst + readOff[r]);
         ++r;
       }
     });
@@ -409,15 +445,6 @@ struct AsmOutput {
   }
 };
 
-/// the kernels read input arenas in aligned dwords: one pad byte behind the last base, taken back on every exit path
-struct SentinelByte {
-  std::vector<uint8_t>& v;
-  explicit SentinelByte(std::vector<uint8_t>& vec) : v(vec) { v.push_back(0); }
-  ~SentinelByte() { v.pop_back(); }
-  SentinelByte(const SentinelByte&) = delete;
-  SentinelByte& operator=(const SentinelByte&) = delete;
-};
-
 struct SmallSvOutput : AsmOutput {
   std::vector<manta_smallsv_alignment_t> aligns;
   std::vector<uint32_t>                  cigar;
@@ -438,13 +465,12 @@ inline void smallSvBatch(
     refOff.push_back(refBytes.size());
   }
   refBytes.push_back(0);
-  SentinelByte guard(in.bases);
   auto check = [&](const int rc) {
     if (rc == MANTA_OK) return;
     throw GeneralException("manta_amd small-SV pipeline: " + std::string(manta_last_error(ctx)), rc);
   };
   if (!b) check(manta_smallsv_create(ctx, &o, &sc, largeIndelScore, &b));  // kept by the caller: device buffers are reused
-  check(manta_smallsv_upload(b, in.nLoci(), in.bases.data(), in.readOff.data(), in.locusBegin.data(), refBytes.data(), refOff.data(),
+  check(manta_smallsv_upload(b, in.nLoci(), in.basesPtr, in.readOff.data(), in.locusBegin.data(), refBytes.data(), refOff.data(),
                              cuts.data()));
   check(manta_smallsv_run(b));
   uint64_t nc = 0, sb = 0, bw = 0, cw = 0;
@@ -484,13 +510,12 @@ inline void spanningBatch(
   }
   ref1Bytes.push_back(0);
   ref2Bytes.push_back(0);
-  SentinelByte guard(in.bases);
   auto check = [&](const int rc) {
     if (rc == MANTA_OK) return;
     throw GeneralException("manta_amd spanning pipeline: " + std::string(manta_last_error(ctx)), rc);
   };
   if (!b) check(manta_spanning_create(ctx, &o, &sc, jumpScore, &b));  // kept by the caller: device buffers are reused
-  check(manta_spanning_upload(b, in.nLoci(), in.bases.data(), in.readOff.data(), in.locusBegin.data(), ref1Bytes.data(), ref1Off.data(),
+  check(manta_spanning_upload(b, in.nLoci(), in.basesPtr, in.readOff.data(), in.locusBegin.data(), ref1Bytes.data(), ref1Off.data(),
                               ref2Bytes.data(), ref2Off.data(), cuts.data()));
   check(manta_spanning_run(b));
   uint64_t nc = 0, sb = 0, bw = 0, cw = 0;
@@ -724,7 +749,7 @@ private:
       cuts.push_back(manta_ref_cuts_t{plans[i].leadingCut, plans[i].trailingCut, plans[i].maxLeadingCut, plans[i].maxTrailingCut});
     }
     if (which.empty()) return;
-    packed.finish(_hostThreads);
+    packed.finish(_hostThreads, &_stage);
     _stats.smallLoci += which.size();
     const double          tPacked = now();
     _times.pack += tPacked - tStart;
@@ -971,7 +996,7 @@ private:
       packed.addLocus(plans[i].reads, maxAsm);
     }
     if (loci.empty()) return;
-    packed.finish(_hostThreads);
+    packed.finish(_hostThreads, &_stage);
     _stats.spanningLoci += loci.size();
 
     // orientation step of alignJumpContigs (:1533-1550)
@@ -1087,6 +1112,7 @@ private:
   mutable manta_ctx_t*          _ctx       = nullptr;
   mutable manta_smallsv_t*      _smallPipe = nullptr;  ///< device pipelines of this refiner (and of the thread that
   mutable manta_spanning_t*     _spanPipe  = nullptr;  ///< first used it: one ABI context per host thread)
+  mutable detail::PinnedArena   _stage;                ///< page-locked staging of a batch's read bases, reused
   unsigned                      _hostThreads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
 };
 

@@ -107,7 +107,10 @@ if sper:
     marker = os.path.join(src, "spanning_pmc_loci.txt")  # (counter passes on fewer loci than the bench line: tools/gpu_r4_q.sh)
     if os.path.exists(marker):
         span_loci = int(open(marker).read().split()[0])
-    st = {"loci": span_loci, "workload": "spanning", "source": traffic["source"], "date": traffic["date"], "note": traffic["note"]}
+    st = {"loci": span_loci, "workload": "spanning", "source": traffic["source"] + " / tools/gpu_r4_q.sh", "date": traffic["date"],
+          "note": "HBM-side bytes of ONE step of `bench.py --workload spanning --loci <loci>` = (FETCH_SIZE + WRITE_SIZE) KiB * 1024 per kernel, rocprofv3 --pmc, "
+                  "separate passes, raw.  `loci` is the size of the counter passes' block: under the profiler the bench line's 65 536-locus block ran into "
+                  "the passes' time limit, so they ran on fewer loci (per-locus traffic is what carries over)"}
     for k, v in sper.items():
         name = "align_kernel<JUMP>" if k.startswith("align_kernel<2") else k
         n = 1 if name.startswith("align_kernel") else max(1, slaunch.get(k, 1))
