@@ -310,6 +310,7 @@ struct PairMultiParams {
   uint32_t        n_order;     ///< <= 6
   uint8_t         order[8];    ///< bucket indices in queue order
   uint8_t         e_of[8];     ///< their E
+  uint32_t        prio_work[3];  ///< a pair of at least this much work (E x (G + 64)) issues at priority 1 / 2 / 3 (s_setprio); 0 = never
 };
 
 template <int E>
@@ -345,6 +346,15 @@ WV_KERNEL_OCC(4) void align_pair_multi_kernel(const PairMultiParams M)
     const uint32_t* ids = M.bucket_ids + uint64_t(M.order[j]) * M.n_slots;
     const unsigned  ia = 2 * p, ib = (2 * p + 1 < n) ? 2 * p + 1 : 2 * p;
     const unsigned  ta = ids[ia], tb = ids[ib];
+    {
+      // The queue hands out the long sweeps first, but a short contig against a whole reference window is one dependent chain of
+      // E x (G + 63) steps' worth of work -- longer than the AVERAGE load of a wave in a block of ~2 pairs per wave -- and under
+      // an even share of a saturated SIMD it would finish last with the device idling around it.  Long pairs therefore issue
+      // ahead of the short ones of their SIMD; the short ones fill the gaps.
+      const unsigned ga = M.A.tasks[ta].ref1_len, gb = M.A.tasks[tb].ref1_len;
+      const unsigned work = unsigned(M.e_of[j]) * (((ga > gb) ? ga : gb) + 64u);
+      wv::setprio((M.prio_work[2] && work >= M.prio_work[2]) ? 3u : (M.prio_work[1] && work >= M.prio_work[1]) ? 2u : (M.prio_work[0] && work >= M.prio_work[0]) ? 1u : 0u);
+    }
     switch (M.e_of[j]) {
     case 1: runPairWidth<1>(M.A, ta, tb, ib != ia, slab); break;
     case 2: runPairWidth<2>(M.A, ta, tb, ib != ia, slab); break;

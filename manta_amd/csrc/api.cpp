@@ -445,7 +445,7 @@ struct AsmStage {
   uint64_t*     hCnt  = nullptr;
   uint64_t      seqUsedDev = 0, bitsUsedDev = 0, nContigsOut = 0, pseudoBytesOut = 0, pseudoCountOut = 0;
   bool          staged = false;
-  uint32_t      ldsFallbacks = 0;  // loci assemble_fast_kernel handed to the general path (valid after stageOut)
+  uint32_t      ldsFallbacks = 0;  // loci the LDS pipeline handed to the general kernel (valid after stageOut)
 
   manta_asm_options_t opt{};
   uint32_t            nLoci = 0, nReadsTotal = 0, maxContigLen = 0, wMax = 0, capWords = 0, capReads = 0, capNodes = 0, capSlots = 0;
@@ -2176,6 +2176,14 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
         M.counts          = dSmall;
         M.n_slots         = uint32_t(nSlots);
         M.n_order         = uint32_t(merged.size());
+        M.prio_work[0] = 2560u;  // (defaults from the config-2 measurement: a typical pair is E x (G + 64) ~ 5 x 384 = 1 920)
+        M.prio_work[1] = 0u;
+        M.prio_work[2] = 4096u;
+        if (const char* e = std::getenv("MANTA_AMD_ALIGN_PRIO")) {  // experiments: "w1,w2,w3" (0 = level unused; "0,0,0" = no priorities)
+          unsigned v[3] = {0, 0, 0};
+          std::sscanf(e, "%u,%u,%u", &v[0], &v[1], &v[2]);
+          for (int i = 0; i < 3; ++i) M.prio_work[i] = v[i];
+        }
         for (size_t i = 0; i < 8; ++i) {
           M.order[i] = uint8_t(i < merged.size() ? merged[i].k : 0);
           M.e_of[i]  = uint8_t(i < merged.size() ? kESet[merged[i].k] : 0);
@@ -3776,7 +3784,7 @@ extern "C" int manta_read_piles_batch(
 }
 
 #ifdef MANTA_WAVE_EMU
-/// tests/emu only: speculation statistics of assemble_fast_kernel since the last call (loci done by it, walk rounds, walks,
+/// tests/emu only: speculation statistics of contig_kernel since the last call (loci done by it, walk rounds, walks,
 /// accepted candidates, cache evictions)
 extern "C" void manta_emu_fast_stats(unsigned long long* out)
 {

@@ -140,18 +140,17 @@ struct AsmParams {
   // small_assemble_kernel only (small_asm.hpp): SmallAssemblerOptions::minSeedReads / maxAssemblyIterations
   uint32_t        small_min_seed_reads;
   uint32_t        small_max_iterations;
-  // assemble_fast_kernel (asm_fast.hpp) hands the loci it does not cover to the general kernel through device memory:
-  // it appends their ids to punt_ids and counts them in *punt_count; the general kernel launched behind it takes
+  // The LDS pipeline (graph_kernel / contig_kernel, asm_lds.hpp) hands the loci it does not cover to the general kernel through
+  // device memory: it appends their ids to punt_ids and counts them in *punt_count; the general kernel launched behind it takes
   // locus_ids = punt_ids and reads its number of loci from *n_loci_dev (nullptr: n_loci) -- no host round trip in between
   uint32_t*       punt_ids;
   uint32_t*       punt_count;
   const uint32_t* n_loci_dev;
-  /// dynamic LDS per wave of assemble_kernel (ASM_LDS_BYTES alone on the device; less when it shares the CUs with
-  /// assemble_fast_kernel, which owns most of the LDS then): peel state / visited bitmaps that do not fit go to the slab
+  /// dynamic LDS per wave of assemble_kernel (ASM_LDS_BYTES; a launch may be given less): peel state / visited bitmaps that do
+  /// not fit go to the slab
   uint32_t        lds_bytes;
-  /// assemble_kernel takes no further locus once the shared work counter has reached this value (0: no limit).  Side by side
-  /// with assemble_fast_kernel the end of the list is left to the fast kernel: a locus takes it a quarter of the time it
-  /// takes a wave of this kernel, so the last loci started here would be the last to finish
+  /// assemble_kernel takes no further locus once the shared work counter has reached this value (0: no limit; unused since the
+  /// LDS pipeline and this kernel no longer share a queue)
   uint32_t        stop_before;
 };
 

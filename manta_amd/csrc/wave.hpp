@@ -108,6 +108,18 @@ WV_DEV unsigned long long atomic_load(const unsigned long long* p) { return __hi
 WV_DEV unsigned atomic_load_system(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 /// back-off inside a polling loop
 WV_DEV void sleep() { __builtin_amdgcn_s_sleep(32); }
+/// issue priority of this wave among the waves of its SIMD (s_setprio 0..3; wave-uniform argument)
+WV_DEV void setprio(const unsigned level)
+{
+  if (level >= 3)
+    __builtin_amdgcn_s_setprio(3);
+  else if (level == 2)
+    __builtin_amdgcn_s_setprio(2);
+  else if (level == 1)
+    __builtin_amdgcn_s_setprio(1);
+  else
+    __builtin_amdgcn_s_setprio(0);
+}
 /// drop this CU's (possibly stale) L1 lines: needed before plain re-reads of memory that was updated by L2 atomics
 WV_DEV void fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 

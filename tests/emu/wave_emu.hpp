@@ -309,6 +309,7 @@ inline unsigned atomic_load(const unsigned* p) { return *p; }
 inline unsigned long long atomic_load(const unsigned long long* p) { return *p; }
 inline unsigned atomic_load_system(const unsigned* p) { return *p; }
 inline void sleep() {}
+inline void setprio(unsigned) {}
 inline void fence_acquire() {}
 
 // packed 16-bit arithmetic (two lanes of 16 bits per 32-bit value), as the hardware's v_pk_* instructions compute it
