@@ -2166,6 +2166,26 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
         P.extra          = b->largeIndel;
         return P;
       };
+      for (size_t i = 0; i < launches.size(); ++i) {
+        const Launch& l(launches[i]);
+        AlignParams   P  = baseParams();
+        P.task_ids       = (l.pair ? dBucketsSorted : dBuckets) + uint64_t(l.k) * nSlots;
+        P.n_tasks        = fromHistory ? uint32_t(nSlots) : hSmall[l.k];
+        P.n_tasks_dev    = fromHistory ? dSmall + l.k : nullptr;
+        P.counter        = dSmall + 40 + l.k;
+        P.ptr_ws         = dWsAll + l.slabOff;
+        P.ptr_ws_stride  = l.stride;
+        {
+          rt::ScopedStream onSide(b->side[i % 3]);  // (restores the pipeline's stream: nothing of this call runs on the null stream)
+          launchAlignKind(MANTA_ALIGNER_LARGE_INDEL, l.k, l.grid, P, l.pair);
+        }
+        if (!fromHistory) {
+          b->stats.n_align_launches++;
+          b->stats.n_alignments += hSmall[l.k];
+        }
+      }
+      // (the packed launch goes last: the buckets above are small or token grids that finish at once on an empty device; queued
+      // behind a grid that fills every SIMD's registers they would sit in the dispatcher until its first waves retire)
       if (!merged.empty()) {
         PairMultiParams M;
         M.A               = baseParams();
@@ -2195,24 +2215,6 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
         if (!fromHistory) {
           b->stats.n_align_launches++;
           for (const Launch& l : merged) b->stats.n_alignments += hSmall[l.k];
-        }
-      }
-      for (size_t i = 0; i < launches.size(); ++i) {
-        const Launch& l(launches[i]);
-        AlignParams   P  = baseParams();
-        P.task_ids       = (l.pair ? dBucketsSorted : dBuckets) + uint64_t(l.k) * nSlots;
-        P.n_tasks        = fromHistory ? uint32_t(nSlots) : hSmall[l.k];
-        P.n_tasks_dev    = fromHistory ? dSmall + l.k : nullptr;
-        P.counter        = dSmall + 40 + l.k;
-        P.ptr_ws         = dWsAll + l.slabOff;
-        P.ptr_ws_stride  = l.stride;
-        {
-          rt::ScopedStream onSide(b->side[i % 3]);  // (restores the pipeline's stream: nothing of this call runs on the null stream)
-          launchAlignKind(MANTA_ALIGNER_LARGE_INDEL, l.k, l.grid, P, l.pair);
-        }
-        if (!fromHistory) {
-          b->stats.n_align_launches++;
-          b->stats.n_alignments += hSmall[l.k];
         }
       }
       // the null stream (events, later copies) continues after every side stream has drained
