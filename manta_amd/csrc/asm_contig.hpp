@@ -300,10 +300,13 @@ struct LdsContig {
     LG_STAT(1, 1);
     LG_STAT(2, unsigned(wv::popc(walkMask)));
     const unsigned seed = has ? unsigned(slotNode[lane]) : 0u;
-    uint64_t*      logBuf   = lane_log + size_t(lane) * CK_LOG_QW;
-    uint64_t       logAcc   = seed;
-    uint32_t*      rightBuf = lane_seq + size_t(lane) * 2 * seqWords;
-    uint32_t*      leftBuf  = rightBuf + seqWords;
+    // The walk buffers are LANE-INTERLEAVED (entry i of lane l at [i * 64 + l]): the lanes of a round advance in step, so the stores of
+    // a step -- one qword of the log every fourth extension, one dword of bases every sixteenth -- fall into one run of consecutive
+    // addresses instead of 64 sectors a buffer's length apart.
+    uint64_t* const logBuf   = lane_log + lane;              // [q * 64]
+    uint64_t        logAcc   = seed;
+    uint32_t* const rightBuf = lane_seq + lane;              // [i * 128]
+    uint32_t* const leftBuf  = lane_seq + 64 + lane;         // [i * 128]
     uint32_t       accR = 0, accL = 0;
     uint64_t       S0 = 0, S1 = 0, R0 = 0, R1 = 0;
     bool           active = has, rep = false, tooLong = false;
@@ -374,21 +377,21 @@ struct LdsContig {
           const unsigned pz = 1 + nRight + nLeft;
           logAcc |= uint64_t(f - 1) << (16 * (pz & 3));
           if ((pz & 3) == 3) {
-            logBuf[pz >> 2] = logAcc;
+            logBuf[size_t(pz >> 2) * 64] = logAcc;
             logAcc          = 0;
           }
           const unsigned sym = fwd ? lg8LastBase(w) : lg8FirstBase(w);
           if (fwd) {
             accR |= sym << (2 * (nRight & 15));
             if ((nRight & 15) == 15) {
-              rightBuf[nRight >> 4] = accR;
+              rightBuf[size_t(nRight >> 4) * 128] = accR;
               accR                  = 0;
             }
             nRight++;
           } else {
             accL |= sym << (2 * (nLeft & 15));
             if ((nLeft & 15) == 15) {
-              leftBuf[nLeft >> 4] = accL;
+              leftBuf[size_t(nLeft >> 4) * 128] = accL;
               accL                = 0;
             }
             nLeft++;
@@ -499,7 +502,7 @@ struct LdsContig {
           const unsigned p = 1 + nRight + nLeft;
           logAcc |= uint64_t(maxNode) << (16 * (p & 3));
           if ((p & 3) == 3) {
-            logBuf[p >> 2] = logAcc;
+            logBuf[size_t(p >> 2) * 64] = logAcc;
             logAcc         = 0;
           }
         }
@@ -507,14 +510,14 @@ struct LdsContig {
         if (isEnd) {  // :363
           accR |= sym << (2 * (nRight & 15));
           if ((nRight & 15) == 15) {
-            rightBuf[nRight >> 4] = accR;
+            rightBuf[size_t(nRight >> 4) * 128] = accR;
             accR                  = 0;
           }
           nRight++;
         } else {
           accL |= sym << (2 * (nLeft & 15));
           if ((nLeft & 15) == 15) {
-            leftBuf[nLeft >> 4] = accL;
+            leftBuf[size_t(nLeft >> 4) * 128] = accL;
             accL                = 0;
           }
           nLeft++;
@@ -553,9 +556,9 @@ struct LdsContig {
       lb[1]        = S1;
       lb[2]        = R0;
       lb[3]        = R1;
-      if (nRight & 15) rightBuf[nRight >> 4] = accR;
-      if (nLeft & 15) leftBuf[nLeft >> 4] = accL;
-      logBuf[(nRight + nLeft + 1) >> 2] = logAcc;  // (the last, partly filled qword; a full one was stored and this one is empty)
+      if (nRight & 15) rightBuf[size_t(nRight >> 4) * 128] = accR;
+      if (nLeft & 15) leftBuf[size_t(nLeft >> 4) * 128] = accL;
+      logBuf[size_t((nRight + nLeft + 1) >> 2) * 64] = logAcc;  // (the last, partly filled qword; a full one was stored and this one is empty)
       int32_t* m = lane_meta + lane * 8;
       m[0]       = int(nLeft);
       m[1]       = int(nRight);
@@ -693,9 +696,9 @@ struct LdsContig {
         nCand++;
         // unusedWords.erase for every word of the accepted walk
         const unsigned  n   = wv::readlane(lenI, int(i));
-        const uint16_t* log = reinterpret_cast<const uint16_t*>(lane_log + size_t(sl) * CK_LOG_QW);
+        const uint64_t* log = lane_log + sl;  // (interleaved: qword q of slot sl at [q * 64 + sl])
         for (unsigned j = lane; j < n; j += 64) {
-          const unsigned w = log[j];
+          const unsigned w = unsigned(log[size_t(j >> 2) * 64] >> (16 * (j & 3))) & 0xffffu;
           wv::atomic_and(&unused_bits[w >> 5], ~(1u << (w & 31)));
         }
         wv::sync();
@@ -792,19 +795,19 @@ struct LdsContig {
       const unsigned sl  = wv::readlane(candSlotV, c);
       const unsigned nL  = wv::readlane(nLeft, c), nR = wv::readlane(nRight, c), len = nL + k + nR;
       const unsigned seedPb = gp[slotNode[sl]];
-      const uint32_t* rightBuf = lane_seq + size_t(sl) * 2 * seqWords;
-      const uint32_t* leftBuf  = rightBuf + seqWords;
+      const uint32_t* rightBuf = lane_seq + sl;       // (interleaved: dword i of slot sl at [i * 128 + sl], the left half 64 further)
+      const uint32_t* leftBuf  = lane_seq + 64 + sl;
       for (unsigned i = lane; i < len; i += 64) {  // reverse(left) + seed + right
         unsigned code;
         if (i < nL) {
           const unsigned j = nL - 1 - i;
-          code             = (leftBuf[j >> 4] >> (2 * (j & 15))) & 3;
+          code             = (leftBuf[size_t(j >> 4) * 128] >> (2 * (j & 15))) & 3;
         } else if (i < nL + k) {
           const unsigned pb = seedPb + (i - nL);
           code              = (gc[pb >> 4] >> (30 - 2 * (pb & 15))) & 3u;
         } else {
           const unsigned j = i - nL - k;
-          code             = (rightBuf[j >> 4] >> (2 * (j & 15))) & 3;
+          code             = (rightBuf[size_t(j >> 4) * 128] >> (2 * (j & 15))) & 3;
         }
         P.seq_arena[so + i] = uint8_t("ACGT"[code]);
       }
