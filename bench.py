@@ -208,9 +208,11 @@ def main():
     workers = args.workers or 1
     block = args.block_loci or max(1, (n_loci + workers - 1) // workers)
     if (node_queue or proc_queue) and not args.block_loci:
-        # about two blocks per device: small enough for the queue to even out unequal parts, but not below the size that fills a
-        # device (measured: blocks under ~4096 loci leave the assembler's persistent workgroups short of work)
-        block = max(min(4096, n_loci), n_loci // 2) if n_dev > 1 else n_loci
+        # one block per part of the node's batch (N parts of n_loci loci on one queue).  Measured on one MI355X with the round-4
+        # kernels: the same 10 000 loci as ONE block 971 k loci/s, as blocks of 5 000 778 k, of 4 096 633 k -- every block pays
+        # its fixed host work and its kernels' tails, so smaller blocks would show up as lost scaling that is not the queue's
+        # (DESIGN.md 7); --block-loci overrides, --mix makes the parts unequal
+        block = n_loci
 
     # ---- this rank's batch (outside the clock: synthetic data generation) ----
     if spanning:

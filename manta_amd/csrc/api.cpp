@@ -2973,11 +2973,13 @@ uint32_t autoBlockLoci(const uint32_t n_loci, const uint64_t totalBases)
 }
 
 /// several devices (or processes) on one queue: blocks small enough that the queue can balance uneven costs -- about eight
-/// per puller would be ideal, but a block below ~1000 loci no longer fills a device
+/// per puller would be ideal -- but not below what keeps a device efficient.  Measured on MI355X with the LDS assembler pipeline
+/// (config-2 loci, one device): 10 000 loci as one block 971 k loci/s, as blocks of 5 000 778 k, of 4 096 633 k (fixed per-block
+/// host work and kernel tails) -- hence a floor of 8 192.
 uint32_t nodeBlockLoci(const uint32_t n_loci, const uint64_t totalBases)
 {
   const uint32_t one = autoBlockLoci(n_loci, totalBases);
-  return std::max<uint32_t>(1, std::min<uint32_t>(one, std::max<uint32_t>(1024, n_loci / 64)));
+  return std::max<uint32_t>(1, std::min<uint32_t>(one, std::max<uint32_t>(8192, n_loci / 64)));
 }
 
 /// contiguous blocks of `blockLoci` loci, ordered by decreasing cost (reads x bases, the same estimate the kernels'
