@@ -982,7 +982,8 @@ struct AsmStage {
       A.G.class_stride = uint32_t(fastIds.size());
       for (unsigned c = 0; c < LG_CLASSES; ++c) A.G.class_bytes[c] = classBytes[c];
       A.G.cls        = 0;
-      A.G.flags      = std::getenv("MANTA_AMD_LG_NO_PROOF") ? LG_FLAG_NO_PROOF : 0u;
+      A.G.flags      = (std::getenv("MANTA_AMD_LG_NO_PROOF") ? LG_FLAG_NO_PROOF : 0u) | (std::getenv("MANTA_AMD_LG_NO_RESCUE") ? LG_FLAG_NO_RESCUE : 0u);
+      A.G.stats      = reinterpret_cast<uint32_t*>(dLg + 8);
       int maxGrid = 1;
       for (unsigned c = 0; c < LG_CLASSES; ++c) maxGrid = std::max(maxGrid, gridContig[c]);
       A.G.cws        = bCws.as<uint8_t>(cwsStride * uint64_t(maxGrid));
@@ -1172,8 +1173,12 @@ struct AsmStage {
     }
     staged = true;
     ldsFallbacks = useFast ? uint32_t(hCnt[14] & 0xffffffffu) - uint32_t(genIds.size()) : 0u;
-    if (std::getenv("MANTA_AMD_DEBUG") && useFast)
-      std::fprintf(stderr, "manta_amd: LDS assembler pipeline: %zu loci, %u handed to the general kernel (+ %zu outside its envelope)\n", fastIds.size(), ldsFallbacks, genIds.size());
+    if (std::getenv("MANTA_AMD_DEBUG") && useFast) {
+      uint32_t st[2] = {0, 0};
+      rt::d2h(st, bLgCnt.as<uint64_t>(16) + 8, sizeof(st));
+      std::fprintf(stderr, "manta_amd: LDS assembler pipeline: %zu loci, %u handed to the general kernel (+ %zu outside its envelope); %u graphs came with a "
+                           "proof of acyclicity, %u reads re-anchored\n", fastIds.size(), ldsFallbacks, genIds.size(), st[0], st[1]);
+    }
     if (std::getenv("MANTA_AMD_PROFILE")) {
       static const char* namesGeneral[8] = {"pack", "table", "links", "cycle-check", "exact", "seed", "walk", "select+emit"};
 #ifdef MANTA_LG_PROFILE_GRAPH

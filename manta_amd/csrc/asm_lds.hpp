@@ -176,11 +176,13 @@ struct LgParams {
   uint32_t            class_bytes[LG_CLASSES];  ///< ascending LDS budgets; 0 = unused class
   uint32_t            cls;         ///< contig_kernel: the class this launch runs
   uint32_t            flags;       ///< LG_FLAG_*
+  uint32_t*           stats;       ///< [0] loci whose graph came with a proof of acyclicity, [1] reads re-anchored by readOffsets' second pass
   uint8_t*            cws;         ///< contig_kernel workspaces
   uint64_t            cws_stride;
 };
 
 static const uint32_t LG_FLAG_NO_PROOF = 1u;  ///< tests / A-B runs: never skip contig_kernel's cycle test
+static const uint32_t LG_FLAG_NO_RESCUE = 2u;  ///< A-B runs: reads without an anchor stay roots of their own (readOffsets)
 
 /// one kernel argument: the assembler's parameters and the pipeline's
 struct LgArgs {
@@ -865,6 +867,7 @@ struct LdsGraph {
     }
     return lo;
   }
+  template <int KW>
   WV_DEV void readOffsets()
   {
     if (tw == 0) {
@@ -872,11 +875,12 @@ struct LdsGraph {
       int32_t*        off  = reinterpret_cast<int32_t*>(lds + LG_OFF_ANCH) + LG_MAX_READS;
       uint8_t*        par  = reinterpret_cast<uint8_t*>(hdr + LG_H_PAR);
       int32_t         myOff[2];
-      unsigned        myPar[2];
+      unsigned        myPar[2], myRoot[2];
       for (unsigned h = 0; h < 2; ++h) {
         const unsigned r = lane + 64 * h;
         myOff[h] = 0;
         myPar[h] = r;
+        myRoot[h] = r;
         if (r < nNormal) {
           const uint32_t a = anch[r];
           if (a != LG_NO_ANCHOR) {
@@ -908,6 +912,7 @@ struct LdsGraph {
             if (pp[h] == myPar[h]) {  // the parent is a root: done after this addition
               off[r] = myOff[h];
               par[r] = uint8_t(r);
+              myRoot[h] = myPar[h];
               myPar[h] = r;
             } else {
               off[r]   = myOff[h];
@@ -922,6 +927,124 @@ struct LdsGraph {
       if (std::getenv("MANTA_EMU_PROOF_TRACE"))
         for (unsigned h = 0; h < 2; ++h)
           if (lane + 64 * h < nNormal) std::fprintf(stderr, "  read %u: anchor %08x off %d par %u\n", lane + 64 * h, anch[lane + 64 * h], myOff[h], myPar[h]);
+#endif
+      // ---- second chance.  A read whose words were all new when it went in -- the reads of a step are inserted by eight waves at
+      // once, so which of two overlapping reads "was first" is a race -- has no anchor and is the root of a tree of its own, at
+      // offset 0: one such tree beside the main one and the proof is lost.  Now that every word is in the table, such a root
+      // looks its words up again and ties itself (and its tree) to the first word that a read of the MAIN tree brought.  Any
+      // function phi proves acyclicity if it rises by one along every edge, so nothing here can make the proof unsound.
+      if (!(G.flags & LG_FLAG_NO_RESCUE)) {
+        uint8_t* rootOf = reinterpret_cast<uint8_t*>(lds + LG_OFF_WHIST);  // (the histograms are not in use before the sort)
+        for (unsigned h = 0; h < 2; ++h) rootOf[lane + 64 * h] = uint8_t(myRoot[h]);
+        wv::sync();
+        // the main tree: the root with the most reads
+        unsigned mainRoot = 0, mainSize = 0;
+        for (unsigned h = 0; h < 2; ++h) {
+          uint64_t roots = wv::ballot(lane + 64 * h < nNormal && myRoot[h] == lane + 64 * h);
+          while (roots) {
+            const unsigned c  = unsigned(wv::ctz(roots)) + 64 * h;
+            roots &= roots - 1;
+            const unsigned sz = unsigned(wv::popc(wv::ballot(lane < nNormal && myRoot[0] == c))) +
+                                unsigned(wv::popc(wv::ballot(lane + 64 < nNormal && myRoot[1] == c)));
+            if (sz > mainSize) {
+              mainSize = sz;
+              mainRoot = c;
+            }
+          }
+        }
+        for (unsigned round = 0; round < 3; ++round) {
+          bool any = false;
+          for (unsigned h = 0; h < 2; ++h) {
+            uint64_t roots = wv::ballot(lane + 64 * h < nNormal && myRoot[h] == lane + 64 * h && lane + 64 * h != mainRoot);
+            while (roots) {
+              const unsigned s = unsigned(wv::ctz(roots)) + 64 * h;
+              roots &= roots - 1;
+              // A word that both trees hold ties them: it was brought by a read of one tree (its first occurrence) and sits in a read of
+              // the other.  Which side brought the shared words is the same race -- a tree whose reads were always first holds no
+              // word of the other's -- so both directions are tried: reads of s against words of the main tree, then reads of the main
+              // tree against words of s; every second position of up to sixteen reads each (the words one tree brought come in runs;
+              // reads at the far end of a tree may not reach the other tree at all, the ones in the middle do).
+              bool    tied  = false;
+              int32_t delta = 0;
+              for (unsigned dir = 0; dir < 2 && !tied; ++dir) {
+                const unsigned fromRoot = dir ? mainRoot : s, toRoot = dir ? s : mainRoot;
+                uint64_t mem0 = wv::ballot(lane < nNormal && myRoot[0] == fromRoot), mem1 = wv::ballot(lane + 64 < nNormal && myRoot[1] == fromRoot);
+                for (unsigned tries = 0; tries < 16 && !tied && (mem0 | mem1); ++tries) {
+                  unsigned x;
+                  if (mem0) {
+                    x = unsigned(wv::ctz(mem0));
+                    mem0 &= mem0 - 1;
+                  } else {
+                    x = 64 + unsigned(wv::ctz(mem1));
+                    mem1 &= mem1 - 1;
+                  }
+                  const unsigned d = rd[x], cwo = d & 0x7ffu, len = (d >> 11) & 0xffffu, mwo = rdm[x];
+                  const bool     rdHasN = (d >> 27) & 1u;
+                  const int32_t  offX   = off[x];
+                  for (unsigned j0 = 0; j0 + k <= len && !tied; j0 += 128) {
+                    const unsigned j     = j0 + 2 * lane;
+                    const bool     valid = (j + k <= len) && !(rdHasN && windowHasN(mwo, j));
+                    unsigned       slot  = ASM_NONE;
+                    if (valid) slot = lookupSlot<KW>(keyAt<KW>(cwo * 16 + j));
+                    bool    ok   = false;
+                    int32_t mine = 0;
+                    if (slot != ASM_NONE) {
+                      const unsigned fpb = slots[slot] & 0x7fffu;
+                      const unsigned o   = readOfPb(fpb);
+                      if (rootOf[o] == toRoot) {
+                        ok = true;
+                        const int32_t there = off[o] + int32_t(fpb - 16u * (rd[o] & 0x7ffu)), here = offX + int32_t(j);
+                        mine = dir ? (here - there) : (there - here);  // the word's coordinate in the main tree minus its coordinate in s
+                      }
+                    }
+                    const uint64_t m = wv::ballot(ok);
+                    if (m) {
+                      tied  = true;
+                      delta = wv::readlane(mine, int(wv::ctz(m)));
+                    }
+                  }
+                }
+              }
+#ifdef MANTA_WAVE_EMU
+              if (std::getenv("MANTA_EMU_PROOF_TRACE2") && lane == 0 && !tied) {  // brute force: every word of every member
+                unsigned links = 0, words = 0, selfOwned = 0, otherTree = 0;
+                for (unsigned x = 0; x < nNormal; ++x) {
+                  if (rootOf[x] != s) continue;
+                  const unsigned d = rd[x], cwo = d & 0x7ffu, len = (d >> 11) & 0xffffu;
+                  for (unsigned j = 0; j + k <= len; ++j) {
+                    if (((d >> 27) & 1u) && windowHasN(rdm[x], j)) continue;
+                    const unsigned slot = lookupSlot<KW>(keyAt<KW>(cwo * 16 + j));
+                    if (slot == ASM_NONE) continue;
+                    ++words;
+                    const unsigned o = readOfPb(slots[slot] & 0x7fffu);
+                    if (rootOf[o] == mainRoot) ++links; else if (rootOf[o] == s) ++selfOwned; else ++otherTree;
+                  }
+                }
+                std::fprintf(stderr, "    brute force over tree %u: %u words, %u owned by the main tree, %u by the tree itself, %u by other trees\n", s, words, links, selfOwned, otherTree);
+              }
+              if (std::getenv("MANTA_EMU_PROOF_TRACE") && lane == 0)
+                std::fprintf(stderr, "  rescue: tree of read %u (main tree: read %u with %u reads): %s, delta %d\n", s, mainRoot, mainSize, tied ? "tied" : "no link", int(delta));
+#endif
+              if (!tied) continue;
+              any = true;
+              for (unsigned g = 0; g < 2; ++g)  // the whole tree of s moves
+                if (myRoot[g] == s) {
+                  myOff[g] += delta;
+                  myRoot[g] = mainRoot;
+                  off[lane + 64 * g]    = myOff[g];
+                  rootOf[lane + 64 * g] = uint8_t(mainRoot);
+                }
+              if (lane == 0 && G.stats) wv::atomic_add(&G.stats[1], 1u);
+              wv::sync();
+            }
+          }
+          if (!any) break;
+        }
+      }
+#ifdef MANTA_WAVE_EMU
+      if (std::getenv("MANTA_EMU_PROOF_TRACE2"))
+        for (unsigned h = 0; h < 2; ++h)
+          if (lane + 64 * h < nNormal) std::fprintf(stderr, "  final read %u: off %d root %u anchor %08x\n", lane + 64 * h, myOff[h], myRoot[h], anch[lane + 64 * h]);
 #endif
       // (rdm is dead after the table pass: its bytes take the offsets; one that does not fit 16 bits only loses the proof)
       for (unsigned h = 0; h < 2; ++h) {
@@ -1175,7 +1298,7 @@ struct LdsGraph {
   WV_DEV bool runK(const unsigned locus)
   {
     if (!tablePass<KW>()) return false;
-    readOffsets();
+    readOffsets<KW>();
     tick(1, 1);
     if (!sortWords<KW>()) return false;
     // slab for this locus
@@ -1192,6 +1315,7 @@ struct LdsGraph {
     uint8_t* slab = G.arena + off;
     if (!buildRecords<KW>(slab, SL)) return false;
     const bool     acyclic = wv::atomic_load(&hdr[LG_H_CYC]) == 0 && !(G.flags & LG_FLAG_NO_PROOF);
+    if (acyclic && tid() == 0 && G.stats) wv::atomic_add(&G.stats[0], 1u);
     const unsigned need    = ckNeed(nNodes, nFat, acyclic);
     unsigned       cls     = LG_CLASSES;
     for (unsigned c = LG_CLASSES; c-- > 0;)
