@@ -1006,22 +1006,6 @@ struct LdsGraph {
                 }
               }
 #ifdef MANTA_WAVE_EMU
-              if (std::getenv("MANTA_EMU_PROOF_TRACE2") && lane == 0 && !tied) {  // brute force: every word of every member
-                unsigned links = 0, words = 0, selfOwned = 0, otherTree = 0;
-                for (unsigned x = 0; x < nNormal; ++x) {
-                  if (rootOf[x] != s) continue;
-                  const unsigned d = rd[x], cwo = d & 0x7ffu, len = (d >> 11) & 0xffffu;
-                  for (unsigned j = 0; j + k <= len; ++j) {
-                    if (((d >> 27) & 1u) && windowHasN(rdm[x], j)) continue;
-                    const unsigned slot = lookupSlot<KW>(keyAt<KW>(cwo * 16 + j));
-                    if (slot == ASM_NONE) continue;
-                    ++words;
-                    const unsigned o = readOfPb(slots[slot] & 0x7fffu);
-                    if (rootOf[o] == mainRoot) ++links; else if (rootOf[o] == s) ++selfOwned; else ++otherTree;
-                  }
-                }
-                std::fprintf(stderr, "    brute force over tree %u: %u words, %u owned by the main tree, %u by the tree itself, %u by other trees\n", s, words, links, selfOwned, otherTree);
-              }
               if (std::getenv("MANTA_EMU_PROOF_TRACE") && lane == 0)
                 std::fprintf(stderr, "  rescue: tree of read %u (main tree: read %u with %u reads): %s, delta %d\n", s, mainRoot, mainSize, tied ? "tied" : "no link", int(delta));
 #endif
@@ -1041,11 +1025,6 @@ struct LdsGraph {
           if (!any) break;
         }
       }
-#ifdef MANTA_WAVE_EMU
-      if (std::getenv("MANTA_EMU_PROOF_TRACE2"))
-        for (unsigned h = 0; h < 2; ++h)
-          if (lane + 64 * h < nNormal) std::fprintf(stderr, "  final read %u: off %d root %u anchor %08x\n", lane + 64 * h, myOff[h], myRoot[h], anch[lane + 64 * h]);
-#endif
       // (rdm is dead after the table pass: its bytes take the offsets; one that does not fit 16 bits only loses the proof)
       for (unsigned h = 0; h < 2; ++h) {
         const int32_t v = myOff[h];
