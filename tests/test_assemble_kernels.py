@@ -387,9 +387,9 @@ def test_emulated_fast_kernel_speculation_hits(emu, oracle, monkeypatch):
     assert st["loci"] == 16 and st["cands"] == 16 * 20, st
     assert st["rounds"] <= 16 * 1.5, st
     # reads of one haplotype that differ by substitutions only: graph_kernel proves the graph acyclic from the reads' offsets
-    # (a potential that rises along every edge) and contig_kernel skips its peel -- unless a read of the first, concurrently
-    # inserted batch found no word of an earlier read to anchor at (then the peel runs: same result)
-    assert st["proofs"] >= 12, st
+    # (a potential that rises along every edge) and contig_kernel skips its peel.  Reads inserted at the same time may end up in
+    # separate anchor trees; readOffsets ties the trees together through a shared word (16 of 16 here; without that pass 12-14)
+    assert st["proofs"] >= 15, st
 
 
 def test_emulated_fast_kernel_without_the_acyclicity_proof(emu, oracle, monkeypatch):
