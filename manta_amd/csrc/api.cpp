@@ -470,6 +470,13 @@ struct AsmStage {
   uint32_t              classBytes[manta_dev::LG_CLASSES] = {0, 0, 0, 0};
   uint64_t              lgArenaCap = 0, cwsStride = 0;
   std::vector<uint32_t> fastIds, genIds;  // cost-ordered work lists of the two paths
+  // the pipeline's big class (graph_big_kernel -> contig_big_kernel, asm_lds_big.hpp): piles of up to 256 reads
+  std::vector<uint32_t> bigIds;
+  int                   gridBig = 1;
+  int                   gridContigBig[manta_dev::LGL_CLASSES] = {0, 0};
+  uint32_t              classBytesBig[manta_dev::LGL_CLASSES] = {0, 0};
+  uint64_t              cwsStrideBig = 0;
+  DevBuf                bLgClassIdsBig, bCwsBig;
   DevBuf                bPunt, bLgArena, bLgOff, bLgClassIds, bLgCnt, bCws;
   uint32_t*             dPunt = nullptr;   // the general kernel's list: genIds, then the loci the LDS pipeline punted
   // packed piles of the uploaded batch (manta_packed_piles_t), device side; dPlCodes == nullptr: 1 byte per base input
@@ -517,12 +524,12 @@ struct AsmStage {
     uint64_t maxLocusBases = 0, maxLocusWords = 0, bitsBound = 0;
     uint32_t maxLocusReads = 0, maxReadLen = 0;
     std::vector<uint64_t> cost(n_loci);
-    uint32_t              ldsFit = 0;  // loci small enough for the LDS-resident fast path
+    uint32_t              ldsFit = 0, ldsFitBig = 0;  // loci small enough for the LDS pipeline's small / big class
     {
       // one pass over every read offset (6.4 MB for the 800 k reads of the metric's batch): a few host threads
       struct Part {
         uint64_t maxLocusBases = 0, maxLocusWords = 0, bitsBound = 0;
-        uint32_t maxLocusReads = 0, maxReadLen = 0, ldsFit = 0;
+        uint32_t maxLocusReads = 0, maxReadLen = 0, ldsFit = 0, ldsFitBig = 0;
         int      bad = 0;  // 1 = locus_read_begin, 2 = read_off
       };
       const unsigned    parts = hostParts(nReadsTotal);
@@ -564,7 +571,11 @@ struct AsmStage {
           cost[l] = b * uint64_t(re - rb);
           if ((re - rb) + 2 * maxAsm <= manta_dev::LG_MAX_READS && w + 2 <= manta_dev::LG_MAX_PILE) {
             p.ldsFit++;
-            cost[l] |= uint64_t(1) << 63;  // (marks the locus for the split below; reads x bases stays far below 2^63)
+            cost[l] |= uint64_t(1) << 63;  // (marks the locus for the split below; reads x bases stays far below 2^62)
+          } else if ((re - rb) + 2 * maxAsm <= manta_dev::LGL_MAX_READS && w + 2 <= manta_dev::LGL_MAX_PILE + 2 &&
+                     (!read_off || b + 64 <= manta_dev::LGL_STAGE_BYTES)) {
+            p.ldsFitBig++;
+            cost[l] |= uint64_t(1) << 62;  // the pipeline's big class
           }
           p.maxLocusBases = std::max(p.maxLocusBases, b);
           p.maxLocusWords = std::max(p.maxLocusWords, w);
@@ -581,6 +592,7 @@ struct AsmStage {
         maxLocusReads = std::max(maxLocusReads, p.maxLocusReads);
         maxReadLen    = std::max(maxReadLen, p.maxReadLen);
         ldsFit += p.ldsFit;
+        ldsFitBig += p.ldsFitBig;
         bitsBound += p.bitsBound;
       }
     }
@@ -589,7 +601,7 @@ struct AsmStage {
     const double tPlan1 = nowMs();
     {
       std::vector<std::pair<uint64_t, uint32_t>> keyed(n_loci);  // (inverted cost, locus): ascending = most expensive first, ties in locus order
-      for (uint32_t l = 0; l < n_loci; ++l) keyed[l] = std::make_pair(~(cost[l] & ~(uint64_t(1) << 63)), l);
+      for (uint32_t l = 0; l < n_loci; ++l) keyed[l] = std::make_pair(~(cost[l] & ~(uint64_t(3) << 62)), l);
       std::sort(keyed.begin(), keyed.end());
       order.resize(n_loci);
       for (uint32_t l = 0; l < n_loci; ++l) order[l] = keyed[l].second;
@@ -600,11 +612,16 @@ struct AsmStage {
     {
       const char*       pathEnv = std::getenv("MANTA_AMD_ASM_PATH");
       const std::string path    = pathEnv ? pathEnv : "";
-      useFast                   = !smallMode && ldsFit > 0 && path != "general";
+      const bool        useBig  = !(std::getenv("MANTA_AMD_LG_BIG") && std::atoi(std::getenv("MANTA_AMD_LG_BIG")) == 0);  // A/B runs: the big class off
+      useFast                   = !smallMode && (ldsFit > 0 || (useBig && ldsFitBig > 0)) && path != "general";
       fastIds.clear();
+      bigIds.clear();
       genIds.clear();
       if (useFast) {
-        for (uint32_t i = 0; i < n_loci; ++i) ((cost[order[i]] >> 63) ? fastIds : genIds).push_back(order[i]);
+        for (uint32_t i = 0; i < n_loci; ++i) {
+          const uint64_t c = cost[order[i]];
+          ((c >> 63) ? fastIds : ((useBig && ((c >> 62) & 1u)) ? bigIds : genIds)).push_back(order[i]);
+        }
       }
     }
     const double   tPlan2   = nowMs();
@@ -676,7 +693,17 @@ struct AsmStage {
         for (unsigned c = 0; c < LG_CLASSES; ++c)
           if (classBytes[c]) std::fprintf(stderr, "manta_amd: contig_kernel class %u: %u bytes of LDS, %d workgroups (%d per CU by the runtime's count)\n", c, classBytes[c], gridContig[c], rt::blocksPerCu(contig_kernel, 64, classBytes[c], -1));
       cwsStride  = ckWorkspaceLayout().total;
-      lgArenaCap = std::min<uint64_t>(uint64_t(fastIds.size()) * lgSlabBytes(LG_MAX_NODES, LG_MAX_NODES, LG_MAX_PILE + 2), wsBudget / 2);
+      // the big class: one graph workgroup per CU; contig_big_kernel in two LDS classes (two loci / one locus per CU)
+      gridBig = int(std::max<uint64_t>(1, std::min<uint64_t>(bigIds.size(), uint64_t(ctx->cuCount))));
+      static const uint32_t kClassBig[LGL_CLASSES] = {81920, 163840};
+      for (unsigned c = 0; c < LGL_CLASSES; ++c) {
+        classBytesBig[c] = kClassBig[c];
+        gridContigBig[c] = int(std::max<uint64_t>(1, std::min<uint64_t>(bigIds.size(), uint64_t(ctx->cuCount) * (163840 / kClassBig[c]))));
+      }
+      cwsStrideBig = ckWorkspaceLayout(LgL::SETW).total;
+      lgArenaCap   = std::min<uint64_t>(uint64_t(fastIds.size()) * lgSlabBytes(LG_MAX_NODES, LG_MAX_NODES, LG_MAX_PILE + 2) +
+                                          uint64_t(bigIds.size()) * lgSlabL(LGL_MAX_NODES, LGL_POOL_CAP, LGL_MAX_PILE + 4).total + 4096,
+                                      wsBudget / 2);
       (void)maxGrid;
     }
     // contig + pseudo-read text one locus can emit at worst; the arena holds the typical case for every locus plus one
@@ -866,15 +893,21 @@ struct AsmStage {
     dOrder  = bOrder.as<uint32_t>(nLoci);
     if (useFast) {
       dPunt = bPunt.as<uint32_t>(nLoci);
-      rt::h2d(dOrder, fastIds.data(), sizeof(uint32_t) * fastIds.size());
-      rt::h2d(dPunt, genIds.data(), sizeof(uint32_t) * genIds.size());
-      int maxGrid = 1;
+      if (!fastIds.empty()) rt::h2d(dOrder, fastIds.data(), sizeof(uint32_t) * fastIds.size());
+      if (!bigIds.empty()) rt::h2d(dOrder + fastIds.size(), bigIds.data(), sizeof(uint32_t) * bigIds.size());  // (behind the small class' list)
+      if (!genIds.empty()) rt::h2d(dPunt, genIds.data(), sizeof(uint32_t) * genIds.size());
+      int maxGrid = 1, maxGridBig = 1;
       for (unsigned c = 0; c < manta_dev::LG_CLASSES; ++c) maxGrid = std::max(maxGrid, gridContig[c]);
+      for (unsigned c = 0; c < manta_dev::LGL_CLASSES; ++c) maxGridBig = std::max(maxGridBig, gridContigBig[c]);
       (void)bLgArena.as<uint8_t>(lgArenaCap + 64);
       (void)bLgOff.as<uint64_t>(nLoci);
-      (void)bLgClassIds.as<uint32_t>(uint64_t(manta_dev::LG_CLASSES) * fastIds.size());
+      (void)bLgClassIds.as<uint32_t>(uint64_t(manta_dev::LG_CLASSES) * std::max<size_t>(1, fastIds.size()));
       (void)bLgCnt.as<uint64_t>(16);
       (void)bCws.as<uint8_t>(cwsStride * uint64_t(maxGrid));
+      if (!bigIds.empty()) {
+        (void)bLgClassIdsBig.as<uint32_t>(uint64_t(manta_dev::LGL_CLASSES) * bigIds.size());
+        (void)bCwsBig.as<uint8_t>(cwsStrideBig * uint64_t(maxGridBig));
+      }
     } else {
       rt::h2d(dOrder, order.data(), sizeof(uint32_t) * nLoci);
     }
@@ -977,7 +1010,7 @@ struct AsmStage {
       A.G.arena_cap    = lgArenaCap;
       A.G.arena_used   = reinterpret_cast<unsigned long long*>(dLg);
       A.G.slab_off     = bLgOff.as<uint64_t>(nLoci);
-      A.G.class_ids    = bLgClassIds.as<uint32_t>(uint64_t(LG_CLASSES) * fastIds.size());
+      A.G.class_ids    = bLgClassIds.as<uint32_t>(uint64_t(LG_CLASSES) * std::max<size_t>(1, fastIds.size()));
       A.G.class_count  = reinterpret_cast<uint32_t*>(dLg + 1);
       A.G.class_stride = uint32_t(fastIds.size());
       for (unsigned c = 0; c < LG_CLASSES; ++c) A.G.class_bytes[c] = classBytes[c];
@@ -994,16 +1027,53 @@ struct AsmStage {
       int gf = gridFast;
       if (streaming && gf >= ctx->cuCount * 2) gf -= std::max(1, ctx->cuCount / 4);
       // (the instantiation by the longest first word length among the loci of this launch: keys of 2 / 4 / 8 dwords)
-      uint32_t firstWl = opt.min_word_length;
-      if (!locusMinWl.empty())
-        for (const uint32_t l : fastIds) firstWl = std::max(firstWl, locusMinWl[l]);
-      if (firstWl <= 32)
-        rt::launchWG(graph_kernel<2>, gf, int(LG_WAVES), LG_BUDGET, A);
-      else if (firstWl <= 64)
-        rt::launchWG(graph_kernel<4>, gf, int(LG_WAVES), LG_BUDGET, A);
-      else
-        rt::launchWG(graph_kernel<8>, gf, int(LG_WAVES), LG_BUDGET, A);
-      for (unsigned c = 0; c < LG_CLASSES; ++c) {
+      if (!fastIds.empty()) {
+        uint32_t firstWl = opt.min_word_length;
+        if (!locusMinWl.empty()) {
+          firstWl = 0;
+          for (const uint32_t l : fastIds) firstWl = std::max(firstWl, locusMinWl[l]);
+        }
+        if (firstWl <= 32)
+          rt::launchWG(graph_kernel<2>, gf, int(LG_WAVES), LG_BUDGET, A);
+        else if (firstWl <= 64)
+          rt::launchWG(graph_kernel<4>, gf, int(LG_WAVES), LG_BUDGET, A);
+        else
+          rt::launchWG(graph_kernel<8>, gf, int(LG_WAVES), LG_BUDGET, A);
+      }
+      if (!bigIds.empty()) {
+        // the big class: its own work list (behind the small class' in dOrder), class lists and counters; slabs and punts shared
+        LgArgs B         = A;
+        B.P.n_loci       = uint32_t(bigIds.size());
+        B.P.locus_ids    = dOrder + fastIds.size();
+        B.P.counter      = reinterpret_cast<uint32_t*>(dLg + 7);
+        B.G.class_ids    = bLgClassIdsBig.as<uint32_t>(uint64_t(LGL_CLASSES) * bigIds.size());
+        B.G.class_count  = reinterpret_cast<uint32_t*>(dLg + 5);
+        B.G.class_stride = uint32_t(bigIds.size());
+        for (unsigned c = 0; c < LG_CLASSES; ++c) B.G.class_bytes[c] = (c < LGL_CLASSES) ? classBytesBig[c] : 0u;
+        B.G.stats        = reinterpret_cast<uint32_t*>(dLg + 11);
+        int maxGridBig = 1;
+        for (unsigned c = 0; c < LGL_CLASSES; ++c) maxGridBig = std::max(maxGridBig, gridContigBig[c]);
+        B.G.cws        = bCwsBig.as<uint8_t>(cwsStrideBig * uint64_t(maxGridBig));
+        B.G.cws_stride = cwsStrideBig;
+        int gb = gridBig;
+        if (streaming && gb >= ctx->cuCount) gb -= std::max(1, ctx->cuCount / 4);  // (as above: one workgroup owns a CU's whole LDS)
+        uint32_t firstWl = opt.min_word_length;
+        if (!locusMinWl.empty()) {
+          firstWl = 0;
+          for (const uint32_t l : bigIds) firstWl = std::max(firstWl, locusMinWl[l]);
+        }
+        if (firstWl <= 80)
+          rt::launchWG(graph_big_kernel<5>, gb, int(LGL_WAVES), LGL_BUDGET, B);
+        else
+          rt::launchWG(graph_big_kernel<8>, gb, int(LGL_WAVES), LGL_BUDGET, B);
+        for (unsigned c = 0; c < LGL_CLASSES; ++c) {
+          B.G.cls       = c;
+          B.P.counter   = reinterpret_cast<uint32_t*>(dLg + 9) + c;
+          B.P.lds_bytes = classBytesBig[c];
+          rt::launchSingle(contig_big_kernel, gridContigBig[c], classBytesBig[c], B);
+        }
+      }
+      for (unsigned c = 0; c < LG_CLASSES && !fastIds.empty(); ++c) {
         if (!classBytes[c]) continue;
         A.G.cls       = c;
         A.P.counter   = reinterpret_cast<uint32_t*>(dLg + 3) + c;
@@ -1174,10 +1244,13 @@ struct AsmStage {
     staged = true;
     ldsFallbacks = useFast ? uint32_t(hCnt[14] & 0xffffffffu) - uint32_t(genIds.size()) : 0u;
     if (std::getenv("MANTA_AMD_DEBUG") && useFast) {
-      uint32_t st[2] = {0, 0};
+      uint32_t st[2] = {0, 0}, stBig[2] = {0, 0}, clsBig[2] = {0, 0};
       rt::d2h(st, bLgCnt.as<uint64_t>(16) + 8, sizeof(st));
-      std::fprintf(stderr, "manta_amd: LDS assembler pipeline: %zu loci, %u handed to the general kernel (+ %zu outside its envelope); %u graphs came with a "
-                           "proof of acyclicity, %u reads re-anchored\n", fastIds.size(), ldsFallbacks, genIds.size(), st[0], st[1]);
+      rt::d2h(stBig, bLgCnt.as<uint64_t>(16) + 11, sizeof(stBig));
+      rt::d2h(clsBig, bLgCnt.as<uint64_t>(16) + 5, sizeof(clsBig));
+      std::fprintf(stderr, "manta_amd: LDS assembler pipeline: %zu + %zu (big class) loci, %u handed to the general kernel (+ %zu outside its envelope); %u + %u graphs came "
+                           "with a proof of acyclicity, %u + %u reads re-anchored; big class: %u / %u loci in its two contig LDS classes\n", fastIds.size(), bigIds.size(),
+                   ldsFallbacks, genIds.size(), st[0], stBig[0], st[1], stBig[1], clsBig[0], clsBig[1]);
     }
     if (std::getenv("MANTA_AMD_PROFILE")) {
       static const char* namesGeneral[8] = {"pack", "table", "links", "cycle-check", "exact", "seed", "walk", "select+emit"};

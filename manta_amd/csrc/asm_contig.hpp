@@ -32,12 +32,13 @@ struct CkWsLayout {
 };
 static const unsigned CK_SEQ_WORDS = CK_MAX_EXT / 16 + 2;   // per direction: 2-bit codes, 16 per dword
 static const unsigned CK_LOG_QW    = (CK_MAX_EXT + 4) / 4;  // per walk: 16-bit word ids, 4 per qword (entry 0 = the seed)
-WV_HD CkWsLayout ckWorkspaceLayout()
+/// `setw`: qwords of a read set (2: the small class, 4: the big one)
+WV_HD CkWsLayout ckWorkspaceLayout(const unsigned setw = 2)
 {
   CkWsLayout L;
   uint64_t   o = 0;
   L.lane_seq  = asmPut(o, 64ull * 2 * 4 * CK_SEQ_WORDS);
-  L.lane_bits = asmPut(o, 64ull * 4 * 8);
+  L.lane_bits = asmPut(o, 64ull * 2 * setw * 8);
   L.lane_meta = asmPut(o, 64ull * 8 * 4);
   L.lane_log  = asmPut(o, 64ull * 8 * CK_LOG_QW);
   L.total     = (o + 255) & ~uint64_t(255);
@@ -46,13 +47,22 @@ WV_HD CkWsLayout ckWorkspaceLayout()
 
 enum { CK_DONE = 0, CK_PUNT = 1 };
 
+template <class C>
 struct LdsContig {
+  typedef LgRec<C>  R;
+  typedef FSetT<C>  Set;
+  typedef CkMap<C>  M;
+  static const unsigned SW  = C::SETW;
+  static const unsigned IDB = C::ID_BITS;
+  static const unsigned IDM = (1u << C::ID_BITS) - 1u;
+  static const unsigned UPL = C::UNUSED_DW / 64;  ///< dwords of the unused-words bitmap a lane owns (consecutive ones)
   const AsmParams& P;
   const LgParams&  G;
   char*            lds;
   const uint8_t*   slab;
   FRec8*           nodes;
-  FSet*            pool;
+  Set*             pool;
+  uint8_t*         rd1;  ///< big class: the only read of a single-read word, by id
   uint32_t*        unused_bits;
   uint16_t *       tent, *slotNode, *sib, *sovf, *povf;
   LgSlab           SL;
@@ -69,16 +79,17 @@ struct LdsContig {
   WV_DEV LdsContig(const AsmParams& p, const LgParams& g, char* base, uint8_t* ws) : P(p), G(g), lds(base)
   {
     lane        = unsigned(wv::lane());
-    unused_bits = reinterpret_cast<uint32_t*>(lds + CK_OFF_UNUSED);
-    tent        = reinterpret_cast<uint16_t*>(lds + CK_OFF_TENT);
-    slotNode    = reinterpret_cast<uint16_t*>(lds + CK_OFF_SLOTND);
-    tbl         = reinterpret_cast<uint8_t*>(lds + CK_OFF_TBL);
-    sib         = reinterpret_cast<uint16_t*>(lds + CK_OFF_SIB);
-    sovf        = reinterpret_cast<uint16_t*>(lds + CK_OFF_SOVF);
-    povf        = reinterpret_cast<uint16_t*>(lds + CK_OFF_POVF);
-    nodes       = reinterpret_cast<FRec8*>(lds + CK_OFF_RECS);
+    unused_bits = reinterpret_cast<uint32_t*>(lds + M::UNUSED);
+    tent        = reinterpret_cast<uint16_t*>(lds + M::TENT);
+    slotNode    = reinterpret_cast<uint16_t*>(lds + M::SLOTND);
+    tbl         = reinterpret_cast<uint8_t*>(lds + M::TBL);
+    sib         = reinterpret_cast<uint16_t*>(lds + M::SIB);
+    sovf        = reinterpret_cast<uint16_t*>(lds + M::SOVF);
+    povf        = reinterpret_cast<uint16_t*>(lds + M::POVF);
+    nodes       = reinterpret_cast<FRec8*>(lds + M::RECS);
     pool        = nullptr;
-    const CkWsLayout L = ckWorkspaceLayout();
+    rd1         = nullptr;
+    const CkWsLayout L = ckWorkspaceLayout(SW);
     lane_seq  = reinterpret_cast<uint32_t*>(ws + L.lane_seq);
     lane_bits = reinterpret_cast<uint64_t*>(ws + L.lane_bits);
     lane_meta = reinterpret_cast<int32_t*>(ws + L.lane_meta);
@@ -101,24 +112,60 @@ struct LdsContig {
   }
 
   WV_DEV bool isUnused(const unsigned nd) const { return (unused_bits[nd >> 5] >> (nd & 31)) & 1u; }
-  WV_DEV char*    scratch() const { return lds + CK_OFF_RECS + ((8 * nNodes + 15) & ~15u); }
+  WV_DEV char*    scratch() const { return lds + M::RECS + ((8 * nNodes + 15) & ~15u) + (C::BIG ? ((nNodes + 15) & ~15u) : 0u); }
 
-  /// read support of word `nd` (record w) as two set words
-  WV_DEV void supOf(const unsigned nd, const FRec8 w, uint64_t& s0, uint64_t& s1) const
+  /// the only read of single-read word nd (record w)
+  WV_DEV unsigned onlyRead(const unsigned nd, const FRec8 w) const { return C::BIG ? unsigned(rd1[nd]) : lg8Read(w); }
+  /// read support of word `nd` (record w)
+  WV_DEV Set supOf(const unsigned nd, const FRec8 w) const
   {
+    Set s;
     if (nd < nFat) {
-      const FSet v = pool[nd];
-      s0           = v.w[0];
-      s1           = v.w[1];
+      s = pool[nd];
     } else {
-      const unsigned ref = lg8Read(w);
-      s0 = (ref < 64) ? (uint64_t(1) << ref) : 0;
-      s1 = (ref >= 64) ? (uint64_t(1) << (ref - 64)) : 0;
+      const unsigned ref = onlyRead(nd, w);
+      for (unsigned q = 0; q < SW; ++q) s.w[q] = ((ref >> 6) == q) ? (uint64_t(1) << (ref & 63)) : 0;
     }
+    return s;
   }
-  /// successors / predecessors of word nd as 4 x 11 bits (id + 1)
-  WV_DEV uint64_t succOf(const unsigned nd, const FRec8 w) const { return lg8Links(w, nd, true, sovf, nSovf); }
-  WV_DEV uint64_t predOf(const unsigned nd, const FRec8 w) const { return lg8Links(w, nd, false, povf, nPovf); }
+  /// successors / predecessors of word nd as 4 x ID_BITS (id + 1)
+  WV_DEV uint64_t succOf(const unsigned nd, const FRec8 w) const { return R::links(w, nd, true, sovf, nSovf); }
+  WV_DEV uint64_t predOf(const unsigned nd, const FRec8 w) const { return R::links(w, nd, false, povf, nPovf); }
+  // set algebra
+  WV_DEV static unsigned popSet(const Set& a)
+  {
+    unsigned n = 0;
+    for (unsigned q = 0; q < SW; ++q) n += unsigned(wv::popc(a.w[q]));
+    return n;
+  }
+  WV_DEV static Set setAnd(const Set& a, const Set& b)
+  {
+    Set r;
+    for (unsigned q = 0; q < SW; ++q) r.w[q] = a.w[q] & b.w[q];
+    return r;
+  }
+  WV_DEV static Set setAndNot(const Set& a, const Set& b)
+  {
+    Set r;
+    for (unsigned q = 0; q < SW; ++q) r.w[q] = a.w[q] & ~b.w[q];
+    return r;
+  }
+  WV_DEV static void setOrIn(Set& a, const Set& b)
+  {
+    for (unsigned q = 0; q < SW; ++q) a.w[q] |= b.w[q];
+  }
+  WV_DEV static Set setZero()
+  {
+    Set r;
+    for (unsigned q = 0; q < SW; ++q) r.w[q] = 0;
+    return r;
+  }
+  WV_DEV static Set setSel(const bool c, const Set& a, const Set& b)
+  {
+    Set r;
+    for (unsigned q = 0; q < SW; ++q) r.w[q] = c ? a.w[q] : b.w[q];
+    return r;
+  }
 
   // ------------------------------------------------------------------------------------------------
   // the slab -> LDS
@@ -139,35 +186,38 @@ struct LdsContig {
     codeWords       = wv::first(gh->codeWords);
     W               = wv::first(gh->W);
     acyclic         = wv::first(gh->acyclic) != 0;
-    if (wv::first(gh->need) > P.lds_bytes || nNodes > LG_MAX_NODES) return false;
-    SL               = lgSlab(nNodes, nFat, codeWords);
+    if (wv::first(gh->need) > P.lds_bytes || nNodes > C::MAX_NODES) return false;
+    SL               = lgSlabOf<C>(nNodes, nFat, codeWords);
     const FRec8* gRec = reinterpret_cast<const FRec8*>(slab + SL.recs);
     for (unsigned i = lane; i < nNodes; i += 64) nodes[i] = gRec[i];
+    if (C::BIG) {
+      rd1                 = reinterpret_cast<uint8_t*>(lds + M::RECS + ((8 * nNodes + 15) & ~15u));
+      const uint32_t* g4  = reinterpret_cast<const uint32_t*>(slab + SL.rd1);
+      uint32_t*       l4  = reinterpret_cast<uint32_t*>(rd1);
+      for (unsigned i = lane; i < (nNodes + 3) / 4; i += 64) l4[i] = g4[i];
+    }
     // the three side tables lie back to back, in the slab and here
     const uint16_t* gt = reinterpret_cast<const uint16_t*>(slab + SL.sib);
-    for (unsigned i = lane; i < 4 * (LG_SIB_CAP + 2 * LG_OVF_CAP); i += 64) sib[i] = gt[i];
+    for (unsigned i = lane; i < 4 * (LG_SIB_CAP + 2 * C::OVF_CAP); i += 64) sib[i] = gt[i];
     // seed eligibility (:679-682): ids in count order, so the seeds are the ids below nEligible
-    {
-      const unsigned lo = 32 * lane;
-      unused_bits[lane] = (nEligible >= lo + 32) ? 0xffffffffu : ((nEligible > lo) ? ((1u << (nEligible - lo)) - 1u) : 0u);
+    for (unsigned u = 0; u < UPL; ++u) {
+      const unsigned d = UPL * lane + u, lo = 32 * d;
+      unused_bits[d]   = (nEligible >= lo + 32) ? 0xffffffffu : ((nEligible > lo) ? ((1u << (nEligible - lo)) - 1u) : 0u);
     }
     wv::sync();
     return true;
   }
-  WV_DEV const FSet*     gPool() const { return reinterpret_cast<const FSet*>(slab + SL.pool); }
+  WV_DEV const Set*      gPool() const { return reinterpret_cast<const Set*>(slab + SL.pool); }
   WV_DEV const uint16_t* gSpecList() const { return reinterpret_cast<const uint16_t*>(slab + SL.spec); }
   WV_DEV const uint16_t* gPb() const { return reinterpret_cast<const uint16_t*>(slab + SL.pb); }
   WV_DEV const uint32_t* gCodes() const { return reinterpret_cast<const uint32_t*>(slab + SL.codes); }
 
   WV_DEV void loadPool()
   {
-    pool              = reinterpret_cast<FSet*>(scratch());
-    const FSet* gp    = gPool();
+    pool              = reinterpret_cast<Set*>(scratch());
+    const Set* gp     = gPool();
     for (unsigned i = lane; i < nFat; i += 64) pool[i] = gp[i];
-    if (nFat == 0 && lane == 0) {  // (a word without a bitset reads entry 0 and masks it out)
-      pool[0].w[0] = 0;
-      pool[0].w[1] = 0;
-    }
+    if (nFat == 0 && lane == 0) pool[0] = setZero();  // (a word without a bitset reads entry 0 and masks it out)
     wv::sync();
   }
 
@@ -190,7 +240,7 @@ struct LdsContig {
       const uint64_t sl = succOf(nd, w), pl = predOf(nd, w);
       unsigned       id = 0, od = 0;
       for (unsigned c = 0; c < 4; ++c) {
-        const unsigned s = lgLinkId(sl, c), p = lgLinkId(pl, c);
+        const unsigned s = R::linkId(sl, c), p = R::linkId(pl, c);
         if (s != ASM_NONE && s != nd) od++;
         if (p != ASM_NONE && p != nd) id++;
       }
@@ -210,13 +260,13 @@ struct LdsContig {
         const FRec8    w  = nodes[nd];
         const uint64_t sl = succOf(nd, w), pl = predOf(nd, w);
         for (unsigned c = 0; c < 4; ++c) {
-          const unsigned s = lgLinkId(sl, c);
+          const unsigned s = R::linkId(sl, c);
           if (s != ASM_NONE && s != nd) {
             const unsigned sh  = 8 * (s & 3);
             const unsigned old = wv::atomic_sub(&st[s >> 2], 1u << sh) >> sh;
             if ((old & 0x7u) == 1u && !(wv::atomic_or(&st[s >> 2], 0x40u << sh) & (0x40u << sh))) queue[wv::atomic_add(qTail, 1u)] = uint16_t(s);
           }
-          const unsigned p = lgLinkId(pl, c);
+          const unsigned p = R::linkId(pl, c);
           if (p != ASM_NONE && p != nd) {
             const unsigned sh  = 8 * (p & 3);
             const unsigned old = wv::atomic_sub(&st[p >> 2], 8u << sh) >> sh;
@@ -235,19 +285,26 @@ struct LdsContig {
   // ------------------------------------------------------------------------------------------------
   WV_DEV unsigned firstUnused(const unsigned T)
   {
-    uint32_t       bits = unused_bits[lane];
-    const unsigned c    = unsigned(wv::popc(bits));
-    unsigned       inc  = c;
+    uint32_t bits[UPL];
+    unsigned c = 0;
+    for (unsigned u = 0; u < UPL; ++u) {
+      bits[u] = unused_bits[UPL * lane + u];
+      c += unsigned(wv::popc(bits[u]));
+    }
+    unsigned inc = c;
     for (int off = 1; off < 64; off <<= 1) {
       const unsigned o = wv::shfl(inc, int(lane) - off);
       if (int(lane) >= off) inc += o;
     }
     const unsigned total = wv::readlane(inc, 63);
     unsigned       at    = inc - c;
-    while (bits && at < T) {
-      const unsigned b = unsigned(wv::ctz(uint64_t(bits)));
-      tent[at++]       = uint16_t(32 * lane + b);
-      bits &= bits - 1;
+    for (unsigned u = 0; u < UPL; ++u) {
+      uint32_t b32 = bits[u];
+      while (b32 && at < T) {
+        const unsigned b = unsigned(wv::ctz(uint64_t(b32)));
+        tent[at++]       = uint16_t(32 * (UPL * lane + u) + b);
+        b32 &= b32 - 1;
+      }
     }
     wv::sync();
     return (total < T) ? total : T;
@@ -257,32 +314,41 @@ struct LdsContig {
   // walks (:149-501), one lane per cache slot
   // ------------------------------------------------------------------------------------------------
   struct Cand {
-    FRec8    w;
-    uint64_t s0, s1;
+    FRec8 w;
+    Set   s;
   };
 
   /// Fetching the word behind a link field `f` (id + 1; 0 = no word) takes two LDS reads: its record and -- if the word has
   /// one (id < nFat) -- its bitset, both addressed by the id, so they go out together.  The walk issues the reads of everything a
   /// step needs first, then combines with mask arithmetic (no selects on loaded values: the compiler would turn those into
   /// branches around the loads and serialise the round trips).  A word without a bitset reads pool entry 0 and masks it out.
-  WV_DEV FRec8 candRec(const unsigned f) const { return nodes[f ? f - 1 : 0]; }
-  WV_DEV FSet  candPool(const unsigned f) const { return pool[(f != 0 && f - 1 < nFat) ? f - 1 : 0u]; }
-  WV_DEV void  candSup(const unsigned f, const FRec8 w, const FSet& p, uint64_t& s0, uint64_t& s1) const
+  /// (Big class: the only read of a single-read word is a third read by the id, from rd1.)
+  WV_DEV FRec8    candRec(const unsigned f) const { return nodes[f ? f - 1 : 0]; }
+  WV_DEV Set      candPool(const unsigned f) const { return pool[(f != 0 && f - 1 < nFat) ? f - 1 : 0u]; }
+  WV_DEV unsigned candRd1(const unsigned f) const { return C::BIG ? unsigned(rd1[f ? f - 1 : 0]) : 0u; }
+  WV_DEV Set      candSup(const unsigned f, const FRec8 w, const Set& p, const unsigned r1) const
   {
-    const unsigned ref  = lg8Read(w);
+    const unsigned ref  = C::BIG ? r1 : lg8Read(w);
     const bool     fat  = f != 0 && f - 1 < nFat;
     const uint64_t useM = fat ? ~uint64_t(0) : 0;
     const uint64_t bit  = uint64_t((f != 0 && !fat) ? 1u : 0u) << (ref & 63);
-    const uint64_t hiM  = (ref & 64u) ? ~uint64_t(0) : 0;
-    s0                  = (p.w[0] & useM) | (bit & ~hiM);
-    s1                  = (p.w[1] & useM) | (bit & hiM);
+    Set            s;
+    if (SW == 2) {
+      const uint64_t hiM = (ref & 64u) ? ~uint64_t(0) : 0;
+      s.w[0]             = (p.w[0] & useM) | (bit & ~hiM);
+      s.w[1]             = (p.w[1] & useM) | (bit & hiM);
+    } else {
+      for (unsigned q = 0; q < SW; ++q) s.w[q] = (p.w[q] & useM) | (((ref >> 6) == q) ? bit : 0);
+    }
+    return s;
   }
   WV_DEV Cand loadCand(const unsigned f) const
   {
-    Cand       c;
-    const FSet p = candPool(f);
-    c.w          = candRec(f);
-    candSup(f, c.w, p, c.s0, c.s1);
+    Cand           c;
+    const Set      p  = candPool(f);
+    const unsigned r1 = candRd1(f);
+    c.w               = candRec(f);
+    c.s               = candSup(f, c.w, p, r1);
     return c;
   }
 
@@ -308,31 +374,26 @@ struct LdsContig {
     uint32_t* const rightBuf = lane_seq + lane;              // [i * 128]
     uint32_t* const leftBuf  = lane_seq + 64 + lane;         // [i * 128]
     uint32_t       accR = 0, accL = 0;
-    uint64_t       S0 = 0, S1 = 0, R0 = 0, R1 = 0;
+    Set            S = setZero(), RJ = setZero();  // contig support (:213) / reject (:214) reads
     bool           active = has, rep = false, tooLong = false;
     unsigned       mode = 0, cur = seed, consOffset = 0, nLeft = 0, nRight = 0;
     int            consEnd = 0, consBegin = 0;
     FRec8          seedRec = 0;
     if (has) {
       seedRec = nodes[seed];
-      supOf(seed, seedRec, S0, S1);
-      if (lg8SelfLoop(seedRec)) {  // :172-179 (repeatWords of an acyclic graph = the self loops)
+      S       = supOf(seed, seedRec);
+      if (R::selfLoop(seedRec)) {  // :172-179 (repeatWords of an acyclic graph = the self loops)
         rep    = true;
         active = false;
       } else {
         // unselected siblings of the seed reject the contig (:185-210).  The words that differ from the seed in the last base
         // only are the other successors of any predecessor of the seed; a seed without a predecessor has them in the side table.
-        const unsigned pf = lg8Pred(seedRec, 0);
+        const unsigned pf = R::pred(seedRec, 0);
         if (pf) {
           const uint64_t zs = succOf(pf - 1, nodes[pf - 1]);
           for (unsigned c = 0; c < 4; ++c) {
-            const unsigned f = unsigned(zs >> (11 * c)) & 0x7ffu;
-            if (f && f - 1 != seed) {
-              uint64_t a, b;
-              supOf(f - 1, nodes[f - 1], a, b);
-              R0 |= a;
-              R1 |= b;
-            }
+            const unsigned f = R::linkField(zs, c);
+            if (f && f - 1 != seed) setOrIn(RJ, supOf(f - 1, nodes[f - 1]));
           }
         } else {
           for (unsigned e = 0; e < nSib; ++e) {
@@ -340,10 +401,7 @@ struct LdsContig {
             for (unsigned q = 1; q < 4; ++q) {
               const unsigned n = sib[4 * e + q];
               if (n == LG_NO_SLOT) continue;
-              uint64_t a, b;
-              supOf(n, nodes[n], a, b);
-              R0 |= a;
-              R1 |= b;
+              setOrIn(RJ, supOf(n, nodes[n]));
             }
           }
         }
@@ -359,17 +417,16 @@ struct LdsContig {
       // runs ahead through its unbranched stretch (up to CK_FAST_CAP words) before the wave takes one general step together.
       for (unsigned it = 0; it < CK_FAST_CAP; ++it) {
         const bool     fwd = (mode == 0);
-        const unsigned f   = unsigned(fwd ? curRec : (curRec >> 22)) & 0x7ffu;
-        const bool     one = active && f != 0 && (unsigned(fwd ? (curRec >> 11) : (curRec >> 33)) & 0x7ffu) == 0 &&
-                         !(fwd ? lg8SOvf(curRec) : lg8POvf(curRec));
+        const unsigned f   = fwd ? R::succ(curRec, 0) : R::pred(curRec, 0);
+        const bool     one = active && f != 0 && (fwd ? R::succ(curRec, 1) : R::pred(curRec, 1)) == 0 && !(fwd ? R::sOvf(curRec) : R::pOvf(curRec));
         const unsigned ff = one ? f : 0u;
         const FRec8    w  = candRec(ff);
-        const FSet     p  = candPool(ff);
-        uint64_t       a0, a1;
-        candSup(ff, w, p, a0, a1);
-        const bool     backOne = (unsigned(fwd ? (w >> 33) : (w >> 11)) & 0x7ffu) == 0 && !(fwd ? lg8POvf(w) : lg8SOvf(w));
-        const unsigned shared  = unsigned(wv::popc(S0 & a0)) + unsigned(wv::popc(S1 & a1));
-        const unsigned wc      = lg8Cnt(w);
+        const Set      p  = candPool(ff);
+        const unsigned r1 = candRd1(ff);
+        const Set      a  = candSup(ff, w, p, r1);
+        const bool     backOne = (fwd ? R::pred(w, 1) : R::succ(w, 1)) == 0 && !(fwd ? R::pOvf(w) : R::sOvf(w));
+        const unsigned shared  = popSet(setAnd(S, a));
+        const unsigned wc      = R::cnt(w);
         const bool     go = one && backOne && shared != 0 && wc >= P.opt.minCoverage && f - 1 != cur &&
                         (k + nRight + nLeft + 1 < maxLen) && (nRight + nLeft < CK_MAX_EXT);
         if (!wv::any(go)) break;
@@ -380,7 +437,7 @@ struct LdsContig {
             logBuf[size_t(pz >> 2) * 64] = logAcc;
             logAcc          = 0;
           }
-          const unsigned sym = fwd ? lg8LastBase(w) : lg8FirstBase(w);
+          const unsigned sym = fwd ? R::lastBase(w) : R::firstBase(w);
           if (fwd) {
             accR |= sym << (2 * (nRight & 15));
             if ((nRight & 15) == 15) {
@@ -397,8 +454,7 @@ struct LdsContig {
             nLeft++;
           }
           if ((consOffset != 0) || (wc < P.opt.minConservativeCoverage)) consOffset += 1;
-          S0 |= a0 & ~R0;
-          S1 |= a1 & ~R1;
+          setOrIn(S, setAndNot(a, RJ));
           cur    = f - 1;
           curRec = w;
         }
@@ -406,54 +462,48 @@ struct LdsContig {
       // ---- the general step ----
       const bool     isEnd = (mode == 0);
       const uint64_t link  = active ? (isEnd ? succOf(cur, curRec) : predOf(cur, curRec)) : 0;  // candidates of the current word in walking direction
-      const Cand     ca = loadCand(unsigned(link) & 0x7ffu), cb = loadCand(unsigned(link >> 11) & 0x7ffu);
+      const Cand     ca = loadCand(R::linkField(link, 0)), cb = loadCand(R::linkField(link, 1));
       // ---- choose the extension (:241-336): candidates a, b in alphabet order, strict '>' on the shared-read count ----
-      const uint64_t A0 = S0 & ca.s0, A1 = S1 & ca.s1, B0 = S0 & cb.s0, B1 = S1 & cb.s1;
-      const unsigned cntA = unsigned(wv::popc(A0)) + unsigned(wv::popc(A1)), cntB = unsigned(wv::popc(B0)) + unsigned(wv::popc(B1));
+      const Set      A = setAnd(S, ca.s), B = setAnd(S, cb.s);
+      const unsigned cntA = popSet(A), cntB = popSet(B);
       const bool     bWins = cntB > cntA;
-      const uint64_t SH0 = A0 & cb.s0, SH1 = A1 & cb.s1;
+      const Set      SH = setAnd(A, cb.s);
       // the loser's shared reads leave the contig, its reads reject it (an ignored candidate -- count 0 -- loses nothing)
       const bool     loserOn = bWins ? (cntA != 0) : (cntB != 0);
-      uint64_t       rm0  = (bWins ? A0 : B0) & ~SH0, rm1 = (bWins ? A1 : B1) & ~SH1;
-      uint64_t       add0 = loserOn ? ((bWins ? ca.s0 : cb.s0) & ~SH0) : 0, add1 = loserOn ? ((bWins ? ca.s1 : cb.s1) & ~SH1) : 0;
-      uint64_t       maxWR0 = bWins ? cb.s0 : ca.s0, maxWR1 = bWins ? cb.s1 : ca.s1;
-      uint64_t       maxCW0 = bWins ? B0 : A0, maxCW1 = bWins ? B1 : A1;  // (empty when neither candidate shares a read)
+      Set            rm  = setAndNot(setSel(bWins, A, B), SH);
+      Set            add = loserOn ? setAndNot(setSel(bWins, ca.s, cb.s), SH) : setZero();
+      Set            maxWR = setSel(bWins, cb.s, ca.s);
+      Set            maxCW = setSel(bWins, B, A);  // (empty when neither candidate shares a read)
       FRec8          maxW   = bWins ? cb.w : ca.w;
       unsigned       maxCnt = bWins ? cntB : cntA;
-      unsigned       maxF   = bWins ? (unsigned(link >> 11) & 0x7ffu) : (unsigned(link) & 0x7ffu);  // id + 1 of the chosen word
+      unsigned       maxF   = bWins ? R::linkField(link, 1) : R::linkField(link, 0);  // id + 1 of the chosen word
       if (maxCnt == 0) maxF = 0;
-      if (wv::any(active && (link >> 22) != 0)) {  // a third / fourth candidate somewhere in the wave (rare)
-        if (maxCnt == 0) maxWR0 = maxWR1 = 0;  // (nothing chosen so far: nothing to lose to a later candidate)
+      if (wv::any(active && (link >> (2 * IDB)) != 0)) {  // a third / fourth candidate somewhere in the wave (rare)
+        if (maxCnt == 0) maxWR = setZero();  // (nothing chosen so far: nothing to lose to a later candidate)
         for (unsigned i = 2; i < 4; ++i) {
-          const unsigned f = active ? (unsigned(link >> (11 * i)) & 0x7ffu) : 0u;
+          const unsigned f = active ? R::linkField(link, i) : 0u;
           if (!wv::any(f != 0)) continue;
-          const Cand c = loadCand(f);
-          const uint64_t C0 = S0 & c.s0, C1 = S1 & c.s1;
-          const unsigned cnt = unsigned(wv::popc(C0)) + unsigned(wv::popc(C1));
+          const Cand     c   = loadCand(f);
+          const Set      Cs  = setAnd(S, c.s);
+          const unsigned cnt = popSet(Cs);
           if (cnt == 0) continue;  // :280
-          const uint64_t T0 = maxCW0 & c.s0, T1 = maxCW1 & c.s1;
+          const Set T = setAnd(maxCW, c.s);
           if (cnt > maxCnt) {  // :283-316
-            rm0 |= maxCW0 & ~T0;
-            rm1 |= maxCW1 & ~T1;
-            add0 |= maxWR0 & ~T0;
-            add1 |= maxWR1 & ~T1;
-            maxWR0 = c.s0;
-            maxWR1 = c.s1;
-            maxCW0 = C0;
-            maxCW1 = C1;
+            setOrIn(rm, setAndNot(maxCW, T));
+            setOrIn(add, setAndNot(maxWR, T));
+            maxWR  = c.s;
+            maxCW  = Cs;
             maxCnt = cnt;
             maxF   = f;
             maxW   = c.w;
           } else {  // :317-335
-            rm0 |= C0 & ~T0;
-            rm1 |= C1 & ~T1;
-            add0 |= c.s0 & ~T0;
-            add1 |= c.s1 & ~T1;
+            setOrIn(rm, setAndNot(Cs, T));
+            setOrIn(add, setAndNot(c.s, T));
           }
         }
       }
       const unsigned maxNode      = maxF - 1;  // (ASM_NONE when nothing was chosen)
-      const unsigned maxBaseCount = maxF ? lg8Cnt(maxW) : 0u;
+      const unsigned maxBaseCount = maxF ? R::cnt(maxW) : 0u;
       bool           stop = false, extend = false;
       if (active) {
         if (maxBaseCount < P.opt.minCoverage) {  // :343 (also "no candidate")
@@ -472,28 +522,25 @@ struct LdsContig {
       const uint64_t back = extend ? (isEnd ? predOf(maxNode, maxW) : succOf(maxNode, maxW)) : 0;
       unsigned       o0 = 0, nOther = 0;
       for (unsigned c = 0; c < 4; ++c) {
-        const unsigned f  = unsigned(back >> (11 * c)) & 0x7ffu;
+        const unsigned f  = R::linkField(back, c);
         const bool     ok = f != 0 && f != cur + 1 && f != maxF;  // :381, :389
         if (ok && nOther == 0) o0 = f;
         nOther += ok ? 1u : 0u;
       }
-      const FRec8    ow = candRec(o0);
-      const FSet     po = candPool(o0);
-      uint64_t       b0, b1;
-      candSup(o0, ow, po, b0, b1);
-      b0 &= ~maxCW0;  // :400-414
-      b1 &= ~maxCW1;
+      const FRec8    ow  = candRec(o0);
+      const Set      po  = candPool(o0);
+      const unsigned or1 = candRd1(o0);
+      Set            bs  = setAndNot(candSup(o0, ow, po, or1), maxCW);  // :400-414
       if (wv::any(nOther > 1)) {  // more than one other neighbour (rare)
         unsigned seen = 0;
         for (unsigned c = 0; c < 4; ++c) {
-          const unsigned f  = unsigned(back >> (11 * c)) & 0x7ffu;
+          const unsigned f  = R::linkField(back, c);
           const bool     ok = f != 0 && f != cur + 1 && f != maxF;
           const bool     want = ok && seen >= 1;
           seen += ok ? 1u : 0u;
           if (!wv::any(want)) continue;
           const Cand x = loadCand(want ? f : 0u);
-          b0 |= x.s0 & ~maxCW0;
-          b1 |= x.s1 & ~maxCW1;
+          setOrIn(bs, setAndNot(x.s, maxCW));
         }
       }
       // ---- finish this step ----
@@ -506,7 +553,7 @@ struct LdsContig {
             logAcc         = 0;
           }
         }
-        const unsigned sym = isEnd ? lg8LastBase(maxW) : lg8FirstBase(maxW);
+        const unsigned sym = isEnd ? R::lastBase(maxW) : R::firstBase(maxW);
         if (isEnd) {  // :363
           accR |= sym << (2 * (nRight & 15));
           if ((nRight & 15) == 15) {
@@ -523,16 +570,11 @@ struct LdsContig {
           nLeft++;
         }
         if ((consOffset != 0) || (maxBaseCount < P.opt.minConservativeCoverage)) consOffset += 1;  // :368-369
-        add0 |= b0;
-        add1 |= b1;
-        rm0 |= b0;
-        rm1 |= b1;
-        R0 |= add0;  // :440-442
-        R1 |= add1;
-        S0 |= maxWR0 & ~R0;  // :458-464
-        S1 |= maxWR1 & ~R1;
-        S0 &= ~rm0;  // :471-473
-        S1 &= ~rm1;
+        setOrIn(add, bs);
+        setOrIn(rm, bs);
+        setOrIn(RJ, add);                   // :440-442
+        setOrIn(S, setAndNot(maxWR, RJ));   // :458-464
+        S      = setAndNot(S, rm);          // :471-473
         cur    = maxNode;
         curRec = maxW;
       }
@@ -551,11 +593,11 @@ struct LdsContig {
     }
 
     if (has) {
-      uint64_t* lb = lane_bits + size_t(lane) * 4;
-      lb[0]        = S0;
-      lb[1]        = S1;
-      lb[2]        = R0;
-      lb[3]        = R1;
+      uint64_t* lb = lane_bits + size_t(lane) * 2 * SW;
+      for (unsigned q = 0; q < SW; ++q) {
+        lb[q]      = S.w[q];
+        lb[SW + q] = RJ.w[q];
+      }
       if (nRight & 15) rightBuf[size_t(nRight >> 4) * 128] = accR;
       if (nLeft & 15) leftBuf[size_t(nLeft >> 4) * 128] = accL;
       logBuf[size_t((nRight + nLeft + 1) >> 2) * 64] = logAcc;  // (the last, partly filled qword; a full one was stored and this one is empty)
@@ -715,15 +757,15 @@ struct LdsContig {
   // ------------------------------------------------------------------------------------------------
   WV_DEV void selectAndEmit(const unsigned locus)
   {
-    uint64_t sup0 = 0, sup1 = 0, rej0 = 0, rej1 = 0;
+    Set      sup = setZero(), rej = setZero();
     unsigned nLeft = 0, nRight = 0, myLen = 0;
     int      consB = 0, consE = 0;
     if (lane < nCand) {
-      const uint64_t* lb = lane_bits + size_t(candSlotV) * 4;
-      sup0               = lb[0];
-      sup1               = lb[1];
-      rej0               = lb[2];
-      rej1               = lb[3];
+      const uint64_t* lb = lane_bits + size_t(candSlotV) * 2 * SW;
+      for (unsigned q = 0; q < SW; ++q) {
+        sup.w[q] = lb[q];
+        rej.w[q] = lb[SW + q];
+      }
       const int32_t* m   = lane_meta + candSlotV * 8;
       nLeft              = unsigned(m[0]);
       nRight             = unsigned(m[1]);
@@ -731,16 +773,16 @@ struct LdsContig {
       consE              = m[3];
       myLen              = nLeft + k + nRight;
     }
-    uint64_t used0 = 0, used1 = 0;  // wave-uniform
+    Set      used = setZero();  // wave-uniform
     bool     aliveL     = lane < nCand;
     unsigned finalCount = 0;
     uint64_t chosen     = 0;  // chosen candidates in order, 6 bits each (maxAssemblyCount <= 10 fits a qword; more: second word)
     uint64_t chosenHi   = 0;
     while (finalCount < P.opt.maxAssemblyCount) {
       if (!wv::any(aliveL)) break;
-      const unsigned usedNormal = unsigned(wv::popc(used0)) + unsigned(wv::popc(used1));  // (no pseudo reads on this path)
+      const unsigned usedNormal = popSet(used);  // (no pseudo reads on this path)
       if (nNormal - usedNormal < P.opt.minUnusedReads) break;  // :750
-      const unsigned nFresh = unsigned(wv::popc(sup0 & ~used0)) + unsigned(wv::popc(sup1 & ~used1));
+      const unsigned nFresh = popSet(setAndNot(sup, used));
       if (aliveL && nFresh < P.opt.minSupportReads) aliveL = false;  // :779-788
       uint64_t key = aliveL ? ((uint64_t(nFresh) << 40) | (uint64_t(myLen) << 8) | uint64_t(63u - lane)) : 0;
       for (int off = 1; off < 64; off <<= 1) {
@@ -754,8 +796,7 @@ struct LdsContig {
       else
         chosenHi |= uint64_t(selected) << (6 * (finalCount - 10));
       if (int(lane) == selected) aliveL = false;
-      used0 |= wv::readlane(sup0, selected);
-      used1 |= wv::readlane(sup1, selected);
+      for (unsigned q = 0; q < SW; ++q) used.w[q] |= wv::readlane(sup.w[q], selected);
       finalCount++;
     }
     auto chosenAt = [&](const unsigned f) { return unsigned(((f < 10) ? (chosen >> (6 * f)) : (chosenHi >> (6 * (f - 10)))) & 63u); };
@@ -811,10 +852,15 @@ struct LdsContig {
         }
         P.seq_arena[so + i] = uint8_t("ACGT"[code]);
       }
-      const uint64_t s0 = wv::readlane(sup0, c), s1 = wv::readlane(sup1, c), r0 = wv::readlane(rej0, c), r1 = wv::readlane(rej1, c);
-      if (lane < 2 * W) {
+      {
+        // lane h * W + w holds word w of the support (h = 0) / reject (h = 1) set
         const unsigned half = lane / W, w = lane % W;
-        P.bits_arena[bo + lane] = half ? (w ? r1 : r0) : (w ? s1 : s0);
+        uint64_t       mine = 0;
+        for (unsigned q = 0; q < SW; ++q) {
+          const uint64_t sq = wv::readlane(sup.w[q], c), rq = wv::readlane(rej.w[q], c);
+          if (w == q) mine = half ? rq : sq;
+        }
+        if (lane < 2 * W) P.bits_arena[bo + lane] = mine;
       }
       const int cb = wv::readlane(consB, c), ce = wv::readlane(consE, c);
       if (lane == 0) {
@@ -839,13 +885,27 @@ struct LdsContig {
   WV_DEV int run(const unsigned locus)
   {
     tMark = wv::clock();
-    if (!load(locus)) return CK_PUNT;
+#ifdef MANTA_WAVE_EMU
+#define CK_TRACE(why) do { if (std::getenv("MANTA_EMU_PUNT_TRACE") && lane == 0) std::fprintf(stderr, "  contig_kernel punts locus %u: %s (%u words, %u with a set, k %u)\n", locus, why, nNodes, nFat, k); } while (0)
+#else
+#define CK_TRACE(why) do { } while (0)
+#endif
+    if (!load(locus)) {
+      CK_TRACE("does not fit this launch's LDS");
+      return CK_PUNT;
+    }
     tick(4);
-    if (!acyclic && graphHasCycle()) return CK_PUNT;  // the exact repeat search is the general path's
+    if (!acyclic && graphHasCycle()) {  // the exact repeat search is the general path's
+      CK_TRACE("cyclic graph");
+      return CK_PUNT;
+    }
     tick(3);
     loadPool();
     tick(4);
-    if (contigRounds() != 0) return CK_PUNT;
+    if (contigRounds() != 0) {
+      CK_TRACE("repeat hit / contig too long");
+      return CK_PUNT;
+    }
     selectAndEmit(locus);
     tick(7);
     LG_STAT(0, 1);
@@ -857,7 +917,8 @@ struct LdsContig {
 
 /// persistent single-wave workgroups with P.lds_bytes of dynamic LDS; works through the loci of size class G.cls
 /// (G.class_ids / G.class_count, filled by graph_kernel); P.counter is this launch's own work counter.
-WV_KERNEL_SINGLE WV_WAVES_PER_SIMD(2) void contig_kernel(const LgArgs A)
+template <class C>
+WV_DEV void contigKernelBody(const LgArgs& A)
 {
   const AsmParams& P = A.P;
   const LgParams&  G = A.G;
@@ -871,12 +932,23 @@ WV_KERNEL_SINGLE WV_WAVES_PER_SIMD(2) void contig_kernel(const LgArgs A)
     slot = wv::first(slot);
     if (slot >= nLoci) break;
     const unsigned locus = ids[slot];
-    LdsContig      c(P, G, lds, ws);
+    LdsContig<C>   c(P, G, lds, ws);
     const int      rc = c.run(locus);
     wv::sync();
     if (rc != CK_DONE && wv::lane() == 0) P.punt_ids[wv::atomic_add(P.punt_count, 1u)] = locus;
     wv::sync();
   }
 }
+WV_KERNEL_SINGLE WV_WAVES_PER_SIMD(2) void contig_kernel(const LgArgs A)
+{
+  contigKernelBody<LgS>(A);
+}
+/// the big class (asm_lds_big.hpp): read sets of four qwords, 13-bit ids; one or two loci per CU
+WV_KERNEL_SINGLE WV_WAVES_PER_SIMD(1) void contig_big_kernel(const LgArgs A)
+{
+  contigKernelBody<LgL>(A);
+}
 
 }  // namespace manta_dev
+
+#include "asm_lds_big.hpp"

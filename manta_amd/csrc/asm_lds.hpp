@@ -113,12 +113,13 @@ struct alignas(16) LgHdr {
   uint32_t pad[3];
 };
 struct LgSlab {
-  uint32_t recs, pool, spec, sib, sovf, povf, pb, codes, total;
+  uint32_t recs, pool, spec, sib, sovf, povf, pb, codes, total, rd1;
 };
 WV_HD LgSlab lgSlab(const unsigned nNodes, const unsigned nFat, const unsigned codeWords)
 {
   LgSlab   L;
   uint32_t o = uint32_t(sizeof(LgHdr));
+  L.rd1   = 0;
   L.recs  = o;
   o += (8u * nNodes + 15u) & ~15u;
   L.pool  = o;
@@ -160,6 +161,139 @@ WV_HD unsigned ckNeed(const unsigned nNodes, const unsigned nFat, const bool acy
   const unsigned kahn = acyclic ? 0u : ((4 * ((nNodes + 3) / 4) + 2 * nNodes + 32 + 15) & ~15u);
   const unsigned pool = 16 * (nFat ? nFat : 1u);
   return CK_OFF_RECS + ((8 * nNodes + 15) & ~15u) + ((pool > kahn) ? pool : kahn);
+}
+
+// ---- the pipeline's second size class ("big": asm_lds_big.hpp): piles of up to 256 reads, several thousand words -- the config-4/5
+// shape (200 reads x 250 bases).  One graph workgroup of LGL_WAVES wavefronts owns a CU's whole LDS; what the two classes share is the
+// shape of the compact graph, and contig_kernel's code is one template over these traits.
+static const unsigned LGL_SLOTS     = 8192;
+static const unsigned LGL_BUCKETS   = LGL_SLOTS / 4;
+static const unsigned LGL_MAX_NODES = 7168;   // 0.875 x slots; ids are stored +1 in 13-bit link fields
+static const unsigned LGL_MAX_READS = 256;    // read sets of four qwords
+static const unsigned LGL_MAX_PILE  = 3598;   // code dwords (+ 2 of padding): a packed base index must fit 16 bits
+static const unsigned LGL_POOL_CAP  = 1280;   // read sets handed out during the table pass (words with more than one read)
+static const unsigned LGL_WAVES     = 16;
+static const unsigned LGL_BUDGET    = 163840;
+static const unsigned LGL_OVF_CAP   = 128;
+static const unsigned LGL_CLASSES   = 2;      // LDS size classes of contig_big_kernel
+
+/// A word of the big class' compact graph, 8 bytes as well:
+///   [0,13) [13,26) successors 0, 1 (id + 1, 0 = none; A,C,G,T order)   [26,39) [39,52) predecessors 0, 1
+///   [52,56) count, saturated at 15   [56,58) first base   [58,60) last base   60 self loop
+///   61 / 62: more than two successors / predecessors -- field 1 then holds the INDEX of the word's overflow entry {second, third,
+///   fourth} instead of the second link (no search).  The only read of a single-read word does not fit: u8 array `rd1` by id.
+struct LgS {
+  static const bool     BIG       = false;
+  static const unsigned ID_BITS   = 11;
+  static const unsigned SETW      = 2;   ///< qwords of a read set
+  static const unsigned MAX_NODES = LG_MAX_NODES;
+  static const unsigned OVF_CAP   = LG_OVF_CAP;
+  static const unsigned UNUSED_DW = 64;  ///< dwords of the "unusedWords" bitmap
+  static const unsigned CNT_SH = 44, FIRST_SH = 55, LAST_SH = 57, SELF_SH = 59, SOVF_SH = 60, POVF_SH = 61;
+};
+struct LgL {
+  static const bool     BIG       = true;
+  static const unsigned ID_BITS   = 13;
+  static const unsigned SETW      = 4;
+  static const unsigned MAX_NODES = LGL_MAX_NODES;
+  static const unsigned OVF_CAP   = LGL_OVF_CAP;
+  static const unsigned UNUSED_DW = 256;
+  static const unsigned CNT_SH = 52, FIRST_SH = 56, LAST_SH = 58, SELF_SH = 60, SOVF_SH = 61, POVF_SH = 62;
+};
+template <class C>
+struct alignas(16) FSetT {
+  uint64_t w[C::SETW];
+};
+/// record fields by class
+template <class C>
+struct LgRec {
+  static const unsigned IDM  = (1u << C::ID_BITS) - 1u;
+  static const uint64_t M2   = (uint64_t(1) << (2 * C::ID_BITS)) - 1;
+  WV_DEV static unsigned succ(const FRec8 w, const unsigned i) { return unsigned(w >> (C::ID_BITS * i)) & IDM; }
+  WV_DEV static unsigned pred(const FRec8 w, const unsigned i) { return unsigned(w >> (C::ID_BITS * (2 + i))) & IDM; }
+  WV_DEV static unsigned cnt(const FRec8 w) { return unsigned(w >> C::CNT_SH) & 15u; }
+  WV_DEV static unsigned firstBase(const FRec8 w) { return unsigned(w >> C::FIRST_SH) & 3u; }
+  WV_DEV static unsigned lastBase(const FRec8 w) { return unsigned(w >> C::LAST_SH) & 3u; }
+  WV_DEV static bool     selfLoop(const FRec8 w) { return (w >> C::SELF_SH) & 1u; }
+  WV_DEV static bool     sOvf(const FRec8 w) { return (w >> C::SOVF_SH) & 1u; }
+  WV_DEV static bool     pOvf(const FRec8 w) { return (w >> C::POVF_SH) & 1u; }
+  /// the (up to four) neighbours of word `nd` as 4 x ID_BITS (id + 1)
+  WV_DEV static uint64_t links(const FRec8 w, const unsigned nd, const bool succ, const uint16_t* ovf, const unsigned nOvf)
+  {
+    uint64_t l = (succ ? w : (w >> (2 * C::ID_BITS))) & M2;
+    if (succ ? sOvf(w) : pOvf(w)) {
+      if (C::BIG) {
+        const unsigned e = unsigned(l >> C::ID_BITS) & IDM;  // (the overflow entry's index sits where the second link would)
+        l = (l & IDM) | (uint64_t(ovf[4 * e]) << C::ID_BITS) | (uint64_t(ovf[4 * e + 1]) << (2 * C::ID_BITS)) | (uint64_t(ovf[4 * e + 2]) << (3 * C::ID_BITS));
+      } else {
+        for (unsigned e = 0; e < nOvf; ++e)
+          if (unsigned(ovf[4 * e]) == nd) l |= (uint64_t(ovf[4 * e + 1]) << 22) | (uint64_t(ovf[4 * e + 2]) << 33);
+      }
+    }
+    return l;
+  }
+  WV_DEV static unsigned linkField(const uint64_t l, const unsigned c) { return unsigned(l >> (C::ID_BITS * c)) & IDM; }  // id + 1
+  WV_DEV static unsigned linkId(const uint64_t l, const unsigned c)
+  {
+    const unsigned f = linkField(l, c);
+    return f ? f - 1 : ASM_NONE;
+  }
+};
+
+/// the big class' slab: LgHdr, FRec8[nNodes], FSetT<LgL>[nFat], u16[64] speculation list, u16[LG_SIB_CAP][4] sibling table,
+/// u16[LGL_OVF_CAP][4] x 2 overflow tables, u8[nNodes] the only read of a single-read word, u16[nNodes] first occurrences, the pile
+WV_HD LgSlab lgSlabL(const unsigned nNodes, const unsigned nFat, const unsigned codeWords)
+{
+  LgSlab   L;
+  uint32_t o = uint32_t(sizeof(LgHdr));
+  L.recs  = o;
+  o += (8u * nNodes + 15u) & ~15u;
+  L.pool  = o;
+  o += 32u * nFat;
+  L.spec  = o;
+  o += 128u;
+  L.sib   = o;
+  o += 8u * LG_SIB_CAP;
+  L.sovf  = o;
+  o += 8u * LGL_OVF_CAP;
+  L.povf  = o;
+  o += 8u * LGL_OVF_CAP;
+  L.rd1   = o;
+  o += (nNodes + 15u) & ~15u;
+  L.pb    = o;
+  o += (2u * nNodes + 15u) & ~15u;
+  L.codes = o;
+  o += (4u * codeWords + 15u) & ~15u;
+  L.total = o;
+  return L;
+}
+template <class C>
+WV_HD LgSlab lgSlabOf(const unsigned nNodes, const unsigned nFat, const unsigned codeWords)
+{
+  return C::BIG ? lgSlabL(nNodes, nFat, codeWords) : lgSlab(nNodes, nFat, codeWords);
+}
+
+/// contig_kernel's LDS map by class (the small class' offsets are the CK_OFF_* above)
+template <class C>
+struct CkMap {
+  static const unsigned UNUSED = 64;
+  static const unsigned TENT   = UNUSED + 4 * C::UNUSED_DW;
+  static const unsigned SLOTND = TENT + 256;
+  static const unsigned TBL    = SLOTND + 128;
+  static const unsigned SIB    = TBL + 64;
+  static const unsigned SOVF   = SIB + 8 * LG_SIB_CAP;
+  static const unsigned POVF   = SOVF + 8 * C::OVF_CAP;
+  static const unsigned RECS   = POVF + 8 * C::OVF_CAP;
+};
+static_assert(CkMap<LgS>::TENT == CK_OFF_TENT && CkMap<LgS>::SLOTND == CK_OFF_SLOTND && CkMap<LgS>::TBL == CK_OFF_TBL && CkMap<LgS>::SIB == CK_OFF_SIB &&
+              CkMap<LgS>::RECS == CK_OFF_RECS, "the small class keeps its map");
+/// ckNeed by class (big: + the u8 array of single-read words' reads behind the records)
+template <class C>
+WV_HD unsigned ckNeedOf(const unsigned nNodes, const unsigned nFat, const bool acyclic)
+{
+  const unsigned kahn = acyclic ? 0u : ((4 * ((nNodes + 3) / 4) + 2 * nNodes + 32 + 15) & ~15u);
+  const unsigned pool = 8 * C::SETW * (nFat ? nFat : 1u);
+  return CkMap<C>::RECS + ((8 * nNodes + 15) & ~15u) + (C::BIG ? ((nNodes + 15) & ~15u) : 0u) + ((pool > kahn) ? pool : kahn);
 }
 
 /// parameters of the pipeline beyond AsmParams (both kernels take the pair)

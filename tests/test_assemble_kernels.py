@@ -7,7 +7,7 @@ import pytest
 
 from manta_amd._capi import assembly_text
 from oracle_lib import asm_opts
-from synth import small_indel_locus, breakend_locus, repeat_rich_pile
+from synth import small_indel_locus, breakend_locus, repeat_rich_pile, config5_locus
 
 EMU_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libmanta_amd_emu.so")
 
@@ -400,3 +400,51 @@ def test_emulated_fast_kernel_without_the_acyclicity_proof(emu, oracle, monkeypa
     _fast_stats(emu)
     assert _check(emu, oracle, cases) == len(cases)
     assert _fast_stats(emu)["proofs"] == 0
+
+
+# ---- the LDS pipeline's big class (graph_big_kernel -> contig_big_kernel, asm_lds_big.hpp): piles of up to 256 reads ----
+def _big_cases():
+    """config-5 shaped loci (200 reads x 250 bases, 1 % N, per-locus word length 25..75) and piles around the class' edges"""
+    cases = []
+    for i in (1, 2, 4, 7, 9):  # k = 55, 25, 65, 40, 75
+        reads, _, _, k, kmax = config5_locus(i)
+        cases.append((asm_opts(minWordLength=k, maxWordLength=kmax, minContigLength=75), reads))
+    reads, _, _, k, kmax = config5_locus(3)  # a tandem-repeat locus: cyclic graph -> handed to the general kernel whole
+    cases.append((asm_opts(minWordLength=k, maxWordLength=kmax, minContigLength=75), reads))
+    # 129 reads (one more than the small class takes), 236 reads (the most this class takes with maxAssemblyCount 10), 237 (one too many)
+    cases.append((asm_opts(minWordLength=31), small_indel_locus(21, n_reads=129, read_len=100, ref_len=600)[0]))
+    cases.append((asm_opts(minWordLength=41), small_indel_locus(22, n_reads=236, read_len=150, ref_len=900, sub_rate=0.004, n_rate=0.005)[0]))
+    cases.append((asm_opts(minWordLength=41), small_indel_locus(23, n_reads=237, read_len=120, ref_len=700)[0]))
+    cases.append((asm_opts(minWordLength=21, minCoverage=2), small_indel_locus(24, n_reads=150, read_len=120, ref_len=700, sub_rate=0.01)[0]))
+    cases.append((asm_opts(minWordLength=15, maxAssemblyCount=3), small_indel_locus(25, n_reads=180, read_len=60, ref_len=400, sub_rate=0.02)[0]))
+    return cases
+
+
+def test_emulated_big_class_matches_oracle(emu, oracle, monkeypatch):
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
+    cases = _big_cases()
+    _fast_stats(emu)
+    assert _check(emu, oracle, cases) == len(cases)
+    # the class took them: every locus but the cyclic one and the 237-read pile went through contig_big_kernel
+    assert _fast_stats(emu)["loci"] >= len(cases) - 3
+
+
+def test_emulated_big_class_in_one_launch_with_the_small_class(emu, oracle, monkeypatch):
+    """one batch: small-class loci, big-class loci, an empty pile and a pile outside both classes (general kernel) side by side"""
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
+    loci = [small_indel_locus(1, n_reads=30, read_len=60, ref_len=300)[0], config5_locus(5)[0], [],
+            small_indel_locus(3, n_reads=300, read_len=50, ref_len=300)[0], config5_locus(6)[0],
+            small_indel_locus(4, n_reads=40, read_len=70, ref_len=300, n_rate=0.02)[0]]
+    o = asm_opts(minWordLength=31, maxWordLength=51, minContigLength=75)
+    for reads, r in zip(loci, emu.assemble_batch(o, loci)):
+        assert assembly_text(r) == oracle.assemble(o, reads)
+
+
+@pytest.mark.gpu
+def test_gpu_big_class_matches_oracle(gpu, oracle, monkeypatch):
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
+    cases = _big_cases()
+    for i in range(20, 52):
+        reads, _, _, k, kmax = config5_locus(i)
+        cases.append((asm_opts(minWordLength=k, maxWordLength=kmax, minContigLength=75), reads))
+    assert _check(gpu, oracle, cases) == len(cases)
