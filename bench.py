@@ -170,10 +170,10 @@ def main():
     spanning = args.workload == "spanning"
     n_loci = args.loci or (65536 if spanning else 10000)
     lib = Lib(device=local_rank)
-    node_queue = multi and args.queue == "node" and not spanning
+    node_queue = multi and args.queue == "node"
     # --queue process: one process, N devices, one cost-ordered block queue inside the library (manta_node_*): the deployment shape
     # INTEGRATION.md B prescribes for a GenerateSVCandidates process.  Rank 0 (or the only process) drives the devices.
-    proc_queue = args.queue == "process" and not spanning
+    proc_queue = args.queue == "process"
     n_dev      = args.gpus if proc_queue else world
     node       = None
     if proc_queue and rank == 0:
@@ -217,10 +217,14 @@ def main():
     # ---- this rank's batch (outside the clock: synthetic data generation) ----
     if spanning:
         distinct = min(n_loci, 2048)  # generating a config-5 locus costs ~10 ms of numpy: larger batches repeat the 2048 digest loci
-        base = [config5_locus(i, seed0=555000 + 1000003 * rank) for i in range(distinct)]
+        # (one queue across the devices: the node's batch = n_dev parts of n_loci loci, every part the digest loci again -- every locus of
+        # every part is then checked against the reference digests by whoever took it)
+        one_queue = node_queue or proc_queue
+        base = [config5_locus(i, seed0=555000 + (0 if one_queue else 1000003 * rank)) for i in range(distinct)]
         reps = (n_loci + distinct - 1) // distinct
         n_loci = reps * distinct
-        loci = [base[i % distinct] for i in range(n_loci)]
+        reps *= n_dev if one_queue else 1
+        loci = [base[i % distinct] for i in range(reps * distinct)]
         cuts = [(100, 100, 100, 100)] * distinct
         pb = pack_spanning([l[0] for l in base], [l[1] for l in base], [l[2] for l in base], cuts)
 
@@ -235,7 +239,8 @@ def main():
         min_wl = np.tile(np.array([l[3] for l in base], dtype=np.uint32), reps)
         max_wl = np.tile(np.array([l[4] for l in base], dtype=np.uint32), reps)
         opts = asm_opts(minWordLength=41, minContigLength=75)
-        out = BatchOutput(lib, "spanning", n_loci, 10, 8192 * n_loci + (1 << 20), 256 * n_loci + 4096, 1024 * n_loci + 4096,
+        n_out = reps * distinct
+        out = BatchOutput(lib, "spanning", n_out, 10, 8192 * n_out + (1 << 20), 256 * n_out + 4096, 1024 * n_out + 4096,
                           pinned=not args.pageable)
     else:
         if args.mix and multi and rank % 4 == 3:
@@ -279,11 +284,33 @@ def main():
                           pinned=not args.pageable)
     dev_batch = batch if args.pageable else tuple(pinned_copy(lib, a) for a in batch)
     n_reads = np.diff(batch[2])
+    # ---- a STREAM of blocks, not one block in a loop: the plain single-queue smallsv run rotates three differently seeded config-2
+    # batches over the steps (batch 0 = the digest workload), so that the library's "sizes from the previous run" paths, the caches
+    # and the sorts see changing data.  (The node / process queue legs keep their one node batch: N parts with different seeds.)
+    rotate = (not spanning) and (not node_queue) and (not proc_queue) and not os.environ.get("MANTA_BENCH_NO_ROTATE")
+    stream = [(batch, dev_batch, out)]
+    if rotate:
+        for j in (1, 2):
+            bj = config2_batch(n_loci, seed=12345 + 1000003 * rank + 7919 * j, n_reads=200 if (args.mix and multi and rank % 4 == 3) else 80)
+            oj = BatchOutput(lib, "smallsv", n_loci, 10, 4096 * n_loci + (1 << 20), 128 * n_loci + 4096, 512 * n_loci + 4096, pinned=not args.pageable)
+            stream.append((bj, bj if args.pageable else tuple(pinned_copy(lib, a) for a in bj), oj))
+    step_i = [0]
+    ran = [False] * len(stream)  # batches of the stream that have been through the library at least once (warm-up or timed)
 
     per_dev = [0] * n_dev
 
     def step():
-        if spanning:
+        if spanning and proc_queue:
+            if node is not None:
+                per_dev[:] = node.spanning_batch(opts, SPAN_SC, JUMP, dev_batch, out, min_wl=min_wl, max_wl=max_wl, block_loci=block, n_workers=workers)
+            return None
+        elif spanning and node_queue:
+            import ctypes as _ct
+            slot = step_no[0]
+            step_no[0] += 1
+            lib.spanning_batch(opts, SPAN_SC, JUMP, dev_batch, out, min_wl=min_wl, max_wl=max_wl, block_loci=block, n_workers=workers,
+                               serial_kernels=args.serial_kernels, shared_queue=_ct.addressof(qcount) + 4 * slot)
+        elif spanning:
             lib.spanning_batch(opts, SPAN_SC, JUMP, dev_batch, out, min_wl=min_wl, max_wl=max_wl, block_loci=block, n_workers=workers, serial_kernels=args.serial_kernels)
         elif proc_queue:
             if node is not None:
@@ -296,7 +323,13 @@ def main():
             lib.smallsv_batch(opts, SCORES, LARGE_INDEL, dev_batch, out, block_loci=block, n_workers=workers, serial_kernels=args.serial_kernels,
                               shared_queue=_ct.addressof(qcount) + 4 * slot)
         else:
-            lib.smallsv_batch(opts, SCORES, LARGE_INDEL, dev_batch, out, block_loci=block, n_workers=workers, serial_kernels=args.serial_kernels)
+            _, cur_dev, cur_out = stream[step_i[0] % len(stream)]
+            ran[step_i[0] % len(stream)] = True
+            step_i[0] += 1
+            lib.smallsv_batch(opts, SCORES, LARGE_INDEL, cur_dev, cur_out, block_loci=block, n_workers=workers, serial_kernels=args.serial_kernels)
+            if multi and not os.environ.get("MANTA_BENCH_SKIP_GATHER"):
+                return gather_bytes(result_blob(cur_out), device="cuda" if backend == "nccl" else "cpu", force_collectives=True)
+            return None
         if multi and not os.environ.get("MANTA_BENCH_SKIP_GATHER"):  # the final candidate gather (north star: "RCCL over xGMI only for the final candidate gather")
             return gather_bytes(result_blob(out), device="cuda" if backend == "nccl" else "cpu", force_collectives=True)
         return None
@@ -314,9 +347,12 @@ def main():
                n_blocks=0, n_align_launches=0, dp_cells=0, wall_ms=0.0)
     gathered_bytes = 0
     t0 = time.perf_counter()
+    used = [0] * len(stream)  # timed steps per batch of the stream
     for _ in range(args.steps):
+        cur = (step_i[0] % len(stream)) if rotate else 0
+        used[cur] += 1
         g = step()
-        st = out.stats_dict()
+        st = stream[cur][2].stats_dict()
         for k in acc:
             acc[k] += st[k]
         if g is not None:
@@ -335,7 +371,34 @@ def main():
     steps = args.steps
     loci_per_rank = [len(taken)]
     node_check = None
-    if node_queue:
+    def span_digest_mismatches(ids):
+        """loci `ids` of this process' results against the reference digests (every part of the node batch repeats the digest loci)"""
+        from test_digests import c5_text
+        raw = open(os.path.join(ROOT, "tests", "golden", "config5_digests.bin"), "rb").read()
+        bad = n = 0
+        for l in ids:
+            i = l % distinct
+            if 32 * i + 32 > len(raw):
+                continue
+            r = results[l]
+            got = [(a["score"], a["jump_insert_size"], a["jump_range"], a["begin1"], a["cigar1"], a["begin2"], a["cigar2"], a["is_uncut"]) for a in r["aligns"]]
+            bad += hashlib.sha256(c5_text(assembly_text(r), got).encode("latin-1")).digest() != raw[32 * i:32 * i + 32]
+            n += 1
+        return bad, n
+
+    if node_queue and spanning:
+        mism, checked = span_digest_mismatches(taken)
+        dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([mism, checked, n_fail, len(taken)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(per, torch.tensor([len(taken)], dtype=torch.int64, device=dev))
+        loci_per_rank = [int(x.item()) for x in per]
+        node_check = [int(x) for x in t.tolist()]
+        if rank == 0 and (node_check[0] or node_check[2] or node_check[3] != n_loci * world):
+            raise SystemExit("PARITY FAILURE (node queue, spanning): %d of %d checked loci differ, %d loci failed, %d of %d loci taken"
+                             % (node_check[0], node_check[1], node_check[2], node_check[3], n_loci * world))
+    elif node_queue:
         # every rank checks what it took: part 0 is the digest workload (config-2, seed 12345), other parts against the CPU
         # restatement on a sample; the verdicts are summed over the ranks
         orc_n = OracleLib()
@@ -362,7 +425,15 @@ def main():
             raise SystemExit("PARITY FAILURE (node queue): %d of %d checked loci differ, %d loci failed, %d of %d loci taken"
                              % (node_check[0], node_check[1], node_check[2], node_check[3], n_loci * world))
 
-    if proc_queue:
+    if proc_queue and spanning:
+        loci_per_rank = list(per_dev)
+        if rank == 0:
+            mism, checked = span_digest_mismatches(taken)
+            node_check = [mism, checked, n_fail, len(taken)]
+            if mism or n_fail or len(taken) != n_loci * n_dev or sum(per_dev) != n_loci * n_dev:
+                raise SystemExit("PARITY FAILURE (process queue, spanning): %d of %d checked loci differ, %d loci failed, %d of %d loci taken (per device: %s)"
+                                 % (mism, checked, n_fail, len(taken), n_loci * n_dev, per_dev))
+    elif proc_queue:
         loci_per_rank = list(per_dev)
         if rank == 0:
             # one process holds every result: part 0 is the digest workload, the other parts against the CPU restatement on a sample
@@ -391,7 +462,9 @@ def main():
         dig_path = os.path.join(ROOT, "tests", "golden", "config5_digests.bin" if spanning else "config2_digests.bin")
         raw = open(dig_path, "rb").read() if os.path.exists(dig_path) else b""
         n_dig = min(len(raw) // 32, n_loci)
-        if spanning:
+        if spanning and (node_queue or proc_queue):
+            checked, how = node_check[1], "reference digests (tests/golden/config5_digests.bin; every part of the node batch repeats the digest loci)" + (", summed over the ranks" if node_queue else "")
+        elif spanning:
             from test_digests import c5_text
             from test_spanning_pipeline import oracle_locus
             for i in range(n_dig):
@@ -412,6 +485,22 @@ def main():
                 mism += small_sv_text(results[l]) != orc.small_sv_locus(opts, SCORES, LARGE_INDEL, reads, ref, cuts)
                 checked += 1
             how = "oracle spot check"
+        stream_res = [results]
+        if rotate and len(stream) > 1:
+            # the other batches of the stream: every locus must have succeeded, a sample against the CPU restatement
+            extra = 0
+            for j, (bj, _, oj) in enumerate(stream[1:], start=1):
+                if not ran[j]:
+                    stream_res.append(None)
+                    continue
+                rj = oj.decode(np.diff(bj[2]))
+                stream_res.append(rj)
+                n_fail += sum(1 for r in rj if r["status"] != 0)
+                for l in range(0, n_loci, max(1, n_loci // 16)):
+                    reads, ref, cuts = unpack_locus(bj, l)
+                    mism += small_sv_text(rj[l]) != orc.small_sv_locus(opts, SCORES, LARGE_INDEL, reads, ref, cuts)
+                    extra += 1
+            how += " + %d loci of the stream's two other batches vs the CPU restatement" % extra
         if mism or n_fail:
             raise SystemExit("PARITY FAILURE: %d of %d checked loci differ (%s), %d loci failed" % (mism, checked, how, n_fail))
 
@@ -419,23 +508,35 @@ def main():
         value = loci_total / elapsed
         asm_sum, align_sum = acc["assemble_ms"], acc["align_ms"]
         if spanning:
-            b_in = sum(sum(len(x) for x in l[0]) + len(l[1]) + len(l[2]) for l in loci)
+            b_in = sum(sum(len(x) for x in loci[i][0]) + len(loci[i][1]) + len(loci[i][2]) for i in taken)
             b_ptr = b_out = 0
-            for i, r in enumerate(results):
+            for i in taken:
+                r = results[i]
                 b_out += len(loci[i][0]) * 8
                 for c, a in zip(r["contigs"], r["aligns"]):
                     q = len(c["seq"])
                     span = (len(loci[i][1]) + len(loci[i][2])) if a["is_uncut"] else (len(loci[i][1]) + len(loci[i][2]) - 400)
                     b_ptr += (q + 1) * (span + 2)  # 1 B cells: the reference's own jump pointer matrix (GlobalJumpAligner.hpp:81-115)
                     b_out += q + 2 * ((len(loci[i][0]) + 7) // 8) + 64
-            asm_bytes, align_bytes, align_name = sum(sum(len(x) for x in l[0]) for l in loci) + b_out, b_ptr, "align_kernel<JUMP>"
+            asm_bytes, align_bytes, align_name = sum(sum(len(x) for x in loci[i][0]) for i in taken) + b_out, b_ptr, "align_kernel<JUMP>"
             workload = ("BASELINE config[4] shape (NOT the metric's configuration): breakend loci, 200 reads x 250 bp, 1 % N, 10 % "
                         "tandem-repeat loci, minWordLength per locus from {25..75} in ONE launch, assemble + "
                         "GlobalJumpAligner(2,-8,-12,-1,-1;-100) on 700+700 bp windows + re-align rule")
         else:
-            b_in, b_ptr, b_out, q_bytes, win_bytes = algorithmic_bytes_smallsv(batch, results, taken)
-            reads_in = sum(int(batch[1][batch[2][l + 1]] - batch[1][batch[2][l]]) for l in taken)
-            asm_bytes, align_bytes, align_name = reads_in + b_out, q_bytes + win_bytes + b_ptr, "align_kernel<LARGE_INDEL>"
+            # (the stream's batches weighted by the timed steps each of them ran)
+            tot_w = max(1, sum(used)) if rotate else 1
+            b_in = b_ptr = b_out = asm_bytes = align_bytes = 0.0
+            for j, rj in enumerate(stream_res):
+                w = (used[j] / tot_w) if rotate else (1.0 if j == 0 else 0.0)
+                if w == 0.0 or rj is None:
+                    continue
+                bj = stream[j][0]
+                tk = taken if j == 0 else list(range(n_loci))
+                bi, bp, bo, qb, wb = algorithmic_bytes_smallsv(bj, rj, tk)
+                rin = sum(int(bj[1][bj[2][l + 1]] - bj[1][bj[2][l]]) for l in tk)
+                b_in, b_ptr, b_out = b_in + w * bi, b_ptr + w * bp, b_out + w * bo
+                asm_bytes, align_bytes = asm_bytes + w * (rin + bo), align_bytes + w * (qb + wb + bp)
+            align_name = "align_kernel<LARGE_INDEL>"
             workload = ("BASELINE config[1]: synthetic small-indel loci, 80 reads/locus x150bp, k=31..76 step 5, "
                         "assemble + 10-mer trim + GlobalLargeIndelAligner(2,-8,-24,-1,-1;-100) on 1800 bp windows")
         # dominant kernel by HIP-event time summed over the timed region.  A launch = one block's kernel; the events of
@@ -450,7 +551,8 @@ def main():
             dom = "assemble_kernel" if os.environ.get("MANTA_AMD_ASM_PATH") == "general" else "assembler_stage"
             dom_bytes, dom_ms, dom_launches = asm_bytes * steps, asm_sum, n_blocks
             dom_note = ("one launch per block" if dom == "assemble_kernel" else
-                        "per block: graph_kernel + contig_kernel (one HIP-event span; rocprofv3 lists the two kernels separately: their averages add up to avg_launch_ms)")
+                        "per block: graph_kernel + contig_kernel (big piles: graph_big_kernel + contig_big_kernel) + assemble_kernel on what they hand back; one HIP-event "
+                        "span, rocprofv3 lists the kernels separately: their averages add up to avg_launch_ms")
         avg_launch_ms = dom_ms / dom_launches
         achieved = (dom_bytes / dom_launches) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         # roofline.traffic is NOT measured in this run: it is the HBM-side byte count of the builder's own rocprofv3 --pmc passes
@@ -476,7 +578,8 @@ def main():
                                            % (backend, "RCCL" if backend == "nccl" else "host memory, developer self-test")) if (multi and not proc_queue) else ""),
                        "host_memory": "pageable" if args.pageable else "page-locked (manta_host_alloc)",
                        "block_loci": block, "workers_per_gpu": workers,
-                       "parallelism": ("one process, %d device(s), one cost-ordered block queue inside the library (manta_node_smallsv_batch)" % n_dev) if proc_queue
+                       "stream": ("%d differently seeded batches rotated over the steps (batch 0 = the digest workload)" % len(stream)) if rotate else "one batch",
+                       "parallelism": ("one process, %d device(s), one cost-ordered block queue inside the library (%s)" % (n_dev, "manta_node_spanning_batch" if spanning else "manta_node_smallsv_batch")) if proc_queue
                                       else ("one cost-ordered block queue across %d rank(s) (shared-memory counter, manta_batch_plan_t::shared_queue)" % world)
                                       if node_queue else ("loci sharded over %d rank(s); per rank a cost-ordered block queue" % world),
                        "queue": "process" if proc_queue else ("node" if node_queue else "rank"), "backend": backend if multi else None,
@@ -493,7 +596,7 @@ def main():
                                            {"achieved_GBps": round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1), "random_access_ceiling_GBps": 3360.0,
                                             "frac": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / 3360.0, 3),
                                             "traffic_over_algorithmic": round(traffic / max(1.0, dom_bytes / dom_launches), 1)}},
-            "kernels_ms_per_step": {"assemble_kernel": round(asm_sum / steps, 3), "schedule_kernel": round(acc["schedule_ms"] / steps, 3),
+            "kernels_ms_per_step": {"assembler_stage": round(asm_sum / steps, 3), "schedule_kernel": round(acc["schedule_ms"] / steps, 3),
                                     "align_kernels": round(align_sum / steps, 3),
                                     "note": "HIP events per block, summed; blocks overlap, so the sum exceeds ms_per_step"},
             "pcie": {"h2d_MB_per_step": round(acc["h2d_bytes"] / steps / 1e6, 2), "d2h_MB_per_step": round(acc["d2h_bytes"] / steps / 1e6, 2),
@@ -548,6 +651,26 @@ def main():
                                  "h2d_MB_per_step": round(h2d / nrun / 1e6, 2),
                                  "note": "read piles as 2-bit codes + N bitmap (manta_packed_piles_t, 0.375 B/base) instead of 1 B/base; "
                                          "same timed region; results identical to the default run"}
+        # ---- the config-4/5 shape (extra key, driver-visible): breakend loci, 200 reads x 250 bp, mixed word lengths, GlobalJumpAligner --
+        # the same script with --workload spanning on 8 192 loci in a process of its own (its own context and arenas), its line cut
+        # down to what a reader of this line needs: rate, the assembler stage's roofline object, kernel times, the parity string
+        if (not spanning and world == 1 and not args.no_extras and not os.environ.get("MANTA_BENCH_NO_SPANNING")
+                and os.path.abspath(lib.path) == os.path.join(ROOT, "manta_amd", "libmanta_amd.so")):
+            try:
+                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "spanning", "--loci", "8192", "--steps", "2", "--warmup", "1",
+                                     "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=900)
+                rows = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+                if pr.returncode == 0 and rows:
+                    sp = json.loads(rows[-1])
+                    o["spanning"] = {"value": sp["value"], "unit": sp["unit"], "ms_per_step": sp["ms_per_step"], "steps": sp["steps"], "warmup": sp["warmup"],
+                                     "loci": sp["config"]["loci_per_gpu"], "workload": sp["config"]["workload"], "parity": sp["config"]["parity"],
+                                     "timed_region": sp["config"]["timed_region"], "roofline": sp["roofline"],
+                                     "kernels_ms_per_step": sp["kernels_ms_per_step"], "algorithmic_bytes_per_locus": sp["algorithmic_bytes_per_locus"],
+                                     "dp_gcups": sp["dp_gcups"], "note": "python bench.py --workload spanning --loci 8192 --steps 2 --warmup 1, run by this script"}
+                else:
+                    o["spanning"] = {"error": (pr.stderr or pr.stdout)[-300:]}
+            except Exception as e:  # (an extra leg never takes the line down)
+                o["spanning"] = {"error": str(e)[-300:]}
         # ---- CPU baseline: the reference's own sources (oracle/_ref) on this box's host cores ----
         # ---- the candidate-level rate (extra key): SVCandidateAssemblyRefiner::getCandidateAssemblyDataBatch, the C++ host adapter a
         # GenerateSVCandidates process would call, on 10 000 config-2 shaped complex candidates: reference and read

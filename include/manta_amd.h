@@ -419,6 +419,17 @@ int manta_spanning_batch(
     uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap, uint64_t* cigar_arena_used,
     const manta_batch_plan_t* plan /* nullable */, manta_batch_stats_t* stats /* nullable */);
 
+/* the same with the read piles in packed form (what manta_read_piles_batch emits for the breakends of a spanning candidate:
+ * SVCandidateAssembler.cpp:677-698 hands assembleSVBreakends' pile to runIterativeAssembler) */
+int manta_spanning_batch_piles(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t jump_score, uint32_t n_loci,
+    const manta_packed_piles_t* piles, const uint8_t* refs1, const uint64_t* ref1_off, const uint8_t* refs2, const uint64_t* ref2_off,
+    const manta_jump_cuts_t* cuts, const uint32_t* locus_min_word_length /* nullable */, const uint32_t* locus_max_word_length /* nullable */,
+    manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_spanning_alignment_t* alignments, uint64_t contigs_cap,
+    uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap,
+    uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap, uint64_t* cigar_arena_used,
+    const manta_batch_plan_t* plan /* nullable */, manta_batch_stats_t* stats /* nullable */);
+
 /* ------------------------------------------------------------------------------------------------------
  * One node, several GPUs, ONE work queue (the reference's partition primitives are the static bins of
  * EdgeRetrieverBin.cpp:38-57 and the --threads worker pool of GenerateSVCandidates.cpp:232-266).

@@ -901,3 +901,22 @@ def _smallsv_batch_piles(self, opts, scores, large_indel_score, piles, refs, ref
 
 
 Lib.smallsv_batch_piles = _smallsv_batch_piles
+
+
+def _spanning_batch_piles(self, opts, scores, jump_score, piles, r1, o1, r2, o2, cuts, out, min_wl=None, max_wl=None, block_loci=0, n_workers=0,
+                          strict=True, serial_kernels=False, streamed_upload=True, shared_queue=None):
+    """manta_spanning_batch_piles: the whole-batch spanning call on packed read piles (PackedPiles)"""
+    o, sc, plan = AsmOptions(*opts), AlignScores(*scores), BatchPlan(block_loci, n_workers, (1 if serial_kernels else 0) | (0 if streamed_upload else 2), 0, shared_queue)
+    n = len(piles.begin) - 1
+    st = piles.struct()
+    f = self.lib.manta_spanning_batch_piles
+    f.restype = ctypes.c_int
+    rc = f(self.ctx, ctypes.byref(o), ctypes.byref(sc), ctypes.c_int32(jump_score), ctypes.c_uint32(n), ctypes.byref(st), _p(r1), _p(o1), _p(r2), _p(o2),
+           _p(cuts), _p(min_wl), _p(max_wl), out.res, out.contigs, out.aligns, ctypes.c_uint64(out.ccap), _p(out.seq), ctypes.c_uint64(len(out.seq)),
+           ctypes.byref(out.used[0]), _p(out.bits), ctypes.c_uint64(len(out.bits)), ctypes.byref(out.used[1]), _p(out.cig),
+           ctypes.c_uint64(len(out.cig)), ctypes.byref(out.used[2]), ctypes.byref(plan), ctypes.byref(out.stats))
+    self._check(rc, allow=(() if strict else (-4, -5, -7)) + ((-10,) if shared_queue else ()))
+    return rc
+
+
+Lib.spanning_batch_piles = _spanning_batch_piles

@@ -41,7 +41,9 @@ WV_HD bool pairEligible(const int E, const int match, const int mismatch, const 
   // (also: open / largeIndel must not be positive beyond the margin, and every per-step addend must fit the packed constants)
   if (open > 0 || extend > 0 || largeIndel > 0 || match < 0 || match > 64 || mismatch < -512 || offEdge < -512 || open < -2048 || largeIndel < -2048 || extend < -512)
     return false;
-  return q * perCol + gaps + up + 64 < 4096;
+  // (a sentinel-derived insert cell may rise by largeIndel - open through the jump-deletion candidate `ins + L - open`: part of the margin)
+  const long liftJD = (largeIndel - open > 0) ? long(largeIndel - open) : 0L;
+  return q * perCol + gaps + up + liftJD + 64 < 4096;
 }
 
 template <int E>

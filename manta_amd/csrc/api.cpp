@@ -184,10 +184,12 @@ void launchAlignE(int eIdx, int grid, const AlignParams& P)
 /// GlobalLargeIndelAligner buckets of short queries run two alignments per wave in packed 16-bit arithmetic (align_pair.hpp) when
 /// the scores leave the margin pairEligible() asks for.  The caller sizes the slabs for it: a wave's cell pairs take twice the
 /// single-alignment slab, and a bucket needs half as many work items.
-bool alignUsesPairs(int kind, int eIdx, int match, int mismatch, int open, int extend, int offEdge, int extra, int allowEdgeIns)
+/// `maxRef`: the longest reference of the bucket -- the packed kernel keeps a traceback start's row in 16 bits (align_pair.hpp: rowKey), so a
+/// bucket with a reference of 65 536 rows or more runs on align_kernel<1, E>
+bool alignUsesPairs(int kind, int eIdx, int match, int mismatch, int open, int extend, int offEdge, int extra, int allowEdgeIns, uint64_t maxRef)
 {
   static const bool off = std::getenv("MANTA_AMD_NO_ALIGN_PAIRS") != nullptr;  // A/B knob
-  return !off && kind == MANTA_ALIGNER_LARGE_INDEL && pairEligible(kESet[eIdx], match, mismatch, open, extend, offEdge, extra, allowEdgeIns);
+  return !off && kind == MANTA_ALIGNER_LARGE_INDEL && maxRef <= 0xfffeu && pairEligible(kESet[eIdx], match, mismatch, open, extend, offEdge, extra, allowEdgeIns);
 }
 
 void launchAlignPair(int eIdx, int grid, const AlignParams& P)
@@ -476,7 +478,11 @@ struct AsmStage {
   int                   gridContigBig[manta_dev::LGL_CLASSES] = {0, 0};
   uint32_t              classBytesBig[manta_dev::LGL_CLASSES] = {0, 0};
   uint64_t              cwsStrideBig = 0;
-  DevBuf                bLgClassIdsBig, bCwsBig;
+  DevBuf                bLgClassIdsBig, bCwsBig, bCycIds, bCycFlag;
+  // piles with a tandem repeat (tandem_detect_kernel) run on assemble_kernel on a second stream WHILE the big class' pipeline runs
+  std::unique_ptr<rt::Stream> sideStream;
+  std::unique_ptr<rt::Event>  evDetect, evSide;
+  int                         lglWaves = 0;  // wavefronts of a graph_big_kernel workgroup in this launch
   DevBuf                bPunt, bLgArena, bLgOff, bLgClassIds, bLgCnt, bCws;
   uint32_t*             dPunt = nullptr;   // the general kernel's list: genIds, then the loci the LDS pipeline punted
   // packed piles of the uploaded batch (manta_packed_piles_t), device side; dPlCodes == nullptr: 1 byte per base input
@@ -1017,6 +1023,7 @@ struct AsmStage {
       A.G.cls        = 0;
       A.G.flags      = (std::getenv("MANTA_AMD_LG_NO_PROOF") ? LG_FLAG_NO_PROOF : 0u) | (std::getenv("MANTA_AMD_LG_NO_RESCUE") ? LG_FLAG_NO_RESCUE : 0u);
       A.G.stats      = reinterpret_cast<uint32_t*>(dLg + 8);
+      A.G.skip       = nullptr;
       int maxGrid = 1;
       for (unsigned c = 0; c < LG_CLASSES; ++c) maxGrid = std::max(maxGrid, gridContig[c]);
       A.G.cws        = bCws.as<uint8_t>(cwsStride * uint64_t(maxGrid));
@@ -1026,6 +1033,7 @@ struct AsmStage {
       // the copies never run and the persistent workgroups wait for their chunks forever (seen on hardware, round 4)
       int gf = gridFast;
       if (streaming && gf >= ctx->cuCount * 2) gf -= std::max(1, ctx->cuCount / 4);
+      bool B_overlapped = false;
       // (the instantiation by the longest first word length among the loci of this launch: keys of 2 / 4 / 8 dwords)
       if (!fastIds.empty()) {
         uint32_t firstWl = opt.min_word_length;
@@ -1055,6 +1063,47 @@ struct AsmStage {
         for (unsigned c = 0; c < LGL_CLASSES; ++c) maxGridBig = std::max(maxGridBig, gridContigBig[c]);
         B.G.cws        = bCwsBig.as<uint8_t>(cwsStrideBig * uint64_t(maxGridBig));
         B.G.cws_stride = cwsStrideBig;
+        // Piles with a tandem repeat have a cyclic graph: the general kernel's, and tens of milliseconds of dependent chain each.
+        // tandem_detect_kernel finds them up front; assemble_kernel takes them on a second stream (no LDS, two waves per SIMD) while
+        // the pipeline -- graph workgroups of 8 wavefronts then, so that both fit a CU's registers -- works on the rest.
+        static const bool noOverlap = std::getenv("MANTA_AMD_NO_TANDEM_OVERLAP") != nullptr;
+        static const size_t overlapMin = std::getenv("MANTA_AMD_TANDEM_OVERLAP_MIN") ? size_t(std::atoi(std::getenv("MANTA_AMD_TANDEM_OVERLAP_MIN"))) : size_t(256);  // (tests: 1)
+        const bool overlap = !noOverlap && !dPlCodes && bigIds.size() >= overlapMin;
+        lglWaves           = overlap ? 8 : int(LGL_WAVES);
+        if (const char* e = std::getenv("MANTA_AMD_LGL_WAVES")) lglWaves = std::max(1, std::min(int(LGL_WAVES), std::atoi(e)));
+        if (overlap) {
+          uint8_t*  dFlag = bCycFlag.as<uint8_t>(nLoci);
+          uint32_t* dCyc  = bCycIds.as<uint32_t>(bigIds.size());
+          rt::dzero(dFlag, nLoci);
+          TandemParams T;
+          T.P         = P;
+          T.ids       = dOrder + fastIds.size();
+          T.n_ids     = uint32_t(bigIds.size());
+          T.flag      = dFlag;
+          T.cyc_ids   = dCyc;
+          T.cyc_count = reinterpret_cast<uint32_t*>(dLg + 13);
+          rt::launch(tandem_detect_kernel, rt::roundGrid(int(std::min<uint64_t>(bigIds.size(), uint64_t(ctx->cuCount) * 16))), 0, T);
+          B.G.skip = dFlag;
+          if (!sideStream) {
+            sideStream.reset(new rt::Stream());
+            evDetect.reset(new rt::Event());
+            evSide.reset(new rt::Event());
+          }
+          evDetect->record();
+          rt::streamWaits(*sideStream, *evDetect);
+          {
+            rt::ScopedStream onSide(*sideStream);
+            AsmParams Q  = P;
+            Q.locus_ids  = dCyc;
+            Q.n_loci     = uint32_t(bigIds.size());
+            Q.n_loci_dev = reinterpret_cast<uint32_t*>(dLg + 13);
+            Q.counter    = reinterpret_cast<uint32_t*>(dLg + 14);
+            Q.lds_bytes  = 0;
+            rt::launch(assemble_kernel, rt::roundGrid(std::min(g, std::max(4, ctx->cuCount * 8))), 0, Q);
+            evSide->recordOn(*sideStream);
+          }
+          B_overlapped = true;
+        }
         int gb = gridBig;
         if (streaming && gb >= ctx->cuCount) gb -= std::max(1, ctx->cuCount / 4);  // (as above: one workgroup owns a CU's whole LDS)
         uint32_t firstWl = opt.min_word_length;
@@ -1063,9 +1112,9 @@ struct AsmStage {
           for (const uint32_t l : bigIds) firstWl = std::max(firstWl, locusMinWl[l]);
         }
         if (firstWl <= 80)
-          rt::launchWG(graph_big_kernel<5>, gb, int(LGL_WAVES), LGL_BUDGET, B);
+          rt::launchWG(graph_big_kernel<5>, gb, lglWaves, LGL_BUDGET, B);
         else
-          rt::launchWG(graph_big_kernel<8>, gb, int(LGL_WAVES), LGL_BUDGET, B);
+          rt::launchWG(graph_big_kernel<8>, gb, lglWaves, LGL_BUDGET, B);
         for (unsigned c = 0; c < LGL_CLASSES; ++c) {
           B.G.cls       = c;
           B.P.counter   = reinterpret_cast<uint32_t*>(dLg + 9) + c;
@@ -1080,13 +1129,16 @@ struct AsmStage {
         A.P.lds_bytes = classBytes[c];
         rt::launchSingle(contig_kernel, gridContig[c], classBytes[c], A);
       }
+      if (B_overlapped) rt::curStreamWaits(*evSide);  // (the two general launches share the per-wave workspaces)
       P.locus_ids  = dPunt;
       P.n_loci     = nLoci;
       P.n_loci_dev = reinterpret_cast<uint32_t*>(dCnt + 14);
       P.counter    = reinterpret_cast<uint32_t*>(dCnt + 15);
       // nothing for this launch unless the pipeline handed something back: a small grid then (its waves find the list
       // length in device memory); the full grid when the host already knows of loci outside the envelope
-      if (nGen == 0) g = std::min(g, rt::roundGrid(std::max(1, ctx->cuCount * 4)));
+      // (the big class hands back the piles with a cyclic graph -- tandem repeats, one in ten of the config-4/5 shape -- and each of those is a
+      // long dependent chain in this kernel: one wave per expected locus, not a queue)
+      if (nGen == 0) g = std::min(g, rt::roundGrid(std::max<int>(ctx->cuCount * 4, int(std::min<uint64_t>(bigIds.size() / 8 + 1, uint64_t(g))))));
       rt::launch(assemble_kernel, g, ASM_LDS_BYTES, P);
     } else {
       rt::launch(assemble_kernel, g, ASM_LDS_BYTES, P);
@@ -1244,13 +1296,15 @@ struct AsmStage {
     staged = true;
     ldsFallbacks = useFast ? uint32_t(hCnt[14] & 0xffffffffu) - uint32_t(genIds.size()) : 0u;
     if (std::getenv("MANTA_AMD_DEBUG") && useFast) {
-      uint32_t st[2] = {0, 0}, stBig[2] = {0, 0}, clsBig[2] = {0, 0};
+      uint32_t st[2] = {0, 0}, stBig[2] = {0, 0}, clsBig[2] = {0, 0}, nCyc = 0;
+      rt::d2h(&nCyc, bLgCnt.as<uint64_t>(16) + 13, sizeof(nCyc));
       rt::d2h(st, bLgCnt.as<uint64_t>(16) + 8, sizeof(st));
       rt::d2h(stBig, bLgCnt.as<uint64_t>(16) + 11, sizeof(stBig));
       rt::d2h(clsBig, bLgCnt.as<uint64_t>(16) + 5, sizeof(clsBig));
       std::fprintf(stderr, "manta_amd: LDS assembler pipeline: %zu + %zu (big class) loci, %u handed to the general kernel (+ %zu outside its envelope); %u + %u graphs came "
-                           "with a proof of acyclicity, %u + %u reads re-anchored; big class: %u / %u loci in its two contig LDS classes\n", fastIds.size(), bigIds.size(),
-                   ldsFallbacks, genIds.size(), st[0], stBig[0], st[1], stBig[1], clsBig[0], clsBig[1]);
+                           "with a proof of acyclicity, %u + %u reads re-anchored; big class: %u / %u loci in its two contig LDS classes, %u piles with a tandem repeat sent to the "
+                           "general kernel up front (graph workgroups of %d wavefronts)\n", fastIds.size(), bigIds.size(),
+                   ldsFallbacks, genIds.size(), st[0], stBig[0], st[1], stBig[1], clsBig[0], clsBig[1], nCyc, lglWaves);
     }
     if (std::getenv("MANTA_AMD_PROFILE")) {
       static const char* namesGeneral[8] = {"pack", "table", "links", "cycle-check", "exact", "seed", "walk", "select+emit"};
@@ -1616,7 +1670,7 @@ int manta_align_batch(
     for (int b = 0; b < kNumESet; ++b) {
       if (buckets[b].empty()) continue;
       const bool     pair   = alignUsesPairs(kind, b, scores->match, scores->mismatch, scores->open, scores->extend, scores->off_edge, extra_score,
-                                             scores->is_allow_edge_insertion ? 1 : 0);
+                                             scores->is_allow_edge_insertion ? 1 : 0, bucketMaxRef[b]);
       const uint64_t stride = ((pair ? 2 : 1) * alignPtrSlabBytes(kind, kESet[b], bucketMaxRef[b]) + 255) & ~uint64_t(255);
       int            grid   = int(std::min<size_t>(pair ? (buckets[b].size() + 1) / 2 : buckets[b].size(), size_t(maxWaves)));
       grid                  = int(std::max<size_t>(1, std::min<size_t>(size_t(grid), wsBudget / stride)));
@@ -2105,7 +2159,7 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     uint32_t* dBucketsSorted = nullptr;
     for (int k = 0; k < kNumESet; ++k)
       if (alignUsesPairs(MANTA_ALIGNER_LARGE_INDEL, k, b->scores.match, b->scores.mismatch, b->scores.open, b->scores.extend, b->scores.off_edge,
-                         b->largeIndel, b->scores.is_allow_edge_insertion ? 1 : 0))
+                         b->largeIndel, b->scores.is_allow_edge_insertion ? 1 : 0, b->maxRef))
         pairMask |= 1u << k;
     if (pairMask) {
       dBucketsSorted = b->dBucketIds2.as<uint32_t>(nSlots * kNumESet);
@@ -2139,7 +2193,7 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     uint64_t            slabBytes = 0;
     auto pairOf = [&](int k) {
       return alignUsesPairs(MANTA_ALIGNER_LARGE_INDEL, k, b->scores.match, b->scores.mismatch, b->scores.open, b->scores.extend, b->scores.off_edge,
-                            b->largeIndel, b->scores.is_allow_edge_insertion ? 1 : 0);
+                            b->largeIndel, b->scores.is_allow_edge_insertion ? 1 : 0, b->maxRef);
     };
     const bool batchCall = b->stageBehindRun && !std::getenv("MANTA_AMD_SYNC_BUCKETS");
     bool       haveCounts = false;
@@ -2217,8 +2271,9 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
           mergedStride = std::max(mergedStride, l.stride);
           mergedWaves += uint64_t(l.grid);
         }
-        mergedWaves = uint64_t(rt::roundGrid(int(std::min<uint64_t>(mergedWaves, uint64_t(maxWaves)))));
-        mergedWaves = std::max<uint64_t>(1, std::min<uint64_t>(mergedWaves, (wsBudget / 3) / mergedStride));
+        // (clamp first, then a whole number of workgroups -- rt::launch divides the grid by the workgroup's wave count -- and at least one)
+        mergedWaves = std::min<uint64_t>(std::min<uint64_t>(mergedWaves, uint64_t(maxWaves)), (wsBudget / 3) / mergedStride);
+        mergedWaves = std::max<uint64_t>(WV_WAVES_PER_WG, (mergedWaves / WV_WAVES_PER_WG) * WV_WAVES_PER_WG);
         slabBytes += mergedStride * mergedWaves;
       }
       uint8_t* dWsAll = b->dPtrWs.as<uint8_t>(slabBytes + 256);
@@ -3357,7 +3412,7 @@ int manta_smallsv_batch_piles(
 namespace {
 int spanningBatchImpl(
     manta_ctx_t* const* ctxs, const uint32_t nCtx, uint32_t* lociPerDevice, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t jump_score, uint32_t n_loci,
-    const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const uint8_t* refs1, const uint64_t* ref1_off,
+    const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, const manta_packed_piles_t* piles, const uint8_t* refs1, const uint64_t* ref1_off,
     const uint8_t* refs2, const uint64_t* ref2_off, const manta_jump_cuts_t* cuts, const uint32_t* locus_min_word_length,
     const uint32_t* locus_max_word_length, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs,
     manta_spanning_alignment_t* alignments, uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t* seq_arena_used,
@@ -3366,7 +3421,7 @@ int spanningBatchImpl(
 {
   if (!ctxs || nCtx == 0 || !ctxs[0]) return MANTA_E_INVALID_ARG;
   manta_ctx_t* ctx = ctxs[0];  // (call-level errors are reported here)
-  if (!opt || !scores || n_loci == 0 || !bases || !read_off || !locus_read_begin || !refs1 || !ref1_off || !refs2 || !ref2_off || !cuts ||
+  if (!opt || !scores || n_loci == 0 || (!piles && (!bases || !read_off)) || !locus_read_begin || !refs1 || !ref1_off || !refs2 || !ref2_off || !cuts ||
       !loci || !contigs || !alignments || !seq_arena || !bits_arena || !cigar_arena)
     return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_batch: null argument or empty batch");
   if (scores->is_allow_edge_insertion) return fail(ctx, MANTA_E_INVALID_ARG, "GlobalJumpAligner does not support isAllowEdgeInsertion");
@@ -3375,7 +3430,7 @@ int spanningBatchImpl(
   for (uint32_t l = 0; l < n_loci; ++l)
     if (locus_read_begin[l + 1] < locus_read_begin[l] || ref1_off[l + 1] < ref1_off[l] || ref2_off[l + 1] < ref2_off[l])
       return fail(ctx, MANTA_E_INVALID_ARG, "manta_spanning_batch: offsets not monotone");
-  const uint64_t totalBases = read_off[locus_read_begin[n_loci]] - read_off[locus_read_begin[0]];
+  const uint64_t totalBases = piles ? 0 : read_off[locus_read_begin[n_loci]] - read_off[locus_read_begin[0]];
   const bool     shared     = (plan && plan->shared_queue) || nCtx > 1;
   const uint32_t blockLoci  = (plan && plan->block_loci) ? plan->block_loci : (shared ? nodeBlockLoci(n_loci, totalBases) : autoBlockLoci(n_loci, totalBases));
   BatchShared    sh;
@@ -3383,7 +3438,7 @@ int spanningBatchImpl(
   sh.sharedQueue    = plan ? plan->shared_queue : nullptr;
   sh.gates          = std::vector<StageGates>(nCtx);
   sh.lociOfCtx.assign(nCtx, 0);
-  planBlocks(sh, n_loci, blockLoci, read_off, locus_read_begin);
+  planBlocks(sh, n_loci, blockLoci, piles ? nullptr : read_off, locus_read_begin, piles ? piles->read_len : nullptr);
   const uint32_t nBlocks  = uint32_t(sh.blockOrder.size());
   const uint32_t perCtx   = std::max(1u, (plan && plan->n_workers) ? plan->n_workers : 1u);
   const uint32_t nWorkers = std::max(1u, std::min(nBlocks, perCtx * nCtx));
@@ -3420,15 +3475,25 @@ int spanningBatchImpl(
         const uint32_t blk = sh.blockOrder[qi];
         const uint32_t l0 = blk * blockLoci, l1 = std::min(n_loci, l0 + blockLoci), n = l1 - l0;
         const uint32_t r0 = locus_read_begin[l0], r1 = locus_read_begin[l1];
-        rebase(rOff, read_off, r0, size_t(r1 - r0) + 1);
+        if (!piles) rebase(rOff, read_off, r0, size_t(r1 - r0) + 1);
         rebase(lBeg, locus_read_begin, l0, size_t(n) + 1);
         rebase(f1Off, ref1_off, l0, size_t(n) + 1);
         rebase(f2Off, ref2_off, l0, size_t(n) + 1);
         setWordLengths(ctx, b->asmStage, n, locus_min_word_length ? locus_min_word_length + l0 : nullptr,
                        locus_max_word_length ? locus_max_word_length + l0 : nullptr);
         const double t0 = nowMs();
-        int          rc = manta_spanning_upload(b, n, bases + read_off[r0], rOff.data(), lBeg.data(), refs1 + ref1_off[l0], f1Off.data(),
-                                                refs2 + ref2_off[l0], f2Off.data(), cuts + l0);
+        int          rc;
+        if (piles) {
+          manta_packed_piles_t pl = *piles;
+          pl.read_len            = piles->read_len + r0;
+          pl.read_code_off       = piles->read_code_off + r0;
+          pl.read_mask_off       = piles->read_mask_off + r0;
+          pl.locus_read_begin    = lBeg.data();
+          rc = manta_spanning_upload_piles(b, n, &pl, refs1 + ref1_off[l0], f1Off.data(), refs2 + ref2_off[l0], f2Off.data(), cuts + l0);
+        } else {
+          rc = manta_spanning_upload(b, n, bases + read_off[r0], rOff.data(), lBeg.data(), refs1 + ref1_off[l0], f1Off.data(), refs2 + ref2_off[l0],
+                                     f2Off.data(), cuts + l0);
+        }
         if (perItemCode(rc)) {  // a locus outside the supported envelope: this block's loci carry the code, the batch goes on
           for (uint32_t l = l0; l < l1; ++l) {
             std::memset(&loci[l], 0, sizeof(loci[l]));
@@ -3510,7 +3575,7 @@ int spanningBatchImpl(
         sh.st.n_align_launches += b->stats.n_align_launches;
         sh.st.dp_cells += b->stats.dp_cells;
         sh.st.ptr_matrix_bytes += b->stats.ptr_matrix_bytes;
-        sh.st.h2d_bytes += (read_off[r1] - read_off[r0]) + (ref1_off[l1] - ref1_off[l0]) + (ref2_off[l1] - ref2_off[l0]) + 8ull * (r1 - r0 + 1) +
+        sh.st.h2d_bytes += (piles ? b->asmStage.plBytes : (read_off[r1] - read_off[r0]) + 8ull * (r1 - r0 + 1)) + (ref1_off[l1] - ref1_off[l0]) + (ref2_off[l1] - ref2_off[l0]) +
                            20ull * (n + 1) + 16ull * n;
         sh.st.d2h_bytes += pipeStagedBytes(b);
       }
@@ -3545,9 +3610,27 @@ int manta_spanning_batch(
     uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
     uint64_t* cigar_arena_used, const manta_batch_plan_t* plan, manta_batch_stats_t* stats)
 {
-  return spanningBatchImpl(&ctx, 1, nullptr, opt, scores, jump_score, n_loci, bases, read_off, locus_read_begin, refs1, ref1_off, refs2, ref2_off,
+  return spanningBatchImpl(&ctx, 1, nullptr, opt, scores, jump_score, n_loci, bases, read_off, locus_read_begin, nullptr, refs1, ref1_off, refs2, ref2_off,
                            cuts, locus_min_word_length, locus_max_word_length, loci, contigs, alignments, contigs_cap, seq_arena, seq_arena_cap,
                            seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used, cigar_arena, cigar_arena_cap, cigar_arena_used, plan, stats);
+}
+
+/* the same with the read piles in packed form (what manta_read_piles_batch emits) */
+int manta_spanning_batch_piles(
+    manta_ctx_t* ctx, const manta_asm_options_t* opt, const manta_align_scores_t* scores, int32_t jump_score, uint32_t n_loci,
+    const manta_packed_piles_t* piles, const uint8_t* refs1, const uint64_t* ref1_off, const uint8_t* refs2, const uint64_t* ref2_off,
+    const manta_jump_cuts_t* cuts, const uint32_t* locus_min_word_length, const uint32_t* locus_max_word_length, manta_asm_locus_result_t* loci,
+    manta_asm_contig_t* contigs, manta_spanning_alignment_t* alignments, uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap,
+    uint64_t* seq_arena_used, uint64_t* bits_arena, uint64_t bits_arena_cap, uint64_t* bits_arena_used, uint32_t* cigar_arena,
+    uint64_t cigar_arena_cap, uint64_t* cigar_arena_used, const manta_batch_plan_t* plan, manta_batch_stats_t* stats)
+{
+  if (!ctx) return MANTA_E_INVALID_ARG;
+  const int rc = checkPiles(ctx, piles, "manta_spanning_batch_piles");
+  if (rc != MANTA_OK) return rc;
+  return spanningBatchImpl(&ctx, 1, nullptr, opt, scores, jump_score, n_loci, nullptr, nullptr, piles->locus_read_begin, piles, refs1, ref1_off, refs2,
+                           ref2_off, cuts, locus_min_word_length, locus_max_word_length, loci, contigs, alignments, contigs_cap, seq_arena,
+                           seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used, cigar_arena, cigar_arena_cap, cigar_arena_used,
+                           plan, stats);
 }
 
 /* ------------------------------------------------------------------------------------------------------
@@ -3615,7 +3698,7 @@ int manta_node_spanning_batch(
 {
   if (!node) return MANTA_E_INVALID_ARG;
   return spanningBatchImpl(node->ctxs.data(), uint32_t(node->ctxs.size()), loci_per_device, opt, scores, jump_score, n_loci, bases, read_off,
-                           locus_read_begin, refs1, ref1_off, refs2, ref2_off, cuts, locus_min_word_length, locus_max_word_length, loci, contigs,
+                           locus_read_begin, nullptr, refs1, ref1_off, refs2, ref2_off, cuts, locus_min_word_length, locus_max_word_length, loci, contigs,
                            alignments, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used, bits_arena, bits_arena_cap, bits_arena_used,
                            cigar_arena, cigar_arena_cap, cigar_arena_used, plan, stats);
 }

@@ -313,6 +313,7 @@ struct LgParams {
   uint32_t*           stats;       ///< [0] loci whose graph came with a proof of acyclicity, [1] reads re-anchored by readOffsets' second pass
   uint8_t*            cws;         ///< contig_kernel workspaces
   uint64_t            cws_stride;
+  const uint8_t*      skip;        ///< graph_big_kernel: loci tandem_detect_kernel has sent to the general kernel already (nullptr: none)
 };
 
 static const uint32_t LG_FLAG_NO_PROOF = 1u;  ///< tests / A-B runs: never skip contig_kernel's cycle test
@@ -1062,6 +1063,21 @@ struct LdsGraph {
         for (unsigned h = 0; h < 2; ++h)
           if (lane + 64 * h < nNormal) std::fprintf(stderr, "  read %u: anchor %08x off %d par %u\n", lane + 64 * h, anch[lane + 64 * h], myOff[h], myPar[h]);
 #endif
+      // (myRoot is the read a read's offset was completed through: the root for the root's children, a finished inner read for the reads
+      // below it.  The roots proper by pointer jumping -- the trees below are told apart by them)
+      {
+        uint8_t* rootTmp = reinterpret_cast<uint8_t*>(lds + LG_OFF_WHIST);  // (the histograms are not in use before the sort)
+        for (unsigned h = 0; h < 2; ++h) rootTmp[lane + 64 * h] = uint8_t(myRoot[h]);
+        wv::sync();
+        for (int round = 0; round < 7; ++round) {
+          unsigned up[2];
+          for (unsigned h = 0; h < 2; ++h) up[h] = rootTmp[rootTmp[lane + 64 * h]];
+          wv::sync();
+          for (unsigned h = 0; h < 2; ++h) rootTmp[lane + 64 * h] = uint8_t(up[h]);
+          wv::sync();
+        }
+        for (unsigned h = 0; h < 2; ++h) myRoot[h] = rootTmp[lane + 64 * h];
+      }
       // ---- second chance.  A read whose words were all new when it went in -- the reads of a step are inserted by eight waves at
       // once, so which of two overlapping reads "was first" is a race -- has no anchor and is the root of a tree of its own, at
       // offset 0: one such tree beside the main one and the proof is lost.  Now that every word is in the table, such a root

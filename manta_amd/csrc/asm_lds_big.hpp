@@ -99,14 +99,22 @@ struct LdsGraphL {
   }
 
   /// per-phase shader clocks of the workgroup's first wave (-DMANTA_ASM_PROFILE; the slots of graph_kernel's coarse profile)
-  WV_DEV void tick(const int phase)
+  /// coarse: 0 pack, 1 table + offsets, 2 sort + records, 4 slab.  -DMANTA_LG_PROFILE_GRAPH: the eight counters split this kernel alone
+  /// (`fine`: 0 pack, 1 table, 2 reads' offsets, 3 sort, 4 sets to the slab + slot rewrite + filter, 5 links, 6 speculation list, 7 slab write)
+  WV_DEV void tick(const int phase, const int fine)
   {
 #ifdef MANTA_ASM_PROFILE
     const uint64_t now = wv::clock();
-    if (P.phase_cycles && tw == 0 && lane == 0) wv::atomic_add(&P.phase_cycles[phase], (unsigned long long)(now - tMark));
+#ifdef MANTA_LG_PROFILE_GRAPH
+    const int slot = fine;
+#else
+    const int slot = phase;
+#endif
+    if (P.phase_cycles && tw == 0 && lane == 0) wv::atomic_add(&P.phase_cycles[slot], (unsigned long long)(now - tMark));
     tMark = now;
 #else
     (void)phase;
+    (void)fine;
 #endif
   }
   WV_DEV void teamSync() const
@@ -936,7 +944,7 @@ struct LdsGraphL {
       }
     }
     teamSync();
-    tick(1);
+    tick(2, 4);
     uint16_t* sib  = reinterpret_cast<uint16_t*>(lds + LGL_OFF_SIB);
     uint16_t* sovf = reinterpret_cast<uint16_t*>(lds + LGL_OFF_SOVF);
     uint16_t* povf = reinterpret_cast<uint16_t*>(lds + LGL_OFF_POVF);
@@ -1026,7 +1034,7 @@ struct LdsGraphL {
     }
     if (wv::any(against) && lane == 0) wv::atomic_or(&hdr[LGL_H_CYC], 1u);
     teamSync();
-    tick(2);
+    tick(2, 5);
     if (wv::atomic_load(&hdr[LGL_H_NSIB]) > LG_SIB_CAP || wv::atomic_load(&hdr[LGL_H_NSOVF]) > LGL_OVF_CAP ||
         wv::atomic_load(&hdr[LGL_H_NPOVF]) > LGL_OVF_CAP)
       return false;
@@ -1139,13 +1147,14 @@ struct LdsGraphL {
       LGL_TRACE("table pass (table or set pool full)");
       return false;
     }
+    tick(1, 1);
     readOffsets<KW>();
-    tick(1);
+    tick(1, 2);
     if (!sortWords<KW>()) {
       LGL_TRACE("too many words");
       return false;
     }
-    tick(2);
+    tick(2, 3);
     // slab for this locus
     const LgSlab   SL    = lgSlabL(nNodes, nFat, codeWords);
     const uint64_t bytes = SL.total;
@@ -1177,6 +1186,7 @@ struct LdsGraphL {
     }
     uint16_t*      gSpec = reinterpret_cast<uint16_t*>(slab + SL.spec);
     const unsigned nSpec = speculationList(gSpec);
+    tick(2, 6);
     // the rest of the slab
     FRec8* gRec = reinterpret_cast<FRec8*>(slab + SL.recs);
     for (unsigned i = tid(); i < nNodes; i += nThreads()) gRec[i] = nodes[i];
@@ -1209,7 +1219,7 @@ struct LdsGraphL {
       G.slab_off[locus]               = off;
       G.class_ids[size_t(cls) * G.class_stride + wv::atomic_add(&G.class_count[cls], 1u)] = locus;
     }
-    tick(4);
+    tick(4, 7);
     return true;
   }
 
@@ -1229,7 +1239,7 @@ struct LdsGraphL {
       LGL_TRACE("pack (envelope / alphabet)");
       return false;
     }
-    tick(0);
+    tick(0, 0);
     const unsigned kw = (k + 15) >> 4;
     if (kw > unsigned(MAXKW)) return false;
     if (kw <= 2) return runK<2>(locus);
@@ -1255,6 +1265,10 @@ WV_KERNEL_WG(LGL_WAVES) WV_WAVES_PER_SIMD(4) void graph_big_kernel(const LgArgs 
     const unsigned slot = wv::first(wv::atomic_load(&hdr[LGL_H_SLOT]));
     if (slot >= P.n_loci) break;
     const unsigned locus   = P.locus_ids ? P.locus_ids[slot] : slot;
+    if (G.skip && G.skip[locus]) {  // (the general kernel has it already: tandem_detect_kernel)
+      wv::wg_barrier();
+      continue;
+    }
     const bool     arrived = !P.upload_chunks_done || asmWaitUploaded(P, locus);
     bool           ok      = false;
     if (arrived) {
@@ -1265,6 +1279,52 @@ WV_KERNEL_WG(LGL_WAVES) WV_WAVES_PER_SIMD(4) void graph_big_kernel(const LgArgs 
     if (tw == 0 && !ok && wv::lane() == 0) P.punt_ids[wv::atomic_add(P.punt_count, 1u)] = locus;
     wv::sync();
     wv::wg_barrier();  // (the slot word is rewritten next)
+  }
+}
+
+/// Which piles hold a word twice in ONE read ?  Such a word closes a walk in the k-mer graph: the graph is cyclic, the locus needs the
+/// exact repeat search and further word lengths -- the general kernel's, and a long dependent chain there (tens of milliseconds per
+/// locus).  This kernel finds them before the pipeline starts so that assemble_kernel can work on them on a second stream WHILE the
+/// pipeline runs, instead of after it: a word of length k repeats at distance u inside a read exactly when k consecutive bases equal
+/// the bases u further on (no N among them).  Periods 1..16 (tandem repeats); anything it misses is found by contig_big_kernel's
+/// cycle test as before -- this is routing, not a result.  One wave per locus; lane = (read of a group of four, period).
+struct TandemParams {
+  AsmParams       P;
+  const uint32_t* ids;       ///< the big class' work list
+  uint32_t        n_ids;
+  uint8_t*        flag;      ///< [n_loci] 1 = sent to the general kernel
+  uint32_t*       cyc_ids;   ///< those loci ...
+  uint32_t*       cyc_count; ///< ... and how many
+};
+WV_KERNEL void tandem_detect_kernel(const TandemParams T)
+{
+  const AsmParams& P    = T.P;
+  const unsigned   lane = unsigned(wv::lane());
+  for (unsigned i = unsigned(wv::block()); i < T.n_ids; i += unsigned(wv::nblocks())) {
+    const unsigned locus = T.ids[i];
+    if (P.pl_codes) break;  // (packed piles: not looked at here)
+    if (P.upload_chunks_done && !asmWaitUploaded(P, locus)) continue;  // (streamed upload: the locus' chunk has landed)
+    const uint32_t shift  = P.chunk_shift ? P.chunk_shift[locus / P.chunk_loci] : 0u;
+    const unsigned k      = P.locus_min_wl ? P.locus_min_wl[locus] : P.opt.minWordLength;
+    const unsigned rBegin = P.locus_read_begin[locus], rEnd = P.locus_read_begin[locus + 1];
+    const unsigned u      = 1 + (lane & 15);
+    bool           hit    = false;
+    for (unsigned rb = rBegin; rb < rEnd && !wv::any(hit); rb += 4) {
+      const unsigned r = rb + (lane >> 4);
+      if (r >= rEnd) continue;
+      const uint8_t* b   = P.bases + P.read_off[r] + shift;
+      const unsigned len = unsigned(P.read_off[r + 1] - P.read_off[r]);
+      unsigned       run = 0;
+      for (unsigned j = 0; j + u < len; ++j) {
+        const uint8_t c = b[j];
+        run             = (c == b[j + u] && c != 'N') ? run + 1 : 0u;
+        if (run >= k) hit = true;
+      }
+    }
+    if (wv::any(hit) && lane == 0) {
+      T.flag[locus]                                   = 1;
+      T.cyc_ids[wv::atomic_add(T.cyc_count, 1u)] = locus;
+    }
   }
 }
 

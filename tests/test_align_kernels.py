@@ -63,6 +63,38 @@ def test_gpu_align_pairs(gpu, oracle):
     assert _run_pairs(gpu, oracle, 29, 160, (60, 130, 200, 270, 330, 380, 520)) == 5 * 7 * 160
 
 
+def _long_ref_cases():
+    """short queries against a reference window of more than 65 535 rows: the packed pair kernel keeps a traceback start's row in 16
+    bits, so such a bucket must run on the unpacked kernel (api.cpp: alignUsesPairs) -- the best start lies beyond row 65 536 here"""
+    import numpy as np
+    from synth import rand_seq, mutate
+    rng = np.random.default_rng(77)
+    probs = []
+    for i in range(4):
+        ref = rand_seq(rng, 66000 + 300 * i)
+        at = 65700 + 37 * i
+        q = np.concatenate([ref[at:at + 25], ref[at + 45:at + 70]]) if i % 2 else ref[at:at + 48]
+        probs.append((mutate(rng, q, 0.02).tobytes(), ref.tobytes()))
+    return probs
+
+
+def test_emulated_align_pairs_reference_beyond_16_bit_rows(emu, oracle):
+    sc = [2, -8, -24, -1, -1, 0]
+    probs = _long_ref_cases()
+    for p, r in zip(probs, emu.align_batch(1, sc, -100, probs)):
+        assert r["status"] == 0 and r["begin1"] > 65535
+        assert align_text(1, r) == oracle.align(1, sc, -100, *p)
+
+
+@pytest.mark.gpu
+def test_gpu_align_pairs_reference_beyond_16_bit_rows(gpu, oracle):
+    sc = [2, -8, -24, -1, -1, 0]
+    probs = _long_ref_cases()
+    for p, r in zip(probs, gpu.align_batch(1, sc, -100, probs)):
+        assert r["status"] == 0 and r["begin1"] > 65535
+        assert align_text(1, r) == oracle.align(1, sc, -100, *p)
+
+
 def test_empty_inputs_report_status(emu):
     res = emu.align_batch(0, [2, -4, -5, -1, -4, 0], 0, [("", "ACGT"), ("ACGT", ""), ("AC", "ACGT")], strict=False)
     assert [r["status"] for r in res] == [-4, -4, 0]

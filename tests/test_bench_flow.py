@@ -110,3 +110,17 @@ def test_bench_extra_legs_on_the_emulator(emu):
     """the kernel_only and packed_input legs of the default run"""
     d, lines = run_bench(["--loci", "5", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
     assert "kernel_only" in d and "packed_input" in d and d["packed_input"]["unit"] == "loci/s"
+
+
+def test_bench_spanning_through_the_queues(emu):
+    """--workload spanning under --queue node (two gloo ranks on the shared-memory counter) and --queue process (one process, eight
+    emulated devices through manta_node_spanning_batch): every locus taken exactly once and equal to the reference digests"""
+    d = run_bench_ranks(2, ["--workload", "spanning", "--gpus", "2", "--loci", "2", "--steps", "1", "--warmup", "0", "--block-loci", "1",
+                            "--no-cpu-baseline", "--no-extras"], 29591)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["queue"] == "node" and sum(c["loci_per_rank"]) == 4 and "0 mismatches" in c["parity"]
+    d, lines = run_bench(["--workload", "spanning", "--gpus", "8", "--queue", "process", "--loci", "1", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-extras"])
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["queue"] == "process" and sum(c["loci_per_rank"]) == 8 and "manta_node_spanning_batch" in c["parallelism"]
+    assert "0 mismatches" in c["parity"]

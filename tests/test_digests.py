@@ -51,7 +51,8 @@ def test_digest_files_match_the_restatement_on_a_sample(oracle):
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("asm_path", ["general", "fast"])
 def test_gpu_config2_all_10000_loci_match_reference_digests(gpu, monkeypatch, asm_path):
-    """general = assemble_kernel (the default); fast = assemble_fast_kernel with its punt list (MANTA_AMD_ASM_PATH)"""
+    """fast = the default: the LDS pipeline (graph_kernel -> contig_kernel) with assemble_kernel on what it hands back;
+    general = assemble_kernel alone (MANTA_AMD_ASM_PATH)"""
     monkeypatch.setenv("MANTA_AMD_ASM_PATH", asm_path)
     want = digests("config2_digests.bin")
     batch = config2_batch(10000, seed=12345)
@@ -64,7 +65,11 @@ def test_gpu_config2_all_10000_loci_match_reference_digests(gpu, monkeypatch, as
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-def test_gpu_config5_2048_loci_match_reference_digests(gpu):
+@pytest.mark.parametrize("asm_path", ["general", "fast"])
+def test_gpu_config5_2048_loci_match_reference_digests(gpu, monkeypatch, asm_path):
+    """fast = the default: the LDS pipeline's big class (graph_big_kernel -> contig_big_kernel) with assemble_kernel on the cyclic piles it
+    hands back; general = assemble_kernel alone"""
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", asm_path)
     want = digests("config5_digests.bin")
     n = len(want)
     loci = [config5_locus(i) for i in range(n)]

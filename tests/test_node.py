@@ -130,3 +130,144 @@ def test_emulated_two_processes_share_one_queue(emu, oracle):
 def test_gpu_node_two_contexts_one_queue(gpu, oracle):
     per_dev = check_node(None, (0, 0), oracle, n=200, block=16)
     assert all(x > 0 for x in per_dev), per_dev
+
+
+# ---- spanning candidates (breakend loci, GlobalJumpAligner) through the same queues --------------------------------------------
+from manta_amd._capi import assembly_text, pack_piles  # noqa: E402
+from synth import breakend_locus  # noqa: E402
+from test_spanning_pipeline import SC as SPAN_SC, oracle_locus  # noqa: E402
+
+SPAN_OPTS = asm_opts(minWordLength=25, maxWordLength=45, minContigLength=40)
+SPAN_CUTS = (20, 20, 20, 20)
+
+
+def spanning_loci(n, seed):
+    """small breakend loci of two sizes, interleaved (every 4th holds three times the reads)"""
+    return [breakend_locus(seed + s, n_reads=(36 if s % 4 == 0 else 12), read_len=70, ref_len=320, tandem_frac=0.0) for s in range(n)]
+
+
+def span_text(r):
+    got = [(a["score"], a["jump_insert_size"], a["jump_range"], a["begin1"], a["cigar1"], a["begin2"], a["cigar2"], a["is_uncut"]) for a in r["aligns"]]
+    return assembly_text(r), got
+
+
+def span_want(oracle, locus):
+    return oracle_locus(oracle, SPAN_OPTS, locus[0], locus[1], locus[2], SPAN_CUTS)
+
+
+def check_span_results(oracle, loci, res, only=None):
+    for l in (range(len(loci)) if only is None else only):
+        text, aligns = span_want(oracle, loci[l])
+        got_text, got = span_text(res[l])
+        assert got_text == text and got == aligns, l
+
+
+def check_node_spanning(path, devices, oracle, n=16, block=3):
+    loci = spanning_loci(n, 300)
+    batch = pack_spanning([l[0] for l in loci], [l[1] for l in loci], [l[2] for l in loci], [SPAN_CUTS] * n)
+    node = Node(path=path, devices=devices)
+    out = BatchOutput(None, "spanning", n, 10, 1 << 20, 1 << 16, 1 << 18)
+    per_dev = node.spanning_batch(SPAN_OPTS, SPAN_SC, -100, batch, out, block_loci=block)
+    assert sum(per_dev) == n and len(per_dev) == len(devices)
+    check_span_results(oracle, loci, out.decode(np.diff(batch[2])))
+    node.close()
+    return per_dev
+
+
+def test_emulated_node_spanning_two_and_eight_contexts(emu, oracle):
+    """manta_node_spanning_batch: every locus exactly once, results equal to the oracle's call-by-call composition"""
+    per_dev = check_node_spanning(EMU, (0, 0), oracle)
+    assert all(x > 0 for x in per_dev), per_dev
+    per_dev = check_node_spanning(EMU, (0,) * 8, oracle, n=32, block=2)
+    assert len(per_dev) == 8 and sum(per_dev) == 32 and all(x > 0 for x in per_dev), per_dev
+
+
+def _span_rank(rank, shm_name, n, block, q, delay):
+    """one process of the node on the spanning call; `delay` seconds late (a rank that arrives after the others took their blocks)"""
+    import ctypes
+    import time
+    shm = shared_memory.SharedMemory(name=shm_name)
+    counter = ctypes.c_uint32.from_buffer(shm.buf)
+    lib = Lib(path=EMU)
+    loci = spanning_loci(n, 300)
+    batch = pack_spanning([l[0] for l in loci], [l[1] for l in loci], [l[2] for l in loci], [SPAN_CUTS] * n)
+    out = BatchOutput(lib, "spanning", n, 10, 1 << 20, 1 << 16, 1 << 18)
+    if delay:
+        time.sleep(delay)
+    lib.spanning_batch(SPAN_OPTS, SPAN_SC, -100, batch, out, block_loci=block, shared_queue=ctypes.addressof(counter))
+    res = out.decode(np.diff(batch[2]))
+    q.put((rank, [(l, span_text(r)) for l, r in enumerate(res) if r["status"] != -10]))
+    del counter
+    shm.close()
+
+
+def _run_span_ranks(world, n, block, delays):
+    shm = shared_memory.SharedMemory(create=True, size=64)
+    shm.buf[:64] = bytes(64)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_span_rank, args=(r, shm.name, n, block, q, delays[r])) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    shm.close()
+    shm.unlink()
+    taken, per_rank = {}, [0] * world
+    for rank, items in got:
+        per_rank[rank] = len(items)
+        for l, text in items:
+            assert l not in taken, "locus %d taken twice" % l
+            taken[l] = text
+    assert sorted(taken) == list(range(n))
+    return taken, per_rank
+
+
+def test_emulated_spanning_shared_queue_two_and_eight_processes(emu, oracle):
+    """manta_spanning_batch with manta_batch_plan_t::shared_queue: one process per device, every locus taken exactly once, the merged
+    result equal to the oracle's"""
+    for world, n, block in ((2, 12, 2), (8, 24, 1)):
+        taken, per_rank = _run_span_ranks(world, n, block, [0.0] * world)
+        loci = spanning_loci(n, 300)
+        for l in range(n):
+            text, aligns = span_want(oracle, loci[l])
+            assert taken[l] == (text, aligns), l
+        assert sum(per_rank) == n
+
+
+def test_emulated_spanning_shared_queue_late_rank(emu, oracle):
+    """a rank that reaches the call seconds after the others: coverage still holds (every locus exactly once) and the late rank simply
+    takes what is left -- possibly nothing; loci_per_rank reports it"""
+    n, block = 12, 1
+    taken, per_rank = _run_span_ranks(2, n, block, [0.0, 3.0])
+    assert sum(per_rank) == n and per_rank[0] >= per_rank[1], per_rank
+    loci = spanning_loci(n, 300)
+    for l in (0, n - 1):
+        text, aligns = span_want(oracle, loci[l])
+        assert taken[l] == (text, aligns)
+
+
+def test_emulated_spanning_batch_piles_equals_the_oracle(emu, oracle):
+    """manta_spanning_batch_piles: the whole-batch spanning call on packed read piles (2-bit codes + N bitmap)"""
+    n = 10
+    loci = spanning_loci(n, 500)
+    batch = pack_spanning([l[0] for l in loci], [l[1] for l in loci], [l[2] for l in loci], [SPAN_CUTS] * n)
+    piles = pack_piles(batch[0], batch[1], batch[2])
+    out = BatchOutput(emu, "spanning", n, 10, 1 << 20, 1 << 16, 1 << 18)
+    emu.spanning_batch_piles(SPAN_OPTS, SPAN_SC, -100, piles, batch[3], batch[4], batch[5], batch[6], batch[7], out, block_loci=4)
+    assert out.stats_dict()["n_blocks"] == 3
+    check_span_results(oracle, loci, out.decode(np.diff(batch[2])))
+
+
+@pytest.mark.gpu
+def test_gpu_node_spanning_two_contexts_and_batch_piles(gpu, oracle):
+    per_dev = check_node_spanning(None, (0, 0), oracle, n=48, block=6)
+    assert all(x > 0 for x in per_dev), per_dev
+    n = 32
+    loci = spanning_loci(n, 500)
+    batch = pack_spanning([l[0] for l in loci], [l[1] for l in loci], [l[2] for l in loci], [SPAN_CUTS] * n)
+    piles = pack_piles(batch[0], batch[1], batch[2])
+    out = BatchOutput(gpu, "spanning", n, 10, 1 << 20, 1 << 16, 1 << 18)
+    gpu.spanning_batch_piles(SPAN_OPTS, SPAN_SC, -100, piles, batch[3], batch[4], batch[5], batch[6], batch[7], out, block_loci=8)
+    check_span_results(oracle, loci, out.decode(np.diff(batch[2])))

@@ -14,7 +14,7 @@ def is_tandem(i, seed0=555000):
     synth.rand_seq(rng, 900); synth.rand_seq(rng, 900)
     return rng.random() < 0.1
 
-lib = Lib(path=os.path.join(ROOT, "manta_amd", "libmanta_amd_prof.so"))
+lib = Lib(path=os.path.join(ROOT, "manta_amd", os.environ.get("MANTA_PROF_LIB", "libmanta_amd_prof.so")))
 tand = [i for i in range(4000) if is_tandem(i)][:int(sys.argv[1]) if len(sys.argv) > 1 else 64]
 plain = [i for i in range(4000) if not is_tandem(i)][:len(tand)]
 for name, ids in (("plain", plain), ("tandem", tand), ("one tandem", tand[:1]), ("another", tand[5:6])):
