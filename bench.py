@@ -651,13 +651,54 @@ def main():
                                  "h2d_MB_per_step": round(h2d / nrun / 1e6, 2),
                                  "note": "read piles as 2-bit codes + N bitmap (manta_packed_piles_t, 0.375 B/base) instead of 1 B/base; "
                                          "same timed region; results identical to the default run"}
+        # ---- loci of very different sizes in one batch (extra key): read counts drawn log-uniformly from 3..1000, Manta's production word
+        # lengths (IterativeAssemblerOptions.hpp:33-58: 41..76 step 5) -- the rate, and how the assembler stage routed the loci (the LDS
+        # pipeline's two classes, what they handed back, what lies outside both envelopes)
+        if not spanning and world == 1 and not args.no_extras and not os.environ.get("MANTA_BENCH_NO_MIXED"):
+            try:
+                from synth import mixed_shape_batch
+                n_mx = min(2048, max(8, n_loci))
+                mx = mixed_shape_batch(n_mx, seed=777, hi=int(os.environ.get("MANTA_BENCH_MIXED_HI", "1000")))  # (the knob: the emulator flow test)
+                mx_dev = mx if args.pageable else tuple(pinned_copy(lib, a) for a in mx)
+                mx_reads = np.diff(mx[2])
+                mx_opts = asm_opts(minWordLength=41, maxWordLength=76, wordStepSize=5)
+                tot_b = int(mx[1][-1])
+                out3 = BatchOutput(lib, "smallsv", n_mx, 10, 2 * tot_b // 8 + 4096 * n_mx + (1 << 20), 40 * int(mx_reads.sum()) // 64 + 128 * n_mx + 4096,
+                                   512 * n_mx + 4096, pinned=not args.pageable)
+                lib.smallsv_batch(mx_opts, SCORES, LARGE_INDEL, mx_dev, out3)
+                t3 = time.perf_counter()
+                for _ in range(2):
+                    lib.smallsv_batch(mx_opts, SCORES, LARGE_INDEL, mx_dev, out3)
+                dt3 = time.perf_counter() - t3
+                st3 = out3.stats_dict()
+                r3 = out3.decode(mx_reads)
+                bad3 = sum(1 for r in r3 if r["status"] != 0)
+                chk = sorted(set([0, n_mx - 1] + [int(i) for i in np.argsort(mx_reads)[[0, n_mx // 2, -1]]]))
+                for l in chk:
+                    reads, ref, cuts = unpack_locus(mx, l)
+                    bad3 += small_sv_text(r3[l]) != orc.small_sv_locus(mx_opts, SCORES, LARGE_INDEL, reads, ref, cuts)
+                if bad3:
+                    raise SystemExit("PARITY FAILURE (mixed_shape): %d loci failed or differ from the CPU restatement" % bad3)
+                o["mixed_shape"] = {"value": round(n_mx * 2 / dt3, 1), "unit": "loci/s", "ms_per_step": round(dt3 / 2 * 1e3, 3), "loci": n_mx,
+                                    "reads_per_locus": {"min": int(mx_reads.min()), "median": int(np.median(mx_reads)), "max": int(mx_reads.max()),
+                                                        "mean": round(float(mx_reads.mean()), 1)},
+                                    "word_lengths": "41..76 step 5",
+                                    "routing": {"lds_small_class": int(st3["n_loci_lds_small"]), "lds_big_class": int(st3["n_loci_lds_big"]),
+                                                "handed_back_to_general_kernel": int(st3["n_loci_handed_back"]), "outside_both_classes": int(st3["n_loci_general"]),
+                                                "frac_off_the_lds_pipeline": round((st3["n_loci_handed_back"] + st3["n_loci_general"]) / max(1, n_mx), 4)},
+                                    "parity": "%d loci vs the CPU restatement (smallest, median, largest pile, first, last): 0 mismatches; every locus status 0" % len(chk),
+                                    "note": "read counts log-uniform 3..1000 x 150 bp, one manta_smallsv_batch call per step, same timed region"}
+            except SystemExit:
+                raise
+            except Exception as e:  # (an extra leg never takes the line down)
+                o["mixed_shape"] = {"error": str(e)[-300:]}
         # ---- the config-4/5 shape (extra key, driver-visible): breakend loci, 200 reads x 250 bp, mixed word lengths, GlobalJumpAligner --
-        # the same script with --workload spanning on 8 192 loci in a process of its own (its own context and arenas), its line cut
+        # the same script with --workload spanning on 65 536 loci (2 048 distinct, tiled) in a process of its own (its own context and arenas), its line cut
         # down to what a reader of this line needs: rate, the assembler stage's roofline object, kernel times, the parity string
         if (not spanning and world == 1 and not args.no_extras and not os.environ.get("MANTA_BENCH_NO_SPANNING")
                 and os.path.abspath(lib.path) == os.path.join(ROOT, "manta_amd", "libmanta_amd.so")):
             try:
-                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "spanning", "--loci", "8192", "--steps", "2", "--warmup", "1",
+                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "spanning", "--loci", os.environ.get("MANTA_BENCH_SPANNING_LOCI", "65536"), "--steps", "2", "--warmup", "1",
                                      "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=900)
                 rows = [l for l in pr.stdout.splitlines() if l.startswith("{")]
                 if pr.returncode == 0 and rows:
@@ -666,7 +707,7 @@ def main():
                                      "loci": sp["config"]["loci_per_gpu"], "workload": sp["config"]["workload"], "parity": sp["config"]["parity"],
                                      "timed_region": sp["config"]["timed_region"], "roofline": sp["roofline"],
                                      "kernels_ms_per_step": sp["kernels_ms_per_step"], "algorithmic_bytes_per_locus": sp["algorithmic_bytes_per_locus"],
-                                     "dp_gcups": sp["dp_gcups"], "note": "python bench.py --workload spanning --loci 8192 --steps 2 --warmup 1, run by this script"}
+                                     "dp_gcups": sp["dp_gcups"], "note": "python bench.py --workload spanning --loci %s --steps 2 --warmup 1, run by this script" % os.environ.get("MANTA_BENCH_SPANNING_LOCI", "65536")}
                 else:
                     o["spanning"] = {"error": (pr.stderr or pr.stdout)[-300:]}
             except Exception as e:  # (an extra leg never takes the line down)

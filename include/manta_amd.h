@@ -387,6 +387,9 @@ typedef struct {
   uint32_t n_blocks, n_workers;
   uint64_t n_alignments, n_align_launches, dp_cells, ptr_matrix_bytes;
   uint64_t h2d_bytes, d2h_bytes;       /* PCIe traffic of the call */
+  /* how the assembler stage routed the loci: the LDS pipeline's two size classes (<= 128 / <= 256 reads), the loci they handed
+     back to the general kernel (cyclic graph, next word length, capacity), the loci outside both envelopes (general kernel) */
+  uint64_t n_loci_lds_small, n_loci_lds_big, n_loci_handed_back, n_loci_general;
 } manta_batch_stats_t;
 
 int manta_smallsv_batch(

@@ -627,7 +627,8 @@ class BatchStats(ctypes.Structure):
                 ("assemble_ms", ctypes.c_float), ("schedule_ms", ctypes.c_float), ("align_ms", ctypes.c_float),
                 ("n_blocks", ctypes.c_uint32), ("n_workers", ctypes.c_uint32), ("n_alignments", ctypes.c_uint64),
                 ("n_align_launches", ctypes.c_uint64), ("dp_cells", ctypes.c_uint64), ("ptr_matrix_bytes", ctypes.c_uint64), ("h2d_bytes", ctypes.c_uint64),
-                ("d2h_bytes", ctypes.c_uint64)]
+                ("d2h_bytes", ctypes.c_uint64), ("n_loci_lds_small", ctypes.c_uint64), ("n_loci_lds_big", ctypes.c_uint64),
+                ("n_loci_handed_back", ctypes.c_uint64), ("n_loci_general", ctypes.c_uint64)]
 
 
 def _p(a):

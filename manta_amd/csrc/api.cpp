@@ -478,11 +478,7 @@ struct AsmStage {
   int                   gridContigBig[manta_dev::LGL_CLASSES] = {0, 0};
   uint32_t              classBytesBig[manta_dev::LGL_CLASSES] = {0, 0};
   uint64_t              cwsStrideBig = 0;
-  DevBuf                bLgClassIdsBig, bCwsBig, bCycIds, bCycFlag;
-  // piles with a tandem repeat (tandem_detect_kernel) run on assemble_kernel on a second stream WHILE the big class' pipeline runs
-  std::unique_ptr<rt::Stream> sideStream;
-  std::unique_ptr<rt::Event>  evDetect, evSide;
-  int                         lglWaves = 0;  // wavefronts of a graph_big_kernel workgroup in this launch
+  DevBuf                bLgClassIdsBig, bCwsBig;
   DevBuf                bPunt, bLgArena, bLgOff, bLgClassIds, bLgCnt, bCws;
   uint32_t*             dPunt = nullptr;   // the general kernel's list: genIds, then the loci the LDS pipeline punted
   // packed piles of the uploaded batch (manta_packed_piles_t), device side; dPlCodes == nullptr: 1 byte per base input
@@ -1023,7 +1019,6 @@ struct AsmStage {
       A.G.cls        = 0;
       A.G.flags      = (std::getenv("MANTA_AMD_LG_NO_PROOF") ? LG_FLAG_NO_PROOF : 0u) | (std::getenv("MANTA_AMD_LG_NO_RESCUE") ? LG_FLAG_NO_RESCUE : 0u);
       A.G.stats      = reinterpret_cast<uint32_t*>(dLg + 8);
-      A.G.skip       = nullptr;
       int maxGrid = 1;
       for (unsigned c = 0; c < LG_CLASSES; ++c) maxGrid = std::max(maxGrid, gridContig[c]);
       A.G.cws        = bCws.as<uint8_t>(cwsStride * uint64_t(maxGrid));
@@ -1033,7 +1028,6 @@ struct AsmStage {
       // the copies never run and the persistent workgroups wait for their chunks forever (seen on hardware, round 4)
       int gf = gridFast;
       if (streaming && gf >= ctx->cuCount * 2) gf -= std::max(1, ctx->cuCount / 4);
-      bool B_overlapped = false;
       // (the instantiation by the longest first word length among the loci of this launch: keys of 2 / 4 / 8 dwords)
       if (!fastIds.empty()) {
         uint32_t firstWl = opt.min_word_length;
@@ -1063,47 +1057,6 @@ struct AsmStage {
         for (unsigned c = 0; c < LGL_CLASSES; ++c) maxGridBig = std::max(maxGridBig, gridContigBig[c]);
         B.G.cws        = bCwsBig.as<uint8_t>(cwsStrideBig * uint64_t(maxGridBig));
         B.G.cws_stride = cwsStrideBig;
-        // Piles with a tandem repeat have a cyclic graph: the general kernel's, and tens of milliseconds of dependent chain each.
-        // tandem_detect_kernel finds them up front; assemble_kernel takes them on a second stream (no LDS, two waves per SIMD) while
-        // the pipeline -- graph workgroups of 8 wavefronts then, so that both fit a CU's registers -- works on the rest.
-        static const bool noOverlap = std::getenv("MANTA_AMD_NO_TANDEM_OVERLAP") != nullptr;
-        static const size_t overlapMin = std::getenv("MANTA_AMD_TANDEM_OVERLAP_MIN") ? size_t(std::atoi(std::getenv("MANTA_AMD_TANDEM_OVERLAP_MIN"))) : size_t(256);  // (tests: 1)
-        const bool overlap = !noOverlap && !dPlCodes && bigIds.size() >= overlapMin;
-        lglWaves           = overlap ? 8 : int(LGL_WAVES);
-        if (const char* e = std::getenv("MANTA_AMD_LGL_WAVES")) lglWaves = std::max(1, std::min(int(LGL_WAVES), std::atoi(e)));
-        if (overlap) {
-          uint8_t*  dFlag = bCycFlag.as<uint8_t>(nLoci);
-          uint32_t* dCyc  = bCycIds.as<uint32_t>(bigIds.size());
-          rt::dzero(dFlag, nLoci);
-          TandemParams T;
-          T.P         = P;
-          T.ids       = dOrder + fastIds.size();
-          T.n_ids     = uint32_t(bigIds.size());
-          T.flag      = dFlag;
-          T.cyc_ids   = dCyc;
-          T.cyc_count = reinterpret_cast<uint32_t*>(dLg + 13);
-          rt::launch(tandem_detect_kernel, rt::roundGrid(int(std::min<uint64_t>(bigIds.size(), uint64_t(ctx->cuCount) * 16))), 0, T);
-          B.G.skip = dFlag;
-          if (!sideStream) {
-            sideStream.reset(new rt::Stream());
-            evDetect.reset(new rt::Event());
-            evSide.reset(new rt::Event());
-          }
-          evDetect->record();
-          rt::streamWaits(*sideStream, *evDetect);
-          {
-            rt::ScopedStream onSide(*sideStream);
-            AsmParams Q  = P;
-            Q.locus_ids  = dCyc;
-            Q.n_loci     = uint32_t(bigIds.size());
-            Q.n_loci_dev = reinterpret_cast<uint32_t*>(dLg + 13);
-            Q.counter    = reinterpret_cast<uint32_t*>(dLg + 14);
-            Q.lds_bytes  = 0;
-            rt::launch(assemble_kernel, rt::roundGrid(std::min(g, std::max(4, ctx->cuCount * 8))), 0, Q);
-            evSide->recordOn(*sideStream);
-          }
-          B_overlapped = true;
-        }
         int gb = gridBig;
         if (streaming && gb >= ctx->cuCount) gb -= std::max(1, ctx->cuCount / 4);  // (as above: one workgroup owns a CU's whole LDS)
         uint32_t firstWl = opt.min_word_length;
@@ -1112,9 +1065,9 @@ struct AsmStage {
           for (const uint32_t l : bigIds) firstWl = std::max(firstWl, locusMinWl[l]);
         }
         if (firstWl <= 80)
-          rt::launchWG(graph_big_kernel<5>, gb, lglWaves, LGL_BUDGET, B);
+          rt::launchWG(graph_big_kernel<5>, gb, int(LGL_WAVES), LGL_BUDGET, B);
         else
-          rt::launchWG(graph_big_kernel<8>, gb, lglWaves, LGL_BUDGET, B);
+          rt::launchWG(graph_big_kernel<8>, gb, int(LGL_WAVES), LGL_BUDGET, B);
         for (unsigned c = 0; c < LGL_CLASSES; ++c) {
           B.G.cls       = c;
           B.P.counter   = reinterpret_cast<uint32_t*>(dLg + 9) + c;
@@ -1129,7 +1082,6 @@ struct AsmStage {
         A.P.lds_bytes = classBytes[c];
         rt::launchSingle(contig_kernel, gridContig[c], classBytes[c], A);
       }
-      if (B_overlapped) rt::curStreamWaits(*evSide);  // (the two general launches share the per-wave workspaces)
       P.locus_ids  = dPunt;
       P.n_loci     = nLoci;
       P.n_loci_dev = reinterpret_cast<uint32_t*>(dCnt + 14);
@@ -1296,15 +1248,13 @@ struct AsmStage {
     staged = true;
     ldsFallbacks = useFast ? uint32_t(hCnt[14] & 0xffffffffu) - uint32_t(genIds.size()) : 0u;
     if (std::getenv("MANTA_AMD_DEBUG") && useFast) {
-      uint32_t st[2] = {0, 0}, stBig[2] = {0, 0}, clsBig[2] = {0, 0}, nCyc = 0;
-      rt::d2h(&nCyc, bLgCnt.as<uint64_t>(16) + 13, sizeof(nCyc));
+      uint32_t st[2] = {0, 0}, stBig[2] = {0, 0}, clsBig[2] = {0, 0};
       rt::d2h(st, bLgCnt.as<uint64_t>(16) + 8, sizeof(st));
       rt::d2h(stBig, bLgCnt.as<uint64_t>(16) + 11, sizeof(stBig));
       rt::d2h(clsBig, bLgCnt.as<uint64_t>(16) + 5, sizeof(clsBig));
       std::fprintf(stderr, "manta_amd: LDS assembler pipeline: %zu + %zu (big class) loci, %u handed to the general kernel (+ %zu outside its envelope); %u + %u graphs came "
-                           "with a proof of acyclicity, %u + %u reads re-anchored; big class: %u / %u loci in its two contig LDS classes, %u piles with a tandem repeat sent to the "
-                           "general kernel up front (graph workgroups of %d wavefronts)\n", fastIds.size(), bigIds.size(),
-                   ldsFallbacks, genIds.size(), st[0], stBig[0], st[1], stBig[1], clsBig[0], clsBig[1], nCyc, lglWaves);
+                           "with a proof of acyclicity, %u + %u reads re-anchored; big class: %u / %u loci in its two contig LDS classes\n", fastIds.size(), bigIds.size(),
+                   ldsFallbacks, genIds.size(), st[0], stBig[0], st[1], stBig[1], clsBig[0], clsBig[1]);
     }
     if (std::getenv("MANTA_AMD_PROFILE")) {
       static const char* namesGeneral[8] = {"pack", "table", "links", "cycle-check", "exact", "seed", "walk", "select+emit"};
@@ -3353,6 +3303,10 @@ int smallsvBatchImpl(
         sh.st.n_align_launches += b->stats.n_align_launches;
         sh.st.dp_cells += b->stats.dp_cells;
         sh.st.ptr_matrix_bytes += b->stats.ptr_matrix_bytes;
+        sh.st.n_loci_lds_small += b->asmStage.fastIds.size();
+        sh.st.n_loci_lds_big += b->asmStage.bigIds.size();
+        sh.st.n_loci_handed_back += b->asmStage.ldsFallbacks;
+        sh.st.n_loci_general += b->asmStage.useFast ? b->asmStage.genIds.size() : size_t(n);
         sh.st.h2d_bytes += (piles ? b->asmStage.plBytes : (read_off[r1] - read_off[r0]) + 8ull * (r1 - r0 + 1)) + (ref_off[l1] - ref_off[l0]) +
                            12ull * (n + 1) + 16ull * n;
         sh.st.d2h_bytes += pipeStagedBytes(b);
@@ -3575,6 +3529,10 @@ int spanningBatchImpl(
         sh.st.n_align_launches += b->stats.n_align_launches;
         sh.st.dp_cells += b->stats.dp_cells;
         sh.st.ptr_matrix_bytes += b->stats.ptr_matrix_bytes;
+        sh.st.n_loci_lds_small += b->asmStage.fastIds.size();
+        sh.st.n_loci_lds_big += b->asmStage.bigIds.size();
+        sh.st.n_loci_handed_back += b->asmStage.ldsFallbacks;
+        sh.st.n_loci_general += b->asmStage.useFast ? b->asmStage.genIds.size() : size_t(n);
         sh.st.h2d_bytes += (piles ? b->asmStage.plBytes : (read_off[r1] - read_off[r0]) + 8ull * (r1 - r0 + 1)) + (ref1_off[l1] - ref1_off[l0]) + (ref2_off[l1] - ref2_off[l0]) +
                            20ull * (n + 1) + 16ull * n;
         sh.st.d2h_bytes += pipeStagedBytes(b);

@@ -313,7 +313,6 @@ struct LgParams {
   uint32_t*           stats;       ///< [0] loci whose graph came with a proof of acyclicity, [1] reads re-anchored by readOffsets' second pass
   uint8_t*            cws;         ///< contig_kernel workspaces
   uint64_t            cws_stride;
-  const uint8_t*      skip;        ///< graph_big_kernel: loci tandem_detect_kernel has sent to the general kernel already (nullptr: none)
 };
 
 static const uint32_t LG_FLAG_NO_PROOF = 1u;  ///< tests / A-B runs: never skip contig_kernel's cycle test

@@ -1265,10 +1265,6 @@ WV_KERNEL_WG(LGL_WAVES) WV_WAVES_PER_SIMD(4) void graph_big_kernel(const LgArgs 
     const unsigned slot = wv::first(wv::atomic_load(&hdr[LGL_H_SLOT]));
     if (slot >= P.n_loci) break;
     const unsigned locus   = P.locus_ids ? P.locus_ids[slot] : slot;
-    if (G.skip && G.skip[locus]) {  // (the general kernel has it already: tandem_detect_kernel)
-      wv::wg_barrier();
-      continue;
-    }
     const bool     arrived = !P.upload_chunks_done || asmWaitUploaded(P, locus);
     bool           ok      = false;
     if (arrived) {
@@ -1279,52 +1275,6 @@ WV_KERNEL_WG(LGL_WAVES) WV_WAVES_PER_SIMD(4) void graph_big_kernel(const LgArgs 
     if (tw == 0 && !ok && wv::lane() == 0) P.punt_ids[wv::atomic_add(P.punt_count, 1u)] = locus;
     wv::sync();
     wv::wg_barrier();  // (the slot word is rewritten next)
-  }
-}
-
-/// Which piles hold a word twice in ONE read ?  Such a word closes a walk in the k-mer graph: the graph is cyclic, the locus needs the
-/// exact repeat search and further word lengths -- the general kernel's, and a long dependent chain there (tens of milliseconds per
-/// locus).  This kernel finds them before the pipeline starts so that assemble_kernel can work on them on a second stream WHILE the
-/// pipeline runs, instead of after it: a word of length k repeats at distance u inside a read exactly when k consecutive bases equal
-/// the bases u further on (no N among them).  Periods 1..16 (tandem repeats); anything it misses is found by contig_big_kernel's
-/// cycle test as before -- this is routing, not a result.  One wave per locus; lane = (read of a group of four, period).
-struct TandemParams {
-  AsmParams       P;
-  const uint32_t* ids;       ///< the big class' work list
-  uint32_t        n_ids;
-  uint8_t*        flag;      ///< [n_loci] 1 = sent to the general kernel
-  uint32_t*       cyc_ids;   ///< those loci ...
-  uint32_t*       cyc_count; ///< ... and how many
-};
-WV_KERNEL void tandem_detect_kernel(const TandemParams T)
-{
-  const AsmParams& P    = T.P;
-  const unsigned   lane = unsigned(wv::lane());
-  for (unsigned i = unsigned(wv::block()); i < T.n_ids; i += unsigned(wv::nblocks())) {
-    const unsigned locus = T.ids[i];
-    if (P.pl_codes) break;  // (packed piles: not looked at here)
-    if (P.upload_chunks_done && !asmWaitUploaded(P, locus)) continue;  // (streamed upload: the locus' chunk has landed)
-    const uint32_t shift  = P.chunk_shift ? P.chunk_shift[locus / P.chunk_loci] : 0u;
-    const unsigned k      = P.locus_min_wl ? P.locus_min_wl[locus] : P.opt.minWordLength;
-    const unsigned rBegin = P.locus_read_begin[locus], rEnd = P.locus_read_begin[locus + 1];
-    const unsigned u      = 1 + (lane & 15);
-    bool           hit    = false;
-    for (unsigned rb = rBegin; rb < rEnd && !wv::any(hit); rb += 4) {
-      const unsigned r = rb + (lane >> 4);
-      if (r >= rEnd) continue;
-      const uint8_t* b   = P.bases + P.read_off[r] + shift;
-      const unsigned len = unsigned(P.read_off[r + 1] - P.read_off[r]);
-      unsigned       run = 0;
-      for (unsigned j = 0; j + u < len; ++j) {
-        const uint8_t c = b[j];
-        run             = (c == b[j + u] && c != 'N') ? run + 1 : 0u;
-        if (run >= k) hit = true;
-      }
-    }
-    if (wv::any(hit) && lane == 0) {
-      T.flag[locus]                                   = 1;
-      T.cyc_ids[wv::atomic_add(T.cyc_count, 1u)] = locus;
-    }
   }
 }
 

@@ -141,3 +141,31 @@ def config5_locus(i, seed0=555000):
     reads, ref1, ref2 = breakend_locus(seed0 + i)
     k = C5_WORD_LENGTHS[int(np.random.default_rng(seed0 + i + 7919).integers(0, len(C5_WORD_LENGTHS)))]
     return reads, ref1, ref2, k, max(76, k)
+
+
+def mixed_shape_batch(n_loci, seed=777, read_len=150, ref_len=1800, sub_rate=0.003, lo=3, hi=1000):
+    """Loci of very different sizes in one batch: the read count of a locus is drawn log-uniformly from lo..hi (small-indel loci
+    otherwise as config2_batch).  Same array layout as config2_batch."""
+    rng = np.random.default_rng(seed)
+    bp = ref_len // 2
+    n_reads = np.exp(rng.uniform(np.log(lo), np.log(hi + 1), size=n_loci)).astype(np.int64).clip(lo, hi)
+    code = rng.integers(0, 4, size=(n_loci, ref_len), dtype=np.uint8)
+    size = rng.integers(10, 61, size=n_loci)
+    is_del = rng.random(n_loci) < 0.5
+    parts = []
+    for l in range(n_loci):
+        s = int(size[l])
+        alt = np.concatenate([code[l, :bp], code[l, bp + s:]]) if is_del[l] else np.concatenate([code[l, :bp], rng.integers(0, 4, size=s, dtype=np.uint8), code[l, bp:]])
+        lo_s, hi_s = max(0, bp - read_len + 10), min(len(alt) - read_len, bp - 10)
+        starts = rng.integers(lo_s, hi_s + 1, size=int(n_reads[l]))
+        r = alt[starts[:, None] + np.arange(read_len)[None, :]]
+        m = rng.random(r.shape) < sub_rate
+        parts.append(np.where(m, (r + rng.integers(1, 4, size=r.shape, dtype=np.uint8)) & 3, r).astype(np.uint8).reshape(-1))
+    bases = ACGT[np.concatenate(parts)]
+    refs = ACGT[code].reshape(-1)
+    begin = np.zeros(n_loci + 1, dtype=np.uint32)
+    np.cumsum(n_reads, out=begin[1:])
+    read_off = (np.arange(int(begin[-1]) + 1, dtype=np.uint64) * np.uint64(read_len))
+    ref_off = (np.arange(n_loci + 1, dtype=np.uint64) * np.uint64(ref_len))
+    cuts = np.tile(np.array([100, 100, 800, 800], dtype=np.int32), (n_loci, 1))
+    return (np.ascontiguousarray(bases), read_off, begin, np.ascontiguousarray(refs), ref_off, np.ascontiguousarray(cuts))

@@ -108,8 +108,12 @@ def test_bench_spanning_flow_on_the_emulator(emu):
 
 def test_bench_extra_legs_on_the_emulator(emu):
     """the kernel_only and packed_input legs of the default run"""
-    d, lines = run_bench(["--loci", "5", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    d, lines = run_bench(["--loci", "5", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], dict(MANTA_BENCH_MIXED_HI="150"))
     assert "kernel_only" in d and "packed_input" in d and d["packed_input"]["unit"] == "loci/s"
+    mx = d["mixed_shape"]
+    assert "error" not in mx and mx["loci"] == 8 and "0 mismatches" in mx["parity"]
+    r = mx["routing"]
+    assert r["lds_small_class"] + r["lds_big_class"] + r["outside_both_classes"] == 8
 
 
 def test_bench_spanning_through_the_queues(emu):
