@@ -559,6 +559,11 @@ struct SVCandidateAssemblyRefiner {
 
   /// host threads used for the per-locus glue after each device batch (default: all hardware threads, at most 64)
   void setHostThreads(const unsigned n) { _hostThreads = (n == 0) ? 1 : n; }
+  /// host threads that call the input source (reference / read callbacks) of a batch concurrently.  Default 1: the callbacks are
+  /// called one candidate after the other, as the reference's worker does.  With more threads the source's two functions must be
+  /// safe to call concurrently (a source that keeps one BAM / FASTA handle per thread, or answers from memory); the cross-candidate
+  /// state of the call itself -- the geometric _spanToComplexAssmRegions filter -- is still applied in list order.
+  void setPlanThreads(const unsigned n) { _planThreads = (n == 0) ? 1 : n; }
 
   /// work counters of this refiner object (no reference counterpart; for logs and tests)
   struct Stats {
@@ -579,22 +584,44 @@ struct SVCandidateAssemblyRefiner {
       std::vector<std::exception_ptr>* errors = nullptr) const
   {
     const size_t n = svs.size();
-    out.assign(n, SVCandidateAssemblyData());
+    out.resize(n);  // (plan() clears every entry)
     std::vector<Plan> plans(n);
     _times = RefinerTimes();
     _errors.assign(n, std::exception_ptr());
     const double t0 = now();
-    for (size_t i = 0; i < n; ++i) {
-      try {
-        plan(svs[i], plans[i], out[i]);
-      } catch (...) {
-        plans[i].kind = Plan::NONE;
-        recordError(i, out);
+    if (_planThreads <= 1) {
+      for (size_t i = 0; i < n; ++i) {
+        try {
+          plan(svs[i], plans[i], out[i], nullptr);
+        } catch (...) {
+          plans[i].kind = Plan::NONE;
+          recordError(i, out);
+        }
       }
+    } else {
+      // the only state that crosses candidates is the interval filter of planSmall: its verdicts in list order first (no callbacks,
+      // pure geometry), then every candidate's reference and read callbacks on the host threads
+      std::vector<Route> routes(n);
+      for (size_t i = 0; i < n; ++i) {
+        try {
+          route(svs[i], routes[i]);
+        } catch (...) {  // (the same exception comes out of plan() below and is recorded there)
+        }
+      }
+      detail::parallelFor(n, _planThreads, [&](const size_t i) {
+        try {
+          plan(svs[i], plans[i], out[i], &routes[i]);
+        } catch (...) {
+          plans[i].kind = Plan::NONE;
+          recordError(i, out);
+        }
+      });
     }
     _times.plan = now() - t0;
     runSmall(plans, isFindLargeInsertions, out);
     runSpanning(plans, out);
+    // (the plans hold a copy of every read: their teardown is spread over the host threads as well)
+    detail::parallelFor(n, _hostThreads, [&](const size_t i) { AssemblyReadInput().swap(plans[i].reads); });
     if (errors) {
       *errors = _errors;
       return;
@@ -633,34 +660,59 @@ private:
 
   /// everything that precedes the assembler call: getCandidateAssemblyData (:1051-1082), the head of getJumpAssembly
   /// (:1745-1822) with assembleJumpContigs (:1422-1514), and the head of getSmallSVAssembly (:1860-1926)
-  void plan(const SVCandidate& sv, Plan& p, SVCandidateAssemblyData& data) const
+  /// what the interval filter of planSmall decided for a candidate (threaded plan: decided up front, in list order)
+  struct Route {
+    bool decided = false, overlapSkip = false;
+  };
+  /// is a spanning candidate handed to the local assembler in single-region form (:1803-1817) ?
+  bool isTransferToSmall(const SVCandidate& sv) const
+  {
+    const pos_t extraRefSize = 250 + 100;
+    if (sv.bp1.interval.tid == sv.bp2.interval.tid && !SVBreakendState::isSameOrientation(sv.bp1.state, sv.bp2.state))
+      return (getSVType(sv) == SV_TYPE::INDEL) && detail::isRefRegionOverlap(_header, extraRefSize, sv);
+    return false;
+  }
+  /// the filter's part of plan(), nothing else: spanning candidates that go to the local assembler add their merged interval, complex
+  /// candidates inside such an interval are skipped (planSmall's first lines)
+  void route(const SVCandidate& sv, Route& r) const
+  {
+    if (isSpanningSV(sv)) {
+      if (isTransferToSmall(sv)) {
+        GenomeInterval merged = sv.bp1.interval;
+        merged.range.merge_range(sv.bp2.interval.range);
+        _spanToComplexAssmRegions.addInterval(merged);
+      }
+    } else if (isComplexSV(sv)) {
+      r.overlapSkip = _spanToComplexAssmRegions.isSubsetOfRegion(sv.bp1.interval);
+    }
+    r.decided = true;
+  }
+
+  void plan(const SVCandidate& sv, Plan& p, SVCandidateAssemblyData& data, const Route* r) const
   {
     data.clear();
     if (isSpanningSV(sv)) {
       data.isCandidateSpanning = true;
-      planJump(sv, p, data);
+      planJump(sv, p, data, r);
     } else if (isComplexSV(sv)) {
       data.isCandidateSpanning = false;
-      planSmall(sv, p, data);
+      planSmall(sv, p, data, r);
     } else {
       throw GeneralException("Unknown candidate SV type");
     }
   }
 
-  void planJump(const SVCandidate& sv, Plan& p, SVCandidateAssemblyData& data) const
+  void planJump(const SVCandidate& sv, Plan& p, SVCandidateAssemblyData& data, const Route* r) const
   {
     const pos_t extraRefEdgeSize = 250, extraRefSplitSize = 100, extraRefSize = extraRefEdgeSize + extraRefSplitSize;
-    if (sv.bp1.interval.tid == sv.bp2.interval.tid && !SVBreakendState::isSameOrientation(sv.bp1.state, sv.bp2.state)) {
-      const SV_TYPE::index_t svType(getSVType(sv));
-      if ((svType == SV_TYPE::INDEL) && detail::isRefRegionOverlap(_header, extraRefSize, sv)) {
-        // breakend regions too close: hand the problem to the local assembler in single-region form (:1803-1817)
-        SVCandidate singleSV = sv;
-        singleSV.bp1.state   = SVBreakendState::COMPLEX;
-        singleSV.bp2.state   = SVBreakendState::UNKNOWN;
-        singleSV.bp1.interval.range.merge_range(sv.bp2.interval.range);
-        planSmall(singleSV, p, data);
-        return;
-      }
+    if (isTransferToSmall(sv)) {
+      // breakend regions too close: hand the problem to the local assembler in single-region form (:1803-1817)
+      SVCandidate singleSV = sv;
+      singleSV.bp1.state   = SVBreakendState::COMPLEX;
+      singleSV.bp2.state   = SVBreakendState::UNKNOWN;
+      singleSV.bp1.interval.range.merge_range(sv.bp2.interval.range);
+      planSmall(singleSV, p, data, r);
+      return;
     }
     data.isSpanning = true;
     BPOrientation& bporient(data.bporient);
@@ -693,10 +745,15 @@ private:
     p.sv   = sv;
   }
 
-  void planSmall(const SVCandidate& sv, Plan& p, SVCandidateAssemblyData& data) const
+  void planSmall(const SVCandidate& sv, Plan& p, SVCandidateAssemblyData& data, const Route* r) const
   {
     data.isSpanning = false;
-    if (data.isCandidateSpanning) {
+    if (r && r->decided) {  // (threaded plan: the filter was applied in list order before the callbacks were spread over threads)
+      if (!data.isCandidateSpanning && r->overlapSkip) {
+        data.isOverlapSkip = true;
+        return;
+      }
+    } else if (data.isCandidateSpanning) {
       _spanToComplexAssmRegions.addInterval(sv.bp1.interval);
     } else if (_spanToComplexAssmRegions.isSubsetOfRegion(sv.bp1.interval)) {
       data.isOverlapSkip = true;
@@ -753,7 +810,7 @@ private:
     _stats.smallLoci += which.size();
     const double          tPacked = now();
     _times.pack += tPacked - tStart;
-    detail::SmallSvOutput dev;
+    detail::SmallSvOutput& dev(_smallDev);  // (kept across calls: no re-allocation and zero-fill of tens of MB per batch)
     detail::smallSvBatch(deviceContext(), _smallPipe, _opt.refineOpt.smallSVAssembleOpt, _opt.refineOpt.largeSVAlignScores, _opt.refineOpt.largeGapOpenScore, packed,
                          refs, cuts, dev);
     const double tDevice = now();
@@ -1033,7 +1090,7 @@ private:
     // assemble -> jump-align (cut references) -> re-align rule -> jump-align (uncut), all on the device
     const double           tPacked = now();
     _times.pack += tPacked - tStart;
-    detail::SpanningOutput dev;
+    detail::SpanningOutput& dev(_spanDev);
     detail::spanningBatch(deviceContext(), _spanPipe, _opt.refineOpt.spanningAssembleOpt, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, packed, refs1,
                           refs2, cuts, dev);
     const double tDevice = now();
@@ -1113,7 +1170,10 @@ private:
   mutable manta_smallsv_t*      _smallPipe = nullptr;  ///< device pipelines of this refiner (and of the thread that
   mutable manta_spanning_t*     _spanPipe  = nullptr;  ///< first used it: one ABI context per host thread)
   mutable detail::PinnedArena   _stage;                ///< page-locked staging of a batch's read bases, reused
+  mutable detail::SmallSvOutput  _smallDev;            ///< the device results of the last batch (reused: capacity stays)
+  mutable detail::SpanningOutput _spanDev;
   unsigned                      _hostThreads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  unsigned                      _planThreads = 1;
 };
 
 }  // namespace manta_amd

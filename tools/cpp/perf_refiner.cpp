@@ -16,23 +16,21 @@ struct Source : RefinerInputSource {
     pos_t             pos;
     AssemblyReadInput reads;
   };
-  std::vector<Pile> piles;  // sorted by (tid,pos) in generation order == query order
-  size_t            cursor = 0;
+  std::vector<Pile> piles;  // sorted by pos (all on tid 0) in generation order
   void getReferenceSeq(const std::string& chrom, pos_t b, pos_t e, std::string& seq) override
   {
     seq = chroms[std::stoul(chrom)].substr(size_t(b), size_t(e - b + 1));
   }
+  /// answers from memory without any state of its own: safe to call from several host threads (setPlanThreads)
   void getBreakendReads(const SVBreakend& bp, bool, const reference_contig_segment&, AssemblyReadInput& reads) override
   {
     if (!reads.empty()) return;
-    for (size_t i = 0; i < piles.size(); ++i) {
-      const Pile& p(piles[(cursor + i) % piles.size()]);
-      if (p.tid == bp.interval.tid && p.pos >= bp.interval.range.begin_pos() && p.pos < bp.interval.range.end_pos()) {
-        reads  = p.reads;
-        cursor = (cursor + i) % piles.size();
-        return;
-      }
+    size_t lo = 0, hi = piles.size();  // first pile at or behind the interval's begin
+    while (lo < hi) {
+      const size_t mid = (lo + hi) / 2;
+      if (piles[mid].pos < bp.interval.range.begin_pos()) lo = mid + 1; else hi = mid;
     }
+    if (lo < piles.size() && piles[lo].tid == bp.interval.tid && piles[lo].pos < bp.interval.range.end_pos()) reads = piles[lo].reads;
   }
 };
 
@@ -98,12 +96,12 @@ int main(int argc, char** argv)
   SVCandidateAssemblyRefiner           refiner(opt, header, src);
   const unsigned hostThreads = argc > 3 ? unsigned(atoi(argv[3])) : std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
   refiner.setHostThreads(hostThreads);
+  refiner.setPlanThreads(hostThreads);  // (the source above answers from memory)
   std::vector<SVCandidateAssemblyData> out;
   double       bestDt = 1e30;
   RefinerTimes bestT;
   size_t       bestSvs = 0, bestContigs = 0;
   for (int rep = 0; rep < 3; ++rep) {
-    src.cursor    = 0;
     const auto t0 = std::chrono::steady_clock::now();
     refiner.getCandidateAssemblyDataBatch(svs, false, out);
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
