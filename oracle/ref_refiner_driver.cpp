@@ -336,6 +336,83 @@ REF_EXPORT int ref_get_candidate_assembly_data(const ref_refine_input_t* in, cha
   }
 }
 
+#ifdef MANTA_AMD_DROPIN_BATCH
+// ------------------------------------------------------------------------------------------------------------------
+// drop-in builds only: the BATCHED refiner call over Manta's own types (manta_amd/host/dropin/batch_refiner.hpp).  n inputs that
+// share chromosomes and options (those of inputs[0]) become ONE BatchRefiner::getCandidateAssemblyDataBatch call on a
+// std::vector<SVCandidate>; the std::vector<SVCandidateAssemblyData> that comes back is dumped by the function above.
+// ------------------------------------------------------------------------------------------------------------------
+#include "batch_refiner.hpp"
+
+namespace {
+struct DriverBatchSource : manta_amd_dropin::BatchInputSource {
+  std::vector<std::string> chroms;
+  struct Pile {
+    int32_t           tid;
+    int               pos;
+    AssemblyReadInput reads;
+  };
+  std::vector<Pile> piles;
+  void getReferenceSeq(const std::string& chrom, int beginPos, int endPos, std::string& seq) override
+  {
+    seq = chroms.at(std::stoul(chrom)).substr(size_t(beginPos), size_t(endPos - beginPos + 1));
+  }
+  void getBreakendReads(const SVBreakend& bp, bool, const reference_contig_segment&, AssemblyReadInput& reads) override
+  {
+    if (!reads.empty()) return;  // the pile holds both breakends' reads already, in final order
+    for (const Pile& p : piles)
+      if (p.tid == bp.interval.tid && p.pos >= bp.interval.range.begin_pos() && p.pos < bp.interval.range.end_pos()) {
+        reads = p.reads;
+        return;
+      }
+  }
+};
+}  // namespace
+
+REF_EXPORT int ref_get_candidate_assembly_data_multi(const ref_refine_input_t* inputs, int n, int /*is_batched*/, char* out, int cap)
+{
+  try {
+    DriverBatchSource source;
+    bam_header_info   header;
+    for (int i = 0; i < inputs[0].n_chrom; ++i) {
+      source.chroms.emplace_back(inputs[0].chrom_seq[i]);
+      header.chrom_data.emplace_back(std::to_string(i).c_str(), unsigned(source.chroms.back().size()));
+    }
+    GSCOptions options;
+    auto setWords = [](IterativeAssemblerOptions& o, const int32_t* w) {
+      if (w[0] > 0) o.minWordLength = w[0];
+      if (w[1] > 0) o.maxWordLength = w[1];
+      if (w[2] > 0) o.wordStepSize = w[2];
+    };
+    setWords(options.refineOpt.smallSVAssembleOpt, inputs[0].small_word);
+    setWords(options.refineOpt.spanningAssembleOpt, inputs[0].spanning_word);
+    std::vector<SVCandidate> svs;
+    for (int k = 0; k < n; ++k) {
+      const ref_refine_input_t& in(inputs[k]);
+      DriverBatchSource::Pile   pile;
+      pile.tid = in.bp_tid[0];
+      pile.pos = in.bp_begin[0];
+      for (int i = 0; i < in.n_reads; ++i) pile.reads.emplace_back(in.reads[i]);
+      source.piles.push_back(pile);
+      SVCandidate sv;
+      sv.bp1.state    = static_cast<SVBreakendState::index_t>(in.bp_state[0]);
+      sv.bp1.interval = GenomeInterval(in.bp_tid[0], in.bp_begin[0], in.bp_end[0]);
+      sv.bp2.state    = static_cast<SVBreakendState::index_t>(in.bp_state[1]);
+      sv.bp2.interval = GenomeInterval(in.bp_tid[1], in.bp_begin[1], in.bp_end[1]);
+      for (int c = 0; c < std::max(1, in.n_calls); ++c) svs.push_back(sv);
+    }
+    const manta_amd_dropin::BatchRefiner refiner(options, header, source);
+    std::vector<SVCandidateAssemblyData> data;
+    refiner.getCandidateAssemblyDataBatch(svs, inputs[0].is_find_large_insertions != 0, data);
+    std::string text;
+    for (const SVCandidateAssemblyData& d : data) text += dumpAssemblyData(d);
+    return emit(text, out, cap);
+  } catch (const std::exception& e) {
+    return emit(std::string("EXCEPTION ") + e.what(), out, cap);
+  }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------------------------
 // candidateSV.vcf records of the refined candidates: the reference's own VcfWriterCandidateSV / VcfWriterSV /
 // JunctionIdGenerator (format/VcfWriter{,Candidate}SV.cpp, manta/JunctionIdGenerator.cpp, unmodified), fed with the

@@ -43,6 +43,31 @@ def test_dropin_refiner_equals_reference_refiner(dropin_emu):
     assert n >= 50
 
 
+def test_dropin_batched_refiner_over_manta_types(dropin_emu):
+    """The BATCHED call over Manta's own types (manta_amd/host/dropin/batch_refiner.hpp): std::vector<SVCandidate> in,
+    std::vector<SVCandidateAssemblyData> out, one device batch inside.  Every scenario call through it equals the all-reference
+    build's single call; a candidate list that exercises the cross-candidate interval filter (a close spanning pair transferred to the
+    local assembler, then the same region as a complex candidate: isOverlapSkip) equals the reference refiner called twice."""
+    import random
+    from refiner_loci import spanning_case
+    ref = lib("libmanta_ref_refiner.so")
+    n = 0
+    for seed in (41, 42):
+        for name, c in scenario_cases(seed):
+            assert dropin_emu.run_multi([c], True) == ref.run(c), (seed, name)
+            n += 1
+    assert n >= 50
+    rng = random.Random(11)
+    close = spanning_case(rng, "RL", same_chrom=True, far=False)
+    cx = dict(close)
+    lo, hi = min(close["begin"]), max(close["end"])
+    cx.update(state=[3, 0], begin=[lo + 1, lo + 1], end=[hi - 1, hi - 1])
+    both = dropin_emu.run_multi([close, cx], True)
+    assert both.startswith(ref.run(close)) and "isOverlapSkip=1" in both
+    twice = dict(close, calls=2)  # (the driver repeats the identical call on ONE reference refiner object)
+    assert dropin_emu.run_multi([twice], True) == ref.run(twice)
+
+
 def test_dropin_refiner_on_demo_piles(dropin_emu):
     for c in json.load(open(DEMO))["cases"]:
         assert dropin_emu.run(c["case"]) == c["ref_text"], c["name"]
@@ -95,4 +120,8 @@ def test_gpu_dropin_refiner_golden(gpu):
     for c in json.load(open(DEMO))["cases"]:
         assert d.run(c["case"]) == c["ref_text"], c["name"]
         assert d.vcf(c["case"]) == c["ref_vcf"], c["name"]
+        assert d.run_multi([c["case"]], True) == c["ref_text"], c["name"]
+    # the batched call over Manta's own types (batch_refiner.hpp) on the device
+    for (name, c), want in zip(scenario_cases(g["seed"]), g["texts"]):
+        assert d.run_multi([c], True) == want, name
     check_dropin_small_assembler(d, 200)
