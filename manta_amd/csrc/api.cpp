@@ -2775,6 +2775,9 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
       };
       std::vector<Launch> launches;
       uint64_t            slabBytes = 0;
+      // (sharing the wave slots among the buckets by work -- tasks x columns x steps -- so that they would end together was measured in
+      // round 5 and lost: 170 ms against 86 per 16 384 config-5 loci.  A bucket's waves are long dependent chains; capping its grid only
+      // lengthens them.)
       for (int k = kNumESet - 1; k >= 0; --k) {
         const uint32_t cnt = hCounts[k];
         if (cnt == 0) continue;
