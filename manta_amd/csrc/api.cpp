@@ -19,7 +19,7 @@
 #include <vector>
 
 #include "align_kernels.hpp"
-#include "align_pair.hpp"
+#include "align_jump_pair.hpp"
 #include "assemble_kernels.hpp"
 #include "asm_lds.hpp"
 #include "small_asm.hpp"
@@ -189,7 +189,27 @@ void launchAlignE(int eIdx, int grid, const AlignParams& P)
 bool alignUsesPairs(int kind, int eIdx, int match, int mismatch, int open, int extend, int offEdge, int extra, int allowEdgeIns, uint64_t maxRef)
 {
   static const bool off = std::getenv("MANTA_AMD_NO_ALIGN_PAIRS") != nullptr;  // A/B knob
-  return !off && kind == MANTA_ALIGNER_LARGE_INDEL && maxRef <= 0xfffeu && pairEligible(kESet[eIdx], match, mismatch, open, extend, offEdge, extra, allowEdgeIns);
+  static const bool offJump = std::getenv("MANTA_AMD_NO_JUMP_PAIRS") != nullptr;
+  if (off || maxRef > 0xfffeu) return false;
+  if (kind == MANTA_ALIGNER_LARGE_INDEL) return pairEligible(kESet[eIdx], match, mismatch, open, extend, offEdge, extra, allowEdgeIns);
+  // GlobalJumpAligner: align_jump_pair.hpp (maxRef: both references together -- the combined rows of a task)
+  if (kind == MANTA_ALIGNER_JUMP) return !offJump && !allowEdgeIns && jumpPairEligible(kESet[eIdx], match, mismatch, open, extend, offEdge, extra);
+  return false;
+}
+
+void launchJumpPair(int eIdx, int grid, const AlignParams& P)
+{
+  if (std::getenv("MANTA_AMD_DEBUG")) std::fprintf(stderr, "manta_amd: align_jump_pair_kernel<%d>: %d waves (two alignments each)\n", kESet[eIdx], grid);
+  switch (kESet[eIdx]) {
+  case 1: rt::launch(align_jump_pair_kernel<1>, grid, 0, P); break;
+  case 2: rt::launch(align_jump_pair_kernel<2>, grid, 0, P); break;
+  case 3: rt::launch(align_jump_pair_kernel<3>, grid, 0, P); break;
+  case 4: rt::launch(align_jump_pair_kernel<4>, grid, 0, P); break;
+  case 5: rt::launch(align_jump_pair_kernel<5>, grid, 0, P); break;
+  case 6: rt::launch(align_jump_pair_kernel<6>, grid, 0, P); break;
+  case 8: rt::launch(align_jump_pair_kernel<8>, grid, 0, P); break;
+  default: throw rt::Error("internal: no packed jump aligner for this E");
+  }
 }
 
 void launchAlignPair(int eIdx, int grid, const AlignParams& P)
@@ -216,7 +236,9 @@ void launchAlignKind(int kind, int eIdx, int grid, const AlignParams& P, bool pa
       launchAlignPair(eIdx, grid, P);
     else
       launchAlignE<1>(eIdx, grid, P);
-  } else
+  } else if (pair)
+    launchJumpPair(eIdx, grid, P);
+  else
     launchAlignE<2>(eIdx, grid, P);
 }
 
@@ -2772,6 +2794,7 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
       struct Launch {
         int      k, grid;
         uint64_t stride, slabOff;
+        bool     pair;
       };
       std::vector<Launch> launches;
       uint64_t            slabBytes = 0;
@@ -2781,11 +2804,14 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
       for (int k = kNumESet - 1; k >= 0; --k) {
         const uint32_t cnt = hCounts[k];
         if (cnt == 0) continue;
-        const uint64_t stride = (alignPtrSlabBytes(MANTA_ALIGNER_JUMP, kESet[k], hMaxref[k]) + 255) & ~uint64_t(255);
-        int            grid   = int(std::min<size_t>(cnt, size_t(maxWaves)));
+        // (two alignments per wave in packed 16-bit arithmetic where the scores allow it: align_jump_pair.hpp)
+        const bool     pair   = alignUsesPairs(MANTA_ALIGNER_JUMP, k, b->scores.match, b->scores.mismatch, b->scores.open, b->scores.extend, b->scores.off_edge,
+                                               b->jumpScore, 0, hMaxref[k]);
+        const uint64_t stride = ((pair ? 2 : 1) * alignPtrSlabBytes(MANTA_ALIGNER_JUMP, kESet[k], hMaxref[k]) + 255) & ~uint64_t(255);
+        int            grid   = int(std::min<size_t>(pair ? (cnt + 1) / 2 : cnt, size_t(maxWaves)));
         grid                  = int(std::max<size_t>(1, std::min<size_t>(size_t(grid), (wsBudget / 3) / stride)));
         grid                  = rt::roundGrid(grid);
-        launches.push_back(Launch{k, grid, stride, slabBytes});
+        launches.push_back(Launch{k, grid, stride, slabBytes, pair});
         slabBytes += stride * uint64_t(grid);
       }
       if (launches.empty()) return;
@@ -2811,7 +2837,7 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
         P.extra          = b->jumpScore;
         {
           rt::ScopedStream onSide(b->side[i % 3]);
-          launchAlignKind(MANTA_ALIGNER_JUMP, l.k, l.grid, P);
+          launchAlignKind(MANTA_ALIGNER_JUMP, l.k, l.grid, P, l.pair);
         }
         b->stats.n_align_launches++;
         b->stats.n_alignments += hCounts[l.k];

@@ -63,6 +63,41 @@ def test_gpu_align_pairs(gpu, oracle):
     assert _run_pairs(gpu, oracle, 29, 160, (60, 130, 200, 270, 330, 380, 520)) == 5 * 7 * 160
 
 
+def _run_jump_pairs(lib, oracle, seed, per_batch, maxlens, n_random_sets=3):
+    """GlobalJumpAligner batches large enough per E bucket for align_jump_pair_kernel (two alignments per wave, packed 16-bit arithmetic in
+    the x4 domain, align_jump_pair.hpp): Manta's spanning scores, score sets at and beyond the kernel's margin (jumpPairEligible() then sends
+    the bucket to the unpacked kernel), and randomly drawn score sets -- the results equal the oracle's either way.  Pairs are formed from
+    neighbours of a bucket: tasks of different reference lengths, hence different seam rows, share a wave."""
+    rng = random.Random(seed)
+    sets = [([2, -8, -12, -1, -1, 0], -100), ([2, -4, -5, -1, -1, 0], -20), ([1, -4, -6, -2, -1, 0], -3), ([2, -8, -100, 0, -1, 0], -100),
+            ([4, -30, -60, -8, -16, 0], -400)]
+    for _ in range(n_random_sets):
+        sets.append(([rng.randint(1, 3), -rng.randint(1, 12), -rng.randint(0, 30), -rng.randint(0, 3), -rng.randint(0, 4), 0], -rng.randint(0, 150)))
+    n = 0
+    for sc, jump in sets:
+        for maxlen in maxlens:
+            probs = [_rand_align_case(rng, 2, maxlen) for _ in range(per_batch)]
+            res = lib.align_batch(2, sc, jump, probs)
+            for p, r in zip(probs, res):
+                assert r["status"] == 0
+                assert align_text(2, r) == oracle.align(2, sc, jump, *p), (sc, jump, p)
+                n += 1
+    return n
+
+
+def test_emulated_align_jump_pairs(emu, oracle, capfd, monkeypatch):
+    monkeypatch.setenv("MANTA_AMD_DEBUG", "1")
+    assert _run_jump_pairs(emu, oracle, 31, 16, (60, 200, 420)) == 8 * 3 * 16
+    assert "align_jump_pair_kernel" in capfd.readouterr().err  # (the packed kernel did run)
+
+
+@pytest.mark.gpu
+def test_gpu_align_jump_pairs(gpu, oracle):
+    """the sweep of tools/sweeps/sweep_align.py brought into the tier for the jump aligner: 8 score sets (3 of them random) x 7 query
+    ranges x 100 alignments"""
+    assert _run_jump_pairs(gpu, oracle, 37, 100, (60, 130, 200, 270, 330, 400, 520)) == 8 * 7 * 100
+
+
 def _long_ref_cases():
     """short queries against a reference window of more than 65 535 rows: the packed pair kernel keeps a traceback start's row in 16
     bits, so such a bucket must run on the unpacked kernel (api.cpp: alignUsesPairs) -- the best start lies beyond row 65 536 here"""
