@@ -501,6 +501,11 @@ struct AsmStage {
   uint32_t              classBytesBig[manta_dev::LGL_CLASSES] = {0, 0};
   uint64_t              cwsStrideBig = 0;
   DevBuf                bLgClassIdsBig, bCwsBig;
+  // ... and its word-length rounds (IterativeAssembler.cpp:856-910 on the pipeline: graph_big -> repeat_big -> contig_big per word length)
+  uint32_t              bigRounds = 0;     // rounds launched (0: rounds off -- a repeat hit / a cyclic graph is handed back to assemble_kernel)
+  int                   gridRepeat = 0;    // repeat_big_kernel wavefronts
+  uint64_t              pseudoArenaDw = 0, rwsStride = 0;
+  DevBuf                bLgIter, bLgPseudo, bLgNext, bLgCyc, bLgRounds, bRws;
   DevBuf                bPunt, bLgArena, bLgOff, bLgClassIds, bLgCnt, bCws;
   uint32_t*             dPunt = nullptr;   // the general kernel's list: genIds, then the loci the LDS pipeline punted
   // packed piles of the uploaded batch (manta_packed_piles_t), device side; dPlCodes == nullptr: 1 byte per base input
@@ -646,6 +651,8 @@ struct AsmStage {
           const uint64_t c = cost[order[i]];
           ((c >> 63) ? fastIds : ((useBig && ((c >> 62) & 1u)) ? bigIds : genIds)).push_back(order[i]);
         }
+        // (Ordering the big class' list by first word length -- so that the tandem piles with most word lengths ahead of them reach the
+        //  general kernel's queue first -- was measured: 1155 vs 1111 ms per 65 536 spanning loci.  The cost order stays.)
       }
     }
     const double   tPlan2   = nowMs();
@@ -725,8 +732,20 @@ struct AsmStage {
         gridContigBig[c] = int(std::max<uint64_t>(1, std::min<uint64_t>(bigIds.size(), uint64_t(ctx->cuCount) * (163840 / kClassBig[c]))));
       }
       cwsStrideBig = ckWorkspaceLayout(LgL::SETW).total;
+      bigRounds    = 0;
+      static const bool roundsOn = !(std::getenv("MANTA_AMD_BIG_ROUNDS") && std::atoi(std::getenv("MANTA_AMD_BIG_ROUNDS")) == 0);  // A/B runs
+      if (roundsOn && !bigIds.empty() && opt.max_assembly_count <= 20) {
+        for (const uint32_t l : bigIds) {
+          const uint32_t lo = locusMinWl.empty() ? opt.min_word_length : locusMinWl[l], hi = locusMaxWl.empty() ? opt.max_word_length : locusMaxWl[l];
+          if (hi >= lo) bigRounds = std::max<uint32_t>(bigRounds, (hi - lo) / opt.word_step_size + 1);
+        }
+        bigRounds     = std::min<uint32_t>(bigRounds, LGL_MAX_ROUNDS);
+        gridRepeat    = rt::roundGrid(int(std::min<uint64_t>(uint64_t(ctx->cuCount) * 16, std::max<uint64_t>(64, bigIds.size() / 4))));
+        rwsStride     = rpbWorkspaceLayout().total;
+        pseudoArenaDw = std::max<uint64_t>(uint64_t(4) << 20, uint64_t(bigIds.size()) * 512);  // dwords
+      }
       lgArenaCap   = std::min<uint64_t>(uint64_t(fastIds.size()) * lgSlabBytes(LG_MAX_NODES, LG_MAX_NODES, LG_MAX_PILE + 2) +
-                                          uint64_t(bigIds.size()) * lgSlabL(LGL_MAX_NODES, LGL_POOL_CAP, LGL_MAX_PILE + 4).total + 4096,
+                                          uint64_t(bigIds.size() + (bigRounds ? 3 * std::min<size_t>(bigIds.size(), 512) : 0)) * lgSlabL(LGL_MAX_NODES, LGL_POOL_CAP, LGL_MAX_PILE_ALL + 4).total + 4096,
                                       wsBudget / 2);
       (void)maxGrid;
     }
@@ -931,6 +950,14 @@ struct AsmStage {
       if (!bigIds.empty()) {
         (void)bLgClassIdsBig.as<uint32_t>(uint64_t(manta_dev::LGL_CLASSES) * bigIds.size());
         (void)bCwsBig.as<uint8_t>(cwsStrideBig * uint64_t(maxGridBig));
+        if (bigRounds) {
+          (void)bLgIter.as<manta_dev::LgIter>(nLoci);
+          (void)bLgPseudo.as<uint32_t>(pseudoArenaDw + 64);
+          (void)bLgNext.as<uint32_t>(2 * bigIds.size());
+          (void)bLgCyc.as<uint32_t>(bigIds.size());
+          (void)bLgRounds.as<uint32_t>(8 * (manta_dev::LGL_MAX_ROUNDS + 1));
+          (void)bRws.as<uint8_t>(rwsStride * uint64_t(gridRepeat));
+        }
       }
     } else {
       rt::h2d(dOrder, order.data(), sizeof(uint32_t) * nLoci);
@@ -1045,6 +1072,14 @@ struct AsmStage {
       for (unsigned c = 0; c < LG_CLASSES; ++c) maxGrid = std::max(maxGrid, gridContig[c]);
       A.G.cws        = bCws.as<uint8_t>(cwsStride * uint64_t(maxGrid));
       A.G.cws_stride = cwsStride;
+      A.G.round = A.G.last_round = 0;
+      A.G.iter        = nullptr;  // (the big class' rounds set these)
+      A.G.parena      = nullptr;
+      A.G.parena_cap  = 0;
+      A.G.parena_used = nullptr;
+      A.G.next_ids = A.G.next_count = A.G.cyc_ids = A.G.cyc_count = nullptr;
+      A.G.rws        = nullptr;
+      A.G.rws_stride = 0;
       // streamed upload: a chunk the runtime moves with a shader copy needs a free workgroup slot (and, as far as this launch can
       // know, LDS): graph_kernel's two workgroups per CU own all 160 KB, so a quarter of the CUs keep one slot free -- without it
       // the copies never run and the persistent workgroups wait for their chunks forever (seen on hardware, round 4)
@@ -1081,20 +1116,72 @@ struct AsmStage {
         B.G.cws_stride = cwsStrideBig;
         int gb = gridBig;
         if (streaming && gb >= ctx->cuCount) gb -= std::max(1, ctx->cuCount / 4);  // (as above: one workgroup owns a CU's whole LDS)
-        uint32_t firstWl = opt.min_word_length;
+        // (the instantiation by the longest word length the kernel may meet: the first one without the rounds, any of them with)
+        uint32_t firstWl = bigRounds ? opt.max_word_length : opt.min_word_length;
         if (!locusMinWl.empty()) {
           firstWl = 0;
-          for (const uint32_t l : bigIds) firstWl = std::max(firstWl, locusMinWl[l]);
+          for (const uint32_t l : bigIds) firstWl = std::max(firstWl, bigRounds ? locusMaxWl[l] : locusMinWl[l]);
         }
-        if (firstWl <= 80)
-          rt::launchWG(graph_big_kernel<5>, gb, int(LGL_WAVES), LGL_BUDGET, B);
-        else
-          rt::launchWG(graph_big_kernel<8>, gb, int(LGL_WAVES), LGL_BUDGET, B);
-        for (unsigned c = 0; c < LGL_CLASSES; ++c) {
-          B.G.cls       = c;
-          B.P.counter   = reinterpret_cast<uint32_t*>(dLg + 9) + c;
-          B.P.lds_bytes = classBytesBig[c];
-          rt::launchSingle(contig_big_kernel, gridContigBig[c], classBytesBig[c], B);
+        if (!bigRounds) {
+          if (firstWl <= 80)
+            rt::launchWG(graph_big_kernel<5>, gb, int(LGL_WAVES), LGL_BUDGET, B);
+          else
+            rt::launchWG(graph_big_kernel<8>, gb, int(LGL_WAVES), LGL_BUDGET, B);
+          for (unsigned c = 0; c < LGL_CLASSES; ++c) {
+            B.G.cls       = c;
+            B.P.counter   = reinterpret_cast<uint32_t*>(dLg + 9) + c;
+            B.P.lds_bytes = classBytesBig[c];
+            rt::launchSingle(contig_big_kernel, gridContigBig[c], classBytesBig[c], B);
+          }
+        } else {
+          // One round per word length.  Round r: graph_big_kernel over the round's list (round 0: the class' work list; later: what
+          // contig_big_kernel of round r - 1 sent on -- a repeat hit, :872-910) -> repeat_big_kernel over the graphs without a proof of
+          // acyclicity (peel, exact repeat search, LDS class) -> contig_big_kernel per LDS class.  Every round has its own counters
+          // (bLgRounds, 8 dwords per round: [0] graph work counter, [1..2] loci per class, [3..4] the class launches' work counters,
+          // [5] graphs without a proof, [6] repeat_big_kernel's work counter, [7] loci sent on); the rounds after the first are launched
+          // blind -- their list lengths sit in device memory -- with small grids: a round without work costs four empty launches.
+          uint32_t* rc = bLgRounds.as<uint32_t>(8 * (LGL_MAX_ROUNDS + 1));
+          rt::dzero(rc, sizeof(uint32_t) * 8 * (LGL_MAX_ROUNDS + 1));
+          uint32_t* nextBuf = bLgNext.as<uint32_t>(2 * bigIds.size());
+          B.G.iter        = bLgIter.as<LgIter>(nLoci);
+          B.G.parena      = bLgPseudo.as<uint32_t>(pseudoArenaDw + 64);
+          B.G.parena_cap  = pseudoArenaDw;
+          B.G.parena_used = reinterpret_cast<unsigned long long*>(rc + 8 * LGL_MAX_ROUNDS);
+          B.G.cyc_ids     = bLgCyc.as<uint32_t>(bigIds.size());
+          B.G.rws         = bRws.as<uint8_t>(rwsStride * uint64_t(gridRepeat));
+          B.G.rws_stride  = rwsStride;
+          B.G.last_round  = bigRounds - 1;
+          const int later = int(std::max<size_t>(32, bigIds.size() / 4));
+          for (uint32_t r = 0; r < bigRounds; ++r) {
+            uint32_t* cr     = rc + 8 * r;
+            LgArgs    R      = B;
+            R.G.round        = r;
+            R.G.class_count  = cr + 1;
+            R.G.cyc_count    = cr + 5;
+            R.G.next_ids     = nextBuf + size_t(r & 1u) * bigIds.size();
+            R.G.next_count   = cr + 7;
+            R.P.counter      = cr;
+            if (r > 0) {
+              R.P.locus_ids  = nextBuf + size_t((r - 1) & 1u) * bigIds.size();
+              R.P.n_loci     = 0;
+              R.P.n_loci_dev = rc + 8 * (r - 1) + 7;
+            }
+            const int gg = (r == 0) ? gb : std::min(gb, later);
+            if (firstWl <= 80)
+              rt::launchWG(graph_big_kernel<5>, gg, int(LGL_WAVES), LGL_BUDGET, R);
+            else
+              rt::launchWG(graph_big_kernel<8>, gg, int(LGL_WAVES), LGL_BUDGET, R);
+            R.P.n_loci_dev = nullptr;
+            R.P.counter    = cr + 6;
+            R.P.lds_bytes  = RPB_LDS_BYTES;
+            rt::launch(repeat_big_kernel, (r == 0) ? gridRepeat : std::min(gridRepeat, rt::roundGrid(2 * later)), RPB_LDS_BYTES, R);
+            for (unsigned c = 0; c < LGL_CLASSES; ++c) {
+              R.G.cls       = c;
+              R.P.counter   = cr + 3 + c;
+              R.P.lds_bytes = classBytesBig[c];
+              rt::launchSingle(contig_big_kernel, (r == 0) ? gridContigBig[c] : std::min(gridContigBig[c], later), classBytesBig[c], R);
+            }
+          }
         }
       }
       for (unsigned c = 0; c < LG_CLASSES && !fastIds.empty(); ++c) {

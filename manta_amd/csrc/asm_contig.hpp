@@ -45,7 +45,7 @@ WV_HD CkWsLayout ckWorkspaceLayout(const unsigned setw = 2)
   return L;
 }
 
-enum { CK_DONE = 0, CK_PUNT = 1 };
+enum { CK_DONE = 0, CK_PUNT = 1, CK_NEXT = 2 };  // CK_NEXT (big class): the locus goes on to the next word length, nothing emitted yet
 
 template <class C>
 struct LdsContig {
@@ -73,6 +73,11 @@ struct LdsContig {
   uint64_t*        lane_log;
   unsigned         lane, nNormal, W, k, nNodes, nFat, nEligible, nSpec, nSib, nSovf, nPovf, codeWords, nCand, maxLen, seqWords;
   bool             acyclic;
+  // big class, word-length rounds: a CYCLIC graph (repeat_big_kernel left the core and repeat-word bitmaps) and pseudo reads
+  bool             cyclic, anyRep;
+  unsigned         nPseudo, nCore, visDw;
+  uint32_t *       coreBits, *repBits, *vis;  ///< vis: one bitmap over the core per lane, dword w of lane l at [w * 64 + l]
+  uint16_t*        corePrefix;
   unsigned         candSlotV;  // lane c: cache slot that holds candidate c's walk
   uint64_t         tMark;
 
@@ -98,6 +103,10 @@ struct LdsContig {
     seqWords  = CK_SEQ_WORDS;
     candSlotV = 0;
     nCand     = 0;
+    cyclic = anyRep = false;
+    nPseudo = nCore = visDw = 0;
+    coreBits = repBits = vis = nullptr;
+    corePrefix = nullptr;
   }
 
   WV_DEV void tick(const int phase)
@@ -186,6 +195,9 @@ struct LdsContig {
     codeWords       = wv::first(gh->codeWords);
     W               = wv::first(gh->W);
     acyclic         = wv::first(gh->acyclic) != 0;
+    cyclic          = C::BIG && wv::first(gh->cyclic) != 0;
+    nPseudo         = C::BIG ? wv::first(gh->nPseudo) : 0u;
+    nCore           = cyclic ? wv::first(gh->nCore) : 0u;
     if (wv::first(gh->need) > P.lds_bytes || nNodes > C::MAX_NODES) return false;
     SL               = lgSlabOf<C>(nNodes, nFat, codeWords);
     const FRec8* gRec = reinterpret_cast<const FRec8*>(slab + SL.recs);
@@ -204,8 +216,53 @@ struct LdsContig {
       const unsigned d = UPL * lane + u, lo = 32 * d;
       unused_bits[d]   = (nEligible >= lo + 32) ? 0xffffffffu : ((nEligible > lo) ? ((1u << (nEligible - lo)) - 1u) : 0u);
     }
+    if (cyclic) {
+      // behind the bitset pool: core bitmap, its prefix counts (a core word's index = words of the core below it), repeat words, and
+      // the walks' visited bitmaps.  A core word carries bit 63 of its record: every step sees it without a further read.
+      char* x    = scratch() + 8 * SW * (nFat ? nFat : 1u);
+      coreBits   = reinterpret_cast<uint32_t*>(x);
+      corePrefix = reinterpret_cast<uint16_t*>(x + 4 * C::UNUSED_DW);
+      repBits    = reinterpret_cast<uint32_t*>(x + 6 * C::UNUSED_DW);
+      vis        = reinterpret_cast<uint32_t*>(x + 10 * C::UNUSED_DW);
+      visDw      = (nCore + 31) / 32;
+      const uint32_t* gf = reinterpret_cast<const uint32_t*>(slab + SL.flags);
+      unsigned        c  = 0;
+      uint32_t        cb[UPL];
+      for (unsigned u = 0; u < UPL; ++u) {
+        const unsigned d = UPL * lane + u;
+        cb[u]            = gf[d];
+        coreBits[d]      = cb[u];
+        repBits[d]       = gf[C::UNUSED_DW + d];
+        c += unsigned(wv::popc(cb[u]));
+      }
+      unsigned inc = c;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = wv::shfl(inc, int(lane) - off);
+        if (int(lane) >= off) inc += o;
+      }
+      unsigned at = inc - c;
+      for (unsigned u = 0; u < UPL; ++u) {
+        corePrefix[UPL * lane + u] = uint16_t(at);
+        at += unsigned(wv::popc(cb[u]));
+      }
+      wv::sync();  // (the records are in)
+      for (unsigned u = 0; u < UPL; ++u) {
+        uint32_t b32 = cb[u];
+        while (b32) {
+          const unsigned b = unsigned(wv::ctz(uint64_t(b32)));
+          b32 &= b32 - 1;
+          nodes[32 * (UPL * lane + u) + b] |= FRec8(1) << 63;
+        }
+      }
+    }
     wv::sync();
     return true;
+  }
+  /// a word the two-sided peel left (cyclic graphs of the big class only: bit 63 of the LDS copy of its record)
+  WV_DEV static bool coreFlag(const FRec8 w) { return C::BIG && (w >> 63) != 0; }
+  WV_DEV unsigned    coreIndex(const unsigned nd) const
+  {
+    return unsigned(corePrefix[nd >> 5]) + unsigned(wv::popc(coreBits[nd >> 5] & ((1u << (nd & 31)) - 1u)));
   }
   WV_DEV const Set*      gPool() const { return reinterpret_cast<const Set*>(slab + SL.pool); }
   WV_DEV const uint16_t* gSpecList() const { return reinterpret_cast<const uint16_t*>(slab + SL.spec); }
@@ -379,13 +436,20 @@ struct LdsContig {
     unsigned       mode = 0, cur = seed, consOffset = 0, nLeft = 0, nRight = 0;
     int            consEnd = 0, consBegin = 0;
     FRec8          seedRec = 0;
+    if (cyclic && has)
+      for (unsigned w = 0; w < visDw; ++w) vis[w * 64 + lane] = 0;  // wordsInContig (:182): only words of the core can come back
     if (has) {
       seedRec = nodes[seed];
       S       = supOf(seed, seedRec);
-      if (R::selfLoop(seedRec)) {  // :172-179 (repeatWords of an acyclic graph = the self loops)
+      const bool repeatSeed = R::selfLoop(seedRec) || (cyclic && ((repBits[seed >> 5] >> (seed & 31)) & 1u));
+      if (repeatSeed) {  // :172-179 (repeatWords of an acyclic graph = the self loops; of a cyclic one: repeat_big_kernel's bitmap)
         rep    = true;
         active = false;
       } else {
+        if (coreFlag(seedRec)) {
+          const unsigned ci = coreIndex(seed);
+          vis[(ci >> 5) * 64 + lane] |= 1u << (ci & 31);
+        }
         // unselected siblings of the seed reject the contig (:185-210).  The words that differ from the seed in the last base
         // only are the other successors of any predecessor of the seed; a seed without a predecessor has them in the side table.
         const unsigned pf = R::pred(seedRec, 0);
@@ -427,7 +491,7 @@ struct LdsContig {
         const bool     backOne = (fwd ? R::pred(w, 1) : R::succ(w, 1)) == 0 && !(fwd ? R::pOvf(w) : R::sOvf(w));
         const unsigned shared  = popSet(setAnd(S, a));
         const unsigned wc      = R::cnt(w);
-        const bool     go = one && backOne && shared != 0 && wc >= P.opt.minCoverage && f - 1 != cur &&
+        const bool     go = one && backOne && shared != 0 && wc >= P.opt.minCoverage && f - 1 != cur && !coreFlag(w) &&
                         (k + nRight + nLeft + 1 < maxLen) && (nRight + nLeft < CK_MAX_EXT);
         if (!wv::any(go)) break;
         if (go) {
@@ -504,11 +568,19 @@ struct LdsContig {
       }
       const unsigned maxNode      = maxF - 1;  // (ASM_NONE when nothing was chosen)
       const unsigned maxBaseCount = maxF ? R::cnt(maxW) : 0u;
+      // :352: the chosen word is one of the contig's own.  Only a word of the core can be (see repeat_big_kernel).
+      const bool     onCore = active && maxF != 0 && coreFlag(maxW);
+      unsigned       ci = 0;
+      bool           seen = false;
+      if (wv::any(onCore)) {
+        ci   = onCore ? coreIndex(maxNode) : 0u;
+        seen = onCore && ((vis[(ci >> 5) * 64 + lane] >> (ci & 31)) & 1u);
+      }
       bool           stop = false, extend = false;
       if (active) {
         if (maxBaseCount < P.opt.minCoverage) {  // :343 (also "no candidate")
           stop = true;
-        } else if (maxNode == cur) {  // :352-358: in an acyclic graph a walk meets its own words again only through a self loop
+        } else if (maxNode == cur || seen) {  // :352-358: in an acyclic graph a walk meets its own words again only through a self loop
           rep  = true;
           stop = true;
         } else if (k + nRight + nLeft + 1 >= maxLen || nRight + nLeft >= CK_MAX_EXT) {
@@ -545,6 +617,7 @@ struct LdsContig {
       }
       // ---- finish this step ----
       if (extend) {
+        if (onCore) vis[(ci >> 5) * 64 + lane] |= 1u << (ci & 31);  // :485
         {  // :482-484: the word leaves unusedWords when this walk is accepted
           const unsigned p = 1 + nRight + nLeft;
           logAcc |= uint64_t(maxNode) << (16 * (p & 3));
@@ -612,8 +685,8 @@ struct LdsContig {
   }
 
   /// buildContigs' contig loop (:685-713): the reference's seed sequence replayed over cached speculative walks.
-  /// Returns 0 = all contigs built without a repeat hit (candidate c's walk sits in cache slot candSlotV of lane c),
-  /// 1 = not for this path (a walk hit a repeat: the reference goes on to the next word length; contig too long).
+  /// Returns 0 = all contigs built (candidate c's walk sits in cache slot candSlotV of lane c; anyRep: one of them hit a repeat,
+  /// the reference goes on to the next word length), 1 = not for this path (contig too long).
   WV_DEV int contigRounds()
   {
     const unsigned capCand = 2 * P.opt.maxAssemblyCount;
@@ -729,10 +802,12 @@ struct LdsContig {
         if (!isUnused(nd)) continue;  // consumed by an accepted walk: not a seed for the reference either
         const unsigned sl = wv::readlane(slot, int(i));
         if (sl == LG_NO_SLOT) break;  // the next seed has not been walked: next round
-        if (wv::readlane(flI, int(i)) != 0) {  // repeat hit (the reference moves on to the next word length) or contig too long
+        const unsigned fl = wv::readlane(flI, int(i));
+        if (fl & 2u) {  // contig too long for this path
           bad = true;
           break;
         }
+        if (fl & 1u) anyRep = true;  // a repeat hit (:699): the contig stays a candidate, the reference moves on to the next word length afterwards
         acc |= uint64_t(1) << sl;
         if (lane == nCand) candSlotV = sl;
         nCand++;
@@ -755,7 +830,80 @@ struct LdsContig {
   // ------------------------------------------------------------------------------------------------
   // selectContigs (:722-842) + output, lane c = candidate c (see Assembler::selectAndEmit for the general form)
   // ------------------------------------------------------------------------------------------------
-  WV_DEV void selectAndEmit(const unsigned locus)
+  /// base i of candidate contig c's text (slot sl, nL left extensions, seed at packed base seedPb): reverse(left) + seed + right
+  WV_DEV unsigned contigCode(const unsigned sl, const unsigned nL, const unsigned seedPb, const unsigned i) const
+  {
+    const uint32_t* gc       = gCodes();
+    const uint32_t* rightBuf = lane_seq + sl;  // (interleaved: dword i of slot sl at [i * 128 + sl], the left half 64 further)
+    const uint32_t* leftBuf  = lane_seq + 64 + sl;
+    if (i < nL) {
+      const unsigned j = nL - 1 - i;
+      return (leftBuf[size_t(j >> 4) * 128] >> (2 * (j & 15))) & 3;
+    }
+    if (i < nL + k) {
+      const unsigned pb = seedPb + (i - nL);
+      return (gc[pb >> 4] >> (30 - 2 * (pb & 15))) & 3u;
+    }
+    const unsigned j = i - nL - k;
+    return (rightBuf[size_t(j >> 4) * 128] >> (2 * (j & 15))) & 3;
+  }
+
+  /// :882-910: this word length's contigs longer than k + wordStepSize become the next length's pseudo reads.  They go to the pseudo
+  /// arena as 2-bit codes in the pile's layout and are described in G.iter[locus] (nPseudo, len, off, codeWords).  False: arena full.
+  WV_DEV bool writePseudo(const unsigned locus)
+  {
+    unsigned nL = 0, nR = 0, len = 0;
+    if (lane < nCand) {
+      const int32_t* m = lane_meta + candSlotV * 8;
+      nL               = unsigned(m[0]);
+      nR               = unsigned(m[1]);
+      len              = nL + k + nR;
+    }
+    const bool     isP  = lane < nCand && len > k + P.opt.wordStepSize;  // :898
+    const uint64_t mP   = wv::ballot(isP);
+    const unsigned nP   = unsigned(wv::popc(mP));
+    const unsigned myC  = isP ? (len + 15) / 16 + 1 : 0u;
+    unsigned       inc  = myC;
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = wv::shfl(inc, int(lane) - off);
+      if (int(lane) >= off) inc += o;
+    }
+    const unsigned total = wv::readlane(inc, 63);
+    const unsigned myOff = inc - myC;
+    if (nP > LGL_MAX_PSEUDO) return false;
+    unsigned long long base = 0;
+    if (lane == 0) base = wv::atomic_add(G.parena_used, (unsigned long long)total);
+    base = wv::readlane(uint64_t(base), 0);
+    if (base + total > G.parena_cap) return false;
+    LgIter* st = &G.iter[locus];
+    if (isP) st->len[wv::popc(mP & ((uint64_t(1) << lane) - 1))] = uint16_t(len);
+    if (lane == 0) {
+      st->nPseudo   = nP;
+      st->off       = base;
+      st->codeWords = total;
+    }
+    const uint16_t* gp = gPb();
+    for (uint64_t m = mP; m; m &= m - 1) {
+      const int      c      = wv::ctz(m);
+      const unsigned sl     = wv::readlane(candSlotV, c);
+      const unsigned cL     = wv::readlane(nL, c), cLen = wv::readlane(len, c), cOff = wv::readlane(myOff, c);
+      const unsigned seedPb = gp[slotNode[sl]];
+      const unsigned nCw    = (cLen + 15) / 16 + 1;
+      for (unsigned wi = lane; wi < nCw; wi += 64) {
+        uint32_t code = 0;
+        for (unsigned b = 0; b < 16; ++b) {
+          const unsigned i = wi * 16 + b;
+          if (i < cLen) code |= contigCode(sl, cL, seedPb, i) << (30 - 2 * b);
+        }
+        G.parena[base + cOff + wi] = code;
+      }
+    }
+    wv::sync();
+    return true;
+  }
+
+  /// `st`: the pseudo reads the result carries (:898-905; nullptr: none), nIter / cycIters: word lengths tried / of them with a cyclic graph
+  WV_DEV void selectAndEmit(const unsigned locus, const LgIter* st, const unsigned nIter, const unsigned cycIters)
   {
     Set      sup = setZero(), rej = setZero();
     unsigned nLeft = 0, nRight = 0, myLen = 0;
@@ -778,12 +926,19 @@ struct LdsContig {
     unsigned finalCount = 0;
     uint64_t chosen     = 0;  // chosen candidates in order, 6 bits each (maxAssemblyCount <= 10 fits a qword; more: second word)
     uint64_t chosenHi   = 0;
+    // index >= nNormal <=> pseudo read (oracle/manta_oracle.cpp selectContigs on stale indices)
+    Set normalS;
+    for (unsigned q = 0; q < SW; ++q) {
+      const unsigned lo = 64 * q;
+      normalS.w[q]      = (nNormal >= lo + 64) ? ~uint64_t(0) : ((nNormal > lo) ? ((uint64_t(1) << (nNormal - lo)) - 1) : uint64_t(0));
+    }
     while (finalCount < P.opt.maxAssemblyCount) {
       if (!wv::any(aliveL)) break;
-      const unsigned usedNormal = popSet(used);  // (no pseudo reads on this path)
+      const unsigned usedNormal = popSet(setAnd(used, normalS));
       if (nNormal - usedNormal < P.opt.minUnusedReads) break;  // :750
-      const unsigned nFresh = popSet(setAndNot(sup, used));
-      if (aliveL && nFresh < P.opt.minSupportReads) aliveL = false;  // :779-788
+      const Set      fresh  = setAndNot(sup, used);
+      const unsigned nFresh = popSet(fresh);
+      if (aliveL && popSet(setAnd(fresh, normalS)) < P.opt.minSupportReads) aliveL = false;  // :779-788
       uint64_t key = aliveL ? ((uint64_t(nFresh) << 40) | (uint64_t(myLen) << 8) | uint64_t(63u - lane)) : 0;
       for (int off = 1; off < 64; off <<= 1) {
         const uint64_t o = wv::shfl(key, wv::lane() ^ off);
@@ -805,14 +960,21 @@ struct LdsContig {
     out.status            = ASM_OK;
     out.n_contigs         = finalCount;
     out.n_words           = W;
-    out.n_pseudo          = 0;
+    const unsigned nP     = st ? wv::first(st->nPseudo) : 0u;
+    out.n_pseudo          = nP;
     out.final_word_length = k;
-    out.n_iterations      = 1;
-    out.cyclic_iterations = 0;
+    out.n_iterations      = nIter;
+    out.cyclic_iterations = cycIters;
     out.reserved          = 0;
     uint64_t seqBytes = 0;
     for (unsigned f = 0; f < finalCount; ++f) seqBytes += wv::readlane(myLen, int(chosenAt(f)));
-    const uint64_t     bitsWords = uint64_t(finalCount) * 2 * W;
+    const unsigned pLen = (lane < nP) ? unsigned(st->len[lane]) : 0u;  // (nP <= 40: lane p holds pseudo read p's length)
+    {
+      unsigned t = pLen;
+      for (int off = 1; off < 64; off <<= 1) t += wv::shfl(t, wv::lane() ^ off);
+      seqBytes += t;
+    }
+    const uint64_t     bitsWords = uint64_t(finalCount) * 2 * W + nP;
     unsigned long long seqBase = 0, bitsBase = 0;
     if (lane == 0) {
       seqBase  = wv::atomic_add(P.seq_used, (unsigned long long)seqBytes);
@@ -829,29 +991,13 @@ struct LdsContig {
       return;
     }
     uint64_t        so = seqBase, bo = bitsBase;
-    const uint32_t* gc = gCodes();
     const uint16_t* gp = gPb();
     for (unsigned f = 0; f < finalCount; ++f) {
       const int      c   = int(chosenAt(f));
       const unsigned sl  = wv::readlane(candSlotV, c);
       const unsigned nL  = wv::readlane(nLeft, c), nR = wv::readlane(nRight, c), len = nL + k + nR;
       const unsigned seedPb = gp[slotNode[sl]];
-      const uint32_t* rightBuf = lane_seq + sl;       // (interleaved: dword i of slot sl at [i * 128 + sl], the left half 64 further)
-      const uint32_t* leftBuf  = lane_seq + 64 + sl;
-      for (unsigned i = lane; i < len; i += 64) {  // reverse(left) + seed + right
-        unsigned code;
-        if (i < nL) {
-          const unsigned j = nL - 1 - i;
-          code             = (leftBuf[size_t(j >> 4) * 128] >> (2 * (j & 15))) & 3;
-        } else if (i < nL + k) {
-          const unsigned pb = seedPb + (i - nL);
-          code              = (gc[pb >> 4] >> (30 - 2 * (pb & 15))) & 3u;
-        } else {
-          const unsigned j = i - nL - k;
-          code             = (rightBuf[size_t(j >> 4) * 128] >> (2 * (j & 15))) & 3;
-        }
-        P.seq_arena[so + i] = uint8_t("ACGT"[code]);
-      }
+      for (unsigned i = lane; i < len; i += 64) P.seq_arena[so + i] = uint8_t("ACGT"[contigCode(sl, nL, seedPb, i)]);
       {
         // lane h * W + w holds word w of the support (h = 0) / reject (h = 1) set
         const unsigned half = lane / W, w = lane % W;
@@ -878,6 +1024,17 @@ struct LdsContig {
     }
     out.pseudo_off     = so;
     out.pseudo_len_off = bo;
+    if (nP) {  // the pseudo reads' text behind the contigs', their lengths behind the contigs' sets (as assemble_kernel's selectAndEmit)
+      const uint32_t* pc = G.parena + st->off;
+      unsigned        cw = 0;
+      for (unsigned p = 0; p < nP; ++p) {
+        const unsigned len = wv::readlane(pLen, int(p));
+        for (unsigned i = lane; i < len; i += 64) P.seq_arena[so + i] = uint8_t("ACGT"[(pc[cw + (i >> 4)] >> (30 - 2 * (i & 15))) & 3u]);
+        if (lane == 0) P.bits_arena[bo + p] = len;
+        so += len;
+        cw += (len + 15) / 16 + 1;
+      }
+    }
     if (lane == 0) P.loci[locus] = out;
   }
 
@@ -895,18 +1052,52 @@ struct LdsContig {
       return CK_PUNT;
     }
     tick(4);
-    if (!acyclic && graphHasCycle()) {  // the exact repeat search is the general path's
+    if (!acyclic && !cyclic && graphHasCycle()) {  // the exact repeat search is repeat_big_kernel's (big class, rounds on) or the general path's
       CK_TRACE("cyclic graph");
       return CK_PUNT;
     }
     tick(3);
     loadPool();
     tick(4);
+    anyRep = false;
     if (contigRounds() != 0) {
-      CK_TRACE("repeat hit / contig too long");
+      CK_TRACE("contig too long");
       return CK_PUNT;
     }
-    selectAndEmit(locus);
+    const bool rounds = C::BIG && G.iter != nullptr;
+    if (anyRep && !rounds) {
+      CK_TRACE("repeat hit");
+      return CK_PUNT;
+    }
+    // runIterativeAssembler :856-910
+    const unsigned round    = rounds ? G.round : 0u;
+    const unsigned nIter    = round + 1;
+    const unsigned cycIters = ((round > 0) ? wv::first(G.iter[locus].cyclicIters) : 0u) + (cyclic ? 1u : 0u);
+    const LgIter*  st       = (round > 0) ? &G.iter[locus] : nullptr;  // the pseudo reads this graph was built with
+    if (anyRep) {
+      if (!writePseudo(locus)) {
+        CK_TRACE("pseudo arena full");
+        return CK_PUNT;
+      }
+      st                   = &G.iter[locus];
+      const unsigned maxWL = P.locus_max_wl ? P.locus_max_wl[locus] : P.opt.maxWordLength;
+      if (k + P.opt.wordStepSize <= maxWL) {
+        if (round >= G.last_round) {
+          CK_TRACE("more word lengths than rounds");
+          return CK_PUNT;
+        }
+        if (lane == 0) {
+          LgIter* w      = &G.iter[locus];
+          w->k           = k + P.opt.wordStepSize;
+          w->nIter       = nIter;
+          w->cyclicIters = cycIters;
+          G.next_ids[wv::atomic_add(G.next_count, 1u)] = locus;
+        }
+        LG_STAT(7, 1);
+        return CK_NEXT;
+      }
+    }
+    selectAndEmit(locus, st, nIter, cycIters);
     tick(7);
     LG_STAT(0, 1);
     LG_STAT(3, nCand);
@@ -935,7 +1126,7 @@ WV_DEV void contigKernelBody(const LgArgs& A)
     LdsContig<C>   c(P, G, lds, ws);
     const int      rc = c.run(locus);
     wv::sync();
-    if (rc != CK_DONE && wv::lane() == 0) P.punt_ids[wv::atomic_add(P.punt_count, 1u)] = locus;
+    if (rc == CK_PUNT && wv::lane() == 0) P.punt_ids[wv::atomic_add(P.punt_count, 1u)] = locus;
     wv::sync();
   }
 }
@@ -952,3 +1143,4 @@ WV_KERNEL_SINGLE WV_WAVES_PER_SIMD(1) void contig_big_kernel(const LgArgs A)
 }  // namespace manta_dev
 
 #include "asm_lds_big.hpp"
+#include "asm_repeat_big.hpp"

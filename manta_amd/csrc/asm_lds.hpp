@@ -110,16 +110,20 @@ struct alignas(16) LgHdr {
   uint32_t W, need;
   uint32_t nSovf, nPovf;
   uint32_t acyclic;       ///< graph_kernel has a proof that the graph has no cycle (potential from the reads' offsets): no peel
-  uint32_t pad[3];
+  uint32_t nPseudo;       ///< big class, later word lengths: reads nNormal .. nNormal + nPseudo - 1 are the previous length's contigs
+  uint32_t cyclic;        ///< big class: repeat_big_kernel found a cycle and left the core / repeat-word bitmaps in the slab
+  uint32_t nCore;         ///< ... words left by the two-sided peel (only these can be met twice by a walk)
 };
 struct LgSlab {
-  uint32_t recs, pool, spec, sib, sovf, povf, pb, codes, total, rd1;
+  uint32_t recs, pool, spec, sib, sovf, povf, pb, codes, total, rd1, lex, flags;
 };
 WV_HD LgSlab lgSlab(const unsigned nNodes, const unsigned nFat, const unsigned codeWords)
 {
   LgSlab   L;
   uint32_t o = uint32_t(sizeof(LgHdr));
   L.rd1   = 0;
+  L.lex   = 0;
+  L.flags = 0;
   L.recs  = o;
   o += (8u * nNodes + 15u) & ~15u;
   L.pool  = o;
@@ -170,7 +174,8 @@ static const unsigned LGL_SLOTS     = 8192;
 static const unsigned LGL_BUCKETS   = LGL_SLOTS / 4;
 static const unsigned LGL_MAX_NODES = 7168;   // 0.875 x slots; ids are stored +1 in 13-bit link fields
 static const unsigned LGL_MAX_READS = 256;    // read sets of four qwords
-static const unsigned LGL_MAX_PILE  = 3598;   // code dwords (+ 2 of padding): a packed base index must fit 16 bits
+static const unsigned LGL_MAX_PILE  = 3598;   // code dwords (+ 2 of padding) of the locus' own reads
+static const unsigned LGL_MAX_PILE_ALL = 4090; // ... with the pseudo reads of a later word length behind them: a packed base index must fit 16 bits
 static const unsigned LGL_POOL_CAP  = 1280;   // read sets handed out during the table pass (words with more than one read)
 static const unsigned LGL_WAVES     = 16;
 static const unsigned LGL_BUDGET    = 163840;
@@ -241,7 +246,8 @@ struct LgRec {
 };
 
 /// the big class' slab: LgHdr, FRec8[nNodes], FSetT<LgL>[nFat], u16[64] speculation list, u16[LG_SIB_CAP][4] sibling table,
-/// u16[LGL_OVF_CAP][4] x 2 overflow tables, u8[nNodes] the only read of a single-read word, u16[nNodes] first occurrences, the pile
+/// u16[LGL_OVF_CAP][4] x 2 overflow tables, u8[nNodes] the only read of a single-read word, u16[nNodes] first occurrences, the pile,
+/// u16[nNodes] lexicographic ranks, the core / repeat-word bitmaps
 WV_HD LgSlab lgSlabL(const unsigned nNodes, const unsigned nFat, const unsigned codeWords)
 {
   LgSlab   L;
@@ -264,6 +270,10 @@ WV_HD LgSlab lgSlabL(const unsigned nNodes, const unsigned nFat, const unsigned 
   o += (2u * nNodes + 15u) & ~15u;
   L.codes = o;
   o += (4u * codeWords + 15u) & ~15u;
+  L.lex   = o;  // u16[nNodes]: the words' lexicographic ranks (written for a graph without a proof of acyclicity only)
+  o += (2u * nNodes + 15u) & ~15u;
+  L.flags = o;  // u32[LgL::UNUSED_DW] core words, u32[LgL::UNUSED_DW] repeat words (repeat_big_kernel)
+  o += 8u * 256u;
   L.total = o;
   return L;
 }
@@ -296,6 +306,35 @@ WV_HD unsigned ckNeedOf(const unsigned nNodes, const unsigned nFat, const bool a
   return CkMap<C>::RECS + ((8 * nNodes + 15) & ~15u) + (C::BIG ? ((nNodes + 15) & ~15u) : 0u) + ((pool > kahn) ? pool : kahn);
 }
 
+/// ... of a CYCLIC graph (big class): + core bitmap, its prefix counts, repeat-word bitmap, one visited bitmap over the core per walk
+static const unsigned LGL_CORE_CAP = 4096;  ///< core words a cyclic graph may have on the pipeline (more: general path)
+template <class C>
+WV_HD unsigned ckCyclicExtra(const unsigned nCore)
+{
+  return 4u * C::UNUSED_DW + 2u * C::UNUSED_DW + 4u * C::UNUSED_DW + 64u * 4u * ((nCore + 31u) / 32u);
+}
+template <class C>
+WV_HD unsigned ckNeedCyclic(const unsigned nNodes, const unsigned nFat, const unsigned nCore)
+{
+  const unsigned pool = 8 * C::SETW * (nFat ? nFat : 1u);
+  return CkMap<C>::RECS + ((8 * nNodes + 15) & ~15u) + (C::BIG ? ((nNodes + 15) & ~15u) : 0u) + pool + ckCyclicExtra<C>(nCore);
+}
+
+/// A big-class locus between two word lengths (IterativeAssembler.cpp:856-910): what contig_big_kernel leaves for graph_big_kernel's
+/// next round.  The pseudo reads lie in the pseudo arena as 2-bit codes in the pile's layout ((len + 15) / 16 + 1 dwords each).
+static const unsigned LGL_MAX_PSEUDO = 40;  // 2 * maxAssemblyCount (<= 20 on the pipeline)
+static const unsigned LGL_MAX_ROUNDS = 24;  // word lengths one launch sequence covers (more: general path)
+struct alignas(16) LgIter {
+  uint32_t k;             ///< the next word length
+  uint32_t nIter;         ///< word lengths done
+  uint32_t cyclicIters;   ///< ... of which had a cyclic graph
+  uint32_t nPseudo;
+  uint64_t off;           ///< dword offset of the pseudo reads' codes in the arena
+  uint32_t codeWords;     ///< their dwords
+  uint32_t slabCap;       ///< bytes of the locus' slab (graph_big_kernel: a later round builds in place when its graph fits)
+  uint16_t len[LGL_MAX_PSEUDO];
+};
+
 /// parameters of the pipeline beyond AsmParams (both kernels take the pair)
 struct LgParams;
 struct LgArgs;
@@ -313,6 +352,19 @@ struct LgParams {
   uint32_t*           stats;       ///< [0] loci whose graph came with a proof of acyclicity, [1] reads re-anchored by readOffsets' second pass
   uint8_t*            cws;         ///< contig_kernel workspaces
   uint64_t            cws_stride;
+  // ---- the big class' word-length rounds (asm_lds_big.hpp / asm_repeat_big.hpp); iter == nullptr: one round, repeat hits are handed back
+  uint32_t            round;       ///< this launch's round (0: the first word length)
+  uint32_t            last_round;  ///< rounds launched - 1: a locus that needs one more is handed back
+  LgIter*             iter;        ///< [n_loci]
+  uint32_t*           parena;      ///< pseudo reads between rounds (dwords)
+  uint64_t            parena_cap;
+  unsigned long long* parena_used;
+  uint32_t*           next_ids;    ///< contig_big_kernel: the loci of the next round
+  uint32_t*           next_count;
+  uint32_t*           cyc_ids;     ///< graph_big_kernel: loci whose graph came without a proof of acyclicity (repeat_big_kernel's list)
+  uint32_t*           cyc_count;
+  uint8_t*            rws;         ///< repeat_big_kernel workspaces (one per wave)
+  uint64_t            rws_stride;
 };
 
 static const uint32_t LG_FLAG_NO_PROOF = 1u;  ///< tests / A-B runs: never skip contig_kernel's cycle test
@@ -1478,7 +1530,7 @@ struct LdsGraph {
       h.nSovf     = nSovf;
       h.nPovf     = nPovf;
       h.acyclic   = acyclic ? 1u : 0u;
-      for (int i = 0; i < 3; ++i) h.pad[i] = 0;
+      h.nPseudo = h.cyclic = h.nCore = 0;
       *reinterpret_cast<LgHdr*>(slab) = h;
       G.slab_off[locus]               = off;
       G.class_ids[size_t(cls) * G.class_stride + wv::atomic_add(&G.class_count[cls], 1u)] = locus;

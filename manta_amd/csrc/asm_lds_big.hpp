@@ -70,6 +70,8 @@ struct LdsGraphL {
   FRec8*           nodes;
   int16_t *        phi, *roff;
   unsigned         nNormal, W, k, nNodes, nFat, nEligible, lowTier, codeWords;
+  unsigned         nReads, nPseudo, pseudoPb0;  ///< later word lengths: the previous length's contigs as reads nNormal .. nReads - 1 (packed bases from pseudoPb0 on)
+  const LgIter*    it;
   uint64_t         tMark;
 
   WV_DEV LdsGraphL(const AsmParams& p, const LgParams& g, char* base) : P(p), G(g), lds(base)
@@ -96,6 +98,9 @@ struct LdsGraphL {
     codes  = reinterpret_cast<uint32_t*>(lds + LGL_OFF_DYN);
     nmask  = codes;
     cntId  = nullptr;
+    nReads = nPseudo = 0;
+    pseudoPb0 = 0x10000u;
+    it        = nullptr;
   }
 
   /// per-phase shader clocks of the workgroup's first wave (-DMANTA_ASM_PROFILE; the slots of graph_kernel's coarse profile)
@@ -316,11 +321,34 @@ struct LdsGraphL {
       nb += wv::readlane(sb, 63);
     }
     if (wv::any(tooLong) || cw + 2 > LGL_MAX_PILE + 2) return false;
+    // the previous word length's contigs behind the locus' own reads (:898-905): codes only, a contig holds no N
+    unsigned pcw = 0;
+    nReads       = nNormal + nPseudo;
+    pseudoPb0    = nPseudo ? 16u * cw : 0x10000u;
+    if (nPseudo) {
+      const unsigned len = (lane < nPseudo) ? unsigned(it->len[lane]) : 0u;
+      const unsigned myC = (lane < nPseudo) ? (len + 15) / 16 + 1 : 0u;
+      unsigned       sc  = myC;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned oc = wv::shfl(sc, wv::lane() - off);
+        if (wv::lane() >= off) sc += oc;
+      }
+      pcw = wv::readlane(sc, 63);
+      if (pcw != it->codeWords || cw + pcw + 2 > LGL_MAX_PILE_ALL + 2) return false;
+      if (tw == 0 && lane < nPseudo) {
+        rd[nNormal + lane]     = (cw + sc - myC) | ((len & 0xffffu) << 12);
+        rdm[nNormal + lane]    = 0;
+        rstart[nNormal + lane] = 0;
+      }
+    }
+    const unsigned cwN = cw;  // the locus' own reads end here
+    cw += pcw;
     const unsigned cwPad = (cw + 2 + 3) & ~3u, mwPad = (mw + 2 + 3) & ~3u;
     if (cwPad + mwPad > LGL_DYN_DWORDS || 4 * cwPad + LGL_MAX_NODES + 16 > 4 * LGL_DYN_DWORDS) return false;
     if (!P.pl_codes && nb + 64 > LGL_STAGE_BYTES) return false;
     codeWords = cw + 2;
     nmask     = codes + cwPad;
+    for (unsigned i = tid(); i < pcw; i += nThreads()) codes[cwN + i] = G.parena[it->off + i];
     cntId     = reinterpret_cast<uint8_t*>(codes + cwPad);  // (the N bitmap is dead once the reads' offsets are known)
     for (unsigned i = tid(); i < mw + 2; i += nThreads()) nmask[i] = 0;
     if (tid() == 0) hdr[LGL_H_FLAG] = 0;
@@ -423,11 +451,11 @@ struct LdsGraphL {
     if (tid() == 0) hdr[LGL_H_POOLN] = 0;
     teamSync();
     bool fail = false;
-    for (unsigned rBase = 0; rBase < nNormal; rBase += 64) {
+    for (unsigned rBase = 0; rBase < nReads; rBase += 64) {
       const unsigned rMine = rBase + lane;
-      const unsigned dV    = (rMine < nNormal) ? rd[rMine] : 0u;
-      const unsigned mV    = (rMine < nNormal) ? unsigned(rdm[rMine]) : 0u;
-      const unsigned rEnd  = (nNormal - rBase < 64) ? (nNormal - rBase) : 64u;
+      const unsigned dV    = (rMine < nReads) ? rd[rMine] : 0u;
+      const unsigned mV    = (rMine < nReads) ? unsigned(rdm[rMine]) : 0u;
+      const unsigned rEnd  = (nReads - rBase < 64) ? (nReads - rBase) : 64u;
       for (unsigned ri = 0; ri < rEnd; ++ri) {
         const unsigned r = rBase + ri;
         if (r % tn != tw) continue;
@@ -533,11 +561,17 @@ struct LdsGraphL {
     return true;
   }
 
+  /// the locus' own reads among the bits of set qword q (the others: pseudo reads)
+  WV_DEV uint64_t normalMask(const unsigned q) const
+  {
+    const unsigned lo = 64 * q;
+    return (nNormal >= lo + 64) ? ~uint64_t(0) : ((nNormal > lo) ? ((uint64_t(1) << (nNormal - lo)) - 1) : uint64_t(0));
+  }
   /// read that owns packed base index pb (the reads' code offsets ascend)
   WV_DEV unsigned readOfPb(const unsigned pb) const
   {
     const unsigned cwd = pb >> 4;
-    unsigned       lo = 0, hi = nNormal;  // rd[lo].cwo <= cwd < rd[hi].cwo
+    unsigned       lo = 0, hi = nReads;  // rd[lo].cwo <= cwd < rd[hi].cwo
     while (hi - lo > 1) {
       const unsigned mid = (lo + hi) >> 1;
       if ((rd[mid] & 0xfffu) <= cwd) lo = mid; else hi = mid;
@@ -563,7 +597,7 @@ struct LdsGraphL {
         myOff[h]  = 0;
         myPar[h]  = r;
         myRoot[h] = r;
-        if (r < nNormal) {
+        if (r < nReads) {
           const uint32_t a = anch[r];
           if (a != LG_NO_ANCHOR) {
             const unsigned apb = a & 0xffffu, j = a >> 16;
@@ -635,7 +669,7 @@ struct LdsGraphL {
         unsigned nRoots = 0;
         for (unsigned h = 0; h < RPL; ++h) {
           const unsigned r    = lane + 64 * h;
-          const bool     isR  = r < nNormal && unsigned(rootOf[r]) == r;
+          const bool     isR  = r < nReads && unsigned(rootOf[r]) == r;
           const uint64_t m    = wv::ballot(isR);
           if (tw == 0 && isR) roots[nRoots + unsigned(wv::popc(m & ((uint64_t(1) << lane) - 1)))] = uint8_t(r);
           nRoots += unsigned(wv::popc(m));
@@ -645,7 +679,7 @@ struct LdsGraphL {
         for (unsigned t = tw; t < nRoots; t += tn) {
           const unsigned s = roots[t];
           uint64_t       mem[RPL], memAll[RPL];
-          for (unsigned h = 0; h < RPL; ++h) memAll[h] = mem[h] = wv::ballot(lane + 64 * h < nNormal && unsigned(rootOf[lane + 64 * h]) == s);
+          for (unsigned h = 0; h < RPL; ++h) memAll[h] = mem[h] = wv::ballot(lane + 64 * h < nReads && unsigned(rootOf[lane + 64 * h]) == s);
           bool     tied = false;
           uint32_t l0 = 0xffffffffu, l1 = 0;
           for (unsigned tries = 0; tries < 12 && !tied; ++tries) {
@@ -733,7 +767,7 @@ struct LdsGraphL {
             wv::sync();
             for (unsigned h = 0; h < RPL; ++h) {  // the whole tree of x moves onto o's axis
               const unsigned r = lane + 64 * h;
-              if (r < nNormal && unsigned(rootOf[r]) == rs) {
+              if (r < nReads && unsigned(rootOf[r]) == rs) {
                 off[r] += delta;
                 rootOf[r] = uint8_t(ro);
               }
@@ -773,11 +807,15 @@ struct LdsGraphL {
       const uint32_t v   = slots[s];
       const bool     occ = v != LG_EMPTY;
       if (occ) {
-        unsigned c = 1;
+        // :537-548: a read adds one to a word's count, a pseudo read minCoverage
+        unsigned c = (aPb(v) >= pseudoPb0) ? P.opt.minCoverage : 1u;
         if (aPool(v)) {
           const Set st = pool[aPool(v) - 1];
           c            = 0;
-          for (unsigned q = 0; q < LgL::SETW; ++q) c += unsigned(wv::popc(st.w[q]));
+          for (unsigned q = 0; q < LgL::SETW; ++q) {
+            const uint64_t nm = normalMask(q);
+            c += unsigned(wv::popc(st.w[q] & nm)) + P.opt.minCoverage * unsigned(wv::popc(st.w[q] & ~nm));
+          }
         }
         cntArr[s] = uint8_t(c);
       }
@@ -917,8 +955,17 @@ struct LdsGraphL {
       const unsigned slot = sortA[i];
       const uint32_t v    = slots[slot];
       const unsigned pb   = aPb(v);
-      if (i < nFat) gPool[i] = pool[aPool(v) - 1];  // (count >= 2 => the word has a set)
       const unsigned r = readOfPb(pb);
+      if (i < nFat) {
+        // count >= 2: the word has a set -- or it is held by ONE pseudo read that counts minCoverage >= 2: its set is made up here
+        Set st;
+        if (aPool(v)) {
+          st = pool[aPool(v) - 1];
+        } else {
+          for (unsigned q = 0; q < LgL::SETW; ++q) st.w[q] = ((r >> 6) == q) ? (uint64_t(1) << (r & 63)) : 0;
+        }
+        gPool[i] = st;
+      }
       gRd1[i]          = uint8_t(r);
       gPb[i]           = uint16_t(pb);
       idPb[i]          = uint16_t(pb);  // (sortA's bytes: id -> first occurrence; entry i is read by this thread only)
@@ -1041,6 +1088,100 @@ struct LdsGraphL {
     return true;
   }
 
+  // ------------------------------------------------------------------------------------------------
+  // A graph without a proof of acyclicity may need the reference's repeat search (repeat_big_kernel), whose visiting order starts from
+  // the insertion order of the words: reads in order, a read's new words in LEXICOGRAPHIC order (:516-548).  The words' lexicographic
+  // ranks go to the slab: two stable byte passes over the ids by the first eight bases, runs of equal prefixes ranked by full compares.
+  // (After buildRecords: lists in the slot table's bytes, histograms in the potentials' bytes -- the records sit where sortWords had them.)
+  // ------------------------------------------------------------------------------------------------
+  WV_DEV void radixPassIds(const uint16_t* src, uint16_t* dst, const unsigned n, const unsigned shift, uint32_t* hist)
+  {
+    const unsigned chunk = (((n + tn - 1) / tn) + 63) & ~63u;
+    const unsigned c0 = chunk * tw, c1 = (c0 + chunk < n) ? (c0 + chunk) : n;
+    uint32_t*      myHist = hist + 256 * tw;
+    for (unsigned i = tid(); i < 256 * tn; i += nThreads()) hist[i] = 0;
+    teamSync();
+    auto digitOf = [&](const unsigned id) -> unsigned { return (prefix32(idPb[id]) >> (16 + shift)) & 255u; };
+    for (unsigned i0 = c0; i0 < c1; i0 += 64) {
+      const unsigned i = i0 + lane;
+      if (i < c1) wv::atomic_add(&myHist[digitOf(src[i])], 1u);
+    }
+    teamSync();
+    for (unsigned q = tw; q < 4; q += tn) {
+      const unsigned d   = 64 * q + lane;
+      unsigned       run = 0;
+      for (unsigned w = 0; w < tn; ++w) {
+        const unsigned c  = hist[256 * w + d];
+        hist[256 * w + d] = run;
+        run += c;
+      }
+      unsigned inc = run;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = wv::shfl(inc, int(lane) - off);
+        if (int(lane) >= off) inc += o;
+      }
+      dbase[d] = inc - run;
+      if (lane == 63) hdr[LGL_H_TOT + q] = inc;
+    }
+    teamSync();
+    for (unsigned q = tw; q < 4; q += tn) {
+      unsigned before = 0;
+      for (unsigned p = 0; p < q; ++p) before += hdr[LGL_H_TOT + p];
+      dbase[64 * q + lane] += before;
+    }
+    teamSync();
+    for (unsigned i0 = c0; i0 < c1; i0 += 64) {
+      const unsigned i     = i0 + lane;
+      const bool     valid = i < c1;
+      const unsigned id    = valid ? unsigned(src[i]) : 0u;
+      const unsigned d     = valid ? digitOf(id) : 0u;
+      uint64_t       peers = wv::ballot(valid);
+      for (int bit = 0; bit < 8; ++bit) {
+        const bool     on = (d >> bit) & 1u;
+        const uint64_t m  = wv::ballot(valid && on);
+        peers &= on ? m : ~m;
+      }
+      unsigned base = 0;
+      if (valid) base = dbase[d] + myHist[d];
+      wv::sync();
+      if (valid) {
+        dst[base + unsigned(wv::popc(peers & ((uint64_t(1) << lane) - 1)))] = uint16_t(id);
+        if ((peers >> lane) == 1u) myHist[d] += unsigned(wv::popc(peers));
+      }
+      wv::sync();
+    }
+    teamSync();
+  }
+  template <int KW>
+  WV_DEV void lexOrder(uint16_t* gLex)
+  {
+    uint16_t* bufA = reinterpret_cast<uint16_t*>(lds + LGL_OFF_SLOTS);
+    uint16_t* bufB = bufA + LGL_SLOTS;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(lds + LGL_OFF_SORTB);
+    const unsigned n = nNodes;
+    for (unsigned i = tid(); i < n; i += nThreads()) bufA[i] = uint16_t(i);
+    teamSync();
+    radixPassIds(bufA, bufB, n, 0, hist);
+    radixPassIds(bufB, bufA, n, 8, hist);
+    for (unsigned i = tid(); i < n; i += nThreads()) {
+      const unsigned id = bufA[i];
+      const unsigned p  = prefix32(idPb[id]) >> 16;
+      unsigned       lo = i, hi = i;
+      while (lo > 0 && (prefix32(idPb[bufA[lo - 1]]) >> 16) == p) lo--;
+      while (hi + 1 < n && (prefix32(idPb[bufA[hi + 1]]) >> 16) == p) hi++;
+      unsigned rank = 0;
+      if (hi > lo) {
+        const Key<KW> mineKey = keyAt<KW>(idPb[id]);
+        for (unsigned j = lo; j <= hi; ++j) {
+          if (j == i) continue;
+          if (keyLess(keyAt<KW>(idPb[bufA[j]]), mineKey)) rank++;
+        }
+      }
+      gLex[id] = uint16_t(lo + rank);
+    }
+    teamSync();
+  }
+
   /// round 0's walk list (LdsGraph::speculationList): the first seed and beside it the two lowest count tiers in seed order, one
   /// word per unbranched stretch
   WV_DEV unsigned speculationList(uint16_t* spec)
@@ -1157,9 +1298,19 @@ struct LdsGraphL {
     tick(2, 3);
     // slab for this locus
     const LgSlab   SL    = lgSlabL(nNodes, nFat, codeWords);
-    const uint64_t bytes = SL.total;
+    uint64_t       bytes = SL.total;
     if (tid() == 0) {
-      const unsigned long long off = wv::atomic_add(G.arena_used, (unsigned long long)bytes);
+      // a later word length of a locus builds in the slab of the previous one when it fits (the words of a pile grow slowly with the
+      // word length: a new slab of a later round comes with a quarter of headroom)
+      unsigned long long off;
+      if (it && bytes <= it->slabCap) {
+        off = G.slab_off[locus];
+      } else {
+        const uint64_t want = it ? (bytes + bytes / 4 + 15) & ~uint64_t(15) : bytes;
+        off                 = wv::atomic_add(G.arena_used, (unsigned long long)want);
+        if (G.iter) G.iter[locus].slabCap = (off + want <= G.arena_cap) ? uint32_t(want) : 0u;
+        if (off + want > G.arena_cap) off = G.arena_cap;  // (full: reported below)
+      }
       hdr[LGL_H_OFF_LO] = uint32_t(off);
       hdr[LGL_H_OFF_HI] = uint32_t(off >> 32);
     }
@@ -1176,11 +1327,14 @@ struct LdsGraphL {
     }
     const bool     acyclic = wv::atomic_load(&hdr[LGL_H_CYC]) == 0 && !(G.flags & LG_FLAG_NO_PROOF);
     if (acyclic && tid() == 0 && G.stats) wv::atomic_add(&G.stats[0], 1u);
+    // with the word-length rounds on, a graph without a proof goes to repeat_big_kernel first (peel, repeat search, LDS class)
+    const bool     toRepeat = !acyclic && G.iter != nullptr;
+    if (toRepeat) lexOrder<KW>(reinterpret_cast<uint16_t*>(slab + SL.lex));
     const unsigned need    = ckNeedOf<LgL>(nNodes, nFat, acyclic);
     unsigned       cls     = LG_CLASSES;
     for (unsigned c = LG_CLASSES; c-- > 0;)
       if (G.class_bytes[c] && need <= G.class_bytes[c]) cls = c;
-    if (cls == LG_CLASSES) {
+    if (cls == LG_CLASSES && !toRepeat) {
       LGL_TRACE("graph fits no contig LDS class");
       return false;
     }
@@ -1214,10 +1368,15 @@ struct LdsGraphL {
       h.nSovf     = nSovf;
       h.nPovf     = nPovf;
       h.acyclic   = acyclic ? 1u : 0u;
-      for (int i = 0; i < 3; ++i) h.pad[i] = 0;
+      h.nPseudo   = nPseudo;
+      h.cyclic    = 0;
+      h.nCore     = 0;
       *reinterpret_cast<LgHdr*>(slab) = h;
       G.slab_off[locus]               = off;
-      G.class_ids[size_t(cls) * G.class_stride + wv::atomic_add(&G.class_count[cls], 1u)] = locus;
+      if (toRepeat)
+        G.cyc_ids[wv::atomic_add(G.cyc_count, 1u)] = locus;
+      else
+        G.class_ids[size_t(cls) * G.class_stride + wv::atomic_add(&G.class_count[cls], 1u)] = locus;
     }
     tick(4, 7);
     return true;
@@ -1235,11 +1394,18 @@ struct LdsGraphL {
     nNodes = 0;
     tMark  = wv::clock();
     hdr[LGL_H_POOLN] = 0;
+    if (G.iter && G.round > 0) {  // a later word length of this locus (contig_big_kernel left the state)
+      it      = &G.iter[locus];
+      k       = it->k;
+      nPseudo = it->nPseudo;
+      if (k < minWL || k > maxWL || nPseudo > LGL_MAX_PSEUDO || nPseudo > 2 * P.opt.maxAssemblyCount) return false;
+    }
     if (!pack(locus)) {
       LGL_TRACE("pack (envelope / alphabet)");
       return false;
     }
     tick(0, 0);
+    if (nNormal + nPseudo * P.opt.minCoverage > 255) return false;  // (counts by slot are bytes)
     const unsigned kw = (k + 15) >> 4;
     if (kw > unsigned(MAXKW)) return false;
     if (kw <= 2) return runK<2>(locus);
@@ -1258,12 +1424,13 @@ WV_KERNEL_WG(LGL_WAVES) WV_WAVES_PER_SIMD(4) void graph_big_kernel(const LgArgs 
   char*          lds = wv::lds_single();
   uint32_t*      hdr = reinterpret_cast<uint32_t*>(lds + LGL_OFF_HDR);
   const unsigned tw  = unsigned(wv::wave_in_wg());
+  const unsigned nLoci = P.n_loci_dev ? wv::first(wv::atomic_load(P.n_loci_dev)) : P.n_loci;  // (later rounds: the previous round's list)
   while (true) {
     if (tw == 0 && wv::lane() == 0) hdr[LGL_H_SLOT] = wv::atomic_add(P.counter, 1u);
     wv::sync();
     wv::wg_barrier();
     const unsigned slot = wv::first(wv::atomic_load(&hdr[LGL_H_SLOT]));
-    if (slot >= P.n_loci) break;
+    if (slot >= nLoci) break;
     const unsigned locus   = P.locus_ids ? P.locus_ids[slot] : slot;
     const bool     arrived = !P.upload_chunks_done || asmWaitUploaded(P, locus);
     bool           ok      = false;
