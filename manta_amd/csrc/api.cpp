@@ -505,7 +505,7 @@ struct AsmStage {
   uint32_t              bigRounds = 0;     // rounds launched (0: rounds off -- a repeat hit / a cyclic graph is handed back to assemble_kernel)
   int                   gridRepeat = 0;    // repeat_big_kernel wavefronts
   uint64_t              pseudoArenaDw = 0, rwsStride = 0;
-  DevBuf                bLgIter, bLgPseudo, bLgNext, bLgCyc, bLgRounds, bRws;
+  DevBuf                bLgIter, bLgPseudo, bLgNext, bLgCyc, bLgRounds, bRws, bGws;
   DevBuf                bPunt, bLgArena, bLgOff, bLgClassIds, bLgCnt, bCws;
   uint32_t*             dPunt = nullptr;   // the general kernel's list: genIds, then the loci the LDS pipeline punted
   // packed piles of the uploaded batch (manta_packed_piles_t), device side; dPlCodes == nullptr: 1 byte per base input
@@ -733,7 +733,14 @@ struct AsmStage {
       }
       cwsStrideBig = ckWorkspaceLayout(LgL::SETW).total;
       bigRounds    = 0;
-      static const bool roundsOn = !(std::getenv("MANTA_AMD_BIG_ROUNDS") && std::atoi(std::getenv("MANTA_AMD_BIG_ROUNDS")) == 0);  // A/B runs
+      // The rounds keep a pile with a tandem repeat on the pipeline through all its word lengths: ~15-20 ms of launches per word length
+      // for the whole block instead of ~20 ms of ONE wave of assemble_kernel per locus and word length.  A gain while the device is not
+      // full -- config-5 loci, ms per block with / without: 8 192: 259 / 299 (before the component scan), 16 384: 374 / 443, 32 768: 633 / 672 --
+      // and none once it is (65 536: 1 150 / 1 128: contig_big_kernel holds a CU per cyclic graph, assemble_kernel a sixteenth of one).
+      // Default: on for blocks of up to MANTA_AMD_BIG_ROUNDS_MAX big-class loci; MANTA_AMD_BIG_ROUNDS = 0 / 1 forces them off / on.
+      const char*    re       = std::getenv("MANTA_AMD_BIG_ROUNDS");
+      const uint64_t roundMax = std::getenv("MANTA_AMD_BIG_ROUNDS_MAX") ? std::strtoull(std::getenv("MANTA_AMD_BIG_ROUNDS_MAX"), nullptr, 10) : uint64_t(49152);
+      const bool     roundsOn = re ? (std::atoi(re) != 0) : (bigIds.size() <= roundMax);
       if (roundsOn && !bigIds.empty() && opt.max_assembly_count <= 20) {
         for (const uint32_t l : bigIds) {
           const uint32_t lo = locusMinWl.empty() ? opt.min_word_length : locusMinWl[l], hi = locusMaxWl.empty() ? opt.max_word_length : locusMaxWl[l];
@@ -745,7 +752,7 @@ struct AsmStage {
         pseudoArenaDw = std::max<uint64_t>(uint64_t(4) << 20, uint64_t(bigIds.size()) * 512);  // dwords
       }
       lgArenaCap   = std::min<uint64_t>(uint64_t(fastIds.size()) * lgSlabBytes(LG_MAX_NODES, LG_MAX_NODES, LG_MAX_PILE + 2) +
-                                          uint64_t(bigIds.size() + (bigRounds ? 3 * std::min<size_t>(bigIds.size(), 512) : 0)) * lgSlabL(LGL_MAX_NODES, LGL_POOL_CAP, LGL_MAX_PILE_ALL + 4).total + 4096,
+                                          uint64_t(bigIds.size() + (bigRounds ? 3 * std::min<size_t>(bigIds.size(), 512) : 0)) * lgSlabL(LGL_MAX_NODES, LGL_POOL_CAP + LGL_POOL_OVF, LGL_MAX_PILE_ALL + 4).total + 4096,
                                       wsBudget / 2);
       (void)maxGrid;
     }
@@ -955,8 +962,9 @@ struct AsmStage {
           (void)bLgPseudo.as<uint32_t>(pseudoArenaDw + 64);
           (void)bLgNext.as<uint32_t>(2 * bigIds.size());
           (void)bLgCyc.as<uint32_t>(bigIds.size());
-          (void)bLgRounds.as<uint32_t>(8 * (manta_dev::LGL_MAX_ROUNDS + 1));
+          (void)bLgRounds.as<uint32_t>(8 * (manta_dev::LGL_MAX_ROUNDS + 1) + 32);
           (void)bRws.as<uint8_t>(rwsStride * uint64_t(gridRepeat));
+          (void)bGws.as<uint8_t>(uint64_t(32) * manta_dev::LGL_POOL_OVF * uint64_t(gridBig));
         }
       }
     } else {
@@ -1080,6 +1088,8 @@ struct AsmStage {
       A.G.next_ids = A.G.next_count = A.G.cyc_ids = A.G.cyc_count = nullptr;
       A.G.rws        = nullptr;
       A.G.rws_stride = 0;
+      A.G.gws        = nullptr;
+      A.G.rprof      = nullptr;
       // streamed upload: a chunk the runtime moves with a shader copy needs a free workgroup slot (and, as far as this launch can
       // know, LDS): graph_kernel's two workgroups per CU own all 160 KB, so a quarter of the CUs keep one slot free -- without it
       // the copies never run and the persistent workgroups wait for their chunks forever (seen on hardware, round 4)
@@ -1140,8 +1150,8 @@ struct AsmStage {
           // (bLgRounds, 8 dwords per round: [0] graph work counter, [1..2] loci per class, [3..4] the class launches' work counters,
           // [5] graphs without a proof, [6] repeat_big_kernel's work counter, [7] loci sent on); the rounds after the first are launched
           // blind -- their list lengths sit in device memory -- with small grids: a round without work costs four empty launches.
-          uint32_t* rc = bLgRounds.as<uint32_t>(8 * (LGL_MAX_ROUNDS + 1));
-          rt::dzero(rc, sizeof(uint32_t) * 8 * (LGL_MAX_ROUNDS + 1));
+          uint32_t* rc = bLgRounds.as<uint32_t>(8 * (LGL_MAX_ROUNDS + 1) + 32);
+          rt::dzero(rc, sizeof(uint32_t) * (8 * (LGL_MAX_ROUNDS + 1) + 32));
           uint32_t* nextBuf = bLgNext.as<uint32_t>(2 * bigIds.size());
           B.G.iter        = bLgIter.as<LgIter>(nLoci);
           B.G.parena      = bLgPseudo.as<uint32_t>(pseudoArenaDw + 64);
@@ -1150,8 +1160,11 @@ struct AsmStage {
           B.G.cyc_ids     = bLgCyc.as<uint32_t>(bigIds.size());
           B.G.rws         = bRws.as<uint8_t>(rwsStride * uint64_t(gridRepeat));
           B.G.rws_stride  = rwsStride;
+          B.G.gws         = bGws.as<uint8_t>(uint64_t(32) * LGL_POOL_OVF * uint64_t(gridBig));
+          B.G.rprof       = std::getenv("MANTA_AMD_DEBUG") ? reinterpret_cast<unsigned long long*>(rc + 8 * (LGL_MAX_ROUNDS + 1)) : nullptr;
           B.G.last_round  = bigRounds - 1;
           const int later = int(std::max<size_t>(32, bigIds.size() / 4));
+          const bool oneClassLater = !(std::getenv("MANTA_AMD_BIG_ONE_CLASS") && std::atoi(std::getenv("MANTA_AMD_BIG_ONE_CLASS")) == 0);
           for (uint32_t r = 0; r < bigRounds; ++r) {
             uint32_t* cr     = rc + 8 * r;
             LgArgs    R      = B;
@@ -1166,6 +1179,10 @@ struct AsmStage {
               R.P.n_loci     = 0;
               R.P.n_loci_dev = rc + 8 * (r - 1) + 7;
             }
+            // (the later rounds hold cyclic graphs, nearly all of which need the large LDS class anyway: one contig launch instead of two
+            // saves a launch tail per word length)
+            if (oneClassLater && r > 0)
+              for (unsigned c = 0; c + 1 < LGL_CLASSES; ++c) R.G.class_bytes[c] = 0;
             const int gg = (r == 0) ? gb : std::min(gb, later);
             if (firstWl <= 80)
               rt::launchWG(graph_big_kernel<5>, gg, int(LGL_WAVES), LGL_BUDGET, R);
@@ -1176,6 +1193,7 @@ struct AsmStage {
             R.P.lds_bytes  = RPB_LDS_BYTES;
             rt::launch(repeat_big_kernel, (r == 0) ? gridRepeat : std::min(gridRepeat, rt::roundGrid(2 * later)), RPB_LDS_BYTES, R);
             for (unsigned c = 0; c < LGL_CLASSES; ++c) {
+              if (oneClassLater && r > 0 && c + 1 < LGL_CLASSES) continue;
               R.G.cls       = c;
               R.P.counter   = cr + 3 + c;
               R.P.lds_bytes = classBytesBig[c];
@@ -1357,13 +1375,31 @@ struct AsmStage {
     staged = true;
     ldsFallbacks = useFast ? uint32_t(hCnt[14] & 0xffffffffu) - uint32_t(genIds.size()) : 0u;
     if (std::getenv("MANTA_AMD_DEBUG") && useFast) {
-      uint32_t st[2] = {0, 0}, stBig[2] = {0, 0}, clsBig[2] = {0, 0};
+      uint32_t st[2] = {0, 0}, stBig[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, clsBig[2] = {0, 0};
       rt::d2h(st, bLgCnt.as<uint64_t>(16) + 8, sizeof(st));
       rt::d2h(stBig, bLgCnt.as<uint64_t>(16) + 11, sizeof(stBig));
       rt::d2h(clsBig, bLgCnt.as<uint64_t>(16) + 5, sizeof(clsBig));
       std::fprintf(stderr, "manta_amd: LDS assembler pipeline: %zu + %zu (big class) loci, %u handed to the general kernel (+ %zu outside its envelope); %u + %u graphs came "
                            "with a proof of acyclicity, %u + %u reads re-anchored; big class: %u / %u loci in its two contig LDS classes\n", fastIds.size(), bigIds.size(),
                    ldsFallbacks, genIds.size(), st[0], stBig[0], st[1], stBig[1], clsBig[0], clsBig[1]);
+      if (!bigIds.empty())
+        std::fprintf(stderr, "manta_amd: big class, %u word-length rounds; handed back: %u envelope, %u table / set pool, %u words / side tables / class, %u slab arena, %u by "
+                             "repeat_big_kernel, %u by contig_big_kernel, %u pseudo arena, %u out of rounds\n", bigRounds, stBig[2], stBig[3], stBig[4], stBig[5], stBig[6],
+                     stBig[7], stBig[8], stBig[9]);
+      if (bigRounds) {
+        unsigned long long rp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0;
+        uint32_t           perRound[8 * manta_dev::LGL_MAX_ROUNDS];
+        uint32_t*          rc = bLgRounds.as<uint32_t>(8 * (manta_dev::LGL_MAX_ROUNDS + 1) + 32);
+        rt::d2h(rp, rc + 8 * (manta_dev::LGL_MAX_ROUNDS + 1), sizeof(rp));
+        rt::d2h(perRound, rc, sizeof(perRound));
+        for (int i = 0; i < 7; ++i) tot += rp[i];
+        std::fprintf(stderr, "manta_amd: repeat_big_kernel clocks: renumbering %.1f%% component scan %.1f%% hash+insertion %.1f%% order1 %.1f%% order2 %.1f%% search in the reference's order %.1f%% rest %.1f%% (%.0f k clocks per graph without a proof, first three rounds)\n",
+                     tot ? 100.0 * rp[0] / tot : 0, tot ? 100.0 * rp[1] / tot : 0, tot ? 100.0 * rp[2] / tot : 0, tot ? 100.0 * rp[3] / tot : 0, tot ? 100.0 * rp[4] / tot : 0,
+                     tot ? 100.0 * rp[5] / tot : 0, tot ? 100.0 * rp[6] / tot : 0, perRound[5] ? double(tot) / 1e3 / double(std::max<uint32_t>(1, perRound[5] + perRound[8 + 5] + perRound[16 + 5])) : 0.0);
+        std::fprintf(stderr, "manta_amd: rounds (graphs without a proof / loci sent on):");
+        for (uint32_t r = 0; r < bigRounds; ++r) std::fprintf(stderr, " %u/%u", perRound[8 * r + 5], perRound[8 * r + 7]);
+        std::fprintf(stderr, "\n");
+      }
     }
     if (std::getenv("MANTA_AMD_PROFILE")) {
       static const char* namesGeneral[8] = {"pack", "table", "links", "cycle-check", "exact", "seed", "walk", "select+emit"};

@@ -1049,6 +1049,7 @@ struct LdsContig {
 #endif
     if (!load(locus)) {
       CK_TRACE("does not fit this launch's LDS");
+      if (C::BIG && lane == 0 && G.stats) wv::atomic_add(&G.stats[7], 1u);
       return CK_PUNT;
     }
     tick(4);
@@ -1062,6 +1063,7 @@ struct LdsContig {
     anyRep = false;
     if (contigRounds() != 0) {
       CK_TRACE("contig too long");
+      if (C::BIG && lane == 0 && G.stats) wv::atomic_add(&G.stats[7], 1u);
       return CK_PUNT;
     }
     const bool rounds = C::BIG && G.iter != nullptr;
@@ -1077,6 +1079,7 @@ struct LdsContig {
     if (anyRep) {
       if (!writePseudo(locus)) {
         CK_TRACE("pseudo arena full");
+        if (lane == 0 && G.stats) wv::atomic_add(&G.stats[8], 1u);
         return CK_PUNT;
       }
       st                   = &G.iter[locus];
@@ -1084,6 +1087,7 @@ struct LdsContig {
       if (k + P.opt.wordStepSize <= maxWL) {
         if (round >= G.last_round) {
           CK_TRACE("more word lengths than rounds");
+          if (lane == 0 && G.stats) wv::atomic_add(&G.stats[9], 1u);
           return CK_PUNT;
         }
         if (lane == 0) {

@@ -176,7 +176,8 @@ static const unsigned LGL_MAX_NODES = 7168;   // 0.875 x slots; ids are stored +
 static const unsigned LGL_MAX_READS = 256;    // read sets of four qwords
 static const unsigned LGL_MAX_PILE  = 3598;   // code dwords (+ 2 of padding) of the locus' own reads
 static const unsigned LGL_MAX_PILE_ALL = 4090; // ... with the pseudo reads of a later word length behind them: a packed base index must fit 16 bits
-static const unsigned LGL_POOL_CAP  = 1280;   // read sets handed out during the table pass (words with more than one read)
+static const unsigned LGL_POOL_CAP  = 1280;   // read sets handed out during the table pass (words with more than one read) that live in LDS
+static const unsigned LGL_POOL_OVF  = 704;    // ... and further ones in the workgroup's device-memory workspace (later word lengths: the pseudo reads share most of their words)
 static const unsigned LGL_WAVES     = 16;
 static const unsigned LGL_BUDGET    = 163840;
 static const unsigned LGL_OVF_CAP   = 128;
@@ -365,6 +366,8 @@ struct LgParams {
   uint32_t*           cyc_count;
   uint8_t*            rws;         ///< repeat_big_kernel workspaces (one per wave)
   uint64_t            rws_stride;
+  uint8_t*            gws;         ///< graph_big_kernel workspaces (one per workgroup: 32 * LGL_POOL_OVF bytes, the overflow read sets)
+  unsigned long long* rprof;       ///< [8] repeat_big_kernel: shader clocks by phase, summed over its loci (debug line; nullptr: not kept)
 };
 
 static const uint32_t LG_FLAG_NO_PROOF = 1u;  ///< tests / A-B runs: never skip contig_kernel's cycle test

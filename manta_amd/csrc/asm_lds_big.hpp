@@ -67,6 +67,7 @@ struct LdsGraphL {
   uint16_t *       rdm, *rstart, *sortA, *sortB, *idPb;
   uint8_t *        cntArr, *cntId;
   Set*             pool;
+  Set*             poolOvf;  ///< sets LGL_POOL_CAP .. of the table pass: device memory (nullptr: none)
   FRec8*           nodes;
   int16_t *        phi, *roff;
   unsigned         nNormal, W, k, nNodes, nFat, nEligible, lowTier, codeWords;
@@ -87,6 +88,7 @@ struct LdsGraphL {
     dbase  = reinterpret_cast<uint32_t*>(lds + LGL_OFF_DBASE);
     whist  = reinterpret_cast<uint32_t*>(lds + LGL_OFF_WHIST);
     pool   = reinterpret_cast<Set*>(lds + LGL_OFF_POOL);
+    poolOvf = g.gws ? reinterpret_cast<Set*>(g.gws + size_t(wv::block_single()) * 32u * LGL_POOL_OVF) : nullptr;
     nodes  = reinterpret_cast<FRec8*>(lds + LGL_OFF_WHIST);
     slots  = reinterpret_cast<uint32_t*>(lds + LGL_OFF_SLOTS);
     sortA  = reinterpret_cast<uint16_t*>(lds + LGL_OFF_SORTA);
@@ -121,6 +123,13 @@ struct LdsGraphL {
     (void)phase;
     (void)fine;
 #endif
+  }
+  /// why a locus was handed back (G.stats[2..9], read by the host's debug line): 2 envelope / alphabet, 3 table or set pool full,
+  /// 4 too many words / side tables / no contig class, 5 slab arena full, 6 repeat_big_kernel, 7 contig kernel (LDS / contig length),
+  /// 8 pseudo arena full, 9 more word lengths than rounds
+  WV_DEV void why(const unsigned code) const
+  {
+    if (G.stats && tid() == 0) wv::atomic_add(&G.stats[code], 1u);
   }
   WV_DEV void teamSync() const
   {
@@ -231,6 +240,28 @@ struct LdsGraphL {
       left -= take;
     }
     return false;
+  }
+
+  /// set `pi` (1-based, as in a slot word) of the table pass: LDS, or -- beyond LGL_POOL_CAP -- the workgroup's device-memory workspace
+  /// (two explicit paths: one pointer for both would make every access a flat one)
+  WV_DEV Set setLoad(const unsigned pi) const
+  {
+    if (pi <= LGL_POOL_CAP) return pool[pi - 1];
+    return poolOvf[pi - 1 - LGL_POOL_CAP];
+  }
+  WV_DEV void setAtomicOr(const unsigned pi, const unsigned q, const unsigned long long bit) const
+  {
+    if (pi <= LGL_POOL_CAP)
+      wv::atomic_or(reinterpret_cast<unsigned long long*>(&pool[pi - 1].w[q]), bit);
+    else
+      wv::atomic_or(reinterpret_cast<unsigned long long*>(&poolOvf[pi - 1 - LGL_POOL_CAP].w[q]), bit);
+  }
+  WV_DEV void setPlainOr(const unsigned pi, const unsigned q, const uint64_t bit) const
+  {
+    if (pi <= LGL_POOL_CAP)
+      pool[pi - 1].w[q] |= bit;
+    else
+      poolOvf[pi - 1 - LGL_POOL_CAP].w[q] |= bit;
   }
 
   // slot words.  Table pass: {first occurrence : 16, pool index + 1 : 11, tag : 5}; after the sort: {id : 13, tag : 19}
@@ -447,6 +478,10 @@ struct LdsGraphL {
     {
       uint64_t* pz = reinterpret_cast<uint64_t*>(pool);
       for (unsigned i = tid(); i < LGL_POOL_CAP * 4; i += nThreads()) pz[i] = 0;
+      if (poolOvf) {  // (22 KB per locus; needed by a few piles in a thousand -- and by most later word lengths: pseudo reads share their words)
+        uint64_t* oz = reinterpret_cast<uint64_t*>(poolOvf);
+        for (unsigned i = tid(); i < LGL_POOL_OVF * 4; i += nThreads()) oz[i] = 0;
+      }
     }
     if (tid() == 0) hdr[LGL_H_POOLN] = 0;
     teamSync();
@@ -511,14 +546,14 @@ struct LdsGraphL {
                 unsigned pi = aPool(sv);
                 if (pi == 0) {
                   const unsigned n = wv::atomic_add(&hdr[LGL_H_POOLN], 1u) + 1u;
-                  if (n > LGL_POOL_CAP) {
+                  if (n > LGL_POOL_CAP + (poolOvf ? LGL_POOL_OVF : 0u)) {
                     fail = true;
                   } else {
                     const uint32_t old = wv::atomic_cas(&slots[4 * b + at], sv, sv | (n << 16));
                     pi                 = (old == sv) ? n : aPool(old);  // (lost: the winner's set; entry n stays empty)
                   }
                 }
-                if (pi != 0) wv::atomic_or(reinterpret_cast<unsigned long long*>(&pool[pi - 1].w[setQ]), setBit);
+                if (pi != 0) setAtomicOr(pi, setQ, setBit);
               }
             } else if (todo) {
               // another word under the tag: next slot of the bucket; a full bucket without the word: next bucket
@@ -550,12 +585,13 @@ struct LdsGraphL {
     if (wv::any(fail) && lane == 0) wv::atomic_or(&hdr[LGL_H_FLAG], 2u);
     teamSync();
     if (wv::atomic_load(&hdr[LGL_H_FLAG]) != 0) return false;
+    wv::fence_acquire();  // (overflow sets: device memory updated by atomics, read plainly from here on)
     // the owners' bits: the read a word's first occurrence lies in
     for (unsigned s = tid(); s < LGL_SLOTS; s += nThreads()) {
       const uint32_t v = slots[s];
       if (v == LG_EMPTY || aPool(v) == 0) continue;
       const unsigned o = readOfPb(aPb(v));
-      pool[aPool(v) - 1].w[o >> 6] |= uint64_t(1) << (o & 63);
+      setPlainOr(aPool(v), o >> 6, uint64_t(1) << (o & 63));
     }
     teamSync();
     return true;
@@ -706,7 +742,7 @@ struct LdsGraphL {
                 fpb              = aPb(v);
                 okA              = unsigned(rootOf[readOfPb(fpb)]) != s;
                 if (!okA && aPool(v)) {
-                  const Set st = pool[aPool(v) - 1];
+                  const Set st = setLoad(aPool(v));
                   for (unsigned h = 0; h < RPL; ++h) {
                     const uint64_t m = st.w[h] & ~memAll[h];
                     if (m && !okB) {
@@ -810,7 +846,7 @@ struct LdsGraphL {
         // :537-548: a read adds one to a word's count, a pseudo read minCoverage
         unsigned c = (aPb(v) >= pseudoPb0) ? P.opt.minCoverage : 1u;
         if (aPool(v)) {
-          const Set st = pool[aPool(v) - 1];
+          const Set st = setLoad(aPool(v));
           c            = 0;
           for (unsigned q = 0; q < LgL::SETW; ++q) {
             const uint64_t nm = normalMask(q);
@@ -960,7 +996,7 @@ struct LdsGraphL {
         // count >= 2: the word has a set -- or it is held by ONE pseudo read that counts minCoverage >= 2: its set is made up here
         Set st;
         if (aPool(v)) {
-          st = pool[aPool(v) - 1];
+          st = setLoad(aPool(v));
         } else {
           for (unsigned q = 0; q < LgL::SETW; ++q) st.w[q] = ((r >> 6) == q) ? (uint64_t(1) << (r & 63)) : 0;
         }
@@ -1286,6 +1322,7 @@ struct LdsGraphL {
     nNodes = 0;
     if (!tablePass<KW>()) {
       LGL_TRACE("table pass (table or set pool full)");
+      why(3);
       return false;
     }
     tick(1, 1);
@@ -1293,6 +1330,7 @@ struct LdsGraphL {
     tick(1, 2);
     if (!sortWords<KW>()) {
       LGL_TRACE("too many words");
+      why(4);
       return false;
     }
     tick(2, 3);
@@ -1318,11 +1356,13 @@ struct LdsGraphL {
     const uint64_t off = (uint64_t(wv::atomic_load(&hdr[LGL_H_OFF_HI])) << 32) | wv::atomic_load(&hdr[LGL_H_OFF_LO]);
     if (off + bytes > G.arena_cap) {
       LGL_TRACE("slab arena full");
+      why(5);
       return false;
     }
     uint8_t* slab = G.arena + off;
     if (!buildRecords<KW>(slab, SL)) {
       LGL_TRACE("side tables full");
+      why(4);
       return false;
     }
     const bool     acyclic = wv::atomic_load(&hdr[LGL_H_CYC]) == 0 && !(G.flags & LG_FLAG_NO_PROOF);
@@ -1336,6 +1376,7 @@ struct LdsGraphL {
       if (G.class_bytes[c] && need <= G.class_bytes[c]) cls = c;
     if (cls == LG_CLASSES && !toRepeat) {
       LGL_TRACE("graph fits no contig LDS class");
+      why(4);
       return false;
     }
     uint16_t*      gSpec = reinterpret_cast<uint16_t*>(slab + SL.spec);
@@ -1402,12 +1443,19 @@ struct LdsGraphL {
     }
     if (!pack(locus)) {
       LGL_TRACE("pack (envelope / alphabet)");
+      why(2);
       return false;
     }
     tick(0, 0);
-    if (nNormal + nPseudo * P.opt.minCoverage > 255) return false;  // (counts by slot are bytes)
+    if (nNormal + nPseudo * P.opt.minCoverage > 255) {  // (counts by slot are bytes)
+      why(2);
+      return false;
+    }
     const unsigned kw = (k + 15) >> 4;
-    if (kw > unsigned(MAXKW)) return false;
+    if (kw > unsigned(MAXKW)) {
+      why(2);
+      return false;
+    }
     if (kw <= 2) return runK<2>(locus);
     if (MAXKW >= 4 && kw <= 4) return runK<(MAXKW >= 4 ? 4 : 2)>(locus);
     return runK<MAXKW>(locus);

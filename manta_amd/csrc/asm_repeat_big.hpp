@@ -44,6 +44,39 @@ WV_HD RpbWs rpbWorkspaceLayout()
 
 enum { RPB_DONE = 0, RPB_PUNT = 1 };
 
+/// std::hash<std::string> of the word at packed base index pb of a 2-bit pile (libstdcxxStringHash<2>, repeat_exact.hpp, with the
+/// eight characters of a step taken from two dwords instead of one load per character)
+WV_DEV uint64_t rpbWordHash(const uint32_t* codes, const unsigned pb, const unsigned len)
+{
+  auto chunk = [&](const unsigned i, const unsigned n) -> uint64_t {
+    const unsigned p  = pb + i;
+    const unsigned wi = p >> 4, sh = (p & 15) * 2;
+    const uint64_t two = (uint64_t(codes[wi]) << 32) | codes[wi + 1];  // (every read of the pile is followed by a padding dword)
+    const uint32_t v   = uint32_t((two << sh) >> 48);                  // eight bases, first base in the top bits
+    uint64_t       data = 0;
+    for (unsigned b = 0; b < n; ++b) {
+      const unsigned c = (v >> (14 - 2 * b)) & 3u;
+      data |= uint64_t((0x54474341u >> (8 * c)) & 0xffu) << (8 * b);   // "ACGT"[c]
+    }
+    return data;
+  };
+  const uint64_t mul  = (uint64_t(0xc6a4a793UL) << 32) + uint64_t(0x5bd1e995UL);
+  uint64_t       hash = uint64_t(0xc70f6907UL) ^ (uint64_t(len) * mul);
+  const unsigned lenAligned = len & ~7u;
+  for (unsigned i = 0; i < lenAligned; i += 8) {
+    const uint64_t data = murmurShiftMix(chunk(i, 8) * mul) * mul;
+    hash ^= data;
+    hash *= mul;
+  }
+  if (len & 7u) {
+    hash ^= chunk(lenAligned, len & 7u);
+    hash *= mul;
+  }
+  hash = murmurShiftMix(hash) * mul;
+  hash = murmurShiftMix(hash);
+  return hash;
+}
+
 struct RepeatBig {
   typedef LgRec<LgL>  R;
   typedef FSetT<LgL>  Set;
@@ -64,89 +97,41 @@ struct RepeatBig {
 
   WV_DEV RepeatBig(const AsmParams& p, const LgParams& g, uint8_t* w, char* l) : P(p), G(g), ws(w), lds(l) { lane = unsigned(wv::lane()); }
 
+  uint64_t tMark;
+  /// phases: 0 renumbering + successors, 1 the components (search in any order), 2 hash + insertion sequence, 3 node order of wordCount,
+  /// 4 of wordIndices, 5 the search in the reference's order, 6 bitmaps + class
+  WV_DEV void tick(const int phase)
+  {
+    const uint64_t now = wv::clock();
+    if (G.rprof && lane == 0) wv::atomic_add(&G.rprof[phase], (unsigned long long)(now - tMark));
+    tMark = now;
+  }
+  // the per-wave workspace
+  uint64_t* h;
+  uint32_t *ins, *seqB, *pool, *vOf, *idOf, *succ4, *flagV, *firstRd, *byLex, *prefix, *rdBase, *sccV;
+  WV_DEV void bind(const RpbWs& L)
+  {
+    h       = reinterpret_cast<uint64_t*>(ws + L.h);
+    ins     = reinterpret_cast<uint32_t*>(ws + L.ins);
+    seqB    = reinterpret_cast<uint32_t*>(ws + L.seqB);
+    pool    = reinterpret_cast<uint32_t*>(ws + L.pool);
+    vOf     = reinterpret_cast<uint32_t*>(ws + L.vOf);
+    idOf    = reinterpret_cast<uint32_t*>(ws + L.idOf);
+    succ4   = reinterpret_cast<uint32_t*>(ws + L.succ4);
+    flagV   = reinterpret_cast<uint32_t*>(ws + L.flagV);
+    firstRd = reinterpret_cast<uint32_t*>(ws + L.firstRd);
+    byLex   = reinterpret_cast<uint32_t*>(ws + L.byLex);
+    prefix  = reinterpret_cast<uint32_t*>(ws + L.prefix);
+    rdBase  = reinterpret_cast<uint32_t*>(ws + L.rdBase);
+    sccV    = reinterpret_cast<uint32_t*>(ws + L.queue);
+  }
   WV_DEV uint64_t succOf(const unsigned nd, const FRec8 w) const { return R::links(w, nd, true, gSovf, nSovf); }
   WV_DEV uint64_t predOf(const unsigned nd, const FRec8 w) const { return R::links(w, nd, false, gPovf, nPovf); }
 
-  /// two-sided Kahn peel over the slab's records; state bytes {in:3, out:3, peeled} in LDS.  Returns the number of words removed.
-  WV_DEV unsigned peel(uint32_t* queue)
+  /// the words renumbered by first occurrence (v = rank of the word's packed base index: an unbranched stretch has consecutive numbers
+  /// again -- the slab's ids are in seed order), the successors in that numbering (alphabet order)
+  WV_DEV void renumber()
   {
-    uint32_t*      st   = reinterpret_cast<uint32_t*>(lds);
-    const unsigned stDw = (n + 3) / 4;
-    uint32_t*      qTail = queue;  // [0]: the tail; entries from [1]
-    if (lane == 0) *qTail = 0;
-    for (unsigned w = lane; w < stDw; w += 64) st[w] = 0;
-    wv::sync();
-    for (unsigned nb = 0; nb < n; nb += 64) {
-      const unsigned nd = nb + lane;
-      if (nd >= n) continue;
-      const FRec8    w  = gRec[nd];
-      const uint64_t sl = succOf(nd, w), pl = predOf(nd, w);
-      unsigned       id = 0, od = 0;
-      for (unsigned c = 0; c < 4; ++c) {
-        const unsigned s = R::linkId(sl, c), p = R::linkId(pl, c);
-        if (s != ASM_NONE && s != nd) od++;
-        if (p != ASM_NONE && p != nd) id++;
-      }
-      const bool     src = (id == 0 || od == 0);
-      const unsigned v   = id | (od << 3) | (src ? 0x40u : 0u);
-      wv::atomic_or(&st[nd >> 2], v << (8 * (nd & 3)));
-      if (src) queue[1 + wv::atomic_add(qTail, 1u)] = nd;
-    }
-    wv::sync();
-    wv::fence_acquire();
-    unsigned head = 0, removed = 0;
-    while (true) {
-      const unsigned tail = wv::first(wv::atomic_load(qTail));
-      if (tail == head) break;
-      removed += tail - head;
-      for (unsigned i = head + lane; i < tail; i += 64) {
-        const unsigned nd = queue[1 + i];
-        const FRec8    w  = gRec[nd];
-        const uint64_t sl = succOf(nd, w), pl = predOf(nd, w);
-        for (unsigned c = 0; c < 4; ++c) {
-          const unsigned s = R::linkId(sl, c);
-          if (s != ASM_NONE && s != nd) {
-            const unsigned sh  = 8 * (s & 3);
-            const unsigned old = wv::atomic_sub(&st[s >> 2], 1u << sh) >> sh;
-            if ((old & 0x7u) == 1u && !(wv::atomic_or(&st[s >> 2], 0x40u << sh) & (0x40u << sh))) queue[1 + wv::atomic_add(qTail, 1u)] = s;
-          }
-          const unsigned p = R::linkId(pl, c);
-          if (p != ASM_NONE && p != nd) {
-            const unsigned sh  = 8 * (p & 3);
-            const unsigned old = wv::atomic_sub(&st[p >> 2], 8u << sh) >> sh;
-            if ((old & 0x38u) == 8u && !(wv::atomic_or(&st[p >> 2], 0x40u << sh) & (0x40u << sh))) queue[1 + wv::atomic_add(qTail, 1u)] = p;
-          }
-        }
-      }
-      wv::sync();
-      wv::fence_acquire();
-      head = tail;
-    }
-    return removed;
-  }
-
-  /// the repeat search; flagV[v] != 0 <=> the word numbered v is a repeat word.  False: not for this path (bucket count beyond the workspace).
-  WV_DEV bool exactSearch(const RpbWs& L)
-  {
-    const unsigned C       = LGL_MAX_NODES;
-    uint64_t*      h       = reinterpret_cast<uint64_t*>(ws + L.h);
-    uint32_t*      ins     = reinterpret_cast<uint32_t*>(ws + L.ins);
-    uint32_t*      seqB    = reinterpret_cast<uint32_t*>(ws + L.seqB);
-    uint32_t*      pool    = reinterpret_cast<uint32_t*>(ws + L.pool);
-    uint32_t*      vOf     = reinterpret_cast<uint32_t*>(ws + L.vOf);
-    uint32_t*      idOf    = reinterpret_cast<uint32_t*>(ws + L.idOf);
-    uint32_t*      succ4   = reinterpret_cast<uint32_t*>(ws + L.succ4);
-    uint32_t*      flagV   = reinterpret_cast<uint32_t*>(ws + L.flagV);
-    uint32_t*      firstRd = reinterpret_cast<uint32_t*>(ws + L.firstRd);
-    uint32_t*      byLex   = reinterpret_cast<uint32_t*>(ws + L.byLex);
-    uint32_t*      prefix  = reinterpret_cast<uint32_t*>(ws + L.prefix);
-    uint32_t*      rdBase  = reinterpret_cast<uint32_t*>(ws + L.rdBase);
-    {
-      unsigned nbMax = 1;
-      for (unsigned s = 0; s < P.n_growth; ++s)
-        if (P.growth_size[s] < n) nbMax = P.growth_buckets[s];
-      if (nbMax > 3 * C + 32) return false;
-    }
     // ---- the words renumbered by first occurrence: v = rank of the word's packed base index ----
     uint32_t* bits = reinterpret_cast<uint32_t*>(lds);  // 65 536 bits
     for (unsigned i = lane; i < 2048; i += 64) bits[i] = 0;
@@ -180,7 +165,6 @@ struct RepeatBig {
     for (unsigned r = 64 + lane; r < 320; r += 64) rdBase[r] = 0;
     wv::sync();
     wv::fence_acquire();
-    // ---- successors in the new numbering, std::hash, first read, the lexicographic list ----
     for (unsigned id = lane; id < n; id += 64) {
       const FRec8    w  = gRec[id];
       const uint64_t sl = succOf(id, w);
@@ -189,8 +173,27 @@ struct RepeatBig {
         const unsigned s = R::linkId(sl, c);
         succ4[4 * v + c] = (s == ASM_NONE) ? ASM_NONE : vOf[s];
       }
-      h[v]     = libstdcxxStringHash<2>(gCodes, gPb[id], k);
       flagV[v] = 0;
+      sccV[v]  = 0;
+    }
+    wv::sync();
+    wv::fence_acquire();
+  }
+
+  /// the reference's root order: iteration order of wordIndices (:627-642).  False: bucket count beyond the workspace.
+  WV_DEV bool rootOrder(const uint32_t*& roots)
+  {
+    const unsigned C = LGL_MAX_NODES;
+    {
+      unsigned nbMax = 1;
+      for (unsigned s = 0; s < P.n_growth; ++s)
+        if (P.growth_size[s] < n) nbMax = P.growth_buckets[s];
+      if (nbMax > 3 * C + 32) return false;
+    }
+    // std::hash, first read, the lexicographic list
+    for (unsigned id = lane; id < n; id += 64) {
+      const unsigned v = vOf[id];
+      h[v]             = rpbWordHash(gCodes, gPb[id], k);
       unsigned fr = 0;
       if (id < nFat) {
         const Set st = gPool[id];
@@ -248,8 +251,8 @@ struct RepeatBig {
       wv::sync();
       wv::fence_acquire();
     }
+    tick(2);
     // ---- libstdc++'s node order of wordCount, then of wordIndices (filled by iterating wordCount, :631-633) ----
-    const uint32_t* roots;
     {
       const unsigned nbCap = 3 * C + 32;
       uint32_t*      chain = pool;
@@ -259,6 +262,7 @@ struct RepeatBig {
       uint32_t*      bh    = bf + nbCap;
       uint32_t*      seqA  = byLex;  // (the lexicographic list is done with)
       uint32_t* order1 = unorderedOrderWave(P, h, ins, seqB, spare, chain, offs, bf, bh, n);
+      tick(3);
       uint32_t* s1     = (order1 == seqB) ? spare : seqB;
       uint32_t* order2 = unorderedOrderWave(P, h, order1, seqA, s1, chain, offs, bf, bh, n);
       if (order2 != seqA && order2 != seqB) {  // the search below reuses the pool: park the root order where it survives
@@ -268,7 +272,20 @@ struct RepeatBig {
       }
       roots = order2;
     }
-    // ---- the search (:555-625), successors in alphabet order; see repeat_exact.hpp for the run arithmetic ----
+    tick(4);
+    return true;
+  }
+
+  /// The search (:555-625), successors in alphabet order; see repeat_exact.hpp for the run arithmetic.  roots == nullptr: roots in
+  /// numbering order -- the strongly connected components do not depend on the order, so this pass tells whether the graph is cyclic at
+  /// all, marks the words that lie on a cycle (sccV: the only ones a walk can meet twice) and finds the smallest component: only a
+  /// component of at most 51 words can pass the reference's small-circle test (:612: index span <= 50), and only then does the order
+  /// matter.  roots != nullptr: the reference's order; flagV[v] != 0 <=> word v is a repeat word.  Returns the smallest component's size.
+  WV_DEV unsigned search(const uint32_t* roots)
+  {
+    const unsigned C      = LGL_MAX_NODES;
+    const bool     exact  = roots != nullptr;
+    unsigned       minScc = 0x7fffffffu;
     {
       const uint32_t ONSTACK = 0x80000000u, INF = 0x7fffffffu, RUNFRAME = 0x80000000u;
       uint32_t*      idxA    = pool;
@@ -304,7 +321,7 @@ struct RepeatBig {
           unsigned root = ASM_NONE;
           while (rootCursor < n) {
             const unsigned ri = rootCursor + lane;
-            const unsigned r  = (ri < n) ? roots[ri] : 0u;
+            const unsigned r  = (ri < n) ? (exact ? roots[ri] : ri) : 0u;
             const bool     un = (ri < n) && (idxA[r] == 0);
             const uint64_t m  = wv::ballot(un);
             if (m) {
@@ -384,7 +401,8 @@ struct RepeatBig {
           for (unsigned i = reqA + lane; i < reqB; i += 64) {
             const unsigned w = stackA[i];
             lowA[w] &= ~ONSTACK;
-            if (reqD && i >= reqC) flagV[w] = 1;
+            if ((reqD & 1u) && i >= reqC) flagV[w] = 1;
+            if ((reqD & 2u) && i >= reqC) sccV[w] = 1;
           }
           req = REQ_NONE;
           wv::sync();
@@ -430,15 +448,21 @@ struct RepeatBig {
               unsigned flagFrom = sp, small = 0;
               if (Lw < firstIdx + len) {
                 flagFrom = p0 + (Lw - firstIdx);
-                small    = ((idxA[stackA[sp - 1]] - Lw) <= 50) ? 1u : 0u;
-                if (sp - flagFrom == 1) small = 0;
+                small    = (exact && (idxA[stackA[sp - 1]] - Lw) <= 50) ? 1u : 0u;
+                if (sp - flagFrom == 1) {
+                  small = 0;
+                } else {
+                  small |= 2u;  // a component of more than one word
+                  if (sp - flagFrom < minScc) minScc = sp - flagFrom;
+                }
               }
               retLow = firstIdx;
               if (sp - p0 <= 4) {
                 for (unsigned i = p0; i < sp; ++i) {
                   const unsigned w = stackA[i];
                   lowA[w] &= ~ONSTACK;
-                  if (small && i >= flagFrom) flagV[w] = 1;
+                  if ((small & 1u) && i >= flagFrom) flagV[w] = 1;
+                  if ((small & 2u) && i >= flagFrom) sccV[w] = 1;
                 }
                 sp = p0;
               } else {
@@ -494,12 +518,14 @@ struct RepeatBig {
                 lowA[nd] &= ~ONSTACK;
                 sp = myPos;
               } else {
-                const unsigned small = ((idxA[stackA[sp - 1]] - idxA[nd]) <= 50) ? 1u : 0u;
+                const unsigned small = ((exact && (idxA[stackA[sp - 1]] - idxA[nd]) <= 50) ? 1u : 0u) | 2u;
+                if (sp - myPos < minScc) minScc = sp - myPos;
                 if (sp - myPos <= 4) {
                   for (unsigned i = myPos; i < sp; ++i) {
                     const unsigned w = stackA[i];
                     lowA[w] &= ~ONSTACK;
-                    if (small) flagV[w] = 1;
+                    if (small & 1u) flagV[w] = 1;
+                    sccV[w] = 1;
                   }
                 } else {
                   req  = REQ_POP;
@@ -528,15 +554,19 @@ struct RepeatBig {
         reqB      = wv::first(reqB);
         reqC      = wv::first(reqC);
         reqD      = wv::first(reqD);
+        minScc    = wv::first(minScc);
       }
     }
     wv::sync();
     wv::fence_acquire();
-    return true;
+    wv::sync();
+    wv::fence_acquire();
+    return minScc;
   }
 
   WV_DEV int run(const unsigned locus)
   {
+    tMark       = wv::clock();
     slab        = G.arena + G.slab_off[locus];
     LgHdr* gh   = reinterpret_cast<LgHdr*>(slab);
     n           = wv::first(gh->nNodes);
@@ -556,48 +586,50 @@ struct RepeatBig {
     gCodes = reinterpret_cast<const uint32_t*>(slab + SL.codes);
     gLex   = reinterpret_cast<const uint16_t*>(slab + SL.lex);
     gFlags = reinterpret_cast<uint32_t*>(slab + SL.flags);
-    const RpbWs    L       = rpbWorkspaceLayout();
-    uint32_t*      queue   = reinterpret_cast<uint32_t*>(ws + L.queue);
-    const unsigned removed = peel(queue);
+    bind(rpbWorkspaceLayout());
+    renumber();
+    tick(0);
+    const unsigned minScc = search(nullptr);
+    tick(1);
+    const bool     cyclic = minScc != 0x7fffffffu;  // (self loops alone: not a cycle for this test -- as the peel of the other paths)
     unsigned       need, nCore = 0;
-    bool           cyclic = removed != n;
     if (!cyclic) {
       need = ckNeedOf<LgL>(n, nFat, true);
     } else {
-      nCore = n - removed;
-      if (nCore > LGL_CORE_CAP) return RPB_PUNT;
-      // the core bitmap (before the LDS is reused)
-      const uint32_t* st = reinterpret_cast<const uint32_t*>(lds);
-      uint32_t        mine[LgL::UNUSED_DW / 64];
-      for (unsigned u = 0; u < LgL::UNUSED_DW / 64; ++u) {
-        const unsigned d = lane + 64 * u;
-        uint32_t       b = 0;
-        for (unsigned j = 0; j < 32; ++j) {
-          const unsigned nd = 32 * d + j;
-          if (nd < n && !((st[nd >> 2] >> (8 * (nd & 3))) & 0x40u)) b |= 1u << j;
-        }
-        mine[u] = b;
+      if (minScc <= 51) {  // :612 can hold for some visiting order: the reference's
+        const uint32_t* roots = nullptr;
+        if (!rootOrder(roots)) return RPB_PUNT;
+        for (unsigned v = lane; v < n; v += 64) flagV[v] = 0;
+        wv::sync();
+        search(roots);
+        tick(5);
       }
-      wv::sync();
-      for (unsigned u = 0; u < LgL::UNUSED_DW / 64; ++u) gFlags[lane + 64 * u] = mine[u];
-      if (!exactSearch(L)) return RPB_PUNT;
-      const uint32_t* vOf   = reinterpret_cast<const uint32_t*>(ws + L.vOf);
-      const uint32_t* flagV = reinterpret_cast<const uint32_t*>(ws + L.flagV);
+      // the words on a cycle / the repeat words by id
       for (unsigned u = 0; u < LgL::UNUSED_DW / 64; ++u) {
         const unsigned d = lane + 64 * u;
-        uint32_t       b = 0;
+        uint32_t       b = 0, c = 0;
         for (unsigned j = 0; j < 32; ++j) {
           const unsigned nd = 32 * d + j;
-          if (nd < n && flagV[vOf[nd]]) b |= 1u << j;
+          if (nd < n) {
+            const unsigned v = vOf[nd];
+            if (flagV[v]) b |= 1u << j;
+            if (sccV[v]) c |= 1u << j;
+          }
         }
+        gFlags[d]                   = c;
         gFlags[LgL::UNUSED_DW + d] = b;
+        unsigned cc = unsigned(wv::popc(c));
+        for (int off = 1; off < 64; off <<= 1) cc += wv::shfl(cc, wv::lane() ^ off);
+        nCore += cc;
       }
+      if (nCore > LGL_CORE_CAP) return RPB_PUNT;
       need = ckNeedCyclic<LgL>(n, nFat, nCore);
     }
     unsigned cls = LG_CLASSES;
     for (unsigned c = LG_CLASSES; c-- > 0;)
       if (G.class_bytes[c] && need <= G.class_bytes[c]) cls = c;
     if (cls == LG_CLASSES) return RPB_PUNT;
+    tick(6);
     wv::sync();
     if (lane == 0) {
       gh->acyclic = cyclic ? 0u : 1u;
@@ -628,7 +660,10 @@ WV_KERNEL_OCC(4) void repeat_big_kernel(const LgArgs A)
     RepeatBig      r(P, G, ws, lds);
     const int      rc = r.run(locus);
     wv::sync();
-    if (rc != RPB_DONE && wv::lane() == 0) P.punt_ids[wv::atomic_add(P.punt_count, 1u)] = locus;
+    if (rc != RPB_DONE && wv::lane() == 0) {
+      P.punt_ids[wv::atomic_add(P.punt_count, 1u)] = locus;
+      if (G.stats) wv::atomic_add(&G.stats[6], 1u);
+    }
     wv::sync();
   }
 }

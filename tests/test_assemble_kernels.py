@@ -370,7 +370,7 @@ def _fast_stats(emu):
     import ctypes
     st = (ctypes.c_ulonglong * 8)()
     emu.lib.manta_emu_fast_stats(st)
-    return dict(loci=st[0], rounds=st[1], walks=st[2], cands=st[3], evictions=st[4], reclaimed=st[5], proofs=st[6])
+    return dict(loci=st[0], rounds=st[1], walks=st[2], cands=st[3], evictions=st[4], reclaimed=st[5], proofs=st[6], sent_on=st[7])
 
 
 def test_emulated_fast_kernel_speculation_hits(emu, oracle, monkeypatch):
@@ -409,7 +409,7 @@ def _big_cases():
     for i in (1, 2, 4, 7, 9):  # k = 55, 25, 65, 40, 75
         reads, _, _, k, kmax = config5_locus(i)
         cases.append((asm_opts(minWordLength=k, maxWordLength=kmax, minContigLength=75), reads))
-    reads, _, _, k, kmax = config5_locus(3)  # a tandem-repeat locus: cyclic graph -> handed to the general kernel whole
+    reads, _, _, k, kmax = config5_locus(37)  # a tandem-repeat locus: cyclic graph at its one word length (repeat_big_kernel, rounds below)
     cases.append((asm_opts(minWordLength=k, maxWordLength=kmax, minContigLength=75), reads))
     # 129 reads (one more than the small class takes), 236 reads (the most this class takes with maxAssemblyCount 10), 237 (one too many)
     cases.append((asm_opts(minWordLength=31), small_indel_locus(21, n_reads=129, read_len=100, ref_len=600)[0]))
@@ -425,8 +425,57 @@ def test_emulated_big_class_matches_oracle(emu, oracle, monkeypatch):
     cases = _big_cases()
     _fast_stats(emu)
     assert _check(emu, oracle, cases) == len(cases)
-    # the class took them: every locus but the cyclic one and the 237-read pile went through contig_big_kernel
-    assert _fast_stats(emu)["loci"] >= len(cases) - 3
+    # the class took them: every locus but the 237-read pile (and at most one more) went through contig_big_kernel
+    assert _fast_stats(emu)["loci"] >= len(cases) - 2
+
+
+# ---- ... and its word-length rounds: cyclic graphs, repeat hits and pseudo reads on the pipeline (IterativeAssembler.cpp:555-642, 856-910) ----
+def _round_cases(n_sweep=12):
+    """piles of 129..236 reads with tandem repeats: config-5 loci whose graph is cyclic at one / two / four word lengths, and random
+    repeat-rich piles under random options (minCoverage up to 3: a pseudo read then counts more than a read; word steps down to 1;
+    maxAssemblyCount 2..10; word lengths from 8) -- every one needs the repeat search in the reference's order and, most, pseudo reads"""
+    import numpy as np
+    cases = []
+    for i in (37, 0, 64):
+        reads, _, _, k, kmax = config5_locus(i)
+        cases.append((asm_opts(minWordLength=k, maxWordLength=kmax, minContigLength=75), reads))
+    for s in range(1, 1 + n_sweep):
+        rng = np.random.default_rng(9000 + s)
+        nr = int(rng.integers(129, 237))
+        if s % 3 == 0:
+            reads = repeat_rich_pile(s, n_reads=nr, read_len=int(rng.integers(40, 90)))
+        elif s % 3 == 1:
+            reads = small_indel_locus(s, n_reads=nr, read_len=int(rng.integers(60, 120)), ref_len=500, sub_rate=0.01, n_rate=0.005, tandem=True)[0]
+        else:
+            reads = breakend_locus(s, n_reads=min(nr, 200), read_len=int(rng.integers(80, 160)), ref_len=600, tandem_frac=1.0)[0]
+        mac = int(rng.integers(2, 11))
+        k0 = int(rng.integers(8, 33))
+        o = asm_opts(minWordLength=k0, maxWordLength=k0 + int(rng.integers(0, 40)), wordStepSize=int(rng.integers(1, 8)), minCoverage=int(rng.integers(1, 4)),
+                     minConservativeCoverage=int(rng.integers(1, 4)), maxAssemblyCount=mac, minContigLength=15,
+                     minUnusedReads=int(rng.integers(1, 5)), minSupportReads=int(rng.integers(1, 4)))
+        if len(reads) + 2 * mac <= 256:
+            cases.append((o, reads))
+    return cases
+
+
+def test_emulated_big_class_word_length_rounds(emu, oracle, monkeypatch):
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
+    cases = _round_cases()
+    _fast_stats(emu)
+    assert _check(emu, oracle, cases) == len(cases)
+    st = _fast_stats(emu)
+    # they stayed on the pipeline: nearly every locus finished in contig_big_kernel, most after being sent on to a further word length
+    assert st["loci"] >= len(cases) - 2 and st["sent_on"] >= 2 * len(cases), st
+
+
+def test_emulated_big_class_rounds_off_hands_repeats_back(emu, oracle, monkeypatch):
+    """MANTA_AMD_BIG_ROUNDS=0 (A/B runs): one word length on the pipeline, a cyclic graph or a repeat hit goes to assemble_kernel"""
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
+    monkeypatch.setenv("MANTA_AMD_BIG_ROUNDS", "0")
+    cases = _round_cases(3)
+    _fast_stats(emu)
+    assert _check(emu, oracle, cases) == len(cases)
+    assert _fast_stats(emu)["sent_on"] == 0
 
 
 def test_emulated_big_class_in_one_launch_with_the_small_class(emu, oracle, monkeypatch):
@@ -445,6 +494,18 @@ def test_gpu_big_class_matches_oracle(gpu, oracle, monkeypatch):
     monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
     cases = _big_cases()
     for i in range(20, 52):
+        reads, _, _, k, kmax = config5_locus(i)
+        cases.append((asm_opts(minWordLength=k, maxWordLength=kmax, minContigLength=75), reads))
+    assert _check(gpu, oracle, cases) == len(cases)
+
+
+@pytest.mark.gpu
+def test_gpu_big_class_word_length_rounds(gpu, oracle, monkeypatch):
+    """the rounds on hardware: tandem-repeat loci of the config-5 generator (up to eleven word lengths, every graph cyclic) and the random
+    repeat-rich piles under random options"""
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
+    cases = _round_cases(40)
+    for i in (3, 14, 25, 35, 72, 77, 114, 129, 260):
         reads, _, _, k, kmax = config5_locus(i)
         cases.append((asm_opts(minWordLength=k, maxWordLength=kmax, minContigLength=75), reads))
     assert _check(gpu, oracle, cases) == len(cases)
