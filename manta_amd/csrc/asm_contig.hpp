@@ -367,6 +367,67 @@ struct LdsContig {
     return (total < T) ? total : T;
   }
 
+  /// the lowest unused word (ASM_NONE: none)
+  WV_DEV unsigned lowestUnused() const
+  {
+    unsigned mine = ASM_NONE;
+    for (unsigned u = UPL; u-- > 0;) {
+      const uint32_t b32 = unused_bits[UPL * lane + u];
+      if (b32) mine = 32 * (UPL * lane + u) + unsigned(wv::ctz(uint64_t(b32)));
+    }
+    const uint64_t m = wv::ballot(mine != ASM_NONE);
+    return m ? wv::readlane(mine, wv::ctz(m)) : ASM_NONE;
+  }
+
+  /// Big class, every walk round after the first: the next unused words in seed order, ONE PER UNBRANCHED STRETCH -- the words of a
+  /// stretch come out of the same walk, so only the lowest of them can be the next seed; with every word listed (the small class'
+  /// list) a round's 64 walks cover a dozen stretches and a config-5 pile needs a third round for its last candidates.  256 unused
+  /// words are looked at, each is followed to the end of its stretch (the label), later words under a label are dropped, the first 64
+  /// kept ones are the list.  The replay stays exact because it only ever accepts THE lowest unused word (contigRounds): a dropped
+  /// word that its stretch's walk did not consume simply ends the replay and heads the next list.
+  WV_DEV unsigned stretchSeedList()
+  {
+    static const unsigned WIN = 4;  // entries per lane: 256 unused words are looked at
+    const unsigned nW = firstUnused(64 * WIN);
+    if (nW <= 1) return nW;
+    unsigned ent[WIN], lab[WIN];
+    for (unsigned h = 0; h < WIN; ++h) {
+      const unsigned i = lane + 64 * h;
+      ent[h]           = (i < nW) ? unsigned(tent[i]) : ASM_NONE;
+      unsigned cur     = (i < nW) ? ent[h] : 0u;
+      for (unsigned steps = 0; steps < 256 && i < nW; ++steps) {
+        const FRec8    w  = nodes[cur];
+        const unsigned f0 = R::succ(w, 0);
+        if (f0 == 0 || R::succ(w, 1) != 0 || R::sOvf(w) || f0 - 1 == cur) break;  // no successor, a branch, a self loop
+        const FRec8 wn = nodes[f0 - 1];
+        if (R::pred(wn, 1) != 0 || R::pOvf(wn)) break;  // the successor has another way in
+        cur = f0 - 1;
+      }
+      lab[h] = (i < nW) ? cur : (ASM_NONE - 1u - i);  // (entries past the end: labels of their own)
+    }
+    bool dup[WIN];
+    for (unsigned h = 0; h < WIN; ++h) dup[h] = false;
+    for (unsigned g = 0; g < WIN; ++g) {
+      const unsigned gEnd = (nW > 64 * g) ? ((nW - 64 * g < 64) ? (nW - 64 * g) : 64u) : 0u;
+      for (unsigned j = 0; j < gEnd; ++j) {
+        const unsigned v = wv::readlane(lab[g], int(j));
+        for (unsigned h = g; h < WIN; ++h)
+          if (64 * g + j < lane + 64 * h && v == lab[h]) dup[h] = true;
+      }
+    }
+    unsigned base = 0;
+    uint64_t keepM[WIN];
+    for (unsigned h = 0; h < WIN; ++h) keepM[h] = wv::ballot(ent[h] != ASM_NONE && !dup[h]);
+    const uint64_t below = (uint64_t(1) << lane) - 1;
+    wv::sync();
+    for (unsigned h = 0; h < WIN; ++h) {
+      if ((keepM[h] >> lane) & 1u) tent[base + unsigned(wv::popc(keepM[h] & below))] = uint16_t(ent[h]);
+      base += unsigned(wv::popc(keepM[h]));
+    }
+    wv::sync();
+    return (base < 64) ? base : 64u;
+  }
+
   // ------------------------------------------------------------------------------------------------
   // walks (:149-501), one lane per cache slot
   // ------------------------------------------------------------------------------------------------
@@ -730,6 +791,13 @@ struct LdsContig {
       };
       findSlots();
       uint64_t miss = wv::ballot(lane < nL && slot == LG_NO_SLOT);
+#ifdef MANTA_WAVE_EMU
+      if (std::getenv("MANTA_EMU_ROUND_TRACE") && lane == 0) {
+        std::fprintf(stderr, "  replay list (%u cands so far, nEligible %u, nFat %u): %u entries, missing mask %016llx; entries (id:count):", nCand, nEligible, nFat, nL, (unsigned long long)miss);
+        for (unsigned i = 0; i < nL && i < 24; ++i) std::fprintf(stderr, " %u:%u%s", unsigned(tent[i]), R::cnt(nodes[tent[i]]), ((miss >> i) & 1u) ? "*" : "");
+        std::fprintf(stderr, "\n");
+      }
+#endif
       tick(5);
       // Walk only when the very next seed has no walk yet.  Otherwise replay first: most rounds end there (enough candidates,
       // or the unwalked seeds turn out consumed -- the other words of a branch whose first word was walked), and a walk
@@ -823,6 +891,121 @@ struct LdsContig {
       if (bad) return 1;
       accAll |= acc;
       tick(7);
+    }
+    return 0;
+  }
+
+  /// The big class' form of the loop above.  The replay is driven by the bitmap, not by a list: the reference's next seed is THE lowest
+  /// unused word (:686-696 with ids in seed order); if a cache slot holds its walk the walk is accepted, otherwise a walk round fills the
+  /// free slots from stretchSeedList -- whose first entry is that word.  Exact for any choice of what else gets walked.
+  WV_DEV int contigRoundsStretch()
+  {
+    const unsigned capCand = 2 * P.opt.maxAssemblyCount;
+    nCand                  = 0;
+    if (nNodes == 0 || nEligible == 0) return 0;
+    slotNode[lane] = uint16_t(LG_NO_SLOT);
+    uint64_t cached = 0, accAll = 0;
+    {  // round 0: the first seed (id 0) and beside it graph_big_kernel's speculation list
+      const uint16_t* spec = gSpecList();
+      const unsigned  n0   = (nSpec < 1) ? 1u : ((nSpec > 64) ? 64u : nSpec);
+      if (lane < n0) slotNode[lane] = (lane == 0) ? uint16_t(0) : spec[lane];
+      cached = (n0 >= 64) ? ~uint64_t(0) : ((uint64_t(1) << n0) - 1);
+      wv::sync();
+      tick(5);
+      walkSlots(cached);
+      tick(6);
+    }
+    while (nCand < capCand) {
+      const unsigned nd = lowestUnused();
+      if (nd == ASM_NONE) break;
+      const uint64_t hit = wv::ballot(((cached >> lane) & 1u) && unsigned(slotNode[lane]) == nd);
+      if (hit) {
+        const unsigned sl = unsigned(wv::ctz(hit));
+        const int32_t* m  = lane_meta + sl * 8;
+        const unsigned fl = unsigned(m[4]), n = 1u + unsigned(m[0]) + unsigned(m[1]);
+        if (fl & 2u) return 1;       // contig too long for this path
+        if (fl & 1u) anyRep = true;  // a repeat hit (:699): the contig stays a candidate, the reference moves on to the next word length afterwards
+        accAll |= uint64_t(1) << sl;
+        if (lane == nCand) candSlotV = sl;
+        nCand++;
+        const uint64_t* log = lane_log + sl;  // unusedWords.erase for every word of the accepted walk
+        for (unsigned j = lane; j < n; j += 64) {
+          const unsigned w = unsigned(log[size_t(j >> 2) * 64] >> (16 * (j & 3))) & 0xffffu;
+          wv::atomic_and(&unused_bits[w >> 5], ~(1u << (w & 31)));
+        }
+        wv::sync();
+        continue;
+      }
+      tick(7);
+      // ---- a walk round: the next seed and, beside it, the words most likely to follow it ----
+      unsigned       nL   = stretchSeedList();
+      const unsigned node = (lane < nL) ? unsigned(tent[lane]) : ASM_NONE;
+      unsigned       slot = LG_NO_SLOT;
+      auto findSlots = [&]() {
+        const unsigned mineNode = ((cached >> lane) & 1u) ? unsigned(slotNode[lane]) : unsigned(LG_NO_SLOT);
+        slot                    = LG_NO_SLOT;
+        for (unsigned s = 0; s < 64; ++s) {
+          const unsigned v = wv::readlane(mineNode, int(s));
+          if (v == node && v != LG_NO_SLOT) slot = s;
+        }
+      };
+      findSlots();
+      uint64_t miss = wv::ballot(lane < nL && slot == LG_NO_SLOT);
+#ifdef MANTA_WAVE_EMU
+      if (std::getenv("MANTA_EMU_ROUND_TRACE") && lane == 0) {
+        std::fprintf(stderr, "  walk round (%u cands so far): list of %u, missing %016llx; entries (id:count):", nCand, nL, (unsigned long long)miss);
+        for (unsigned i = 0; i < nL && i < 24; ++i) std::fprintf(stderr, " %u:%u%s", unsigned(tent[i]), R::cnt(nodes[tent[i]]), ((miss >> i) & 1u) ? "*" : "");
+        std::fprintf(stderr, "\n");
+      }
+#endif
+      if (unsigned(wv::popc(~cached)) < unsigned(wv::popc(miss))) {
+        // short of slots: take back those whose seed has been consumed since (such a walk can never be accepted)
+        const unsigned sn   = unsigned(slotNode[lane]);
+        const uint64_t dead = wv::ballot(((cached & ~accAll) >> lane) & 1u && sn != LG_NO_SLOT && !isUnused(sn));
+        if (dead) {
+          if ((dead >> lane) & 1u) slotNode[lane] = uint16_t(LG_NO_SLOT);
+          cached &= ~dead;
+          LG_STAT(5, unsigned(wv::popc(dead)));
+          wv::sync();
+        }
+      }
+      if (cached == ~uint64_t(0)) {
+        // still full (and the next seed has no walk): drop every cached walk that is not an accepted candidate
+        // (making room for the first few missing entries only, at the cost of the cached walks latest in seed order, was tried: fewer
+        // walks, the same number of rounds -- the single-read words' walks it gives up are the ones needed last)
+        if (!((accAll >> lane) & 1u)) slotNode[lane] = uint16_t(LG_NO_SLOT);
+        cached = accAll;
+        LG_STAT(4, 1);
+        wv::sync();
+        findSlots();
+        miss = wv::ballot(lane < nL && slot == LG_NO_SLOT);
+      }
+      // the r-th missing entry takes the r-th free slot; entries past the free slots wait for a later round
+      const uint64_t freeMask = ~cached;
+      const unsigned nFree    = unsigned(wv::popc(freeMask));
+      if ((freeMask >> lane) & 1u) tbl[wv::popc(freeMask & ((uint64_t(1) << lane) - 1))] = uint8_t(lane);
+      wv::sync();
+      const bool     isMiss = (miss >> lane) & 1u;
+      const unsigned rnk    = unsigned(wv::popc(miss & ((uint64_t(1) << lane) - 1)));
+      const bool     take   = isMiss && rnk < nFree;
+      if (take) {
+        slot           = tbl[rnk];
+        slotNode[slot] = uint16_t(node);
+      }
+      uint64_t walkMask = 0;
+      {
+        const unsigned mineSlot = take ? slot : 64u;
+        for (int off = 0; off < 64; ++off) {
+          const unsigned v = wv::readlane(mineSlot, off);
+          if (v < 64) walkMask |= uint64_t(1) << v;
+        }
+      }
+      cached |= walkMask;
+      wv::sync();
+      if (!(miss & 1u) || nFree == 0 || walkMask == 0) return 1;  // (cannot happen: the list's first entry is the word without a walk, and the eviction frees a slot)
+      tick(5);
+      walkSlots(walkMask);
+      tick(6);
     }
     return 0;
   }
@@ -1061,7 +1244,7 @@ struct LdsContig {
     loadPool();
     tick(4);
     anyRep = false;
-    if (contigRounds() != 0) {
+    if ((C::BIG ? contigRoundsStretch() : contigRounds()) != 0) {
       CK_TRACE("contig too long");
       if (C::BIG && lane == 0 && G.stats) wv::atomic_add(&G.stats[7], 1u);
       return CK_PUNT;

@@ -289,7 +289,7 @@ template <class C>
 struct CkMap {
   static const unsigned UNUSED = 64;
   static const unsigned TENT   = UNUSED + 4 * C::UNUSED_DW;
-  static const unsigned SLOTND = TENT + 256;
+  static const unsigned SLOTND = TENT + (C::BIG ? 512 : 256);  // (big class: 256 words looked at per list, stretchSeedList)
   static const unsigned TBL    = SLOTND + 128;
   static const unsigned SIB    = TBL + 64;
   static const unsigned SOVF   = SIB + 8 * LG_SIB_CAP;

@@ -937,7 +937,7 @@ struct LdsGraphL {
         const unsigned minCov = P.opt.minCoverage;
         hdr[LGL_H_TOT + 4] = dbase[254];                                                      // count >= 2
         hdr[LGL_H_TOT + 5] = (minCov <= 1) ? n : ((minCov > 255) ? 0u : dbase[256 - minCov]);   // count >= minCoverage
-        hdr[LGL_H_TOT + 6] = (minCov + 2 > 255) ? 0u : dbase[255 - (minCov + 1)];               // first id with count <= minCoverage + 1
+        hdr[LGL_H_TOT + 6] = (minCov + 4 > 255) ? 0u : dbase[255 - (minCov + 3)];               // first id with count <= minCoverage + 3
       }
       uint16_t* t = src;
       src         = dst;
@@ -1218,14 +1218,18 @@ struct LdsGraphL {
     teamSync();
   }
 
-  /// round 0's walk list (LdsGraph::speculationList): the first seed and beside it the two lowest count tiers in seed order, one
-  /// word per unbranched stretch
-  WV_DEV unsigned speculationList(uint16_t* spec)
+  /// round 0's walk list: the first seed and beside it the words most likely to follow it -- the low count tiers in seed order, ONE WORD
+  /// PER UNBRANCHED STRETCH (the words of a stretch come out of one walk; contig_big_kernel's stretchSeedList makes the later lists the
+  /// same way).  The first contig takes the well-covered words with it; what follows starts a few counts above minCoverage (a pile's
+  /// second seed typically has count 3-4: the window starts at count <= minCoverage + 3) and runs through the count-2 words into the
+  /// single-read ones: 256 words are looked at.  (After lexOrder: the chain arrays lie in the potentials' bytes.)
+  WV_DEV unsigned speculationList(uint16_t* spec, const bool topToo)
   {
-    uint16_t* label = reinterpret_cast<uint16_t*>(lds + LGL_OFF_CHAIN);
-    uint16_t* dist  = label + 128;
-    uint32_t* dupW  = reinterpret_cast<uint32_t*>(dist + 128);  // [4] duplicate bits of the 128 entries
-    const unsigned e0 = lowTier, e1 = (nEligible < lowTier + 128) ? nEligible : (lowTier + 128);
+    static const unsigned WIN = 256;
+    uint16_t* label = reinterpret_cast<uint16_t*>(lds + LGL_OFF_SORTB);
+    uint16_t* dist  = label + WIN;
+    uint32_t* dupW  = reinterpret_cast<uint32_t*>(dist + WIN);  // [WIN / 32] duplicate bits
+    const unsigned e0 = lowTier, e1 = (nEligible < lowTier + WIN) ? nEligible : (lowTier + WIN);
     const unsigned nE = (e1 > e0) ? (e1 - e0) : 0u;
     // a word's only successor / number of predecessors, self loops aside (a word with an overflow entry has three or more)
     auto outOnly = [&](const FRec8 w, const unsigned nd, unsigned& od) -> unsigned {
@@ -1253,60 +1257,67 @@ struct LdsGraphL {
       }
       return id;
     };
-    if (tid() < 4) dupW[tid()] = 0;
-    if (tid() < nE) {
-      unsigned cur = e0 + tid(), steps = 0;
-      while (steps < 192) {
-        unsigned       od;
-        const unsigned nx = outOnly(nodes[cur], cur, od);
-        if (od != 1 || inDeg(nodes[nx], nx) != 1) break;
-        cur = nx;
-        steps++;
+    // one window of the seed order: entries e0 .. e0 + nE, one per stretch, appended to the list up to `quota` entries in all
+    unsigned n0 = (nEligible > 0) ? 1u : 0u;  // (entry 0: the first seed, id 0)
+    auto addWindow = [&](const unsigned w0, const unsigned wN, const unsigned quota) {
+      if (tid() < WIN / 32) dupW[tid()] = 0;
+      if (tid() < wN) {
+        unsigned cur = w0 + tid(), steps = 0;
+        while (steps < 192) {
+          unsigned       od;
+          const unsigned nx = outOnly(nodes[cur], cur, od);
+          if (od != 1 || inDeg(nodes[nx], nx) != 1) break;
+          cur = nx;
+          steps++;
+        }
+        label[tid()] = uint16_t(cur);
+        dist[tid()]  = uint16_t(steps);
       }
-      label[tid()] = uint16_t(cur);
-      dist[tid()]  = uint16_t(steps);
-    }
-    teamSync();
-    if (nE > 0) {
-      unsigned eL[2], eD[2];
-      bool     dup[2] = {false, false};
-      for (unsigned h = 0; h < 2; ++h) {
-        const unsigned i = lane + 64 * h;
-        eL[h]            = (i < nE) ? unsigned(label[i]) : ASM_NONE;
-        eD[h]            = (i < nE) ? unsigned(dist[i]) : 0u;
-      }
-      for (unsigned j = tw; j < nE; j += tn) {
-        const unsigned lj = label[j], dj = dist[j];
-        for (unsigned h = 0; h < 2; ++h)
-          if (j < lane + 64 * h && lj == eL[h] && dj > eD[h]) dup[h] = true;
-      }
-      for (unsigned h = 0; h < 2; ++h) {
-        const uint64_t m = wv::ballot(dup[h]);
-        if (lane == 0 && m) {
-          wv::atomic_or(&dupW[2 * h], uint32_t(m));
-          wv::atomic_or(&dupW[2 * h + 1], uint32_t(m >> 32));
+      teamSync();
+      if (wN > 0) {
+        // entry i is dropped when an earlier entry of its stretch lies upstream of it (that entry's walk comes through here first)
+        unsigned eL[WIN / 64], eD[WIN / 64];
+        bool     dup[WIN / 64];
+        for (unsigned h = 0; h < WIN / 64; ++h) {
+          const unsigned i = lane + 64 * h;
+          eL[h]            = (i < wN) ? unsigned(label[i]) : ASM_NONE;
+          eD[h]            = (i < wN) ? unsigned(dist[i]) : 0u;
+          dup[h]           = false;
+        }
+        for (unsigned j = tw; j < wN; j += tn) {
+          const unsigned lj = label[j], dj = dist[j];
+          for (unsigned h = 0; h < WIN / 64; ++h)
+            if (j < lane + 64 * h && lj == eL[h] && dj > eD[h]) dup[h] = true;
+        }
+        for (unsigned h = 0; h < WIN / 64; ++h) {
+          const uint64_t m = wv::ballot(dup[h]);
+          if (lane == 0 && m) {
+            wv::atomic_or(&dupW[2 * h], uint32_t(m));
+            wv::atomic_or(&dupW[2 * h + 1], uint32_t(m >> 32));
+          }
         }
       }
-    }
-    teamSync();
-    unsigned n0 = 0;
-    if (tw == 0) {
-      if (nEligible > 0) {
-        n0 = 1;
-        for (unsigned h = 0; h < 2; ++h) {
-          const unsigned i    = lane + 64 * h;
-          const bool     dup  = (dupW[2 * h + (lane >> 5)] >> (lane & 31)) & 1u;
-          const bool     keep = (i < nE) && !dup && (e0 + i) != 0u;
-          const uint64_t mk   = wv::ballot(keep);
-          const unsigned pos  = n0 + unsigned(wv::popc(mk & ((uint64_t(1) << lane) - 1)));
-          if (keep && pos < 64) spec[pos] = uint16_t(e0 + i);
-          n0 += unsigned(wv::popc(mk));
-        }
-        if (n0 > 64) n0 = 64;
-        if (lane == 0) spec[0] = 0;  // the first seed: highest count, smallest word = id 0
+      teamSync();
+      for (unsigned h = 0; h < WIN / 64; ++h) {  // (every wave counts, wave 0 writes)
+        const unsigned i    = lane + 64 * h;
+        const bool     dup  = (dupW[2 * h + (lane >> 5)] >> (lane & 31)) & 1u;
+        const bool     keep = (i < wN) && !dup && (w0 + i) != 0u;
+        const uint64_t mk   = wv::ballot(keep);
+        const unsigned pos  = n0 + unsigned(wv::popc(mk & ((uint64_t(1) << lane) - 1)));
+        if (tw == 0 && keep && pos < quota) spec[pos] = uint16_t(w0 + i);
+        n0 += unsigned(wv::popc(mk));
+        if (n0 > quota) n0 = quota;
       }
-      if (lane == 0) hdr[LGL_H_NSPEC] = n0;
+      teamSync();
+    };
+    if (nEligible > 0) {
+      // A graph without a proof of acyclicity is probably cyclic: its first contig ends at the repeat and the next seeds are more of the
+      // well-covered words -- a third of the list goes to the top of the seed order.
+      if (topToo) addWindow(1, (nEligible > 1 + 128) ? 128u : (nEligible - 1), 22);
+      addWindow(e0, nE, 64);
+      if (tid() == 0) spec[0] = 0;  // the first seed: highest count, smallest word = id 0
     }
+    if (tid() == 0) hdr[LGL_H_NSPEC] = n0;
     teamSync();
     return wv::atomic_load(&hdr[LGL_H_NSPEC]);
   }
@@ -1380,7 +1391,7 @@ struct LdsGraphL {
       return false;
     }
     uint16_t*      gSpec = reinterpret_cast<uint16_t*>(slab + SL.spec);
-    const unsigned nSpec = speculationList(gSpec);
+    const unsigned nSpec = speculationList(gSpec, !acyclic);
     tick(2, 6);
     // the rest of the slab
     FRec8* gRec = reinterpret_cast<FRec8*>(slab + SL.recs);
