@@ -733,13 +733,13 @@ struct AsmStage {
       }
       cwsStrideBig = ckWorkspaceLayout(LgL::SETW).total;
       bigRounds    = 0;
-      // The rounds keep a pile with a tandem repeat on the pipeline through all its word lengths: ~15-20 ms of launches per word length
-      // for the whole block instead of ~20 ms of ONE wave of assemble_kernel per locus and word length.  A gain while the device is not
-      // full -- config-5 loci, ms per block with / without: 8 192: 259 / 299 (before the component scan), 16 384: 374 / 443, 32 768: 633 / 672 --
-      // and none once it is (65 536: 1 150 / 1 128: contig_big_kernel holds a CU per cyclic graph, assemble_kernel a sixteenth of one).
-      // Default: on for blocks of up to MANTA_AMD_BIG_ROUNDS_MAX big-class loci; MANTA_AMD_BIG_ROUNDS = 0 / 1 forces them off / on.
+      // The rounds keep a pile with a tandem repeat on the pipeline through all its word lengths: ~15 ms of launches per word length for
+      // the whole block instead of ~20 ms of ONE wave of assemble_kernel per locus and word length.  The gain shrinks as the device fills
+      // (contig_big_kernel holds a CU per cyclic graph, assemble_kernel a sixteenth of one) -- config-5 loci, ms per block with / without
+      // the rounds: 16 384: 342 / 431, 65 536: 1 043 / 1 062 -- so blocks beyond MANTA_AMD_BIG_ROUNDS_MAX big-class loci (not measured)
+      // hand their cyclic graphs to assemble_kernel as before; MANTA_AMD_BIG_ROUNDS = 0 / 1 forces the rounds off / on.
       const char*    re       = std::getenv("MANTA_AMD_BIG_ROUNDS");
-      const uint64_t roundMax = std::getenv("MANTA_AMD_BIG_ROUNDS_MAX") ? std::strtoull(std::getenv("MANTA_AMD_BIG_ROUNDS_MAX"), nullptr, 10) : uint64_t(49152);
+      const uint64_t roundMax = std::getenv("MANTA_AMD_BIG_ROUNDS_MAX") ? std::strtoull(std::getenv("MANTA_AMD_BIG_ROUNDS_MAX"), nullptr, 10) : uint64_t(65536);
       const bool     roundsOn = re ? (std::atoi(re) != 0) : (bigIds.size() <= roundMax);
       if (roundsOn && !bigIds.empty() && opt.max_assembly_count <= 20) {
         for (const uint32_t l : bigIds) {
@@ -747,7 +747,7 @@ struct AsmStage {
           if (hi >= lo) bigRounds = std::max<uint32_t>(bigRounds, (hi - lo) / opt.word_step_size + 1);
         }
         bigRounds     = std::min<uint32_t>(bigRounds, LGL_MAX_ROUNDS);
-        gridRepeat    = rt::roundGrid(int(std::min<uint64_t>(uint64_t(ctx->cuCount) * 16, std::max<uint64_t>(64, bigIds.size() / 4))));
+        gridRepeat    = rt::roundGrid(int(std::min<uint64_t>(uint64_t(ctx->cuCount) * 4 * MANTA_RPB_OCC, std::max<uint64_t>(64, bigIds.size() / 4))));
         rwsStride     = rpbWorkspaceLayout().total;
         pseudoArenaDw = std::max<uint64_t>(uint64_t(4) << 20, uint64_t(bigIds.size()) * 512);  // dwords
       }

@@ -937,7 +937,7 @@ struct LdsGraphL {
         const unsigned minCov = P.opt.minCoverage;
         hdr[LGL_H_TOT + 4] = dbase[254];                                                      // count >= 2
         hdr[LGL_H_TOT + 5] = (minCov <= 1) ? n : ((minCov > 255) ? 0u : dbase[256 - minCov]);   // count >= minCoverage
-        hdr[LGL_H_TOT + 6] = (minCov + 4 > 255) ? 0u : dbase[255 - (minCov + 3)];               // first id with count <= minCoverage + 3
+        hdr[LGL_H_TOT + 6] = (minCov + 4 > 255) ? 0u : dbase[255 - (minCov + 3)];               // first id with count <= minCoverage + 3 (+ 5: the same number of walk rounds)
       }
       uint16_t* t = src;
       src         = dst;

@@ -642,9 +642,14 @@ struct RepeatBig {
   }
 };
 
+// waves per SIMD the register allocator must leave room for (4: 128 VGPRs, 264 of them spilled; 2: 256 VGPRs -- the kernel is a chain of
+// dependent accesses per graph and a round rarely has more graphs than 8 waves per CU take)
+#ifndef MANTA_RPB_OCC
+#define MANTA_RPB_OCC 2
+#endif
 /// persistent wavefronts over graph_big_kernel's list of graphs without a proof (G.cyc_ids / G.cyc_count); P.counter: this launch's own
 /// work counter; P.lds_bytes = RPB_LDS_BYTES per wave; G.rws / G.rws_stride: a workspace per wave
-WV_KERNEL_OCC(4) void repeat_big_kernel(const LgArgs A)
+WV_KERNEL_OCC(MANTA_RPB_OCC) void repeat_big_kernel(const LgArgs A)
 {
   const AsmParams& P     = A.P;
   const LgParams&  G     = A.G;
