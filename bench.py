@@ -551,7 +551,7 @@ def main():
             dom = "assemble_kernel" if os.environ.get("MANTA_AMD_ASM_PATH") == "general" else "assembler_stage"
             dom_bytes, dom_ms, dom_launches = asm_bytes * steps, asm_sum, n_blocks
             dom_note = ("one launch per block" if dom == "assemble_kernel" else
-                        "per block: graph_kernel + contig_kernel (big piles: graph_big_kernel + contig_big_kernel) + assemble_kernel on what they hand back; one HIP-event "
+                        "per block: graph_kernel + contig_kernel (big piles: graph_big_kernel + repeat_big_kernel + contig_big_kernel, one round per word length) + assemble_kernel on what they hand back; one HIP-event "
                         "span, rocprofv3 lists the kernels separately: their averages add up to avg_launch_ms")
         avg_launch_ms = dom_ms / dom_launches
         achieved = (dom_bytes / dom_launches) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0

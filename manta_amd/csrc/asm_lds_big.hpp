@@ -1188,6 +1188,7 @@ struct LdsGraphL {
     }
     teamSync();
   }
+  // (as a real call -- one graph in seven takes it -- the kernel spills more, not less: 144 VGPRs and 1 KB of scratch against 109 / 180 B)
   template <int KW>
   WV_DEV void lexOrder(uint16_t* gLex)
   {
