@@ -47,6 +47,27 @@ def test_digest_files_match_the_restatement_on_a_sample(oracle):
         assert hashlib.sha256(c5_text(text, aligns).encode("latin-1")).digest() == d5[i]
 
 
+def test_emulated_spanning_batch_with_tandem_piles_matches_reference_digests(emu, monkeypatch):
+    """the whole spanning call (per-locus word lengths, assembler + jump aligner) on config-5 loci 0, 1, 37 and 64 against the reference's
+    digests: two of them are tandem-repeat piles whose k-mer graph is cyclic at one / at all four of their word lengths -- the big class'
+    word-length rounds (graph_big -> repeat_big -> contig_big) inside the fused pipeline, two blocks"""
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
+    want = digests("config5_digests.bin")
+    ids = (0, 1, 37, 64)
+    loci = [config5_locus(i) for i in ids]
+    batch = pack_spanning([l[0] for l in loci], [l[1] for l in loci], [l[2] for l in loci], [C5_CUTS] * len(ids))
+    min_wl = np.array([l[3] for l in loci], dtype=np.uint32)
+    max_wl = np.array([l[4] for l in loci], dtype=np.uint32)
+    out = BatchOutput(emu, "spanning", len(ids), 10, 8 << 20, 1 << 20, 2 << 20)
+    emu.spanning_batch(asm_opts(minWordLength=41, minContigLength=75), SPAN_SC, -100, batch, out, min_wl=min_wl, max_wl=max_wl, block_loci=2, n_workers=1)
+    res = out.decode(np.diff(batch[2]))
+    for i, r in zip(ids, res):
+        got = [(a["score"], a["jump_insert_size"], a["jump_range"], a["begin1"], a["cigar1"], a["begin2"], a["cigar2"], a["is_uncut"])
+               for a in r["aligns"]]
+        assert hashlib.sha256(c5_text(assembly_text(r), got).encode("latin-1")).digest() == want[i], i
+        assert r["n_iterations"] == {0: 2, 1: 1, 37: 1, 64: 4}[i] and r["cyclic_iterations"] == {0: 1, 1: 0, 37: 1, 64: 4}[i]
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("asm_path", ["general", "fast"])
@@ -67,8 +88,8 @@ def test_gpu_config2_all_10000_loci_match_reference_digests(gpu, monkeypatch, as
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("asm_path", ["general", "fast"])
 def test_gpu_config5_2048_loci_match_reference_digests(gpu, monkeypatch, asm_path):
-    """fast = the default: the LDS pipeline's big class (graph_big_kernel -> contig_big_kernel) with assemble_kernel on the cyclic piles it
-    hands back; general = assemble_kernel alone"""
+    """fast = the default: the LDS pipeline's big class, one round of graph_big_kernel -> repeat_big_kernel -> contig_big_kernel per word
+    length (the 186 tandem-repeat piles of the set stay on it through up to eleven word lengths); general = assemble_kernel alone"""
     monkeypatch.setenv("MANTA_AMD_ASM_PATH", asm_path)
     want = digests("config5_digests.bin")
     n = len(want)
