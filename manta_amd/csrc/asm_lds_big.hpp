@@ -1219,6 +1219,78 @@ struct LdsGraphL {
     teamSync();
   }
 
+  // ------------------------------------------------------------------------------------------------
+  // A graph without a proof: the two-sided Kahn peel (contig_kernel's cycle test, here by sixteen waves on the records in LDS; self loops
+  // aside as there).  Everything peeled: the graph is acyclic after all.  What is left is the CORE -- every cycle lies inside it -- and
+  // goes to the slab as a bitmap: repeat_big_kernel looks for the strongly connected components among those words only.
+  // (After buildRecords: state bytes in the presence filter's bytes, the queue in the slot table's.)  Returns the size of the core.
+  // ------------------------------------------------------------------------------------------------
+  WV_DEV unsigned peelCore(uint32_t* gCore)
+  {
+    uint32_t*       st    = reinterpret_cast<uint32_t*>(lds + LGL_OFF_CNT);
+    uint16_t*       queue = reinterpret_cast<uint16_t*>(lds + LGL_OFF_SLOTS);
+    const uint16_t* sovf  = reinterpret_cast<const uint16_t*>(lds + LGL_OFF_SOVF);
+    const uint16_t* povf  = reinterpret_cast<const uint16_t*>(lds + LGL_OFF_POVF);
+    const unsigned  nS = wv::atomic_load(&hdr[LGL_H_NSOVF]), nP = wv::atomic_load(&hdr[LGL_H_NPOVF]);
+    const unsigned  n = nNodes, stDw = (n + 3) / 4;
+    for (unsigned w = tid(); w < stDw; w += nThreads()) st[w] = 0;
+    if (tid() == 0) hdr[LGL_H_N] = 0;  // the queue's tail
+    teamSync();
+    for (unsigned nd = tid(); nd < n; nd += nThreads()) {
+      const FRec8    w  = nodes[nd];
+      const uint64_t sl = R::links(w, nd, true, sovf, nS), pl = R::links(w, nd, false, povf, nP);
+      unsigned       id = 0, od = 0;
+      for (unsigned c = 0; c < 4; ++c) {
+        const unsigned s2 = R::linkId(sl, c), p2 = R::linkId(pl, c);
+        if (s2 != ASM_NONE && s2 != nd) od++;
+        if (p2 != ASM_NONE && p2 != nd) id++;
+      }
+      const bool     src = (id == 0 || od == 0);
+      const unsigned v   = id | (od << 3) | (src ? 0x40u : 0u);
+      wv::atomic_or(&st[nd >> 2], v << (8 * (nd & 3)));
+      if (src) queue[wv::atomic_add(&hdr[LGL_H_N], 1u)] = uint16_t(nd);
+    }
+    teamSync();
+    unsigned head = 0;
+    while (true) {
+      const unsigned tail = wv::atomic_load(&hdr[LGL_H_N]);
+      teamSync();  // (every wave has read the tail before any of them appends to the queue again)
+      if (tail == head) break;
+      for (unsigned i = head + tid(); i < tail; i += nThreads()) {
+        const unsigned nd = queue[i];
+        const FRec8    w  = nodes[nd];
+        const uint64_t sl = R::links(w, nd, true, sovf, nS), pl = R::links(w, nd, false, povf, nP);
+        for (unsigned c = 0; c < 4; ++c) {
+          const unsigned s2 = R::linkId(sl, c);
+          if (s2 != ASM_NONE && s2 != nd) {
+            const unsigned sh  = 8 * (s2 & 3);
+            const unsigned old = wv::atomic_sub(&st[s2 >> 2], 1u << sh) >> sh;
+            if ((old & 0x7u) == 1u && !(wv::atomic_or(&st[s2 >> 2], 0x40u << sh) & (0x40u << sh))) queue[wv::atomic_add(&hdr[LGL_H_N], 1u)] = uint16_t(s2);
+          }
+          const unsigned p2 = R::linkId(pl, c);
+          if (p2 != ASM_NONE && p2 != nd) {
+            const unsigned sh  = 8 * (p2 & 3);
+            const unsigned old = wv::atomic_sub(&st[p2 >> 2], 8u << sh) >> sh;
+            if ((old & 0x38u) == 8u && !(wv::atomic_or(&st[p2 >> 2], 0x40u << sh) & (0x40u << sh))) queue[wv::atomic_add(&hdr[LGL_H_N], 1u)] = uint16_t(p2);
+          }
+        }
+      }
+      teamSync();
+      head = tail;
+    }
+    const unsigned nCore = n - head;
+    for (unsigned d = tid(); d < LgL::UNUSED_DW; d += nThreads()) {
+      uint32_t b = 0;
+      for (unsigned j = 0; j < 32 && nCore; ++j) {
+        const unsigned nd = 32 * d + j;
+        if (nd < n && !((st[nd >> 2] >> (8 * (nd & 3))) & 0x40u)) b |= 1u << j;
+      }
+      gCore[d] = b;
+    }
+    teamSync();
+    return nCore;
+  }
+
   /// round 0's walk list: the first seed and beside it the words most likely to follow it -- the low count tiers in seed order, ONE WORD
   /// PER UNBRANCHED STRETCH (the words of a stretch come out of one walk; contig_big_kernel's stretchSeedList makes the later lists the
   /// same way).  The first contig takes the well-covered words with it; what follows starts a few counts above minCoverage (a pile's
@@ -1377,9 +1449,15 @@ struct LdsGraphL {
       why(4);
       return false;
     }
-    const bool     acyclic = wv::atomic_load(&hdr[LGL_H_CYC]) == 0 && !(G.flags & LG_FLAG_NO_PROOF);
+    bool           acyclic = wv::atomic_load(&hdr[LGL_H_CYC]) == 0 && !(G.flags & LG_FLAG_NO_PROOF);
     if (acyclic && tid() == 0 && G.stats) wv::atomic_add(&G.stats[0], 1u);
-    // with the word-length rounds on, a graph without a proof goes to repeat_big_kernel first (peel, repeat search, LDS class)
+    // With the word-length rounds on, a graph without a proof is peeled here; if something is left it goes to repeat_big_kernel first
+    // (components, repeat search, LDS class), with the words' lexicographic ranks and the core's bitmap in its slab.
+    unsigned       nCorePeel = 0;
+    if (!acyclic && G.iter != nullptr) {
+      nCorePeel = peelCore(reinterpret_cast<uint32_t*>(slab + SL.flags));
+      if (nCorePeel == 0) acyclic = true;  // (no proof from the reads' offsets, but nothing survives the peel)
+    }
     const bool     toRepeat = !acyclic && G.iter != nullptr;
     if (toRepeat) lexOrder<KW>(reinterpret_cast<uint16_t*>(slab + SL.lex));
     const unsigned need    = ckNeedOf<LgL>(nNodes, nFat, acyclic);
@@ -1423,7 +1501,7 @@ struct LdsGraphL {
       h.acyclic   = acyclic ? 1u : 0u;
       h.nPseudo   = nPseudo;
       h.cyclic    = 0;
-      h.nCore     = 0;
+      h.nCore     = nCorePeel;  // (repeat_big_kernel: the peel's core; it leaves the number of words on cycles here)
       *reinterpret_cast<LgHdr*>(slab) = h;
       G.slab_off[locus]               = off;
       if (toRepeat)

@@ -1,14 +1,15 @@
 // repeat_big_kernel: between graph_big_kernel and contig_big_kernel, for the big-class loci whose graph came WITHOUT a proof of
-// acyclicity (a handful per thousand -- but every pile with a tandem repeat, at most of its word lengths).  One wavefront per locus,
+// acyclicity that its peel could not empty (every pile with a tandem repeat, at most of its word lengths).  One wavefront per locus,
 // the compact graph read from the locus' slab, a per-wave workspace in device memory, 8 KB of LDS:
 //
-//   1. two-sided Kahn peel (as contig_kernel's cycle test): acyclic after all -> the slab says so, done.  What the peel cannot remove
-//      is the CORE: the only words a walk can meet twice (asm_contig.hpp keeps a visited bitmap over them).
-//   2. cyclic: the reference's repeat search (IterativeAssembler.cpp:555-642) EXACTLY -- its visiting order is the iteration order of
-//      a std::unordered_map, and which circles count as small (:612) depends on it.  Same construction as repeat_exact.hpp
-//      (insertion sequence -> std::hash -> libstdc++ node order, twice -> Tarjan with whole unbranched runs per step), on the
-//      compact graph: the words are renumbered by FIRST OCCURRENCE so that an unbranched stretch has consecutive numbers again
-//      (the ids of the slab are in seed order), the lexicographic ranks inside a read's group come from graph_big_kernel.
+//   1. the strongly connected components, in any order and only among the words graph_big_kernel's two-sided peel left (every cycle lies
+//      in that core; a graph the peel empties never comes here): which words lie on a cycle -- the only ones a walk can meet twice
+//      (asm_contig.hpp keeps a visited bitmap over them) -- and how large the smallest component is.
+//   2. only a component of at most 51 words can pass the reference's small-circle rule (IterativeAssembler.cpp:612), and only then does the
+//      visiting order matter: the reference's repeat search (:555-642) EXACTLY -- its order is the iteration order of a std::unordered_map.
+//      Same construction as repeat_exact.hpp (insertion sequence -> std::hash -> libstdc++ node order, twice -> Tarjan with whole
+//      unbranched runs per step), on the compact graph: the words are renumbered by FIRST OCCURRENCE so that an unbranched stretch has
+//      consecutive numbers again (the ids of the slab are in seed order), the lexicographic ranks inside a read's group come from graph_big_kernel.
 //   3. core and repeat-word bitmaps into the slab, the locus into contig_big_kernel's LDS class list (the class depends on the core's size).
 #pragma once
 #include "asm_lds.hpp"
@@ -18,7 +19,7 @@ namespace manta_dev {
 static const unsigned RPB_LDS_BYTES = 8192;  ///< per wave: peel state (a byte per word), then the first-occurrence bitmap (65 536 bits)
 
 struct RpbWs {
-  uint64_t h, ins, seqB, pool, vOf, idOf, succ4, flagV, firstRd, byLex, queue, prefix, rdBase, total;
+  uint64_t h, ins, seqB, pool, vOf, idOf, succ4, flagV, firstRd, byLex, queue, prefix, rdBase, coreV, total;
 };
 WV_HD RpbWs rpbWorkspaceLayout()
 {
@@ -38,6 +39,7 @@ WV_HD RpbWs rpbWorkspaceLayout()
   L.queue   = asmPut(o, 4 * (C + 64));
   L.prefix  = asmPut(o, 4 * 2048);
   L.rdBase  = asmPut(o, 4 * 320);
+  L.coreV   = asmPut(o, 4 * C);
   L.total   = (o + 255) & ~uint64_t(255);
   return L;
 }
@@ -108,7 +110,7 @@ struct RepeatBig {
   }
   // the per-wave workspace
   uint64_t* h;
-  uint32_t *ins, *seqB, *pool, *vOf, *idOf, *succ4, *flagV, *firstRd, *byLex, *prefix, *rdBase, *sccV;
+  uint32_t *ins, *seqB, *pool, *vOf, *idOf, *succ4, *flagV, *firstRd, *byLex, *prefix, *rdBase, *sccV, *coreV;
   WV_DEV void bind(const RpbWs& L)
   {
     h       = reinterpret_cast<uint64_t*>(ws + L.h);
@@ -124,6 +126,7 @@ struct RepeatBig {
     prefix  = reinterpret_cast<uint32_t*>(ws + L.prefix);
     rdBase  = reinterpret_cast<uint32_t*>(ws + L.rdBase);
     sccV    = reinterpret_cast<uint32_t*>(ws + L.queue);
+    coreV   = reinterpret_cast<uint32_t*>(ws + L.coreV);
   }
   WV_DEV uint64_t succOf(const unsigned nd, const FRec8 w) const { return R::links(w, nd, true, gSovf, nSovf); }
   WV_DEV uint64_t predOf(const unsigned nd, const FRec8 w) const { return R::links(w, nd, false, gPovf, nPovf); }
@@ -175,6 +178,7 @@ struct RepeatBig {
       }
       flagV[v] = 0;
       sccV[v]  = 0;
+      coreV[v] = (gFlags[id >> 5] >> (id & 31)) & 1u;  // graph_big_kernel's peel left the word
     }
     wv::sync();
     wv::fence_acquire();
@@ -277,8 +281,8 @@ struct RepeatBig {
   }
 
   /// The search (:555-625), successors in alphabet order; see repeat_exact.hpp for the run arithmetic.  roots == nullptr: roots in
-  /// numbering order -- the strongly connected components do not depend on the order, so this pass tells whether the graph is cyclic at
-  /// all, marks the words that lie on a cycle (sccV: the only ones a walk can meet twice) and finds the smallest component: only a
+  /// numbering order and only inside the core graph_big_kernel's peel left (every cycle lies in it) -- the strongly connected components
+  /// do not depend on the order, so this pass marks the words that lie on a cycle (sccV: the only ones a walk can meet twice) and finds the smallest component: only a
   /// component of at most 51 words can pass the reference's small-circle test (:612: index span <= 50), and only then does the order
   /// matter.  roots != nullptr: the reference's order; flagV[v] != 0 <=> word v is a repeat word.  Returns the smallest component's size.
   WV_DEV unsigned search(const uint32_t* roots)
@@ -303,6 +307,7 @@ struct RepeatBig {
           const unsigned sx = succ4[4 * nd + c];
           if (sx == ASM_NONE) continue;
           if (sx == nd) self = true;
+          if (!exact && sx != nd && !coreV[sx]) continue;  // (the component scan stays inside the core)
           only = sx;
           ++cnt;
         }
@@ -322,7 +327,7 @@ struct RepeatBig {
           while (rootCursor < n) {
             const unsigned ri = rootCursor + lane;
             const unsigned r  = (ri < n) ? (exact ? roots[ri] : ri) : 0u;
-            const bool     un = (ri < n) && (idxA[r] == 0);
+            const bool     un = (ri < n) && (idxA[r] == 0) && (exact || coreV[r] != 0);
             const uint64_t m  = wv::ballot(un);
             if (m) {
               const int l = wv::ctz(m);
@@ -491,6 +496,7 @@ struct RepeatBig {
                 continue;
               }
               if (sx == ASM_NONE) continue;
+              if (!exact && !coreV[sx]) continue;
               if (idxA[sx] == 0) {
                 if (runNext[sx] != ASM_NONE) {
                   req  = REQ_DESCEND;
