@@ -79,6 +79,134 @@ WV_DEV uint64_t rpbWordHash(const uint32_t* codes, const unsigned pb, const unsi
   return hash;
 }
 
+/// unorderedOrderWave (repeat_exact.hpp) for this kernel, built for latency: one wave, arrays in device memory, so a pass is a chain of
+/// dependent round trips per element -- here every lane carries FOUR elements through a pass (four loads / atomics in flight), and the two
+/// passes over the buckets (run lengths, emission) became passes over the elements: an element finds its bucket's first time and its own rank
+/// in the bucket (members with a later time) by walking the bucket's chain, 1-2 links on average.  chain[t] = {next time : 16 (0xffff:
+/// none), bucket : 16}.  Same result as unorderedOrderWave: buckets by first time, latest first; inside a bucket by time, latest first.
+WV_DEV uint32_t* unorderedOrderWave4(
+    const AsmParams& P, const uint64_t* h, const uint32_t* ins, uint32_t* a, uint32_t* b, uint32_t* chain, uint32_t* offs, uint32_t* bf,
+    uint32_t* bh, const unsigned n)
+{
+  const uint32_t NIL   = 0xffffffffu;
+  const unsigned NIL16 = 0xffffu;
+  const unsigned lane  = unsigned(wv::lane());
+  uint32_t*      cur   = a;
+  uint32_t*      out   = b;
+  unsigned       m0    = 0;
+  unsigned       sched = 0;
+  unsigned       nb    = 1;
+  while (m0 < n) {
+    while (sched < P.n_growth && P.growth_size[sched] <= m0) nb = P.growth_buckets[sched++];
+    unsigned m1 = n;
+    if (sched < P.n_growth && P.growth_size[sched] < m1) m1 = P.growth_size[sched];
+    for (unsigned i = lane; i < nb; i += 64) {
+      bf[i] = NIL;
+      bh[i] = NIL;
+    }
+    wv::sync();
+    // A. every element into its bucket's chain; the bucket's first time
+    for (unsigned t0 = lane; t0 < m1; t0 += 256) {
+      unsigned tt[4], bk[4];
+      uint32_t node[4], old[4];
+      uint64_t hv[4];
+      bool     ok[4];
+      for (unsigned u = 0; u < 4; ++u) {
+        tt[u]   = t0 + 64 * u;
+        ok[u]   = tt[u] < m1;
+        node[u] = ok[u] ? ((tt[u] < m0) ? cur[tt[u]] : ins[tt[u]]) : 0u;
+      }
+      for (unsigned u = 0; u < 4; ++u) hv[u] = ok[u] ? h[node[u]] : uint64_t(0);
+      for (unsigned u = 0; u < 4; ++u)
+        if (ok[u] && tt[u] >= m0) cur[tt[u]] = node[u];
+      for (unsigned u = 0; u < 4; ++u) bk[u] = unsigned(hv[u] % nb);
+      for (unsigned u = 0; u < 4; ++u) old[u] = ok[u] ? wv::atomic_exch(&bh[bk[u]], tt[u]) : NIL;
+      for (unsigned u = 0; u < 4; ++u)
+        if (ok[u]) wv::atomic_min(&bf[bk[u]], tt[u]);
+      for (unsigned u = 0; u < 4; ++u)
+        if (ok[u]) chain[tt[u]] = (old[u] & 0xffffu) | (bk[u] << 16);
+    }
+    wv::sync();
+    wv::fence_acquire();
+    // B. run lengths at the buckets' first times
+    for (unsigned t0 = lane; t0 < m1; t0 += 256) {
+      unsigned tt[4], x[4], cnt[4];
+      bool     ok[4], isFirst[4];
+      for (unsigned u = 0; u < 4; ++u) {
+        tt[u] = t0 + 64 * u;
+        ok[u] = tt[u] < m1;
+      }
+      for (unsigned u = 0; u < 4; ++u) {
+        const unsigned bkt   = ok[u] ? (chain[tt[u]] >> 16) : 0u;
+        const uint32_t first = ok[u] ? wv::atomic_load(&bf[bkt]) : NIL;
+        isFirst[u]           = ok[u] && first == tt[u];
+        x[u]                 = isFirst[u] ? (wv::atomic_load(&bh[bkt]) & 0xffffu) : NIL16;
+        cnt[u]               = 0;
+      }
+      while (x[0] != NIL16 || x[1] != NIL16 || x[2] != NIL16 || x[3] != NIL16) {
+        for (unsigned u = 0; u < 4; ++u)
+          if (x[u] != NIL16) {
+            cnt[u]++;
+            x[u] = chain[x[u]] & 0xffffu;
+          }
+      }
+      for (unsigned u = 0; u < 4; ++u)
+        if (ok[u]) offs[tt[u]] = isFirst[u] ? cnt[u] : 0u;
+    }
+    wv::sync();
+    // exclusive suffix sum over time, top chunk first (as unorderedOrderWave)
+    {
+      unsigned carry = 0;
+      for (unsigned top = ((m1 + 63) / 64) * 64; top > 0; top -= 64) {
+        const unsigned t   = top - 64 + (63 - lane);
+        const unsigned w   = (t < m1) ? offs[t] : 0u;
+        unsigned       inc = w;
+        for (int off = 1; off < 64; off <<= 1) {
+          const unsigned o = wv::shfl(inc, int(lane) - off);
+          if (int(lane) >= off) inc += o;
+        }
+        if (t < m1) offs[t] = carry + inc - w;
+        carry += wv::shfl(inc, 63);
+      }
+    }
+    wv::sync();
+    // C. every element to its place: its bucket's run starts at offs[first time], inside the run latest time first
+    for (unsigned t0 = lane; t0 < m1; t0 += 256) {
+      unsigned tt[4], x[4], rank[4], base[4];
+      uint32_t node[4];
+      bool     ok[4];
+      for (unsigned u = 0; u < 4; ++u) {
+        tt[u] = t0 + 64 * u;
+        ok[u] = tt[u] < m1;
+      }
+      for (unsigned u = 0; u < 4; ++u) {
+        const unsigned bkt   = ok[u] ? (chain[tt[u]] >> 16) : 0u;
+        const uint32_t first = ok[u] ? wv::atomic_load(&bf[bkt]) : 0u;
+        base[u]              = ok[u] ? offs[first] : 0u;
+        x[u]                 = ok[u] ? (wv::atomic_load(&bh[bkt]) & 0xffffu) : NIL16;
+        node[u]              = ok[u] ? cur[tt[u]] : 0u;
+        rank[u]              = 0;
+      }
+      while (x[0] != NIL16 || x[1] != NIL16 || x[2] != NIL16 || x[3] != NIL16) {
+        for (unsigned u = 0; u < 4; ++u)
+          if (x[u] != NIL16) {
+            if (x[u] > tt[u]) rank[u]++;
+            x[u] = chain[x[u]] & 0xffffu;
+          }
+      }
+      for (unsigned u = 0; u < 4; ++u)
+        if (ok[u]) out[base[u] + rank[u]] = node[u];
+    }
+    wv::sync();
+    wv::fence_acquire();
+    uint32_t* tmpPtr = cur;
+    cur              = out;
+    out              = tmpPtr;
+    m0               = m1;
+  }
+  return cur;
+}
+
 struct RepeatBig {
   typedef LgRec<LgL>  R;
   typedef FSetT<LgL>  Set;
@@ -265,10 +393,10 @@ struct RepeatBig {
       uint32_t*      bf    = pool + 3 * size_t(C);
       uint32_t*      bh    = bf + nbCap;
       uint32_t*      seqA  = byLex;  // (the lexicographic list is done with)
-      uint32_t* order1 = unorderedOrderWave(P, h, ins, seqB, spare, chain, offs, bf, bh, n);
+      uint32_t* order1 = unorderedOrderWave4(P, h, ins, seqB, spare, chain, offs, bf, bh, n);
       tick(3);
       uint32_t* s1     = (order1 == seqB) ? spare : seqB;
-      uint32_t* order2 = unorderedOrderWave(P, h, order1, seqA, s1, chain, offs, bf, bh, n);
+      uint32_t* order2 = unorderedOrderWave4(P, h, order1, seqA, s1, chain, offs, bf, bh, n);
       if (order2 != seqA && order2 != seqB) {  // the search below reuses the pool: park the root order where it survives
         for (unsigned i = lane; i < n; i += 64) seqB[i] = order2[i];
         wv::sync();
