@@ -310,4 +310,20 @@ WV_KERNEL_OCC(E >= 6 ? 4 : 1) void align_jump_pair_kernel(const AlignParams P)
   }
 }
 
+#if MANTA_TU != MANTA_TU_ALL
+#if MANTA_TU == MANTA_TU_JUMP_PAIR
+#define MANTA_X
+#else
+#define MANTA_X extern
+#endif
+MANTA_X template __global__ void align_jump_pair_kernel<1>(const AlignParams);
+MANTA_X template __global__ void align_jump_pair_kernel<2>(const AlignParams);
+MANTA_X template __global__ void align_jump_pair_kernel<3>(const AlignParams);
+MANTA_X template __global__ void align_jump_pair_kernel<4>(const AlignParams);
+MANTA_X template __global__ void align_jump_pair_kernel<5>(const AlignParams);
+MANTA_X template __global__ void align_jump_pair_kernel<6>(const AlignParams);
+MANTA_X template __global__ void align_jump_pair_kernel<8>(const AlignParams);
+#undef MANTA_X
+#endif
+
 }  // namespace manta_dev

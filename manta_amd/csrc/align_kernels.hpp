@@ -818,4 +818,31 @@ WV_KERNEL_OCC(E == 8 ? 4 : 1) void align_kernel(const AlignParams P)
   }
 }
 
+#if MANTA_TU != MANTA_TU_ALL
+// one translation unit per aligner kind (wave.hpp: MANTA_TU); E = the bucket widths of api.cpp's kESet
+#define MANTA_ALIGN_INST(X, KIND) \
+  X template __global__ void align_kernel<KIND, 1>(const AlignParams);  X template __global__ void align_kernel<KIND, 2>(const AlignParams);  \
+  X template __global__ void align_kernel<KIND, 3>(const AlignParams);  X template __global__ void align_kernel<KIND, 4>(const AlignParams);  \
+  X template __global__ void align_kernel<KIND, 5>(const AlignParams);  X template __global__ void align_kernel<KIND, 6>(const AlignParams);  \
+  X template __global__ void align_kernel<KIND, 8>(const AlignParams);  X template __global__ void align_kernel<KIND, 10>(const AlignParams); \
+  X template __global__ void align_kernel<KIND, 12>(const AlignParams); X template __global__ void align_kernel<KIND, 16>(const AlignParams); \
+  X template __global__ void align_kernel<KIND, 24>(const AlignParams); X template __global__ void align_kernel<KIND, 32>(const AlignParams);
+#if MANTA_TU == MANTA_TU_ALIGN0
+MANTA_ALIGN_INST(, 0)
+#else
+MANTA_ALIGN_INST(extern, 0)
+#endif
+#if MANTA_TU == MANTA_TU_ALIGN1
+MANTA_ALIGN_INST(, 1)
+#else
+MANTA_ALIGN_INST(extern, 1)
+#endif
+#if MANTA_TU == MANTA_TU_ALIGN2
+MANTA_ALIGN_INST(, 2)
+#else
+MANTA_ALIGN_INST(extern, 2)
+#endif
+#undef MANTA_ALIGN_INST
+#endif
+
 }  // namespace manta_dev

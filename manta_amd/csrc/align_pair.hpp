@@ -321,6 +321,9 @@ WV_DEV void runPairWidth(const AlignParams& A, const unsigned ta, const unsigned
   PairAligner<E>(A).run(A.tasks[ta], A.tasks[tb], A.results[ta], A.results[tb], haveB, slab);
 }
 
+#if !MANTA_TU_DEFINES(MANTA_TU_ALIGN_PAIR)
+WV_KERNEL_OCC(4) void align_pair_multi_kernel(const PairMultiParams M);
+#else
 WV_KERNEL_OCC(4) void align_pair_multi_kernel(const PairMultiParams M)
 {
   uint8_t* slab = M.A.ptr_ws + uint64_t(wv::block()) * M.A.ptr_ws_stride;
@@ -368,5 +371,21 @@ WV_KERNEL_OCC(4) void align_pair_multi_kernel(const PairMultiParams M)
     wv::sync();
   }
 }
+#endif
+
+#if MANTA_TU != MANTA_TU_ALL
+#if MANTA_TU == MANTA_TU_ALIGN_PAIR
+#define MANTA_X
+#else
+#define MANTA_X extern
+#endif
+MANTA_X template __global__ void align_pair_kernel<1>(const AlignParams);
+MANTA_X template __global__ void align_pair_kernel<2>(const AlignParams);
+MANTA_X template __global__ void align_pair_kernel<3>(const AlignParams);
+MANTA_X template __global__ void align_pair_kernel<4>(const AlignParams);
+MANTA_X template __global__ void align_pair_kernel<5>(const AlignParams);
+MANTA_X template __global__ void align_pair_kernel<6>(const AlignParams);
+#undef MANTA_X
+#endif
 
 }  // namespace manta_dev

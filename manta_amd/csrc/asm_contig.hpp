@@ -1317,15 +1317,23 @@ WV_DEV void contigKernelBody(const LgArgs& A)
     wv::sync();
   }
 }
+#if !MANTA_TU_DEFINES(MANTA_TU_CONTIG)
+WV_KERNEL_SINGLE WV_WAVES_PER_SIMD(2) void contig_kernel(const LgArgs A);
+#else
 WV_KERNEL_SINGLE WV_WAVES_PER_SIMD(2) void contig_kernel(const LgArgs A)
 {
   contigKernelBody<LgS>(A);
 }
+#endif
 /// the big class (asm_lds_big.hpp): read sets of four qwords, 13-bit ids; one or two loci per CU
+#if !MANTA_TU_DEFINES(MANTA_TU_CONTIG)
+WV_KERNEL_SINGLE WV_WAVES_PER_SIMD(1) void contig_big_kernel(const LgArgs A);
+#else
 WV_KERNEL_SINGLE WV_WAVES_PER_SIMD(1) void contig_big_kernel(const LgArgs A)
 {
   contigKernelBody<LgL>(A);
 }
+#endif
 
 }  // namespace manta_dev
 

@@ -1597,6 +1597,18 @@ WV_KERNEL_WG(LG_WAVES) WV_WAVES_PER_SIMD(MANTA_LG_WAVES_PER_SIMD) void graph_ker
   }
 }
 
+#if MANTA_TU != MANTA_TU_ALL
+#if MANTA_TU == MANTA_TU_GRAPH
+#define MANTA_X
+#else
+#define MANTA_X extern
+#endif
+MANTA_X template __global__ void graph_kernel<2>(const LgArgs);
+MANTA_X template __global__ void graph_kernel<4>(const LgArgs);
+MANTA_X template __global__ void graph_kernel<8>(const LgArgs);
+#undef MANTA_X
+#endif
+
 }  // namespace manta_dev
 
 #include "asm_contig.hpp"

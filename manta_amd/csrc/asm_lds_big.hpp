@@ -1583,4 +1583,15 @@ WV_KERNEL_WG(LGL_WAVES) WV_WAVES_PER_SIMD(4) void graph_big_kernel(const LgArgs 
   }
 }
 
+#if MANTA_TU != MANTA_TU_ALL
+#if MANTA_TU == MANTA_TU_GRAPH_BIG
+#define MANTA_X
+#else
+#define MANTA_X extern
+#endif
+MANTA_X template __global__ void graph_big_kernel<5>(const LgArgs);
+MANTA_X template __global__ void graph_big_kernel<8>(const LgArgs);
+#undef MANTA_X
+#endif
+
 }  // namespace manta_dev

@@ -783,6 +783,9 @@ struct RepeatBig {
 #endif
 /// persistent wavefronts over graph_big_kernel's list of graphs without a proof (G.cyc_ids / G.cyc_count); P.counter: this launch's own
 /// work counter; P.lds_bytes = RPB_LDS_BYTES per wave; G.rws / G.rws_stride: a workspace per wave
+#if !MANTA_TU_DEFINES(MANTA_TU_REPEAT)
+WV_KERNEL_OCC(MANTA_RPB_OCC) void repeat_big_kernel(const LgArgs A);
+#else
 WV_KERNEL_OCC(MANTA_RPB_OCC) void repeat_big_kernel(const LgArgs A)
 {
   const AsmParams& P     = A.P;
@@ -806,5 +809,6 @@ WV_KERNEL_OCC(MANTA_RPB_OCC) void repeat_big_kernel(const LgArgs A)
     wv::sync();
   }
 }
+#endif
 
 }  // namespace manta_dev

@@ -1773,6 +1773,9 @@ WV_DEV bool asmWaitUploaded(const AsmParams& P, const unsigned locus)
 #ifndef MANTA_ASM_OCC
 #define MANTA_ASM_OCC 4
 #endif
+#if !MANTA_TU_DEFINES(MANTA_TU_ASM)
+WV_KERNEL_OCC(MANTA_ASM_OCC) void assemble_kernel(const AsmParams P);
+#else
 WV_KERNEL_OCC(MANTA_ASM_OCC) void assemble_kernel(const AsmParams P)
 {
   uint8_t* wsBase = P.ws + uint64_t(wv::block()) * P.ws_stride;
@@ -1801,11 +1804,15 @@ WV_KERNEL_OCC(MANTA_ASM_OCC) void assemble_kernel(const AsmParams P)
     wv::sync();
   }
 }
+#endif
 
 #ifndef MANTA_DEV_NO_GENERIC  // (developer variants of the library leave the byte-generic kernel out: it is most of the compile time)
 /// the byte-generic form (AssemblerT<8>) for the loci assemble_kernel reports ASM_E_ALPHABET for: same launch contract; the
 /// workspace capacities count code dwords of 4 symbols.  Rare by construction (a byte outside {A,C,G,T,N} that cannot be
 /// masked exactly), so this kernel is about being right, not fast.
+#if !MANTA_TU_DEFINES(MANTA_TU_ASM_GENERIC)
+WV_KERNEL_OCC(MANTA_ASM_OCC) void assemble_generic_kernel(const AsmParams P);
+#else
 WV_KERNEL_OCC(MANTA_ASM_OCC) void assemble_generic_kernel(const AsmParams P)
 {
   uint8_t*       wsBase = P.ws + uint64_t(wv::block()) * P.ws_stride;
@@ -1831,6 +1838,7 @@ WV_KERNEL_OCC(MANTA_ASM_OCC) void assemble_generic_kernel(const AsmParams P)
     wv::sync();
   }
 }
+#endif
 #endif
 
 }  // namespace manta_dev

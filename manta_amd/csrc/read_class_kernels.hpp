@@ -700,6 +700,9 @@ struct ReadClass {
 };
 
 /// record-parallel: the per-record tests of every record of the batch (a wave per 64 records of one query)
+#if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
+WV_KERNEL void read_test_kernel(const ReadClassParams P);
+#else
 WV_KERNEL void read_test_kernel(const ReadClassParams P)
 {
   ReadClass rc(P);
@@ -714,8 +717,12 @@ WV_KERNEL void read_test_kernel(const ReadClassParams P)
     wv::sync();
   }
 }
+#endif
 
 /// persistent waves: one candidate at a time
+#if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
+WV_KERNEL void read_class_kernel(const ReadClassParams P);
+#else
 WV_KERNEL void read_class_kernel(const ReadClassParams P)
 {
   uint32_t* wsBase = P.ws + uint64_t(wv::block()) * P.ws_stride;
@@ -729,8 +736,12 @@ WV_KERNEL void read_class_kernel(const ReadClassParams P)
     wv::sync();
   }
 }
+#endif
 
 /// one wave: exclusive scans of the per-candidate totals (pile reads, code dwords, mask dwords)
+#if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
+WV_KERNEL void read_pile_offsets_kernel(const ReadClassParams P);
+#else
 WV_KERNEL void read_pile_offsets_kernel(const ReadClassParams P)
 {
   if (wv::block() != 0) return;
@@ -757,7 +768,11 @@ WV_KERNEL void read_pile_offsets_kernel(const ReadClassParams P)
     P.read_mask_off[run[0]]      = run[2];
   }
 }
+#endif
 
+#if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
+WV_KERNEL void read_pile_pack_kernel(const ReadClassParams P);
+#else
 WV_KERNEL void read_pile_pack_kernel(const ReadClassParams P)
 {
   ReadClass rc(P);
@@ -770,8 +785,12 @@ WV_KERNEL void read_pile_pack_kernel(const ReadClassParams P)
     wv::sync();
   }
 }
+#endif
 
 /// pile-read-parallel: eight reads per wave step
+#if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
+WV_KERNEL void read_pile_bases_kernel(const ReadClassParams P);
+#else
 WV_KERNEL void read_pile_bases_kernel(const ReadClassParams P)
 {
   ReadClass                rc(P);
@@ -785,5 +804,6 @@ WV_KERNEL void read_pile_bases_kernel(const ReadClassParams P)
     wv::sync();
   }
 }
+#endif
 
 }  // namespace manta_dev

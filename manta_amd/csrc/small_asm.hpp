@@ -441,6 +441,9 @@ struct SmallAsm {
 };
 
 /// persistent waves over the pile queue, as assemble_kernel; P.opt.maxAssemblyCount = maxAssemblyIterations + 1 record slots
+#if !MANTA_TU_DEFINES(MANTA_TU_ASM)
+WV_KERNEL void small_assemble_kernel(const AsmParams P);
+#else
 WV_KERNEL void small_assemble_kernel(const AsmParams P)
 {
   uint8_t* wsBase = P.ws + uint64_t(wv::block()) * P.ws_stride;
@@ -456,5 +459,6 @@ WV_KERNEL void small_assemble_kernel(const AsmParams P)
     wv::sync();
   }
 }
+#endif
 
 }  // namespace manta_dev

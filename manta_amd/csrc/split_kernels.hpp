@@ -173,6 +173,9 @@ WV_DEV void splitReadTask(const SplitParams& P, const unsigned t)
   if (lane == 0) P.results[t] = R;
 }
 
+#if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
+WV_KERNEL void split_read_kernel(const SplitParams P);
+#else
 WV_KERNEL void split_read_kernel(const SplitParams P)
 {
   while (true) {
@@ -184,5 +187,6 @@ WV_KERNEL void split_read_kernel(const SplitParams P)
     wv::sync();
   }
 }
+#endif
 
 }  // namespace manta_dev

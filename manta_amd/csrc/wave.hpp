@@ -6,6 +6,32 @@
 #pragma once
 #include <cstdint>
 
+// Translation units of the product library.  manta_amd/build.py compiles csrc/kernels_tu.cpp once per kernel family (-DMANTA_TU=<id>: that
+// family's kernels are DEFINED, device code and host stubs) and the host sources with MANTA_TU_HOST (every kernel only DECLARED: a kernel's
+// handle is an ordinary external symbol), all in parallel; editing host code no longer recompiles ~70 kernel instantiations.  A TU built
+// without MANTA_TU (the wave-emulator build of tests/emu, the profile variants) defines everything, as the single-TU build did.
+#define MANTA_TU_ALL 0
+#define MANTA_TU_HOST 1
+#define MANTA_TU_ASM 2          // assemble_kernel, small_assemble_kernel
+#define MANTA_TU_ASM_GENERIC 3  // assemble_generic_kernel
+#define MANTA_TU_GRAPH 4        // graph_kernel<2 / 4 / 8>
+#define MANTA_TU_GRAPH_BIG 5    // graph_big_kernel<5 / 8>
+#define MANTA_TU_CONTIG 6       // contig_kernel, contig_big_kernel
+#define MANTA_TU_REPEAT 7       // repeat_big_kernel
+#define MANTA_TU_ALIGN0 8       // align_kernel<0, E>
+#define MANTA_TU_ALIGN1 9       // align_kernel<1, E>
+#define MANTA_TU_ALIGN2 10      // align_kernel<2, E>
+#define MANTA_TU_ALIGN_PAIR 11  // align_pair_kernel<E>, align_pair_multi_kernel
+#define MANTA_TU_JUMP_PAIR 12   // align_jump_pair_kernel<E>
+#define MANTA_TU_GLUE 13        // pipeline_kernels.hpp, split_kernels.hpp, read_class_kernels.hpp
+#define MANTA_TU_COUNT 14
+#ifndef MANTA_TU
+#define MANTA_TU MANTA_TU_ALL
+#endif
+#define MANTA_TU_DEFINES(tu) (MANTA_TU == MANTA_TU_ALL || MANTA_TU == (tu))
+// (a template kernel is explicitly instantiated in its own TU and `extern template` -- no implicit instantiation -- in every other one:
+// the lists behind the kernels' definitions)
+
 #ifdef MANTA_WAVE_EMU
 #include "wave_emu.hpp"  // tests/emu/
 #else
