@@ -113,6 +113,37 @@ def cores_available():
         return os.cpu_count() or 1
 
 
+def host_cpu_topology():
+    """what the CPU baseline can use: hardware threads in the affinity mask, physical cores among them (sysfs thread siblings), and the
+    cgroup's CPU quota (a container may see 256 threads and be throttled to a few CPUs' worth of time)"""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in cpus:
+        try:
+            sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
+        except OSError:
+            sib = str(c)
+        cores.add(sib)
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return {"threads": len(cpus), "physical_cores": len(cores), "cgroup_cpu_quota": quota}
+
+
 def result_blob(out):
     """what the final candidate gather moves: the rank's result records and the used part of its arenas"""
     res = np.frombuffer(out.res, dtype=np.uint32).reshape(-1, 12)[:out.n_loci]  # manta_asm_locus_result_t = 12 dwords: status, n_contigs, ...
@@ -565,6 +596,12 @@ def main():
                 if tj.get("loci") == n_loci and tj.get("workload", "smallsv") == args.workload:
                     traffic = tj.get(dom)
                     traffic_source = "%s: %s, %s" % (os.path.relpath(tpath, ROOT), tj.get("source", "builder-run rocprofv3 --pmc passes"), tj.get("date", "round 2"))
+                elif spanning and tj.get("workload") == "spanning" and tj.get("loci") and n_loci % tj["loci"] == 0 and tj.get(dom) is not None:
+                    # the spanning block TILES the distinct loci the counter passes ran on (2 048: the digest set; under the profiler larger
+                    # blocks run into the passes' time limit), so a launch's traffic is the counted bytes x the number of copies
+                    traffic = int(tj[dom] * (n_loci // tj["loci"]))
+                    traffic_source = ("%s: %s, %s; counted on %d loci, x %d: the block repeats those loci" %
+                                      (os.path.relpath(tpath, ROOT), tj.get("source", "builder-run rocprofv3 --pmc passes"), tj.get("date", ""), tj["loci"], n_loci // tj["loci"]))
             except Exception:
                 traffic = None
         o = {
@@ -752,17 +789,42 @@ def main():
                                                % (n_s, min(cores, n_s), secs, secs1),
                                      "single_thread_value": round(1.0 / secs1, 2)}
             else:
-                n_1 = 96
-                sb1 = config2_batch(n_1, seed=12345)
-                secs1 = cpu.bench_small_sv(opts, SCORES, LARGE_INDEL, sb1[0], sb1[1], sb1[2], sb1[3], sb1[4], (100, 100, 800, 800), 1)
-                n_s = args.cpu_sample or min(n_loci, max(128, 8 * cores))
-                sb = config2_batch(n_s, seed=12345)
-                secs = cpu.bench_small_sv(opts, SCORES, LARGE_INDEL, sb[0], sb[1], sb[2], sb[3], sb[4], (100, 100, 800, 800), cores)
-                o["cpu_baseline"] = {"value": round(n_s / secs, 2), "unit": "loci/s", "cores": cores, "kind": kind,
-                                     "sample": "%d loci of the same workload on %d host threads (one aligner per thread, as "
-                                               "GenerateSVCandidates.cpp:232-266), %.1f s wall; single thread: %d loci in %.1f s"
-                                               % (n_s, cores, secs, n_1, secs1),
-                                     "single_thread_value": round(n_1 / secs1, 2)}
+                # The unmodified reference on host threads (one aligner per thread, as GenerateSVCandidates.cpp:232-266), through the thread
+                # harness of oracle/bench_harness.hpp: threads started and pinned BEFORE the clock, at least 64 loci per thread (the batch's
+                # loci round robin), a few seconds per thread count -- 1, 8, 32, the physical cores, every hardware thread.  (Round 5 timed
+                # 8 loci per thread with thread start-up inside the clock: 716 loci/s on "256 threads" = 11 x one thread.)
+                topo = host_cpu_topology()
+                sb = config2_batch(min(n_loci, 2048), seed=12345)
+                counts = sorted(set(t for t in (1, 8, 32, topo["physical_cores"], cores) if 1 <= t <= cores))
+                budget = 24.0 / len(counts)
+                table, best = [], None
+                rate1 = None
+                for t in counts:
+                    want = 96 if t == 1 else 64 * t
+                    if hasattr(cpu.lib, cpu.prefix + "bench_small_sv_timed"):
+                        secs, done = cpu.bench_small_sv_timed(opts, SCORES, LARGE_INDEL, sb[0], sb[1], sb[2], sb[3], sb[4], (100, 100, 800, 800), t, want, budget)
+                    else:  # (an oracle/_ref built before the harness existed)
+                        nn = min(len(sb[2]) - 1, want)
+                        sbn = config2_batch(nn, seed=12345)
+                        secs, done = cpu.bench_small_sv(opts, SCORES, LARGE_INDEL, sbn[0], sbn[1], sbn[2], sbn[3], sbn[4], (100, 100, 800, 800), t), nn
+                    rate = done / secs if secs > 0 else 0.0
+                    if t == 1:
+                        rate1 = rate
+                    row = {"threads": t, "loci": int(done), "seconds": round(secs, 2), "loci_per_s": round(rate, 1),
+                           "speedup_vs_1": round(rate / rate1, 1) if rate1 else None}
+                    table.append(row)
+                    if best is None or rate > best["loci_per_s"]:
+                        best = row
+                ideal = (rate1 or 0.0) * topo["physical_cores"]
+                o["cpu_baseline"] = {"value": best["loci_per_s"], "unit": "loci/s", "cores": best["threads"], "kind": kind,
+                                     "sample": "the best row of `scaling`: %d loci of the same workload on %d pinned host threads (one aligner per thread, as "
+                                               "GenerateSVCandidates.cpp:232-266), %.1f s wall, threads started before the clock" % (best["loci"], best["threads"], best["seconds"]),
+                                     "single_thread_value": round(rate1 or 0.0, 2),
+                                     "scaling": table, "host": topo,
+                                     "allocator": "glibc malloc, MALLOC_ARENA_MAX=%s" % os.environ.get("MALLOC_ARENA_MAX", "default (8 x cores)"),
+                                     "single_thread_x_physical_cores": round(ideal, 1),
+                                     "note": ("the best row is %.2f of single-thread rate x physical cores" % (best["loci_per_s"] / ideal if ideal else 0.0))
+                                             + ("; the container's cgroup limits the process to %.1f CPUs' worth of time" % topo["cgroup_cpu_quota"] if topo["cgroup_cpu_quota"] else "")}
         line = json.dumps(o)
     # The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio (seen after the line when stdout
     # is a pipe), so every rank flushes its C buffers, the group is torn down, and only then rank 0 prints.

@@ -503,6 +503,11 @@ struct AsmStage {
   DevBuf                bLgClassIdsBig, bCwsBig;
   // ... and its word-length rounds (IterativeAssembler.cpp:856-910 on the pipeline: graph_big -> repeat_big -> contig_big per word length)
   uint32_t              bigRounds = 0;     // rounds launched (0: rounds off -- a repeat hit / a cyclic graph is handed back to assemble_kernel)
+  // launch(): called on the assembler's stream between the first word length's launches (the small class' contig_kernel included) and the
+  // later ones -- only when there are later ones (bigRounds > 1).  What is ASM_OK in the locus records at that point of the stream is final:
+  // a pipeline starts aligning those contigs while the remaining word lengths of the tandem piles run (spanningRunImpl).
+  std::function<void()> afterFirstRound;
+  bool                  firstRoundHookRan = false;
   int                   gridRepeat = 0;    // repeat_big_kernel wavefronts
   uint64_t              pseudoArenaDw = 0, rwsStride = 0;
   DevBuf                bLgIter, bLgPseudo, bLgNext, bLgCyc, bLgRounds, bRws, bGws;
@@ -1109,6 +1114,22 @@ struct AsmStage {
         else
           rt::launchWG(graph_kernel<8>, gf, int(LG_WAVES), LG_BUDGET, A);
       }
+      // contig_kernel over the small class' lists.  With the big class' word-length rounds in the same launch sequence it goes right behind the
+      // first round: the metric's tail does not wait behind rounds it has no part in, and afterFirstRound() -- the point after which the
+      // records of every locus that is done at its first word length are final -- covers the small class too
+      bool smallContigsLaunched = false;
+      auto launchSmallContigs   = [&] {
+        if (smallContigsLaunched) return;
+        smallContigsLaunched = true;
+        for (unsigned c = 0; c < LG_CLASSES && !fastIds.empty(); ++c) {
+          if (!classBytes[c]) continue;
+          A.G.cls       = c;
+          A.P.counter   = reinterpret_cast<uint32_t*>(dLg + 3) + c;
+          A.P.lds_bytes = classBytes[c];
+          rt::launchSingle(contig_kernel, gridContig[c], classBytes[c], A);
+        }
+      };
+      firstRoundHookRan = false;
       if (!bigIds.empty()) {
         // the big class: its own work list (behind the small class' in dOrder), class lists and counters; slabs and punts shared
         LgArgs B         = A;
@@ -1199,16 +1220,17 @@ struct AsmStage {
               R.P.lds_bytes = classBytesBig[c];
               rt::launchSingle(contig_big_kernel, (r == 0) ? gridContigBig[c] : std::min(gridContigBig[c], later), classBytesBig[c], R);
             }
+            if (r == 0 && bigRounds > 1) {
+              launchSmallContigs();
+              if (afterFirstRound) {
+                afterFirstRound();
+                firstRoundHookRan = true;
+              }
+            }
           }
         }
       }
-      for (unsigned c = 0; c < LG_CLASSES && !fastIds.empty(); ++c) {
-        if (!classBytes[c]) continue;
-        A.G.cls       = c;
-        A.P.counter   = reinterpret_cast<uint32_t*>(dLg + 3) + c;
-        A.P.lds_bytes = classBytes[c];
-        rt::launchSingle(contig_kernel, gridContig[c], classBytes[c], A);
-      }
+      launchSmallContigs();
       P.locus_ids  = dPunt;
       P.n_loci     = nLoci;
       P.n_loci_dev = reinterpret_cast<uint32_t*>(dCnt + 14);
@@ -1607,6 +1629,16 @@ struct manta_spanning {
   manta_smallsv_stats_t stats{};
   DevBuf                dFirst, dPacked, dCigPacked, dPackCnt;
   PinnedBuf             pFirst, pPacked, pCig, pPackCnt;
+  // the early alignment pass (spanningRunImpl): the contigs of the loci that are final after the first word length are aligned while the
+  // word-length rounds of the tandem piles still run on `main`
+  // (`early` is a CU-masked stream like its side streams: the runtime multiplexes ordinary streams onto a few hardware queues -- the first
+  // hardware run had `early` on main's queue, behind every launch of the rounds; a masked stream owns its queue)
+  std::unique_ptr<rt::Stream> early;
+  std::unique_ptr<rt::Stream> sideEarly[3];  // its aligner buckets: CU-masked streams (a share of the CUs stays free for the rounds' kernels)
+  int                   sideEarlyReserved = -1;
+  rt::Event             evRound0;
+  DevBuf                dPassMask;
+  uint32_t              earlyLoci = 0;      // loci the last run aligned early
   std::vector<JumpCuts> hostCuts;  // the caller's cuts of the uploaded batch
   uint32_t*             hFirst  = nullptr;
   PackedContigOut*      hPacked = nullptr;
@@ -2849,33 +2881,9 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
       std::fprintf(stderr, "manta_amd: spanning_run %s\n", what);
       std::fflush(stderr);
     };
-    uint64_t asmCnt[4];
-    {
-      GateLock only(gates, &StageGates::asmMu);
-      std::unique_lock<std::mutex> streamedOnly(streamedAsmMu(ctx), std::defer_lock);  // see smallsvRunImpl
-      if (as.streaming) streamedOnly.lock();
-      as.stageQueued = false;  // (a run that failed behind its queued staging must not leave the flag to the next one)
-      b->evStart.record();
-      as.launch();
-      b->evAsm.record();
-      rt::d2h(asmCnt, as.dCnt, sizeof(asmCnt));  // (waits for the assembler)
-      if (asmCnt[3]) {  // loci that did not fit the typical-case workspace (see smallsvRunImpl)
-        as.rerunCapacityFailures(asmCnt[3]);
-        rt::d2h(asmCnt, as.dCnt, sizeof(asmCnt));  // the text arena grew
-      }
-    }
-    stage("assembled");
-    GateLock alignOnly(gates, &StageGates::alignMu);
-    if (b->refsOnCopy) rt::curStreamWaits(b->refsReady);  // reference windows of a streamed upload (manta_spanning_upload)
-    // CIGAR scratch, sized from what the assembler produced: a task takes 4 * contig length + 16 words (spanFileTask), every
-    // contig is aligned at most twice (second round: spanning_realign_kernel), and the text arena counter bounds the summed
-    // contig lengths.  (A fixed worst case of max_contig_len per slot is ~40x the real need at 200 x 250 bp loci.)
-    const uint64_t cigarCap = 2 * (4ull * std::min<uint64_t>(asmCnt[1], as.devSeqCap) + 16ull * nSlots) + 64;
-    if (cigarCap + 16 > 0xffffffffull)
-      return fail(ctx, MANTA_E_UNSUPPORTED, "manta_spanning_run: alignment scratch of this block exceeds 2^32 words; use smaller blocks "
-                                         "(manta_spanning_batch splits a batch into blocks, manta_batch_plan_t::block_loci)");
-    uint32_t* dCigar = b->dCigar.as<uint32_t>(cigarCap + 16);
-
+    // ---- the alignment stage as a function of (which loci, on which streams): it runs once over every locus, or -- the early pass --
+    // first over the loci that are final after the assembler's first word length, concurrently with the later word lengths, and then
+    // over the rest.
     SpanParams S;
     S.loci               = as.dLoci;
     S.contigs            = as.dCont;
@@ -2897,22 +2905,37 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
     S.bucket_count2      = dSmall + 32;
     S.bucket_maxref2     = dSmall + 48;
     S.cigar_used         = reinterpret_cast<unsigned long long*>(dSmall + 64);
-    S.cigar_cap          = cigarCap;
+    S.cigar_cap          = 0;
     S.results            = dResults;
-    S.cigar              = dCigar;
+    S.cigar              = nullptr;
     S.n_e                = kNumESet;
     for (int i = 0; i < kNumESet; ++i) S.e_set[i] = uint32_t(kESet[i]);
+    S.pass_mask  = nullptr;
+    S.pass_value = 0;
     const int glueGrid = rt::roundGrid(int(std::min<uint64_t>((nSlots + 63) / 64, uint64_t(std::max(1, ctx->cuCount * 8)))));
-    rt::launch(spanning_schedule_kernel, glueGrid, 0, S);
-    b->evSched.record();
-    stage("scheduled");
-
     b->stats.n_align_launches = 0;
     b->stats.n_alignments     = 0;
-    const int    maxWaves = std::max(1, ctx->cuCount * alignWavesPerCu());
     const size_t wsBudget = workspaceBudget(size_t(48) << 30);
-    auto alignRound = [&](const uint32_t* hCounts, const uint32_t* hMaxref, const AlignTaskDev* tasks, AlignResultDev* results,
-                          const uint32_t* bucketIds, uint32_t* counters) {
+    uint32_t*    dCigar   = nullptr;
+    // CIGAR scratch, sized from what the assembler produced: a task takes 4 * contig length + 16 words (spanFileTask), every
+    // contig is aligned at most twice (second round: spanning_realign_kernel), and the text arena counter bounds the summed
+    // contig lengths.  (A fixed worst case of max_contig_len per slot is ~40x the real need at 200 x 250 bp loci.)
+    // `keepWords` > 0: the buffer already holds that many words of the early pass -- a larger one takes them over.
+    auto cigarScratch = [&](const uint64_t seqUsed, const uint64_t keepWords) -> uint64_t {
+      const uint64_t need = 2 * (4ull * std::min<uint64_t>(seqUsed, as.devSeqCap) + 16ull * nSlots) + 64;
+      if (keepWords && (need + 16) * sizeof(uint32_t) > b->dCigar.cap) {
+        DevBuf bigger;
+        uint32_t* q = bigger.as<uint32_t>(need + 16);
+        rt::d2d(q, b->dCigar.p, sizeof(uint32_t) * keepWords);
+        rt::sync();
+        std::swap(bigger.p, b->dCigar.p);
+        std::swap(bigger.cap, b->dCigar.cap);
+      }
+      dCigar = b->dCigar.as<uint32_t>(need + 16);
+      return need;
+    };
+    auto alignRound = [&](rt::Stream* const* sides, const int maxWaves, const uint32_t* hCounts, const uint32_t* hMaxref, const AlignTaskDev* tasks,
+                          AlignResultDev* results, const uint32_t* bucketIds, uint32_t* counters) {
       // buckets on side streams, one slab region each (see manta_smallsv_run)
       struct Launch {
         int      k, grid;
@@ -2959,25 +2982,127 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
         P.allow_edge_ins = 0;
         P.extra          = b->jumpScore;
         {
-          rt::ScopedStream onSide(b->side[i % 3]);
+          rt::ScopedStream onSide(*sides[i % 3]);
           launchAlignKind(MANTA_ALIGNER_JUMP, l.k, l.grid, P, l.pair);
         }
         b->stats.n_align_launches++;
         b->stats.n_alignments += hCounts[l.k];
       }
       for (size_t i = 0; i < std::min<size_t>(launches.size(), 3); ++i) {
-        b->sideDone[i].recordOn(b->side[i]);
+        b->sideDone[i].recordOn(*sides[i]);
         rt::curStreamWaits(b->sideDone[i]);
       }
       rt::sync();  // the next stage reads the results and may re-size the slab buffer
     };
-    uint32_t hSmall[64];
-    rt::d2h(hSmall, dSmall, sizeof(hSmall));
-    alignRound(hSmall, hSmall + 16, dTasks, dResults, dBuckets, dSmall + 72);
-    stage("aligned round 1");
-    rt::launch(spanning_realign_kernel, rt::roundGrid(int(std::min<uint64_t>((nLoci + 63) / 64, uint64_t(std::max(1, ctx->cuCount * 8))))), 0, S);
-    rt::d2h(hSmall, dSmall, sizeof(hSmall));
-    alignRound(hSmall + 32, hSmall + 48, dTasks2, dResults2, dBuckets2, dSmall + 88);
+    /// schedule -> round 1 -> re-align rule -> round 2 over the loci of S.pass_mask / S.pass_value, on the current stream + `sides`
+    auto alignPass = [&](rt::Stream* const* sides, const int maxWaves, const char* what) {
+      S.cigar = dCigar;
+      rt::launch(spanning_schedule_kernel, glueGrid, 0, S);
+      uint32_t hSmall[64];
+      rt::d2h(hSmall, dSmall, sizeof(hSmall));
+      alignRound(sides, maxWaves, hSmall, hSmall + 16, dTasks, dResults, dBuckets, dSmall + 72);
+      stage(what);
+      rt::launch(spanning_realign_kernel, rt::roundGrid(int(std::min<uint64_t>((nLoci + 63) / 64, uint64_t(std::max(1, ctx->cuCount * 8))))), 0, S);
+      rt::d2h(hSmall, dSmall, sizeof(hSmall));
+      alignRound(sides, maxWaves, hSmall + 32, hSmall + 48, dTasks2, dResults2, dBuckets2, dSmall + 88);
+    };
+    rt::Stream* const plainSides[3] = {&b->side[0], &b->side[1], &b->side[2]};
+
+    // The early pass: after the first word length 94 % of the config-4/5 loci are final, while the tandem piles go through up to ten more
+    // word lengths -- launches that are latency-bound on small lists and leave most of the device idle.  The jump aligner of the final loci
+    // runs beside them: a mark kernel on the assembler's stream freezes "who is final" (span_mark_kernel), the pass itself runs on `early`
+    // + CU-masked side streams (a persistent aligner grid on every CU would keep graph_big_kernel -- one workgroup owns a CU -- from ever
+    // starting; MANTA_AMD_EARLY_RESERVE_CUS, default a quarter of the CUs, stay free for the rounds), the rest of the loci follow when the
+    // assembler is done.  Not with stage gates (pipelined workers hold one stage at a time).  MANTA_AMD_EARLY_ALIGN=0 switches it off.
+    static const bool earlyOff = std::getenv("MANTA_AMD_EARLY_ALIGN") && std::atoi(std::getenv("MANTA_AMD_EARLY_ALIGN")) == 0;
+    const bool        early    = !earlyOff && !gates && as.useFast && as.bigRounds > 1 && !as.bigIds.empty();
+    uint8_t*          dMask    = early ? b->dPassMask.as<uint8_t>(nLoci) : nullptr;
+    uint64_t asmCnt[4];
+    b->earlyLoci = 0;
+    {
+      GateLock only(gates, &StageGates::asmMu);
+      std::unique_lock<std::mutex> streamedOnly(streamedAsmMu(ctx), std::defer_lock);  // see smallsvRunImpl
+      if (as.streaming) streamedOnly.lock();
+      as.stageQueued = false;  // (a run that failed behind its queued staging must not leave the flag to the next one)
+      b->evStart.record();
+      if (early) {
+        as.afterFirstRound = [&] {
+          SpanMarkParams K;
+          K.loci    = as.dLoci;
+          K.n_loci  = nLoci;
+          K.mask    = dMask;
+          K.counter = dSmall + 120;
+          rt::launch(span_mark_kernel, rt::roundGrid(int(std::min<uint64_t>((nLoci + 63) / 64, uint64_t(std::max(1, ctx->cuCount * 4))))), 0, K);
+          b->evRound0.record();
+        };
+      }
+      struct HookReset {
+        AsmStage& a;
+        ~HookReset() { a.afterFirstRound = nullptr; }
+      } hookReset{as};
+      as.launch();
+      b->evAsm.record();
+      if (early && as.firstRoundHookRan) {
+        // (everything below is queued behind evRound0 on `early`; `main` keeps running the word-length rounds)
+        static const int reserveEnv = std::getenv("MANTA_AMD_EARLY_RESERVE_CUS") ? std::atoi(std::getenv("MANTA_AMD_EARLY_RESERVE_CUS")) : -1;
+        const int reserve = std::max(8, std::min(ctx->cuCount - 8, reserveEnv >= 0 ? (reserveEnv / 8) * 8 : ((ctx->cuCount / 4) / 8) * 8));
+        if (b->sideEarlyReserved != reserve) {
+          b->early.reset(new rt::Stream(ctx->cuCount, reserve));
+          for (int i = 0; i < 3; ++i) b->sideEarly[i].reset(new rt::Stream(ctx->cuCount, reserve));
+          b->sideEarlyReserved = reserve;
+          if (dbg) std::fprintf(stderr, "manta_amd: early alignment pass: %d of %d CUs reserved for the word-length rounds (CU mask %s)\n", reserve, ctx->cuCount,
+                                b->sideEarly[0]->masked() ? "set" : "not available");
+        }
+        rt::ScopedStream onEarly(*b->early);
+        rt::curStreamWaits(b->evRound0);
+        if (b->refsOnCopy) rt::curStreamWaits(b->refsReady);
+        rt::Stream* const earlySides[3] = {b->sideEarly[0].get(), b->sideEarly[1].get(), b->sideEarly[2].get()};
+        uint64_t cnt0[4];
+        uint32_t nEarly = 0;
+        rt::d2h(cnt0, as.dCnt, sizeof(cnt0));  // (text arena in use: at least what the final loci wrote -- the rounds keep adding)
+        rt::d2h(&nEarly, dSmall + 120, sizeof(nEarly));
+        b->earlyLoci = nEarly;
+        if (nEarly) {
+          // (room for a quarter more text than is there now, so that the second pass seldom has to move the buffer)
+          S.cigar_cap  = std::min<uint64_t>(cigarScratch(cnt0[1] + cnt0[1] / 4 + 65536, 0), 0xfffffff0ull);
+          S.pass_mask  = dMask;
+          S.pass_value = 1;
+          static const int wavesEnv = std::getenv("MANTA_AMD_EARLY_WAVES_PER_CU") ? std::atoi(std::getenv("MANTA_AMD_EARLY_WAVES_PER_CU")) : 0;
+          const int maxWavesEarly = std::max(1, (ctx->cuCount - (b->sideEarly[0]->masked() ? reserve : 0)) * (wavesEnv > 0 ? wavesEnv : alignWavesPerCu()));
+          alignPass(earlySides, maxWavesEarly, "aligned round 1 (early pass)");
+          stage("aligned round 2 (early pass)");
+        }
+      }
+      rt::d2h(asmCnt, as.dCnt, sizeof(asmCnt));  // (waits for the assembler)
+      if (asmCnt[3]) {  // loci that did not fit the typical-case workspace (see smallsvRunImpl)
+        as.rerunCapacityFailures(asmCnt[3]);
+        rt::d2h(asmCnt, as.dCnt, sizeof(asmCnt));  // the text arena grew
+      }
+    }
+    stage("assembled");
+    GateLock alignOnly(gates, &StageGates::alignMu);
+    if (b->refsOnCopy) rt::curStreamWaits(b->refsReady);  // reference windows of a streamed upload (manta_spanning_upload)
+    uint64_t cigarCap = 0;
+    {
+      uint64_t keepWords = 0;
+      if (b->earlyLoci) {
+        // second pass: fresh bucket lists (the allocator of the CIGAR scratch goes on where the early pass stopped)
+        rt::d2h(&keepWords, dSmall + 64, sizeof(keepWords));
+        keepWords = std::min<uint64_t>(keepWords, S.cigar_cap);
+        rt::dzero(dSmall, sizeof(uint32_t) * 64);
+        rt::dzero(dSmall + 72, sizeof(uint32_t) * 32);
+        S.pass_mask  = dMask;
+        S.pass_value = 0;
+      }
+      cigarCap = cigarScratch(asmCnt[1], keepWords);
+      if (cigarCap + 16 > 0xffffffffull)
+        return fail(ctx, MANTA_E_UNSUPPORTED, "manta_spanning_run: alignment scratch of this block exceeds 2^32 words; use smaller blocks "
+                                           "(manta_spanning_batch splits a batch into blocks, manta_batch_plan_t::block_loci)");
+      S.cigar_cap = cigarCap;
+    }
+    b->evSched.record();
+    const int maxWaves = std::max(1, ctx->cuCount * alignWavesPerCu());
+    alignPass(plainSides, maxWaves, "aligned round 1");
     launchPack(b, dTasks, dTasks2, dResults, dResults2, nullptr, dInfo, dCigar, cigarCap);
     b->evAlign.record();
     if (b->stageBehindRun) pipeStageEnqueue(b);

@@ -292,6 +292,9 @@ WV_DEV void schedFlush(const ScheduleParams& P, SchedPending* pend, const unsign
   wv::sync();
 }
 
+#if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
+WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P);
+#else
 WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
 {
   const unsigned lane   = unsigned(wv::lane());
@@ -346,6 +349,7 @@ WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
   for (unsigned b = 0; b < P.n_e; ++b) schedFlush(P, pend, b, total);
   if (lane == 0 && pend->cigarWords) wv::atomic_add(P.cigar_used, (unsigned long long)pend->cigarWords);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // bucket_sort_kernel: the tasks of an E bucket by descending reference length (counting sort over length / 8, one workgroup per
@@ -363,6 +367,9 @@ struct BucketSortParams {
   uint32_t            total;
   uint32_t            mask;          ///< buckets to sort (one workgroup per bucket; the others return at once)
 };
+#if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
+WV_KERNEL_WG(4) void bucket_sort_kernel(const BucketSortParams P);
+#else
 WV_KERNEL_WG(4) void bucket_sort_kernel(const BucketSortParams P)
 {
   const unsigned b = unsigned(wv::block_single());
@@ -407,6 +414,7 @@ WV_KERNEL_WG(4) void bucket_sort_kernel(const BucketSortParams P)
     out[wv::atomic_add(&hist[cls(id)], 1u)] = id;
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // Fused "spanning" locus pipeline (SVCandidateAssemblyRefiner::getJumpAssembly -> alignJumpContigs, DNA branch,
@@ -451,7 +459,33 @@ struct SpanParams {
   const uint32_t*       cigar;
   uint32_t            e_set[16];
   uint32_t            n_e;
+  // two passes over one block (api.cpp: spanningRunImpl): a pass takes the loci with pass_mask[locus] == pass_value (nullptr: every
+  // locus) -- the loci the assembler finished at its first word length are aligned while the later word lengths of the others still run
+  const uint8_t*      pass_mask;
+  uint32_t            pass_value;
 };
+
+/// written between the first word length's launches and the later ones, on the assembler's stream: which loci are final already
+struct SpanMarkParams {
+  const AsmLocusOut* loci;
+  uint32_t           n_loci;
+  uint8_t*           mask;     // out: 1 = the locus' record is final (status ASM_OK)
+  uint32_t*          counter;  // out: how many
+};
+#if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
+WV_KERNEL void span_mark_kernel(const SpanMarkParams P);
+#else
+WV_KERNEL void span_mark_kernel(const SpanMarkParams P)
+{
+  for (unsigned base = unsigned(wv::block()) * 64u; base < P.n_loci; base += unsigned(wv::nblocks()) * 64u) {
+    const unsigned locus = base + unsigned(wv::lane());
+    const bool     done  = locus < P.n_loci && P.loci[locus].status == ASM_OK;
+    if (locus < P.n_loci) P.mask[locus] = done ? 1 : 0;
+    const unsigned n = unsigned(wv::popc(wv::ballot(done)));
+    if (wv::lane() == 0 && n) wv::atomic_add(P.counter, n);
+  }
+}
+#endif
 
 WV_DEV void spanAtomicMax(uint32_t* p, const unsigned v)
 {
@@ -495,11 +529,15 @@ WV_DEV int spanFileTask(
   return bucket;
 }
 
+#if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
+WV_KERNEL void spanning_schedule_kernel(const SpanParams P);
+#else
 WV_KERNEL void spanning_schedule_kernel(const SpanParams P)
 {
   const unsigned total = P.n_loci * P.max_assembly_count;
   for (unsigned slot = unsigned(wv::block()) * 64u + unsigned(wv::lane()); slot < total; slot += unsigned(wv::nblocks()) * 64u) {
     const unsigned    locus = slot / P.max_assembly_count, ci = slot % P.max_assembly_count;
+    if (P.pass_mask && P.pass_mask[locus] != P.pass_value) continue;
     const AsmLocusOut lo    = P.loci[locus];
     SpanTaskInfo      info  = {0, -1, -1, 0};
     if (lo.status == ASM_OK && ci < lo.n_contigs) {
@@ -518,14 +556,19 @@ WV_KERNEL void spanning_schedule_kernel(const SpanParams P)
     P.info[slot] = info;
   }
 }
+#endif
 
 /// the re-align rule (:1672-1713), one lane per locus: the first contig (in contig order) whose junction holds an
 /// insertion while a breakend sits within 5 bases of a cut edge zeroes the cuts -- for itself and, because the
 /// reference's AlignData is shared by the contig loop, for every later contig of the locus.
+#if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
+WV_KERNEL void spanning_realign_kernel(const SpanParams P);
+#else
 WV_KERNEL void spanning_realign_kernel(const SpanParams P)
 {
   const unsigned total = P.n_loci * P.max_assembly_count;
   for (unsigned locus = unsigned(wv::block()) * 64u + unsigned(wv::lane()); locus < P.n_loci; locus += unsigned(wv::nblocks()) * 64u) {
+    if (P.pass_mask && P.pass_mask[locus] != P.pass_value) continue;
     const AsmLocusOut lo = P.loci[locus];
     if (lo.status != ASM_OK) continue;
     const JumpCuts c    = P.cuts[locus];
@@ -568,6 +611,7 @@ WV_KERNEL void spanning_realign_kernel(const SpanParams P)
     }
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------------
 // Result packing: the last kernel of both pipelines.  The stages above keep one record per (locus, contig slot) --
@@ -604,6 +648,9 @@ struct PackParams {
   uint32_t*              counters;      ///< [0] packed contigs, [1] packed cigar words (zeroed before launch)
 };
 
+#if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
+WV_KERNEL void pack_results_kernel(const PackParams P);
+#else
 WV_KERNEL void pack_results_kernel(const PackParams P)
 {
   for (unsigned locus = unsigned(wv::block()) * 64 + unsigned(wv::lane()); locus < P.n_loci; locus += unsigned(wv::nblocks()) * 64) {
@@ -656,6 +703,7 @@ WV_KERNEL void pack_results_kernel(const PackParams P)
     }
   }
 }
+#endif
 
 /// how many loci ended with `code` (after assemble_kernel: ASM_E_TABLE_FULL -> AsmStage::rerunCapacityFailures).  A separate tiny
 /// launch instead of a counter inside assemble_kernel: that kernel's code stays exactly what was measured.
@@ -665,6 +713,9 @@ struct CountStatusParams {
   int32_t            code;
   unsigned long long* counter;
 };
+#if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
+WV_KERNEL void count_status_kernel(const CountStatusParams P);
+#else
 WV_KERNEL void count_status_kernel(const CountStatusParams P)
 {
   unsigned n = 0;
@@ -673,5 +724,6 @@ WV_KERNEL void count_status_kernel(const CountStatusParams P)
   for (int off = 1; off < 64; off <<= 1) n += wv::shfl(n, wv::lane() ^ off);
   if (wv::lane() == 0 && n) wv::atomic_add(P.counter, (unsigned long long)n);
 }
+#endif
 
 }  // namespace manta_dev

@@ -24,6 +24,7 @@ inline void* dmallocFine(size_t n) { return dmalloc(n); }
 inline void  h2d(void* d, const void* h, size_t n) { if (n) std::memcpy(d, h, n); }
 inline void  d2h(void* h, const void* d, size_t n) { if (n) std::memcpy(h, d, n); }
 inline void  d2hAsync(void* h, const void* d, size_t n) { if (n) std::memcpy(h, d, n); }
+inline void  d2d(void* to, const void* from, size_t n) { if (n) std::memcpy(to, from, n); }
 inline bool  streamWrite32(void* d, uint32_t v) { *static_cast<uint32_t*>(d) = v; return true; }
 inline void  setDevice(int) {}
 inline int   currentDevice() { return 0; }
@@ -39,7 +40,11 @@ inline void launchWG(K kernel, int grid, int nWaves, size_t ldsBytes, const P& p
 inline int roundGrid(int waves) { return waves; }
 template <typename K>
 inline int blocksPerCu(K, int, size_t, int fallback) { return fallback; }
-struct Stream {};
+struct Stream {
+  Stream() {}
+  Stream(int, int) {}
+  bool masked() const { return false; }
+};
 inline void useStream(Stream*) {}
 struct ScopedStream { explicit ScopedStream(Stream&) {} };
 struct Event { void record() {} void recordOn(Stream&) {} };
@@ -113,7 +118,29 @@ inline void* dmallocFine(size_t n)
 /// hipDeviceSynchronize).
 struct Stream {
   hipStream_t s = nullptr;
+  bool        cuMasked = false;
   Stream() { check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"); }
+  /// a stream whose kernels run on `cuCount - reservedCus` of the device's CUs only: the lowest `reservedCus` bits of the queue's CU mask
+  /// are cleared.  The mask's bits interleave the XCDs (bit i belongs to XCD i mod 8), so a multiple of 8 takes the same number of CUs out
+  /// of every XCD.  What is left out stays free for the kernels of the other streams -- a persistent launch on this stream cannot starve
+  /// them.  Falls back to an ordinary stream if the runtime refuses the mask (masked() says which).
+  Stream(int cuCount, int reservedCus)
+  {
+    if (reservedCus > 0 && reservedCus < cuCount) {
+      uint32_t mask[32];
+      const unsigned words = unsigned(cuCount + 31) / 32;
+      for (unsigned w = 0; w < 32; ++w) mask[w] = 0;
+      for (int cu = reservedCus; cu < cuCount; ++cu) mask[cu >> 5] |= 1u << (cu & 31);
+      if (words <= 32 && hipExtStreamCreateWithCUMask(&s, words, mask) == hipSuccess) {
+        cuMasked = true;
+        return;
+      }
+      (void)hipGetLastError();
+      s = nullptr;
+    }
+    check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+  }
+  bool masked() const { return cuMasked; }
   ~Stream() { if (s) (void)hipStreamDestroy(s); }
   Stream(const Stream&) = delete;
   Stream& operator=(const Stream&) = delete;
@@ -142,6 +169,8 @@ inline void d2h(void* h, const void* d, size_t n)
   check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, launchStream()), "hipMemcpy D2H");
   sync();
 }
+/// device -> device on the current stream (asynchronous)
+inline void d2d(void* to, const void* from, size_t n) { if (n) check(hipMemcpyAsync(to, from, n, hipMemcpyDeviceToDevice, launchStream()), "hipMemcpy D2D"); }
 /// same without the wait: several copies, then one sync()
 inline void d2hAsync(void* h, const void* d, size_t n) { if (n) check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, launchStream()), "hipMemcpy D2H"); }
 /// a 32-bit write performed by the command processor once everything queued on the current stream before it has completed: no

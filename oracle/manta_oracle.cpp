@@ -15,6 +15,7 @@
 //
 // Results are rendered as canonical text (same format as oracle/ref_driver.cpp, see oracle/FORMAT.md).
 
+#include "bench_harness.hpp"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -1262,6 +1263,25 @@ double orc_bench_small_sv(
   const auto t1 = std::chrono::steady_clock::now();
   if (n_done) *n_done = done.load();
   return std::chrono::duration<double>(t1 - t0).count();
+}
+
+/// orc_bench_small_sv with the thread harness of bench_harness.hpp (see ref_driver.cpp: ref_bench_small_sv_timed)
+double orc_bench_small_sv_timed(
+    const uint32_t* opts, const int32_t* scores, int32_t largeIndelScore, int n_loci, const char* bases,
+    const uint64_t* read_off, const uint32_t* locus_read_begin, const char* refs, const uint64_t* ref_off, int leadingCut,
+    int trailingCut, int maxLeadingCut, int maxTrailingCut, int n_threads, uint64_t loci_total, double max_seconds, int pin, uint64_t* n_done)
+{
+  const orc::AsmOpts opt(makeOpt(opts));
+  const orc::Scores  sc(makeScores(scores));
+  auto makeWorker = [&]() {
+    return [&](const int li) {
+      std::vector<std::string> in;
+      for (uint32_t r = locus_read_begin[li]; r < locus_read_begin[li + 1]; ++r) in.emplace_back(bases + read_off[r], read_off[r + 1] - read_off[r]);
+      const std::string ref(refs + ref_off[li], ref_off[li + 1] - ref_off[li]);
+      orc::smallSvLocus(opt, sc, largeIndelScore, in, ref, leadingCut, trailingCut, maxLeadingCut, maxTrailingCut, false);
+    };
+  };
+  return bench_harness::run(n_threads, loci_total, max_seconds, pin != 0, n_loci, makeWorker, n_done);
 }
 
 /// test hook: emulated libstdc++ unordered_map<string,...> iteration order for distinct keys given in insertion order

@@ -13,6 +13,9 @@
 // No reference source is copied here; the reference headers are #included from /root/reference at build
 // time and the resulting shared object lives in oracle/_ref/ (git-ignored).
 
+#include "bench_harness.hpp"
+#include <memory>
+
 #include "alignment/GlobalAligner.hpp"
 #include "alignment/GlobalJumpAligner.hpp"
 #include "alignment/GlobalLargeIndelAligner.hpp"
@@ -315,6 +318,29 @@ double ref_bench_small_sv(
   const auto t1 = std::chrono::steady_clock::now();
   if (n_contigs_out) *n_contigs_out = ncontigs.load();
   return std::chrono::duration<double>(t1 - t0).count();
+}
+
+/// the same with the thread harness of bench_harness.hpp: threads started (and pinned if `pin`) before the clock, `loci_total` loci taken
+/// round robin from the batch, at most `max_seconds`.  Returns wall seconds; *n_done = loci processed.
+double ref_bench_small_sv_timed(
+    const uint32_t* opts, const int32_t* scores, int32_t largeIndelScore, int n_loci, const char* bases,
+    const uint64_t* read_off, const uint32_t* locus_read_begin, const char* refs, const uint64_t* ref_off,
+    int leadingCut, int trailingCut, int maxLeadingCut, int maxTrailingCut, int n_threads, uint64_t loci_total, double max_seconds,
+    int pin, uint64_t* n_done)
+{
+  const IterativeAssemblerOptions opt(makeAsmOpt(opts));
+  const AlignmentScores<int>      sc(makeScores(scores));
+  auto makeWorker = [&]() {
+    auto aligner = std::make_shared<GlobalLargeIndelAligner<int>>(sc, largeIndelScore);
+    return [&, aligner](const int li) {
+      AssemblyReadInput in;
+      for (uint32_t r = locus_read_begin[li]; r < locus_read_begin[li + 1]; ++r) in.emplace_back(bases + read_off[r], read_off[r + 1] - read_off[r]);
+      const std::string ref(refs + ref_off[li], ref_off[li + 1] - ref_off[li]);
+      const std::string txt(smallSvLocus(opt, *aligner, in, ref, leadingCut, trailingCut, maxLeadingCut, maxTrailingCut, false));
+      (void)txt;
+    };
+  };
+  return bench_harness::run(n_threads, loci_total, max_seconds, pin != 0, n_loci, makeWorker, n_done);
 }
 
 }  // extern "C"

@@ -136,8 +136,9 @@ void setOptions(const ref_refine_input_t& in, GSCOptions& options)
 
 thread_local SVCandidateAssemblyRefiner::Stats g_stats;
 
-/// n inputs that share chromosomes/options (those of inputs[0]); is_batched != 0 -> ONE getCandidateAssemblyDataBatch
-/// call, else consecutive single calls on the same refiner object.  Text = the dumps in order.
+/// n inputs that share chromosomes/options (those of inputs[0]); is_batched == 1 -> ONE getCandidateAssemblyDataBatch
+/// call, 0 -> consecutive single calls on the same refiner object; > 1 / -1 -> one batched call with that many plan threads / one
+/// (setPlanThreads) and per-candidate errors.  Text = the dumps in order.
 MINE_EXPORT int mine_get_candidate_assembly_data_multi(const ref_refine_input_t* inputs, int n, int is_batched, char* out, int cap)
 {
   try {
@@ -162,7 +163,26 @@ MINE_EXPORT int mine_get_candidate_assembly_data_multi(const ref_refine_input_t*
     const SVCandidateAssemblyRefiner refiner(options, header, source);
     const bool                       large = inputs[0].is_find_large_insertions != 0;
     std::string                      text;
-    if (is_batched) {
+    if (is_batched < 0 || is_batched > 1) {
+      // per-candidate error isolation, with the input callbacks of the candidates on |is_batched| host threads (-1: one thread, the
+      // sequential plan): a candidate whose processing throws reports its exception, every other one its result
+      SVCandidateAssemblyRefiner& r(const_cast<SVCandidateAssemblyRefiner&>(refiner));
+      r.setPlanThreads(is_batched < 0 ? 1u : unsigned(is_batched));
+      std::vector<SVCandidateAssemblyData> data;
+      std::vector<std::exception_ptr>      errors;
+      refiner.getCandidateAssemblyDataBatch(svs, large, data, &errors);
+      for (size_t i = 0; i < data.size(); ++i) {
+        if (errors[i]) {
+          try {
+            std::rethrow_exception(errors[i]);
+          } catch (const std::exception& e) {
+            text += std::string("EXCEPTION ") + e.what() + "\n";
+          }
+        } else {
+          text += dumpAssemblyData(data[i]);
+        }
+      }
+    } else if (is_batched) {
       std::vector<SVCandidateAssemblyData> data;
       refiner.getCandidateAssemblyDataBatch(svs, large, data);
       for (const auto& d : data) text += dumpAssemblyData(d);

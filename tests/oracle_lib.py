@@ -118,6 +118,24 @@ class _TextLib:
         assert done.value == n_loci
         return secs
 
+    def bench_small_sv_timed(self, opts, scores, large_indel_score, bases, read_off, locus_read_begin, refs, ref_off, cuts,
+                             n_threads, loci_total, max_seconds, pin=True):
+        """the same pipeline with the thread harness of oracle/bench_harness.hpp: threads started (and pinned) before the clock,
+        `loci_total` loci taken round robin from the batch, at most `max_seconds`.  Returns (wall seconds, loci done)."""
+        fn = getattr(self.lib, self.prefix + "bench_small_sv_timed")
+        fn.restype = ctypes.c_double
+        o = (ctypes.c_uint32 * 9)(*opts)
+        s = (ctypes.c_int32 * 6)(*scores)
+        n_loci = len(locus_read_begin) - 1
+        done = ctypes.c_uint64(0)
+        secs = fn(o, s, large_indel_score, n_loci, bases.ctypes.data_as(ctypes.c_char_p),
+                  read_off.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                  locus_read_begin.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                  refs.ctypes.data_as(ctypes.c_char_p),
+                  ref_off.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), cuts[0], cuts[1], cuts[2], cuts[3],
+                  n_threads, ctypes.c_uint64(loci_total), ctypes.c_double(max_seconds), 1 if pin else 0, ctypes.byref(done))
+        return secs, done.value
+
 
 class RefLib(_TextLib):
     prefix = "ref_"

@@ -63,13 +63,16 @@ class RefinerLib:
         getattr(self.lib, self.prefix + "_candidate_vcf_records")(ctypes.byref(inp), buf, len(buf))
         return buf.value.decode()
 
-    def run_multi(self, cases, batched):
+    def run_multi(self, cases, batched, plan_threads=None):
+        """plan_threads (product adapter only): ONE batched call with per-candidate error isolation and that many host threads calling the
+        input source (SVCandidateAssemblyRefiner::setPlanThreads); 1 = the sequential plan"""
         keep = []
         arr = (RefineInput * len(cases))()
         for i, c in enumerate(cases):
             fill(arr[i], c, keep)
         buf = ctypes.create_string_buffer(1 << 24)
-        self.multi(arr, len(cases), 1 if batched else 0, buf, len(buf))
+        mode = (1 if batched else 0) if plan_threads is None else (-1 if plan_threads <= 1 else plan_threads)
+        self.multi(arr, len(cases), mode, buf, len(buf))
         return buf.value.decode()
 
 

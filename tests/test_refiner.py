@@ -156,6 +156,33 @@ def test_overlap_skip_and_batch(mine_emu, ref):
             assert mine_emu.run_multi([c], batched=True) == ref.run(c)
 
 
+def test_threaded_plan_equals_sequential_plan(mine_emu, ref):
+    """setPlanThreads(8): the interval filter's verdicts are taken in list order first (route()), the reference / read callbacks of the
+    candidates then run on host threads.  Must give what the sequential plan gives -- on the scenario list, on the interval-filter
+    sequence (close spanning pair, then the same region as a complex candidate, twice over), and with a candidate in the middle of
+    the list whose callback throws (per-candidate error isolation)."""
+    rng = random.Random(11)
+    close = spanning_case(rng, "RL", same_chrom=True, far=False)
+    cx = dict(close)
+    lo, hi = min(close["begin"]), max(close["end"])
+    cx.update(state=[3, 0], begin=[lo + 1, lo + 1], end=[hi - 1, hi - 1])
+    bad = dict(close)  # a breakend region beyond the chromosome end: getBpReferenceInterval throws (test_off_chromosome_exception)
+    n = len(close["chroms"][0])
+    bad.update(begin=[close["begin"][0], n + 500], end=[close["end"][0], n + 550])
+    seq = [close, cx, bad, close, cx]
+    one = mine_emu.run_multi(seq, batched=True, plan_threads=1)
+    many = mine_emu.run_multi(seq, batched=True, plan_threads=8)
+    assert one == many
+    assert one.count("isOverlapSkip=1") == 2 and one.count("EXCEPTION getBpReferenceInterval") == 1
+    # ... and the sequential plan with error isolation is what consecutive single calls give for the candidates before the throwing one
+    assert one.startswith(mine_emu.run_multi([close, cx], batched=False))
+    assert one.startswith(ref.run(close))
+    # a sample of the scenario families (own chromosomes each: one candidate per call), both plans against the plain batched call
+    for _, c in scenario_cases(404)[::4]:
+        a = mine_emu.run_multi([c], batched=True, plan_threads=8)
+        assert a == mine_emu.run_multi([c], batched=True, plan_threads=1) == mine_emu.run_multi([c], batched=True)
+
+
 @pytest.mark.gpu
 def test_refiner_on_gpu(mine_gpu):
     """same comparison on the real device (golden texts: /root/reference does not exist on the GPU box)"""
