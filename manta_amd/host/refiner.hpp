@@ -21,6 +21,7 @@
 #include <sstream>
 #include <thread>
 
+#include "pile_dump.hpp"
 #include "sv_types.hpp"
 
 namespace manta_amd {
@@ -564,6 +565,9 @@ struct SVCandidateAssemblyRefiner {
   /// safe to call concurrently (a source that keeps one BAM / FASTA handle per thread, or answers from memory); the cross-candidate
   /// state of the call itself -- the geometric _spanToComplexAssmRegions filter -- is still applied in list order.
   void setPlanThreads(const unsigned n) { _planThreads = (n == 0) ? 1 : n; }
+  /// every candidate that reaches the assembler + aligner is also written to `w` (pile_dump.hpp: read pile, reference windows, cuts,
+  /// options -- the inputs of the whole-batch ABI calls), for tools/replay_piles.py; nullptr switches it off
+  void setPileDump(PileDumpWriter* w) { _pileDump = w; }
 
   /// work counters of this refiner object (no reference counterpart; for logs and tests)
   struct Stats {
@@ -806,6 +810,10 @@ private:
       cuts.push_back(manta_ref_cuts_t{plans[i].leadingCut, plans[i].trailingCut, plans[i].maxLeadingCut, plans[i].maxTrailingCut});
     }
     if (which.empty()) return;
+    if (_pileDump)
+      for (size_t w = 0; w < which.size(); ++w)
+        _pileDump->small(_opt.refineOpt.smallSVAssembleOpt, _opt.refineOpt.largeSVAlignScores, _opt.refineOpt.largeGapOpenScore, plans[which[w]].reads, *refs[w],
+                         cuts[w].leading_cut, cuts[w].trailing_cut, cuts[w].max_leading_cut, cuts[w].max_trailing_cut);
     packed.finish(_hostThreads, &_stage);
     _stats.smallLoci += which.size();
     const double          tPacked = now();
@@ -1087,6 +1095,10 @@ private:
       cuts.push_back(manta_jump_cuts_t{sl.a1Lead, sl.a1Trail, sl.a2Lead, sl.a2Trail});
     }
 
+    if (_pileDump)
+      for (size_t l = 0; l < loci.size(); ++l)
+        _pileDump->spanning(_opt.refineOpt.spanningAssembleOpt, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, plans[loci[l].planIndex].reads, *refs1[l],
+                            *refs2[l], cuts[l].align1_leading_cut, cuts[l].align1_trailing_cut, cuts[l].align2_leading_cut, cuts[l].align2_trailing_cut);
     // assemble -> jump-align (cut references) -> re-align rule -> jump-align (uncut), all on the device
     const double           tPacked = now();
     _times.pack += tPacked - tStart;
@@ -1174,6 +1186,7 @@ private:
   mutable detail::SpanningOutput _spanDev;
   unsigned                      _hostThreads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
   unsigned                      _planThreads = 1;
+  PileDumpWriter*               _pileDump = nullptr;
 };
 
 }  // namespace manta_amd

@@ -1,6 +1,8 @@
 // Test-only C surface over manta_amd/host/refiner.hpp (the product's SVCandidateAssemblyRefiner) with the same POD
 // input and the same text dump as ref_get_candidate_assembly_data in oracle/ref_refiner_driver.cpp (the reference's
 // own refiner run in memory).  Linked against the emulator build (CPU tier) or libmanta_amd.so (GPU tier).
+#include <fstream>
+#include <memory>
 #include <cstdint>
 #include <cstring>
 #include <sstream>
@@ -136,6 +138,22 @@ void setOptions(const ref_refine_input_t& in, GSCOptions& options)
 
 thread_local SVCandidateAssemblyRefiner::Stats g_stats;
 
+// pile dump of every candidate the following calls send to the device (pile_dump.hpp; tools/replay_piles.py)
+static std::unique_ptr<std::ofstream>  g_dumpFile;
+static std::unique_ptr<PileDumpWriter> g_dump;
+/// path: start a dump file (truncates); nullptr: close it.  Returns the number of records written so far.
+MINE_EXPORT uint64_t mine_set_pile_dump(const char* path)
+{
+  const uint64_t n = g_dump ? g_dump->count() : 0;
+  g_dump.reset();
+  g_dumpFile.reset();
+  if (path) {
+    g_dumpFile.reset(new std::ofstream(path));
+    g_dump.reset(new PileDumpWriter(*g_dumpFile));
+  }
+  return n;
+}
+
 /// n inputs that share chromosomes/options (those of inputs[0]); is_batched == 1 -> ONE getCandidateAssemblyDataBatch
 /// call, 0 -> consecutive single calls on the same refiner object; > 1 / -1 -> one batched call with that many plan threads / one
 /// (setPlanThreads) and per-candidate errors.  Text = the dumps in order.
@@ -161,6 +179,7 @@ MINE_EXPORT int mine_get_candidate_assembly_data_multi(const ref_refine_input_t*
       for (int c = 0; c < std::max(1, in.n_calls); ++c) svs.push_back(makeSV(in));
     }
     const SVCandidateAssemblyRefiner refiner(options, header, source);
+    const_cast<SVCandidateAssemblyRefiner&>(refiner).setPileDump(g_dump.get());
     const bool                       large = inputs[0].is_find_large_insertions != 0;
     std::string                      text;
     if (is_batched < 0 || is_batched > 1) {
