@@ -380,6 +380,15 @@ typedef struct {
                              blocks, shows up as loci nobody filled: status MANTA_E_NOT_TAKEN in every process' records) */
 } manta_batch_plan_t;
 
+/* The ABI's version and the size of the statistics record the library writes.  manta_batch_stats_t has grown between rounds (the
+   routing counters), and the library writes the whole record: a caller -- or a ctypes / cgo mirror of the struct -- compiled against
+   an older header would be written past its end.  Check both once after loading the library:
+     manta_abi_version() == MANTA_ABI_VERSION  and  manta_batch_stats_size() == sizeof(manta_batch_stats_t)
+   (manta_amd/_capi.py does).  The version changes whenever a struct of this header changes size or meaning. */
+#define MANTA_ABI_VERSION 6
+uint32_t manta_abi_version(void);
+uint64_t manta_batch_stats_size(void);
+
 typedef struct {
   double   wall_ms;                    /* call entry -> all results host-visible */
   double   h2d_ms, kernel_ms, d2h_ms;  /* host wall time per phase, summed over blocks (blocks overlap) */

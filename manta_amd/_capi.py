@@ -16,6 +16,9 @@ CIGAR_OPS = "MIDNSHP=X"
 ALIGNER_GLOBAL, ALIGNER_LARGE_INDEL, ALIGNER_JUMP = 0, 1, 2
 
 
+ABI_VERSION = 6  # include/manta_amd.h: MANTA_ABI_VERSION
+
+
 class MantaError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("manta_amd error %d: %s" % (code, msg))
@@ -156,6 +159,12 @@ class Lib:
         L.manta_ctx_device_name.argtypes = [ctypes.c_void_p]
         L.manta_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.manta_ctx_destroy.argtypes = [ctypes.c_void_p]
+        # the ctypes mirrors below follow include/manta_amd.h of this ABI version: the library writes whole records
+        L.manta_abi_version.restype = ctypes.c_uint32
+        L.manta_batch_stats_size.restype = ctypes.c_uint64
+        if L.manta_abi_version() != ABI_VERSION or L.manta_batch_stats_size() != ctypes.sizeof(BatchStats):
+            raise MantaError(-2, "%s speaks ABI version %d (manta_batch_stats_t: %d bytes); this binding mirrors version %d (%d bytes): rebuild the library"
+                             % (self.path, L.manta_abi_version(), L.manta_batch_stats_size(), ABI_VERSION, ctypes.sizeof(BatchStats)))
         self.ctx = ctypes.c_void_p()
         rc = L.manta_ctx_create(device, ctypes.byref(self.ctx))
         if rc != 0:

@@ -1683,6 +1683,9 @@ void launchPack(Pipe* b, const AlignTaskDev* tasks, const AlignTaskDev* tasks2, 
 
 extern "C" {
 
+uint32_t manta_abi_version(void) { return MANTA_ABI_VERSION; }
+uint64_t manta_batch_stats_size(void) { return sizeof(manta_batch_stats_t); }
+
 int manta_ctx_create(int device_id, manta_ctx_t** out)
 {
   if (!out) {

@@ -58,9 +58,8 @@ WV_DEV unsigned AssemblerT<SB>::selectTentative(const unsigned T)
   if (U > T) {
     // Both thresholds come from histograms in LDS (one pass over the compacted arrays each) instead of binary searches
     // that re-read the arrays once per probe.
-    // (a launch without LDS -- the tandem loci running beside the LDS pipeline -- keeps the bins in the slab, behind the three arrays
-    // above: the exact repeat search's scratch holds 14 words per node)
-    uint32_t*      hist = (P.lds_bytes >= 4096) ? reinterpret_cast<uint32_t*>(wv::lds(P.lds_bytes)) : (exact_ws + 64 + 4 * size_t(P.cap_nodes));
+    // (every launch of the general kernel carries ASM_LDS_BYTES of LDS per wave: 2 * HBINS bins fit)
+    uint32_t*      hist = reinterpret_cast<uint32_t*>(wv::lds(P.lds_bytes));
     const unsigned cmax = waveMax(myMax);
     // ---- count level: largest c with #{cnt >= c} >= T.  Counts above HBINS-1 share the top bin (they are all taken
     // when the cut falls below it; if the cut falls inside the top bin the binary search below resolves it). ----

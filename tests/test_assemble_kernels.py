@@ -509,3 +509,30 @@ def test_gpu_big_class_word_length_rounds(gpu, oracle, monkeypatch):
         reads, _, _, k, kmax = config5_locus(i)
         cases.append((asm_opts(minWordLength=k, maxWordLength=kmax, minContigLength=75), reads))
     assert _check(gpu, oracle, cases) == len(cases)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_gpu_rounds_sweep_first_500_seeds(gpu, oracle, monkeypatch):
+    """the first 500 seeds of the round-5 hardware sweep of the word-length rounds (tools/sweeps/sweep_rounds.py, profiles/r05_rounds_sweep.txt:
+    8 000 piles by hand): random repeat-rich piles of 129..236 reads, every pile under its own random option block (word lengths 8..72,
+    steps 1..7, minCoverage 1..3, maxAssemblyCount 2..10), each against the CPU restatement; every fifth one also against the unmodified
+    reference where oracle/_ref is present"""
+    from oracle_lib import RefLib, have_ref
+    from rounds_cases import rounds_case
+    monkeypatch.setenv("MANTA_AMD_ASM_PATH", "fast")
+    ref = RefLib() if have_ref() else None
+    bad, n, iters = [], 0, 0
+    for s in range(1000, 1500):
+        c = rounds_case(s)
+        if not c:
+            continue
+        o, reads = c
+        r = gpu.assemble_batch(o, [reads])[0]
+        got = assembly_text(r) if r["status"] == 0 else "STATUS %d" % r["status"]
+        n += 1
+        iters += r["n_iterations"]
+        if got != oracle.assemble(o, reads) or (ref is not None and s % 5 == 0 and got != ref.assemble(o, reads)):
+            bad.append(s)
+    assert not bad, "%d of %d piles differ: seeds %s" % (len(bad), n, bad[:10])
+    assert n > 450 and iters > 2000  # the piles do go through several word lengths each
