@@ -774,6 +774,25 @@ def main():
                     o["refiner_batch"] = {"error": (pr.stderr or pr.stdout)[-300:]}
             except Exception as e:  # (an extra leg never takes the line down)
                 o["refiner_batch"] = {"error": str(e)[-300:]}
+            # ... and the same batch through manta_amd_dropin::BatchRefiner over Manta's REAL types (::SVCandidate in, ::SVCandidateAssemblyData
+            # out, conversions inside the clock): the drop-in build of oracle/_ref -- the reference's own headers -- holds the probe
+            # (oracle/ref_refiner_driver.cpp: ref_perf_batch_refiner); the file is prebuilt where /root/reference existed
+            dso = os.path.join(ROOT, "oracle", "_ref", "libmanta_ref_dropin_gpu.so")
+            if isinstance(o.get("refiner_batch"), dict) and "error" not in o["refiner_batch"] and os.path.exists(dso):
+                try:
+                    import ctypes
+                    dl = ctypes.CDLL(dso)
+                    if hasattr(dl, "ref_perf_batch_refiner"):
+                        res3 = (ctypes.c_double * 3)()
+                        ht = int(o["refiner_batch"].get("host_threads", 16))
+                        real = {}
+                        for name, pt in (("threaded_plan", ht), ("sequential_plan", 1)):
+                            if dl.ref_perf_batch_refiner(10000, ht, pt, res3) == 0:
+                                real[name] = {"candidates_per_s": round(10000 / res3[0], 1), "seconds": round(res3[0], 4), "refined_svs": int(res3[1]), "contigs": int(res3[2])}
+                        real["call"] = "manta_amd_dropin::BatchRefiner::getCandidateAssemblyDataBatch(std::vector<::SVCandidate>, ..., std::vector<::SVCandidateAssemblyData>&)"
+                        o["refiner_batch"]["real_types"] = real
+                except Exception as e:
+                    o["refiner_batch"]["real_types"] = {"error": str(e)[-300:]}
         if world == 1 and not args.no_cpu_baseline:
             cores = cores_available()
             kind, cpu = ("reference", RefLib()) if have_ref() else ("port", orc)

@@ -2295,12 +2295,12 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
       dBucketsSorted = b->dBucketIds2.as<uint32_t>(nSlots * kNumESet);
       BucketSortParams BS;
       BS.tasks        = dTasks;
-      BS.ids_in       = dBuckets;
+      BS.info         = dInfo;
       BS.ids_out      = dBucketsSorted;
       BS.bucket_count = dSmall;
       BS.total        = uint32_t(nSlots);
       BS.mask         = pairMask;
-      rt::launchWG(bucket_sort_kernel, kNumESet, 4, 4 * BS_CLASSES, BS);
+      rt::launchWG(bucket_sort_kernel, kNumESet, int(BS_WAVES), BS_LDS_BYTES, BS);
     }
     b->evSched.record();
     stage("scheduled");
@@ -3443,7 +3443,7 @@ int smallsvBatchImpl(
   const uint32_t nBlocks    = uint32_t(sh.blockOrder.size());
   const uint32_t perCtx     = std::max(1u, (plan && plan->n_workers) ? plan->n_workers : 1u);
   const uint32_t nWorkers   = std::max(1u, std::min(nBlocks, perCtx * nCtx));
-  sh.pipelineStages         = perCtx > 1;
+  sh.pipelineStages         = perCtx > 1 && !std::getenv("MANTA_AMD_NO_STAGE_GATES");  // (experiments: concurrent workers without the stage gates)
   if (sh.sharedQueue)  // blocks another process of the node takes stay marked; the caller merges (bench.py: the final gather)
     for (uint32_t l = 0; l < n_loci; ++l) {
       std::memset(&loci[l], 0, sizeof(loci[l]));
@@ -3676,7 +3676,7 @@ int spanningBatchImpl(
   const uint32_t nBlocks  = uint32_t(sh.blockOrder.size());
   const uint32_t perCtx   = std::max(1u, (plan && plan->n_workers) ? plan->n_workers : 1u);
   const uint32_t nWorkers = std::max(1u, std::min(nBlocks, perCtx * nCtx));
-  sh.pipelineStages       = perCtx > 1;
+  sh.pipelineStages       = perCtx > 1 && !std::getenv("MANTA_AMD_NO_STAGE_GATES");  // (experiments: concurrent workers without the stage gates)
   if (sh.sharedQueue)
     for (uint32_t l = 0; l < n_loci; ++l) {
       std::memset(&loci[l], 0, sizeof(loci[l]));

@@ -359,14 +359,21 @@ WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
 // bucket).  Longest first also keeps the launch's tail short.
 // ------------------------------------------------------------------------------------------------------------------
 static const unsigned BS_CLASSES = 512;
+static const unsigned BS_WAVES   = 4;
+static const unsigned BS_LDS_BYTES = 4 * (BS_WAVES * BS_CLASSES + BS_CLASSES + 8);
 struct BucketSortParams {
-  const AlignTaskDev* tasks;
-  const uint32_t*     ids_in;        ///< n_buckets * total
-  uint32_t*           ids_out;       ///< same layout
-  const uint32_t*     bucket_count;
-  uint32_t            total;
-  uint32_t            mask;          ///< buckets to sort (one workgroup per bucket; the others return at once)
+  const AlignTaskDev*    tasks;
+  const SmallSvTaskInfo* info;          ///< per slot: which bucket the schedule kernel filed it in (-1: none)
+  uint32_t*              ids_out;       ///< n_buckets * total: the sorted lists
+  const uint32_t*        bucket_count;
+  uint32_t               total;
+  uint32_t               mask;          ///< buckets to sort (one workgroup per bucket; the others return at once)
 };
+// The list is rebuilt from the per-slot records IN SLOT ORDER and the counting sort is stable, so the sorted order -- and with it which
+// two tasks share a wave in align_pair_kernel -- depends on the batch alone.  (The schedule kernel's own bucket lists are in the order
+// its waves' atomic appends happened to land: up to round 5 the pairing, and so the aligner's time to the last few percent, differed from
+// run to run.)  Every wave takes a contiguous quarter of the slots and keeps its own class histogram; class bases are the exclusive scan
+// over (class, wave); inside a 64-slot chunk the lanes of a class rank themselves by ballots (asm_lds_big.hpp: radixPassIds).
 #if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
 WV_KERNEL_WG(4) void bucket_sort_kernel(const BucketSortParams P);
 #else
@@ -374,26 +381,42 @@ WV_KERNEL_WG(4) void bucket_sort_kernel(const BucketSortParams P)
 {
   const unsigned b = unsigned(wv::block_single());
   if (!((P.mask >> b) & 1u)) return;
-  uint32_t*       hist = reinterpret_cast<uint32_t*>(wv::lds_single());
-  const unsigned  tw = unsigned(wv::wave_in_wg()), tn = unsigned(wv::wg_waves()), lane = unsigned(wv::lane());
-  const unsigned  tid = 64 * tw + lane, nt = 64 * tn;
-  const unsigned  n = P.bucket_count[b];
-  const uint32_t* in  = P.ids_in + size_t(b) * P.total;
-  uint32_t*       out = P.ids_out + size_t(b) * P.total;
+  uint32_t*      hist  = reinterpret_cast<uint32_t*>(wv::lds_single());  // [wave][class]
+  uint32_t*      dbase = hist + BS_WAVES * BS_CLASSES;                   // [class]
+  const unsigned tw = unsigned(wv::wave_in_wg()), tn = unsigned(wv::wg_waves()), lane = unsigned(wv::lane());
+  const unsigned tid = 64 * tw + lane, nt = 64 * tn;
+  uint32_t*      out    = P.ids_out + size_t(b) * P.total;
+  uint32_t*      myHist = hist + BS_CLASSES * tw;
+  const unsigned chunk  = (((P.total + tn - 1) / tn) + 63) & ~63u;
+  const unsigned c0 = chunk * tw, c1 = (c0 + chunk < P.total) ? (c0 + chunk) : P.total;
   auto cls = [&](const unsigned id) {
     const unsigned c = P.tasks[id].ref1_len >> 3;
     return (BS_CLASSES - 1) - ((c < BS_CLASSES - 1) ? c : (BS_CLASSES - 1));
   };
-  for (unsigned i = tid; i < BS_CLASSES; i += nt) hist[i] = 0;
+  for (unsigned i = tid; i < BS_WAVES * BS_CLASSES + BS_CLASSES; i += nt) hist[i] = 0;
   wv::sync();
   wv::wg_barrier();
-  for (unsigned i = tid; i < n; i += nt) wv::atomic_add(&hist[cls(in[i])], 1u);
+  for (unsigned i0 = c0; i0 < c1; i0 += 64) {
+    const unsigned slot = i0 + lane;
+    if (slot < c1 && P.info[slot].bucket == int(b)) wv::atomic_add(&myHist[cls(slot)], 1u);
+  }
+  wv::sync();
+  wv::wg_barrier();
+  for (unsigned d = tid; d < BS_CLASSES; d += nt) {  // per class: the waves' counts -> their offsets inside the class, and the class total
+    unsigned run = 0;
+    for (unsigned w = 0; w < BS_WAVES; ++w) {
+      const unsigned c          = (w < tn) ? hist[BS_CLASSES * w + d] : 0u;
+      hist[BS_CLASSES * w + d] = run;
+      run += c;
+    }
+    dbase[d] = run;
+  }
   wv::sync();
   wv::wg_barrier();
   if (tw == 0) {  // exclusive prefix over the classes: 8 per lane
     unsigned v[8], sum = 0;
     for (int j = 0; j < 8; ++j) {
-      v[j] = hist[8 * lane + j];
+      v[j] = dbase[8 * lane + j];
       sum += v[j];
     }
     unsigned inc = sum;
@@ -403,15 +426,30 @@ WV_KERNEL_WG(4) void bucket_sort_kernel(const BucketSortParams P)
     }
     unsigned run = inc - sum;
     for (int j = 0; j < 8; ++j) {
-      hist[8 * lane + j] = run;
+      dbase[8 * lane + j] = run;
       run += v[j];
     }
   }
   wv::sync();
   wv::wg_barrier();
-  for (unsigned i = tid; i < n; i += nt) {
-    const unsigned id = in[i];
-    out[wv::atomic_add(&hist[cls(id)], 1u)] = id;
+  for (unsigned i0 = c0; i0 < c1; i0 += 64) {
+    const unsigned slot  = i0 + lane;
+    const bool     valid = slot < c1 && P.info[slot].bucket == int(b);
+    const unsigned d     = valid ? cls(slot) : 0u;
+    uint64_t       peers = wv::ballot(valid);
+    for (int bit = 0; bit < 9; ++bit) {
+      const bool     on = (d >> bit) & 1u;
+      const uint64_t m  = wv::ballot(valid && on);
+      peers &= on ? m : ~m;
+    }
+    unsigned base = 0;
+    if (valid) base = dbase[d] + myHist[d];
+    wv::sync();
+    if (valid) {
+      out[base + unsigned(wv::popc(peers & ((uint64_t(1) << lane) - 1)))] = slot;
+      if ((peers >> lane) == 1u) myHist[d] += unsigned(wv::popc(peers));  // (the class' highest lane of this chunk)
+    }
+    wv::sync();
   }
 }
 #endif

@@ -416,6 +416,27 @@ struct PackedReads {
   uint32_t nLoci() const { return uint32_t(locusBegin.size() - 1); }
 };
 
+/// reference windows of a batch back to back (+ one pad byte) in page-locked memory: a pageable source is staged by the runtime at a
+/// few GB/s, and 10 000 windows of 1 800 bases appended one by one to a std::vector cost more than their DMA
+struct PackedRefs {
+  const uint8_t*        bytes = nullptr;
+  std::vector<uint64_t> off;
+  std::vector<uint8_t>  fallback;
+  void pack(const std::vector<const std::string*>& refs, const unsigned threads, PinnedArena& stage)
+  {
+    off.assign(refs.size() + 1, 0);
+    for (size_t i = 0; i < refs.size(); ++i) off[i + 1] = off[i] + refs[i]->size();
+    uint8_t* dst = stage.ensure(off.back() + 16);
+    if (!dst) {
+      fallback.resize(off.back() + 16);
+      dst = fallback.data();
+    }
+    parallelFor(refs.size(), threads, [&](const size_t i) { std::copy(refs[i]->begin(), refs[i]->end(), dst + off[i]); });
+    dst[off.back()] = 0;
+    bytes           = dst;
+  }
+};
+
 struct AsmOutput {
   std::vector<manta_asm_locus_result_t> loci;
   std::vector<manta_asm_contig_t>       contigs;
@@ -454,18 +475,14 @@ struct SmallSvOutput : AsmOutput {
 /// the fused device pipeline for a batch of complex loci
 inline void smallSvBatch(
     manta_ctx_t* ctx, manta_smallsv_t*& b, const IterativeAssemblerOptions& opt, const AlignmentScores<int>& scores, const int largeIndelScore,
-    PackedReads& in, const std::vector<const std::string*>& refs, const std::vector<manta_ref_cuts_t>& cuts, SmallSvOutput& out)
+    PackedReads& in, const std::vector<const std::string*>& refs, const std::vector<manta_ref_cuts_t>& cuts, SmallSvOutput& out, const unsigned threads,
+    PinnedArena& refStage)
 {
   if (in.nLoci() == 0) return;
   const manta_asm_options_t  o   = toAbi(opt);
   const manta_align_scores_t sc  = toAbi(scores);
-  std::vector<uint8_t>       refBytes;
-  std::vector<uint64_t>      refOff{0};
-  for (const std::string* r : refs) {
-    refBytes.insert(refBytes.end(), r->begin(), r->end());
-    refOff.push_back(refBytes.size());
-  }
-  refBytes.push_back(0);
+  PackedRefs                 R;
+  R.pack(refs, threads, refStage);
   auto check = [&](const int rc) {
     if (rc == MANTA_OK) return;
     throw GeneralException("manta_amd small-SV pipeline: " + std::string(manta_last_error(ctx)), rc);
@@ -490,7 +507,7 @@ inline void smallSvBatch(
     if (out.bits.size() < bitsCap) out.bits.resize(bitsCap);
     if (out.cigar.size() < cigCap) out.cigar.resize(cigCap);
     uint64_t  su = 0, bu = 0, cu = 0;
-    const int rc = manta_smallsv_batch(ctx, &o, &sc, largeIndelScore, n, in.basesPtr, in.readOff.data(), in.locusBegin.data(), refBytes.data(), refOff.data(),
+    const int rc = manta_smallsv_batch(ctx, &o, &sc, largeIndelScore, n, in.basesPtr, in.readOff.data(), in.locusBegin.data(), R.bytes, R.off.data(),
                                        cuts.data(), nullptr, nullptr, out.loci.data(), out.contigs.data(), out.aligns.data(), out.contigs.size(), out.seq.data(),
                                        out.seq.size(), &su, out.bits.data(), out.bits.size(), &bu, out.cigar.data(), out.cigar.size(), &cu, nullptr, nullptr);
     if (rc == MANTA_E_CAPACITY && attempt < 6) {
@@ -515,21 +532,14 @@ struct SpanningOutput : AsmOutput {
 inline void spanningBatch(
     manta_ctx_t* ctx, manta_spanning_t*& b, const IterativeAssemblerOptions& opt, const AlignmentScores<int>& scores, const int jumpScore, PackedReads& in,
     const std::vector<const std::string*>& refs1, const std::vector<const std::string*>& refs2, const std::vector<manta_jump_cuts_t>& cuts,
-    SpanningOutput& out)
+    SpanningOutput& out, const unsigned threads, PinnedArena& ref1Stage, PinnedArena& ref2Stage)
 {
   if (in.nLoci() == 0) return;
   const manta_asm_options_t  o   = toAbi(opt);
   const manta_align_scores_t sc  = toAbi(scores);
-  std::vector<uint8_t>       ref1Bytes, ref2Bytes;
-  std::vector<uint64_t>      ref1Off{0}, ref2Off{0};
-  for (size_t i = 0; i < refs1.size(); ++i) {
-    ref1Bytes.insert(ref1Bytes.end(), refs1[i]->begin(), refs1[i]->end());
-    ref1Off.push_back(ref1Bytes.size());
-    ref2Bytes.insert(ref2Bytes.end(), refs2[i]->begin(), refs2[i]->end());
-    ref2Off.push_back(ref2Bytes.size());
-  }
-  ref1Bytes.push_back(0);
-  ref2Bytes.push_back(0);
+  PackedRefs                 R1, R2;
+  R1.pack(refs1, threads, ref1Stage);
+  R2.pack(refs2, threads, ref2Stage);
   auto check = [&](const int rc) {
     if (rc == MANTA_OK) return;
     throw GeneralException("manta_amd spanning pipeline: " + std::string(manta_last_error(ctx)), rc);
@@ -551,8 +561,8 @@ inline void spanningBatch(
     if (out.bits.size() < bitsCap) out.bits.resize(bitsCap);
     if (out.cigar.size() < cigCap) out.cigar.resize(cigCap);
     uint64_t  su = 0, bu = 0, cu = 0;
-    const int rc = manta_spanning_batch(ctx, &o, &sc, jumpScore, n, in.basesPtr, in.readOff.data(), in.locusBegin.data(), ref1Bytes.data(), ref1Off.data(),
-                                        ref2Bytes.data(), ref2Off.data(), cuts.data(), nullptr, nullptr, out.loci.data(), out.contigs.data(), out.aligns.data(),
+    const int rc = manta_spanning_batch(ctx, &o, &sc, jumpScore, n, in.basesPtr, in.readOff.data(), in.locusBegin.data(), R1.bytes, R1.off.data(),
+                                        R2.bytes, R2.off.data(), cuts.data(), nullptr, nullptr, out.loci.data(), out.contigs.data(), out.aligns.data(),
                                         out.contigs.size(), out.seq.data(), out.seq.size(), &su, out.bits.data(), out.bits.size(), &bu, out.cigar.data(),
                                         out.cigar.size(), &cu, nullptr, nullptr);
     if (rc == MANTA_E_CAPACITY && attempt < 6) {
@@ -856,7 +866,7 @@ private:
     _times.pack += tPacked - tStart;
     detail::SmallSvOutput& dev(_smallDev);  // (kept across calls: no re-allocation and zero-fill of tens of MB per batch)
     detail::smallSvBatch(deviceContext(), _smallPipe, _opt.refineOpt.smallSVAssembleOpt, _opt.refineOpt.largeSVAlignScores, _opt.refineOpt.largeGapOpenScore, packed,
-                         refs, cuts, dev);
+                         refs, cuts, dev, _hostThreads, _refStage);
     const double tDevice = now();
     _times.device += tDevice - tPacked;
 
@@ -1140,7 +1150,7 @@ private:
     _times.pack += tPacked - tStart;
     detail::SpanningOutput& dev(_spanDev);
     detail::spanningBatch(deviceContext(), _spanPipe, _opt.refineOpt.spanningAssembleOpt, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, packed, refs1,
-                          refs2, cuts, dev);
+                          refs2, cuts, dev, _hostThreads, _refStage, _ref2Stage);
     const double tDevice = now();
     _times.device += tDevice - tPacked;
 
@@ -1218,6 +1228,7 @@ private:
   mutable manta_smallsv_t*      _smallPipe = nullptr;  ///< device pipelines of this refiner (and of the thread that
   mutable manta_spanning_t*     _spanPipe  = nullptr;  ///< first used it: one ABI context per host thread)
   mutable detail::PinnedArena   _stage;                ///< page-locked staging of a batch's read bases, reused
+  mutable detail::PinnedArena   _refStage, _ref2Stage; ///< ... and of its reference windows
   mutable detail::SmallSvOutput  _smallDev;            ///< the device results of the last batch (reused: capacity stays)
   mutable detail::SpanningOutput _spanDev;
   unsigned                      _hostThreads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));

@@ -411,6 +411,99 @@ REF_EXPORT int ref_get_candidate_assembly_data_multi(const ref_refine_input_t* i
     return emit(std::string("EXCEPTION ") + e.what(), out, cap);
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Throughput of that batched call over Manta's REAL types (bench.py's `refiner_batch.real_types`): n config-2 shaped complex
+// candidates -- the generator of tools/cpp/perf_refiner.cpp -- as ::SVCandidate objects in, ::SVCandidateAssemblyData out, the
+// conversions to and from the mirror types inside the clock.  out[0] = best seconds of three calls, out[1] = refined SVs,
+// out[2] = contigs.  plan_threads > 1 only because this source answers from memory.
+// ------------------------------------------------------------------------------------------------------------------
+#include <chrono>
+#include <random>
+namespace {
+struct PerfBatchSource : manta_amd_dropin::BatchInputSource {
+  std::vector<std::string> chroms;
+  struct Pile {
+    int               pos;
+    AssemblyReadInput reads;
+  };
+  std::vector<Pile> piles;  // by position, all on tid 0
+  void getReferenceSeq(const std::string& chrom, int b, int e, std::string& seq) override { seq = chroms[std::stoul(chrom)].substr(size_t(b), size_t(e - b + 1)); }
+  void getBreakendReads(const SVBreakend& bp, bool, const reference_contig_segment&, AssemblyReadInput& reads) override
+  {
+    if (!reads.empty()) return;
+    size_t lo = 0, hi = piles.size();
+    while (lo < hi) {
+      const size_t mid = (lo + hi) / 2;
+      if (piles[mid].pos < bp.interval.range.begin_pos()) lo = mid + 1; else hi = mid;
+    }
+    if (lo < piles.size() && bp.interval.tid == 0 && piles[lo].pos < bp.interval.range.end_pos()) reads = piles[lo].reads;
+  }
+};
+}  // namespace
+
+REF_EXPORT int ref_perf_batch_refiner(int n, int hostThreads, int planThreads, double* out)
+{
+  try {
+    std::mt19937 g(12345);
+    auto randSeq = [&](size_t len) {
+      std::string s(len, 'A');
+      for (char& c : s) c = "ACGT"[g() & 3];
+      return s;
+    };
+    PerfBatchSource src;
+    const size_t    spacing = 4000;
+    src.chroms.push_back(randSeq(size_t(n) * spacing + 8000));
+    std::vector<SVCandidate> svs;
+    for (int i = 0; i < n; ++i) {
+      const int             pos = int(2000 + size_t(i) * spacing);
+      PerfBatchSource::Pile pile;
+      pile.pos = pos;
+      const int         d   = 10 + int(g() % 50);
+      const std::string hap = src.chroms[0].substr(size_t(pos) - 400, 400) + src.chroms[0].substr(size_t(pos) + d, 400);
+      SVCandidate       sv;
+      sv.bp1.state    = SVBreakendState::COMPLEX;
+      sv.bp1.interval = GenomeInterval(0, pos - 20, pos + 20);
+      sv.bp2.state    = SVBreakendState::UNKNOWN;
+      sv.bp2.interval = sv.bp1.interval;
+      for (int r = 0; r < 80; ++r) {
+        const size_t lo = 400 - 150 + 15, hi = 400 - 15;
+        std::string  rd = hap.substr(lo + g() % (hi - lo), 150);
+        for (char& c : rd)
+          if (g() % 333 == 0) c = "ACGT"[g() & 3];
+        pile.reads.push_back(rd);
+      }
+      src.piles.push_back(pile);
+      svs.push_back(sv);
+    }
+    bam_header_info header;
+    header.chrom_data.emplace_back("0", unsigned(src.chroms[0].size()));
+    GSCOptions options;
+    options.refineOpt.smallSVAssembleOpt.minWordLength = 31;
+    manta_amd_dropin::BatchRefiner refiner(options, header, src);
+    refiner.setThreads(unsigned(std::max(1, hostThreads)), unsigned(std::max(1, planThreads)));
+    std::vector<SVCandidateAssemblyData> data;
+    double best = 1e30;
+    size_t nsv = 0, ncontig = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+      const auto t0 = std::chrono::steady_clock::now();
+      refiner.getCandidateAssemblyDataBatch(svs, false, data);
+      best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+      nsv = ncontig = 0;
+      for (const SVCandidateAssemblyData& d : data) {
+        nsv += d.svs.size();
+        ncontig += d.contigs.size();
+      }
+    }
+    out[0] = best;
+    out[1] = double(nsv);
+    out[2] = double(ncontig);
+    return 0;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "ref_perf_batch_refiner: %s\n", e.what());
+    return -1;
+  }
+}
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------
