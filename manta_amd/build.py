@@ -21,7 +21,7 @@ KERNEL_TUS = {
     2: "asm", 3: "asm_generic", 4: "graph", 5: "graph_big", 6: "contig", 7: "repeat", 8: "align0", 9: "align1", 10: "align2",
     11: "align_pair", 12: "jump_pair", 13: "glue",
 }
-HOST_SOURCES = ["api.cpp"]
+HOST_SOURCES = ["api.cpp", "api_batch.cpp", "api_reads.cpp"]
 
 
 def units():
@@ -85,7 +85,7 @@ def build_profile_variant(verbose=True):
     """developer tool: same library with the per-phase shader-clock counters of assemble_kernel compiled in
     (tools/profile_phases.py); one translation unit; never used by tests, bench.py or the product path"""
     out = os.path.join(HERE, "libmanta_amd_prof.so")
-    cmd = [HIPCC] + FLAGS + ["-shared", "-DMANTA_ASM_PROFILE", "-o", out, os.path.join(CSRC, "api.cpp")]
+    cmd = [HIPCC] + FLAGS + ["-shared", "-DMANTA_ASM_PROFILE", "-o", out, os.path.join(CSRC, "api_unity.cpp")]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

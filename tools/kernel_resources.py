@@ -16,7 +16,7 @@ def remarks():
         return open(sys.argv[1]).read()
     with tempfile.TemporaryDirectory() as d:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "-I", CSRC,
-               "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(d, "lib.so"), os.path.join(CSRC, "api.cpp")]
+               "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(d, "lib.so"), os.path.join(CSRC, "api_unity.cpp")]
         return subprocess.run(cmd, stderr=subprocess.PIPE, text=True, check=True).stderr
 
 
