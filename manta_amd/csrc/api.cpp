@@ -579,9 +579,11 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
       dBucketsSorted = b->dBucketIds2.as<uint32_t>(nSlots * kNumESet);
       BucketSortParams BS;
       BS.tasks        = dTasks;
+      BS.loci         = as.dLoci;
       BS.info         = dInfo;
       BS.ids_out      = dBucketsSorted;
-      BS.bucket_count = dSmall;
+      BS.n_loci       = nLoci;
+      BS.max_assembly_count = maxAsm;
       BS.total        = uint32_t(nSlots);
       BS.mask         = pairMask;
       rt::launchWG(bucket_sort_kernel, kNumESet, int(BS_WAVES), BS_LDS_BYTES, BS);

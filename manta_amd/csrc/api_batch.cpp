@@ -101,13 +101,13 @@ void planBlocks(BatchShared& sh, uint32_t n_loci, uint32_t blockLoci, const uint
 /// call of the metric -- takes the caller's array as it is: no 6.4 MB copy of the read offsets into fresh (page-faulting, pageable) memory
 /// in front of every upload; other blocks are rebased into `out`, which belongs to the worker's pipeline object and keeps its pages.
 template <typename T>
-const T* rebase(std::vector<T>& out, const T* src, size_t first, size_t count)
+const T* rebase(PinnedBuf& out, const T* src, size_t first, size_t count)
 {
   const T base = src[first];
   if (base == 0) return src + first;
-  out.resize(count);
-  for (size_t i = 0; i < count; ++i) out[i] = src[first + i] - base;
-  return out.data();
+  T* dst = out.as<T>(count);  // (page-locked: the upload of a later block is a DMA as well)
+  for (size_t i = 0; i < count; ++i) dst[i] = src[first + i] - base;
+  return dst;
 }
 
 }  // namespace
@@ -204,8 +204,7 @@ int smallsvBatchImpl(
       b->largeIndel    = large_indel_score;
       b->streamUploads = !(plan && (plan->flags & MANTA_BATCH_NO_STREAMED_UPLOAD));
       b->asmStage.wavesPerCuCap = sh.pipelineStages ? kPipelinedAsmWavesPerCu : 0;
-      std::vector<uint64_t>&rOffBuf(b->hostOff[0]), &fOffBuf(b->hostOff[1]);
-      std::vector<uint32_t>& lBegBuf(b->hostBegin);
+      PinnedBuf &rOffBuf(b->hostOff[0]), &fOffBuf(b->hostOff[1]), &lBegBuf(b->hostBegin);
       while (!sh.stop()) {
         const uint32_t qi = sh.takeNext();
         if (qi >= nBlocks) break;
@@ -434,8 +433,7 @@ int spanningBatchImpl(
       b->jumpScore = jump_score;
       b->streamUploads = !(plan && (plan->flags & MANTA_BATCH_NO_STREAMED_UPLOAD));
       b->asmStage.wavesPerCuCap = sh.pipelineStages ? kPipelinedAsmWavesPerCu : 0;
-      std::vector<uint64_t>&rOffBuf(b->hostOff[0]), &f1OffBuf(b->hostOff[1]), &f2OffBuf(b->hostOff[2]);
-      std::vector<uint32_t>& lBegBuf(b->hostBegin);
+      PinnedBuf &rOffBuf(b->hostOff[0]), &f1OffBuf(b->hostOff[1]), &f2OffBuf(b->hostOff[2]), &lBegBuf(b->hostBegin);
       while (!sh.stop()) {
         const uint32_t qi = sh.takeNext();
         if (qi >= nBlocks) break;

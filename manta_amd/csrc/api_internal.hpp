@@ -1622,8 +1622,7 @@ struct manta_smallsv {
   bool                  bucketHistory = false;
   bool                  stageBehindRun = false;  // whole-batch calls: the run queues the staging behind its last kernel
   bool                  staged = false;
-  std::vector<uint64_t> hostOff[3];  // whole-batch worker: a block's rebased offset arrays (api_batch.cpp: rebase), kept across calls
-  std::vector<uint32_t> hostBegin;
+  PinnedBuf             hostOff[3], hostBegin;  // whole-batch worker: a block's rebased offset arrays (api_batch.cpp: rebase), kept across calls
   explicit manta_smallsv(manta_ctx_t* c) : ctx(c), asmStage(c) {}
 };
 
@@ -1666,8 +1665,7 @@ struct manta_spanning {
   uint64_t              packLast[2] = {0, 0}, packedCopied = 0, cigCopied = 0;
   bool                  stageBehindRun = false;
   bool                  staged = false;
-  std::vector<uint64_t> hostOff[3];  // whole-batch worker: a block's rebased offset arrays, kept across calls
-  std::vector<uint32_t> hostBegin;
+  PinnedBuf             hostOff[3], hostBegin;  // whole-batch worker: a block's rebased offset arrays, kept across calls
   explicit manta_spanning(manta_ctx_t* c) : ctx(c), asmStage(c) {}
 };
 

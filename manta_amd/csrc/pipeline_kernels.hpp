@@ -363,17 +363,20 @@ static const unsigned BS_WAVES   = 4;
 static const unsigned BS_LDS_BYTES = 4 * (BS_WAVES * BS_CLASSES + BS_CLASSES + 8);
 struct BucketSortParams {
   const AlignTaskDev*    tasks;
+  const AsmLocusOut*     loci;          ///< contigs per locus: the slots worth looking at
   const SmallSvTaskInfo* info;          ///< per slot: which bucket the schedule kernel filed it in (-1: none)
   uint32_t*              ids_out;       ///< n_buckets * total: the sorted lists
-  const uint32_t*        bucket_count;
+  uint32_t               n_loci, max_assembly_count;
   uint32_t               total;
   uint32_t               mask;          ///< buckets to sort (one workgroup per bucket; the others return at once)
 };
-// The list is rebuilt from the per-slot records IN SLOT ORDER and the counting sort is stable, so the sorted order -- and with it which
-// two tasks share a wave in align_pair_kernel -- depends on the batch alone.  (The schedule kernel's own bucket lists are in the order
-// its waves' atomic appends happened to land: up to round 5 the pairing, and so the aligner's time to the last few percent, differed from
-// run to run.)  Every wave takes a contiguous quarter of the slots and keeps its own class histogram; class bases are the exclusive scan
-// over (class, wave); inside a 64-slot chunk the lanes of a class rank themselves by ballots (asm_lds_big.hpp: radixPassIds).
+// The list is rebuilt from the per-slot records in a FIXED order -- the loci in order, 64 at a time, their first contigs, then their second
+// ones, ... -- and the counting sort is stable, so the sorted order, and with it which two tasks share a wave in align_pair_kernel,
+// depends on the batch alone.  (The schedule kernel's own bucket lists are in the order its waves' atomic appends happened to land: up
+// to round 5 the pairing, and so the aligner's time to the last few percent, differed from run to run.)  Every wave takes a contiguous
+// quarter of the loci and keeps its own class histogram; class bases are the exclusive scan over (class, wave); inside a step the lanes of
+// a class rank themselves by ballots (asm_lds_big.hpp: radixPassIds).  Only the slots that hold a contig are read: n_loci records and
+// ~1.5 slots per locus, not n_loci x maxAssemblyCount.
 #if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
 WV_KERNEL_WG(4) void bucket_sort_kernel(const BucketSortParams P);
 #else
@@ -387,18 +390,26 @@ WV_KERNEL_WG(4) void bucket_sort_kernel(const BucketSortParams P)
   const unsigned tid = 64 * tw + lane, nt = 64 * tn;
   uint32_t*      out    = P.ids_out + size_t(b) * P.total;
   uint32_t*      myHist = hist + BS_CLASSES * tw;
-  const unsigned chunk  = (((P.total + tn - 1) / tn) + 63) & ~63u;
-  const unsigned c0 = chunk * tw, c1 = (c0 + chunk < P.total) ? (c0 + chunk) : P.total;
+  const unsigned chunk  = (((P.n_loci + tn - 1) / tn) + 63) & ~63u;
+  const unsigned c0 = chunk * tw, c1 = (c0 + chunk < P.n_loci) ? (c0 + chunk) : P.n_loci;
   auto cls = [&](const unsigned id) {
     const unsigned c = P.tasks[id].ref1_len >> 3;
     return (BS_CLASSES - 1) - ((c < BS_CLASSES - 1) ? c : (BS_CLASSES - 1));
+  };
+  auto contigsOf = [&](const unsigned locus) -> unsigned {
+    if (locus >= c1) return 0u;
+    const AsmLocusOut lo = P.loci[locus];
+    return (lo.status == ASM_OK) ? lo.n_contigs : 0u;
   };
   for (unsigned i = tid; i < BS_WAVES * BS_CLASSES + BS_CLASSES; i += nt) hist[i] = 0;
   wv::sync();
   wv::wg_barrier();
   for (unsigned i0 = c0; i0 < c1; i0 += 64) {
-    const unsigned slot = i0 + lane;
-    if (slot < c1 && P.info[slot].bucket == int(b)) wv::atomic_add(&myHist[cls(slot)], 1u);
+    const unsigned locus = i0 + lane, n = contigsOf(locus);
+    for (unsigned ci = 0; ci < n; ++ci) {
+      const unsigned slot = locus * P.max_assembly_count + ci;
+      if (P.info[slot].bucket == int(b)) wv::atomic_add(&myHist[cls(slot)], 1u);
+    }
   }
   wv::sync();
   wv::wg_barrier();
@@ -433,23 +444,31 @@ WV_KERNEL_WG(4) void bucket_sort_kernel(const BucketSortParams P)
   wv::sync();
   wv::wg_barrier();
   for (unsigned i0 = c0; i0 < c1; i0 += 64) {
-    const unsigned slot  = i0 + lane;
-    const bool     valid = slot < c1 && P.info[slot].bucket == int(b);
-    const unsigned d     = valid ? cls(slot) : 0u;
-    uint64_t       peers = wv::ballot(valid);
-    for (int bit = 0; bit < 9; ++bit) {
-      const bool     on = (d >> bit) & 1u;
-      const uint64_t m  = wv::ballot(valid && on);
-      peers &= on ? m : ~m;
+    const unsigned locus = i0 + lane, n = contigsOf(locus);
+    unsigned       nMax  = n;  // the most contigs of a locus of this step (wave-uniform loop bound)
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned o = wv::shfl(nMax, int(lane) ^ off);
+      nMax             = (o > nMax) ? o : nMax;
     }
-    unsigned base = 0;
-    if (valid) base = dbase[d] + myHist[d];
-    wv::sync();
-    if (valid) {
-      out[base + unsigned(wv::popc(peers & ((uint64_t(1) << lane) - 1)))] = slot;
-      if ((peers >> lane) == 1u) myHist[d] += unsigned(wv::popc(peers));  // (the class' highest lane of this chunk)
+    for (unsigned ci = 0; ci < nMax; ++ci) {
+      const unsigned slot  = locus * P.max_assembly_count + ci;
+      const bool     valid = ci < n && P.info[slot].bucket == int(b);
+      const unsigned d     = valid ? cls(slot) : 0u;
+      uint64_t       peers = wv::ballot(valid);
+      for (int bit = 0; bit < 9; ++bit) {
+        const bool     on = (d >> bit) & 1u;
+        const uint64_t m  = wv::ballot(valid && on);
+        peers &= on ? m : ~m;
+      }
+      unsigned base = 0;
+      if (valid) base = dbase[d] + myHist[d];
+      wv::sync();
+      if (valid) {
+        out[base + unsigned(wv::popc(peers & ((uint64_t(1) << lane) - 1)))] = slot;
+        if ((peers >> lane) == 1u) myHist[d] += unsigned(wv::popc(peers));  // (the class' highest lane of this step)
+      }
+      wv::sync();
     }
-    wv::sync();
   }
 }
 #endif
