@@ -35,3 +35,33 @@ def test_emulated_replay_of_the_demo_pile_dump_matches_the_reference(emu):
 @pytest.mark.gpu
 def test_gpu_replay_of_the_demo_pile_dump_matches_the_reference(gpu):
     run(gpu)
+
+
+def test_refiner_writes_a_dump_that_replays_to_the_reference(emu, tmp_path):
+    """the refiner's own dump hook (SVCandidateAssemblyRefiner::setPileDump, manta_amd/host/pile_dump.hpp): synthetic complex and spanning
+    candidates go through the product refiner with the dump switched on; the records it wrote -- reads, oriented reference windows, cuts,
+    options -- replayed through the whole-batch calls equal the unmodified reference run on those same records"""
+    import ctypes
+    import random
+    import replay_piles
+    from oracle_lib import RefLib, have_ref
+    from refiner_loci import complex_case, spanning_case
+    from test_refiner import build_mine
+    import os as _os
+    if not have_ref():
+        pytest.skip("oracle/_ref/libmanta_ref.so not built")
+    mine = build_mine(_os.path.join(ROOT, "tests", "emu"), "manta_amd_emu", "emu")
+    mine.lib.mine_set_pile_dump.restype = ctypes.c_uint64
+    path = str(tmp_path / "dump.txt")
+    rng = random.Random(5)
+    cases = [complex_case(rng, "del"), complex_case(rng, "ins"), spanning_case(rng, "RL"), spanning_case(rng, "LL", ins_len=7), spanning_case(rng, "RR")]
+    mine.lib.mine_set_pile_dump(path.encode())
+    for c in cases:
+        assert not mine.run(c).startswith("EXCEPTION")
+    assert mine.lib.mine_set_pile_dump(None) == len(cases)
+    recs = replay_piles.parse_dump(path)
+    assert [r["kind"] for r in recs] == ["S", "S", "J", "J", "J"]
+    texts, _ = replay_piles.replay(emu, recs)
+    ref = RefLib()
+    for r in recs:
+        assert replay_piles.checker_text(ref, r) == texts[r["id"]], r["id"]

@@ -1,6 +1,6 @@
 """Kernel resource table (registers, spills, scratch, occupancy, LDS) of the product library, from
 `hipcc -Rpass-analysis=kernel-resource-usage`.  usage: kernel_resources.py [remarks.txt] > profiles/rNN_kernel_resources.txt
-Without an argument the library is compiled here (cross-compiles without a GPU, ~3 min)."""
+Without an argument the kernel translation units are compiled here (cross-compiles without a GPU, ~3 min on 8 cores)."""
 import os
 import re
 import subprocess
@@ -14,10 +14,18 @@ CSRC = os.path.join(ROOT, "manta_amd", "csrc")
 def remarks():
     if len(sys.argv) > 1:
         return open(sys.argv[1]).read()
-    with tempfile.TemporaryDirectory() as d:
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "-I", CSRC,
-               "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(d, "lib.so"), os.path.join(CSRC, "api_unity.cpp")]
-        return subprocess.run(cmd, stderr=subprocess.PIPE, text=True, check=True).stderr
+    # one compile per kernel family (manta_amd/build.py: the translation units of the product library), in parallel
+    sys.path.insert(0, ROOT)
+    from concurrent.futures import ThreadPoolExecutor
+    from manta_amd import build as b
+
+    def one(tu):
+        with tempfile.TemporaryDirectory() as d:
+            cmd = [b.HIPCC] + b.FLAGS + ["-DMANTA_TU=%d" % tu, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, "kernels_tu.cpp"),
+                   "-o", os.path.join(d, "k.o")]
+            return subprocess.run(cmd, stderr=subprocess.PIPE, text=True, check=True).stderr
+    with ThreadPoolExecutor(8) as ex:
+        return "".join(ex.map(one, sorted(b.KERNEL_TUS)))
 
 
 def main():
