@@ -18,7 +18,8 @@ for which in ("fetch", "write"):
         k = short(row["Kernel_Name"])
         if "rocclr" not in k:
             tot[k] += float(row["Counter_Value"]) * 1024
-st = {"loci": loci, "workload": "spanning", "source": "tools/gpu_r5_z.sh (builder-run counter passes on the final build, not the driver's run)", "date": "2026-09-27",
+st = {"loci": loci, "workload": "spanning", "source": "tools/gpu_r6_final.sh (builder-run counter passes on the final build, not the driver's run)",
+      "date": __import__("datetime").date.today().isoformat(),
       "note": "HBM-side bytes of ONE step of `bench.py --workload spanning --loci <loci>` = (FETCH_SIZE + WRITE_SIZE) KiB * 1024 per kernel, rocprofv3 --pmc, "
               "separate passes, raw, summed over all launches of the step (graph_big / repeat_big / contig_big: one launch per word length).  Counter "
               "passes on 2 048 loci (the whole digest set, 186 tandem-repeat piles among them): under the profiler larger blocks run into the passes' time limit"}
