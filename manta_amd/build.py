@@ -92,15 +92,19 @@ def build_profile_variant(verbose=True):
     return out
 
 
-def build(force=False, verbose=True, extra_flags=(), out=OUT):
+def build(force=False, verbose=True, extra_flags=(), out=OUT, obj_dir=None):
+    """obj_dir: developer variants (extra_flags) keep their objects apart from the product's"""
     extra_flags = list(extra_flags)
     if not force and not extra_flags and out == OUT and not needs_build():
         return OUT
-    os.makedirs(OBJ, exist_ok=True)
-    todo = [u for u in units() if force or _stale(u[0], extra_flags)]
+    us = units()
+    if obj_dir:
+        us = [(os.path.join(obj_dir, os.path.basename(o)), src, tu) for o, src, tu in us]
+    os.makedirs(obj_dir or OBJ, exist_ok=True)
+    todo = [u for u in us if force or _stale(u[0], extra_flags)]
     with ThreadPoolExecutor(max_workers=_jobs()) as pool:
         list(pool.map(lambda u: _compile(u, extra_flags, verbose), todo))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [o for o, _, _ in units()]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [o for o, _, _ in us]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -227,6 +227,18 @@ struct LdsGraphL {
     if (k < 16) v &= ~((1u << (32 - 2 * k)) - 1u);
     return v;
   }
+  /// byte `b` of the word at pile position pb: its bases [4 b, 4 b + 4) as eight bits, bases beyond the word length read as zero.  Comparing
+  /// words byte by byte from b = 0 is comparing their text (2-bit codes, A < C < G < T): the digits of the radix sorts below.
+  WV_DEV unsigned keyByte(const unsigned pb, const unsigned b) const
+  {
+    const unsigned at = pb + 4 * b, wi = at >> 4, sh = (at & 15) * 2;
+    uint32_t       v  = codes[wi] << sh;
+    if (sh > 24) v |= codes[wi + 1] >> (32 - sh);
+    v >>= 24;
+    const unsigned have = k - 4 * b;  // (callers pass b < ceil(k / 4))
+    if (have < 4) v &= ~((1u << (8 - 2 * have)) - 1u);
+    return v;
+  }
   WV_DEV bool windowHasN(const unsigned maskWordBase, const unsigned j) const
   {
     unsigned pos = j, left = k;
@@ -830,8 +842,12 @@ struct LdsGraphL {
   }
 
   // ------------------------------------------------------------------------------------------------
-  // the words in seed order (:686-696: count descending, k-mer ascending), as LdsGraph::sortWords: three-pass LSD radix sort over
-  // {first 8 bases (two digits), 255 - count}, ties ranked by full key compares inside their run.  Result: sortA[id] = slot.
+  // the words in seed order (:686-696: count descending, k-mer ascending): an LSD radix sort over the WHOLE word -- ceil(k / 4) byte passes
+  // from the last four bases to the first -- and then over 255 - count.  Result: sortA[id] = slot.
+  // (Up to round 5: three passes over {first 8 bases, count} and the ties ranked by full key compares inside their run, as the small class
+  // does.  A config-5 pile holds ~17-33 single-read error words per start position that share count and first bases, a tandem pile several
+  // times that: the compare loop was four fifths of this phase -- 20 % of the kernel -- on plain piles and, with lexOrder's twin of it,
+  // three quarters of the kernel on tandem piles; `tools/perf_big_rounds.py`.)
   // ------------------------------------------------------------------------------------------------
   template <int KW>
   WV_DEV bool sortWords()
@@ -871,16 +887,16 @@ struct LdsGraphL {
       nFat = nEligible = lowTier = 0;
       return true;
     }
-    auto pre16 = [&](const unsigned slot) -> unsigned { return prefix32(aPb(slots[slot])) >> 16; };  // the first 8 bases
     const unsigned chunk = (((n + tn - 1) / tn) + 63) & ~63u;  // elements of one wave, in order
     const unsigned c0 = chunk * tw, c1 = (c0 + chunk < n) ? (c0 + chunk) : n;
     uint16_t *     src = sortA, *dst = sortB;
     uint32_t*      myHist = whist + 256 * tw;
-    for (int pass = 0; pass < 3; ++pass) {
+    const int      nb = int((k + 3) >> 2);  // bytes of a word
+    for (int pass = 0; pass <= nb; ++pass) {
       for (unsigned i = tid(); i < 256 * tn; i += nThreads()) whist[i] = 0;
       teamSync();
       auto digitOf = [&](const unsigned slot) -> unsigned {
-        return (pass < 2) ? ((pre16(slot) >> (8 * pass)) & 255u) : (255u - unsigned(cntArr[slot]));
+        return (pass < nb) ? keyByte(aPb(slots[slot]), unsigned(nb - 1 - pass)) : (255u - unsigned(cntArr[slot]));
       };
       for (unsigned i0 = c0; i0 < c1; i0 += 64) {
         const unsigned i = i0 + lane;
@@ -932,7 +948,7 @@ struct LdsGraphL {
         wv::sync();
       }
       teamSync();
-      if (pass == 2 && tid() == 0) {
+      if (pass == nb && tid() == 0) {
         // ids below dbase[d] have counts above 255 - d
         const unsigned minCov = P.opt.minCoverage;
         hdr[LGL_H_TOT + 4] = dbase[254];                                                      // count >= 2
@@ -947,31 +963,9 @@ struct LdsGraphL {
     nFat      = hdr[LGL_H_TOT + 4];
     nEligible = hdr[LGL_H_TOT + 5];
     lowTier   = hdr[LGL_H_TOT + 6];
-    // three passes: the sorted list sits in sortB (= src); runs of equal {count, first 8 bases} -> exact order into sortA
-    for (unsigned i = tid(); i < n; i += nThreads()) {
-      const unsigned slot = src[i];
-      const unsigned c = cntArr[slot], p = pre16(slot);
-      unsigned       lo = i, hi = i;
-      while (lo > 0) {
-        const unsigned o = src[lo - 1];
-        if (unsigned(cntArr[o]) != c || pre16(o) != p) break;
-        lo--;
-      }
-      while (hi + 1 < n) {
-        const unsigned o = src[hi + 1];
-        if (unsigned(cntArr[o]) != c || pre16(o) != p) break;
-        hi++;
-      }
-      unsigned rank = 0;
-      if (hi > lo) {
-        const Key<KW> mineKey = keyAt<KW>(aPb(slots[slot]));
-        for (unsigned j = lo; j <= hi; ++j) {
-          if (j == i) continue;
-          if (keyLess(keyAt<KW>(aPb(slots[src[j]])), mineKey)) rank++;
-        }
-      }
-      dst[lo + rank] = uint16_t(slot);
-    }
+    // nb + 1 passes: the sorted list sits in `src`; the callers read sortA
+    if (src != sortA)
+      for (unsigned i = tid(); i < n; i += nThreads()) sortA[i] = src[i];
     teamSync();
     return true;
   }
@@ -1127,17 +1121,17 @@ struct LdsGraphL {
   // ------------------------------------------------------------------------------------------------
   // A graph without a proof of acyclicity may need the reference's repeat search (repeat_big_kernel), whose visiting order starts from
   // the insertion order of the words: reads in order, a read's new words in LEXICOGRAPHIC order (:516-548).  The words' lexicographic
-  // ranks go to the slab: two stable byte passes over the ids by the first eight bases, runs of equal prefixes ranked by full compares.
+  // ranks go to the slab: stable byte passes over the ids, the whole word, last byte first.
   // (After buildRecords: lists in the slot table's bytes, histograms in the potentials' bytes -- the records sit where sortWords had them.)
   // ------------------------------------------------------------------------------------------------
-  WV_DEV void radixPassIds(const uint16_t* src, uint16_t* dst, const unsigned n, const unsigned shift, uint32_t* hist)
+  WV_DEV void radixPassIds(const uint16_t* src, uint16_t* dst, const unsigned n, const unsigned byteIdx, uint32_t* hist)
   {
     const unsigned chunk = (((n + tn - 1) / tn) + 63) & ~63u;
     const unsigned c0 = chunk * tw, c1 = (c0 + chunk < n) ? (c0 + chunk) : n;
     uint32_t*      myHist = hist + 256 * tw;
     for (unsigned i = tid(); i < 256 * tn; i += nThreads()) hist[i] = 0;
     teamSync();
-    auto digitOf = [&](const unsigned id) -> unsigned { return (prefix32(idPb[id]) >> (16 + shift)) & 255u; };
+    auto digitOf = [&](const unsigned id) -> unsigned { return keyByte(idPb[id], byteIdx); };
     for (unsigned i0 = c0; i0 < c1; i0 += 64) {
       const unsigned i = i0 + lane;
       if (i < c1) wv::atomic_add(&myHist[digitOf(src[i])], 1u);
@@ -1198,24 +1192,16 @@ struct LdsGraphL {
     const unsigned n = nNodes;
     for (unsigned i = tid(); i < n; i += nThreads()) bufA[i] = uint16_t(i);
     teamSync();
-    radixPassIds(bufA, bufB, n, 0, hist);
-    radixPassIds(bufB, bufA, n, 8, hist);
-    for (unsigned i = tid(); i < n; i += nThreads()) {
-      const unsigned id = bufA[i];
-      const unsigned p  = prefix32(idPb[id]) >> 16;
-      unsigned       lo = i, hi = i;
-      while (lo > 0 && (prefix32(idPb[bufA[lo - 1]]) >> 16) == p) lo--;
-      while (hi + 1 < n && (prefix32(idPb[bufA[hi + 1]]) >> 16) == p) hi++;
-      unsigned rank = 0;
-      if (hi > lo) {
-        const Key<KW> mineKey = keyAt<KW>(idPb[id]);
-        for (unsigned j = lo; j <= hi; ++j) {
-          if (j == i) continue;
-          if (keyLess(keyAt<KW>(idPb[bufA[j]]), mineKey)) rank++;
-        }
-      }
-      gLex[id] = uint16_t(lo + rank);
+    // LSD over the whole word, last byte first (see sortWords: ranking the runs of an 8-base prefix by full key compares was the larger
+    // half of this kernel's time on tandem piles)
+    uint16_t *src = bufA, *dst = bufB;
+    for (int b = int((k + 3) >> 2) - 1; b >= 0; --b) {
+      radixPassIds(src, dst, n, unsigned(b), hist);
+      uint16_t* t = src;
+      src         = dst;
+      dst         = t;
     }
+    for (unsigned i = tid(); i < n; i += nThreads()) gLex[src[i]] = uint16_t(i);
     teamSync();
   }
 
@@ -1251,12 +1237,14 @@ struct LdsGraphL {
       if (src) queue[wv::atomic_add(&hdr[LGL_H_N], 1u)] = uint16_t(nd);
     }
     teamSync();
+    // The peel itself runs on ONE wave.  A k-mer graph is chains: a level of the peel holds two or three words, a pile's graph takes a few
+    // thousand levels, and sixteen waves only added two workgroup barriers to every one of them (round 5; `tools/perf_big_rounds.py`: with the
+    // lexicographic ranks this was 43-48 % of the kernel on tandem piles).  One wave needs no barrier: its LDS operations are ordered.
     unsigned head = 0;
-    while (true) {
-      const unsigned tail = wv::atomic_load(&hdr[LGL_H_N]);
-      teamSync();  // (every wave has read the tail before any of them appends to the queue again)
+    while (tw == 0) {
+      const unsigned tail = wv::first(wv::atomic_load(&hdr[LGL_H_N]));
       if (tail == head) break;
-      for (unsigned i = head + tid(); i < tail; i += nThreads()) {
+      for (unsigned i = head + lane; i < tail; i += 64) {
         const unsigned nd = queue[i];
         const FRec8    w  = nodes[nd];
         const uint64_t sl = R::links(w, nd, true, sovf, nS), pl = R::links(w, nd, false, povf, nP);
@@ -1275,9 +1263,11 @@ struct LdsGraphL {
           }
         }
       }
-      teamSync();
+      wv::sync();
       head = tail;
     }
+    teamSync();
+    head = wv::atomic_load(&hdr[LGL_H_N]);  // (the queue's final length = the words peeled: every entry was processed)
     const unsigned nCore = n - head;
     for (unsigned d = tid(); d < LgL::UNUSED_DW; d += nThreads()) {
       uint32_t b = 0;

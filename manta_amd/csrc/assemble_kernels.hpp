@@ -348,7 +348,7 @@ struct AssemblerT {
   /// optional per-phase shader-clock profile (compiled in with -DMANTA_ASM_PROFILE; costs registers)
   WV_DEV void tick(int phase)
   {
-#ifdef MANTA_ASM_PROFILE
+#if defined(MANTA_ASM_PROFILE) && !defined(MANTA_LG_PROFILE_GRAPH)  // (-DMANTA_LG_PROFILE_GRAPH: the eight counters are the graph kernels' alone)
 #ifdef MANTA_ASM_PROFILE_EXACT  // developer build: the eight counters split the exact repeat search (tickExact), everything else is counter 7
     phase = 7;
 #endif
