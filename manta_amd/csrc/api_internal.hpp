@@ -985,7 +985,7 @@ struct AsmStage {
           (void)bLgCyc.as<uint32_t>(bigIds.size());
           (void)bLgRounds.as<uint32_t>(8 * (manta_dev::LGL_MAX_ROUNDS + 1) + 32);
           (void)bRws.as<uint8_t>(rwsStride * uint64_t(gridRepeat));
-          (void)bGws.as<uint8_t>(uint64_t(32) * manta_dev::LGL_POOL_OVF * uint64_t(gridBig));
+          (void)bGws.as<uint8_t>(uint64_t(manta_dev::LGL_GWS_BYTES) * uint64_t(gridBig));
         }
       }
     } else {
@@ -1197,7 +1197,7 @@ struct AsmStage {
           B.G.cyc_ids     = bLgCyc.as<uint32_t>(bigIds.size());
           B.G.rws         = bRws.as<uint8_t>(rwsStride * uint64_t(gridRepeat));
           B.G.rws_stride  = rwsStride;
-          B.G.gws         = bGws.as<uint8_t>(uint64_t(32) * LGL_POOL_OVF * uint64_t(gridBig));
+          B.G.gws         = bGws.as<uint8_t>(uint64_t(LGL_GWS_BYTES) * uint64_t(gridBig));
           B.G.rprof       = std::getenv("MANTA_AMD_DEBUG") ? reinterpret_cast<unsigned long long*>(rc + 8 * (LGL_MAX_ROUNDS + 1)) : nullptr;
           B.G.last_round  = bigRounds - 1;
           const int later = int(std::max<size_t>(32, bigIds.size() / 4));

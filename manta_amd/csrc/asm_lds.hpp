@@ -178,6 +178,10 @@ static const unsigned LGL_MAX_PILE  = 3598;   // code dwords (+ 2 of padding) of
 static const unsigned LGL_MAX_PILE_ALL = 4090; // ... with the pseudo reads of a later word length behind them: a packed base index must fit 16 bits
 static const unsigned LGL_POOL_CAP  = 1280;   // read sets handed out during the table pass (words with more than one read) that live in LDS
 static const unsigned LGL_POOL_OVF  = 704;    // ... and further ones in the workgroup's device-memory workspace (later word lengths: the pseudo reads share most of their words)
+// graph_big_kernel's device-memory workspace per workgroup: the overflow read sets, then the words' lexicographic ranks by table slot and by id
+// (they fall out of the seed-order sort's byte passes; the repeat search of a cyclic graph wants them: LdsGraphL::sortWords / lexOrder)
+static const unsigned LGL_GWS_SETS  = 32 * LGL_POOL_OVF;
+static const unsigned LGL_GWS_BYTES = LGL_GWS_SETS + 2 * 8192 + 2 * 8192;
 static const unsigned LGL_WAVES     = 16;
 static const unsigned LGL_BUDGET    = 163840;
 static const unsigned LGL_OVF_CAP   = 128;
@@ -366,7 +370,7 @@ struct LgParams {
   uint32_t*           cyc_count;
   uint8_t*            rws;         ///< repeat_big_kernel workspaces (one per wave)
   uint64_t            rws_stride;
-  uint8_t*            gws;         ///< graph_big_kernel workspaces (one per workgroup: 32 * LGL_POOL_OVF bytes, the overflow read sets)
+  uint8_t*            gws;         ///< graph_big_kernel workspaces (one per workgroup: LGL_GWS_BYTES -- the overflow read sets, the lexicographic ranks)
   unsigned long long* rprof;       ///< [8] repeat_big_kernel: shader clocks by phase, summed over its loci (debug line; nullptr: not kept)
 };
 

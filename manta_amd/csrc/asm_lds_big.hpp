@@ -68,6 +68,7 @@ struct LdsGraphL {
   uint8_t *        cntArr, *cntId;
   Set*             pool;
   Set*             poolOvf;  ///< sets LGL_POOL_CAP .. of the table pass: device memory (nullptr: none)
+  uint16_t *       lexBySlot, *lexById;  ///< the words' lexicographic ranks (device memory, rounds only): sortWords leaves them, lexOrder copies them
   FRec8*           nodes;
   int16_t *        phi, *roff;
   unsigned         nNormal, W, k, nNodes, nFat, nEligible, lowTier, codeWords;
@@ -88,7 +89,9 @@ struct LdsGraphL {
     dbase  = reinterpret_cast<uint32_t*>(lds + LGL_OFF_DBASE);
     whist  = reinterpret_cast<uint32_t*>(lds + LGL_OFF_WHIST);
     pool   = reinterpret_cast<Set*>(lds + LGL_OFF_POOL);
-    poolOvf = g.gws ? reinterpret_cast<Set*>(g.gws + size_t(wv::block_single()) * 32u * LGL_POOL_OVF) : nullptr;
+    poolOvf = g.gws ? reinterpret_cast<Set*>(g.gws + size_t(wv::block_single()) * LGL_GWS_BYTES) : nullptr;
+    lexBySlot = g.gws ? reinterpret_cast<uint16_t*>(g.gws + size_t(wv::block_single()) * LGL_GWS_BYTES + LGL_GWS_SETS) : nullptr;
+    lexById   = lexBySlot ? lexBySlot + 8192 : nullptr;
     nodes  = reinterpret_cast<FRec8*>(lds + LGL_OFF_WHIST);
     slots  = reinterpret_cast<uint32_t*>(lds + LGL_OFF_SLOTS);
     sortA  = reinterpret_cast<uint16_t*>(lds + LGL_OFF_SORTA);
@@ -893,6 +896,10 @@ struct LdsGraphL {
     uint32_t*      myHist = whist + 256 * tw;
     const int      nb = int((k + 3) >> 2);  // bytes of a word
     for (int pass = 0; pass <= nb; ++pass) {
+      // after the byte passes `src` is the words in lexicographic order: the repeat search of a cyclic graph wants exactly these ranks
+      // (lexOrder) -- kept by table slot in the workgroup's device-memory workspace instead of sorting the words a second time
+      if (pass == nb && lexBySlot)
+        for (unsigned i = tid(); i < n; i += nThreads()) lexBySlot[src[i]] = uint16_t(i);
       for (unsigned i = tid(); i < 256 * tn; i += nThreads()) whist[i] = 0;
       teamSync();
       auto digitOf = [&](const unsigned slot) -> unsigned {
@@ -966,6 +973,9 @@ struct LdsGraphL {
     // nb + 1 passes: the sorted list sits in `src`; the callers read sortA
     if (src != sortA)
       for (unsigned i = tid(); i < n; i += nThreads()) sortA[i] = src[i];
+    teamSync();
+    if (lexById)  // ... and by id, while sortA still says which slot an id is (buildRecords turns it into id -> first occurrence)
+      for (unsigned i = tid(); i < n; i += nThreads()) lexById[i] = lexBySlot[sortA[i]];
     teamSync();
     return true;
   }
@@ -1186,10 +1196,15 @@ struct LdsGraphL {
   template <int KW>
   WV_DEV void lexOrder(uint16_t* gLex)
   {
+    const unsigned n = nNodes;
+    if (lexById) {  // sortWords left them
+      for (unsigned i = tid(); i < n; i += nThreads()) gLex[i] = lexById[i];
+      teamSync();
+      return;
+    }
     uint16_t* bufA = reinterpret_cast<uint16_t*>(lds + LGL_OFF_SLOTS);
     uint16_t* bufB = bufA + LGL_SLOTS;
     uint32_t* hist = reinterpret_cast<uint32_t*>(lds + LGL_OFF_SORTB);
-    const unsigned n = nNodes;
     for (unsigned i = tid(); i < n; i += nThreads()) bufA[i] = uint16_t(i);
     teamSync();
     // LSD over the whole word, last byte first (see sortWords: ranking the runs of an 8-base prefix by full key compares was the larger
@@ -1215,31 +1230,61 @@ struct LdsGraphL {
   {
     uint32_t*       st    = reinterpret_cast<uint32_t*>(lds + LGL_OFF_CNT);
     uint16_t*       queue = reinterpret_cast<uint16_t*>(lds + LGL_OFF_SLOTS);
+    uint16_t*       jf    = queue + LGL_SLOTS;                                   // second half of the slot table's bytes
+    uint16_t*       jb    = reinterpret_cast<uint16_t*>(lds + LGL_OFF_SORTB);    // (the potentials are done with)
     const uint16_t* sovf  = reinterpret_cast<const uint16_t*>(lds + LGL_OFF_SOVF);
     const uint16_t* povf  = reinterpret_cast<const uint16_t*>(lds + LGL_OFF_POVF);
     const unsigned  nS = wv::atomic_load(&hdr[LGL_H_NSOVF]), nP = wv::atomic_load(&hdr[LGL_H_NPOVF]);
     const unsigned  n = nNodes, stDw = (n + 3) / 4;
+    // A k-mer graph is chains: a node-by-node peel takes as many levels as the longest path has words (thousands, two or three words per
+    // level: 25 % of this kernel on tandem piles, `tools/perf_big_rounds.py`).  So the chains are contracted first.  An INNER word has
+    // exactly one predecessor and one successor (self loops aside); pointer jumping gives every inner word the two non-inner words
+    // (terminals) its chain hangs between.  A chain b -> ... -> t goes exactly when b goes (its first word loses its only predecessor, and
+    // so on down to t's in-degree) or when t goes (backwards, down to b's out-degree): for the peel it is ONE edge b -> t.  The peel then
+    // runs over the terminals only -- tens of levels -- on one wave (no workgroup barrier per level), and an inner word is peeled iff one of
+    // its two terminals is.  A cycle of inner words alone never resolves to a terminal and stays, as it must.  The fixpoint of "remove
+    // what has no predecessor or no successor" does not depend on the order, so the core is the one the node-by-node peel left.
+    // State byte: in-degree : 3, out-degree : 3, 0x40 queued / peeled (terminals), 0x80 inner.
     for (unsigned w = tid(); w < stDw; w += nThreads()) st[w] = 0;
     if (tid() == 0) hdr[LGL_H_N] = 0;  // the queue's tail
     teamSync();
+    auto stByte = [&](const unsigned nd) -> unsigned { return (st[nd >> 2] >> (8 * (nd & 3))) & 0xffu; };
     for (unsigned nd = tid(); nd < n; nd += nThreads()) {
       const FRec8    w  = nodes[nd];
       const uint64_t sl = R::links(w, nd, true, sovf, nS), pl = R::links(w, nd, false, povf, nP);
-      unsigned       id = 0, od = 0;
+      unsigned       id = 0, od = 0, onlyS = nd, onlyP = nd;
       for (unsigned c = 0; c < 4; ++c) {
         const unsigned s2 = R::linkId(sl, c), p2 = R::linkId(pl, c);
-        if (s2 != ASM_NONE && s2 != nd) od++;
-        if (p2 != ASM_NONE && p2 != nd) id++;
+        if (s2 != ASM_NONE && s2 != nd) {
+          od++;
+          onlyS = s2;
+        }
+        if (p2 != ASM_NONE && p2 != nd) {
+          id++;
+          onlyP = p2;
+        }
       }
-      const bool     src = (id == 0 || od == 0);
-      const unsigned v   = id | (od << 3) | (src ? 0x40u : 0u);
+      const bool     src   = (id == 0 || od == 0);
+      const bool     inner = (id == 1 && od == 1);
+      const unsigned v     = id | (od << 3) | (src ? 0x40u : 0u) | (inner ? 0x80u : 0u);
       wv::atomic_or(&st[nd >> 2], v << (8 * (nd & 3)));
       if (src) queue[wv::atomic_add(&hdr[LGL_H_N], 1u)] = uint16_t(nd);
+      jf[nd] = uint16_t(inner ? onlyS : nd);
+      jb[nd] = uint16_t(inner ? onlyP : nd);
     }
     teamSync();
-    // The peel itself runs on ONE wave.  A k-mer graph is chains: a level of the peel holds two or three words, a pile's graph takes a few
-    // thousand levels, and sixteen waves only added two workgroup barriers to every one of them (round 5; `tools/perf_big_rounds.py`: with the
-    // lexicographic ranks this was 43-48 % of the kernel on tandem piles).  One wave needs no barrier: its LDS operations are ordered.
+    {
+      unsigned rounds = 1;
+      while ((1u << rounds) < n) ++rounds;
+      for (unsigned r = 0; r < rounds; ++r) {  // (in place: a pointer only ever moves further along its chain)
+        for (unsigned nd = tid(); nd < n; nd += nThreads()) {
+          if (!(stByte(nd) & 0x80u)) continue;
+          jf[nd] = jf[jf[nd]];
+          jb[nd] = jb[jb[nd]];
+        }
+        teamSync();
+      }
+    }
     unsigned head = 0;
     while (tw == 0) {
       const unsigned tail = wv::first(wv::atomic_load(&hdr[LGL_H_N]));
@@ -1249,17 +1294,23 @@ struct LdsGraphL {
         const FRec8    w  = nodes[nd];
         const uint64_t sl = R::links(w, nd, true, sovf, nS), pl = R::links(w, nd, false, povf, nP);
         for (unsigned c = 0; c < 4; ++c) {
-          const unsigned s2 = R::linkId(sl, c);
+          unsigned s2 = R::linkId(sl, c);
           if (s2 != ASM_NONE && s2 != nd) {
-            const unsigned sh  = 8 * (s2 & 3);
-            const unsigned old = wv::atomic_sub(&st[s2 >> 2], 1u << sh) >> sh;
-            if ((old & 0x7u) == 1u && !(wv::atomic_or(&st[s2 >> 2], 0x40u << sh) & (0x40u << sh))) queue[wv::atomic_add(&hdr[LGL_H_N], 1u)] = uint16_t(s2);
+            if (stByte(s2) & 0x80u) s2 = jf[s2];  // the terminal at the far end of the chain
+            if (!(stByte(s2) & 0x80u)) {
+              const unsigned sh  = 8 * (s2 & 3);
+              const unsigned old = wv::atomic_sub(&st[s2 >> 2], 1u << sh) >> sh;
+              if ((old & 0x7u) == 1u && !(wv::atomic_or(&st[s2 >> 2], 0x40u << sh) & (0x40u << sh))) queue[wv::atomic_add(&hdr[LGL_H_N], 1u)] = uint16_t(s2);
+            }
           }
-          const unsigned p2 = R::linkId(pl, c);
+          unsigned p2 = R::linkId(pl, c);
           if (p2 != ASM_NONE && p2 != nd) {
-            const unsigned sh  = 8 * (p2 & 3);
-            const unsigned old = wv::atomic_sub(&st[p2 >> 2], 8u << sh) >> sh;
-            if ((old & 0x38u) == 8u && !(wv::atomic_or(&st[p2 >> 2], 0x40u << sh) & (0x40u << sh))) queue[wv::atomic_add(&hdr[LGL_H_N], 1u)] = uint16_t(p2);
+            if (stByte(p2) & 0x80u) p2 = jb[p2];
+            if (!(stByte(p2) & 0x80u)) {
+              const unsigned sh  = 8 * (p2 & 3);
+              const unsigned old = wv::atomic_sub(&st[p2 >> 2], 8u << sh) >> sh;
+              if ((old & 0x38u) == 8u && !(wv::atomic_or(&st[p2 >> 2], 0x40u << sh) & (0x40u << sh))) queue[wv::atomic_add(&hdr[LGL_H_N], 1u)] = uint16_t(p2);
+            }
           }
         }
       }
@@ -1267,18 +1318,28 @@ struct LdsGraphL {
       head = tail;
     }
     teamSync();
-    head = wv::atomic_load(&hdr[LGL_H_N]);  // (the queue's final length = the words peeled: every entry was processed)
-    const unsigned nCore = n - head;
+    if (tid() == 0) hdr[LGL_H_N] = 0;  // now: the words left
+    teamSync();
     for (unsigned d = tid(); d < LgL::UNUSED_DW; d += nThreads()) {
       uint32_t b = 0;
-      for (unsigned j = 0; j < 32 && nCore; ++j) {
+      for (unsigned j = 0; j < 32; ++j) {
         const unsigned nd = 32 * d + j;
-        if (nd < n && !((st[nd >> 2] >> (8 * (nd & 3))) & 0x40u)) b |= 1u << j;
+        if (nd >= n) break;
+        const unsigned v = stByte(nd);
+        bool           gone;
+        if (!(v & 0x80u)) {
+          gone = (v & 0x40u) != 0;
+        } else {
+          const unsigned vf = stByte(jf[nd]), vb = stByte(jb[nd]);
+          gone = (!(vf & 0x80u) && (vf & 0x40u)) || (!(vb & 0x80u) && (vb & 0x40u));
+        }
+        if (!gone) b |= 1u << j;
       }
       gCore[d] = b;
+      if (b) wv::atomic_add(&hdr[LGL_H_N], unsigned(wv::popc(b)));
     }
     teamSync();
-    return nCore;
+    return wv::atomic_load(&hdr[LGL_H_N]);
   }
 
   /// round 0's walk list: the first seed and beside it the words most likely to follow it -- the low count tiers in seed order, ONE WORD
@@ -1445,11 +1506,20 @@ struct LdsGraphL {
     // (components, repeat search, LDS class), with the words' lexicographic ranks and the core's bitmap in its slab.
     unsigned       nCorePeel = 0;
     if (!acyclic && G.iter != nullptr) {
+#ifdef MANTA_LG_PROFILE_PEEL  // (one-off: what came before the peel to slot 6, the peel to slot 0, the ranks to slot 1, the speculation list to slot 6)
+      tick(2, 6);
+#endif
       nCorePeel = peelCore(reinterpret_cast<uint32_t*>(slab + SL.flags));
+#ifdef MANTA_LG_PROFILE_PEEL
+      tick(0, 0);
+#endif
       if (nCorePeel == 0) acyclic = true;  // (no proof from the reads' offsets, but nothing survives the peel)
     }
     const bool     toRepeat = !acyclic && G.iter != nullptr;
     if (toRepeat) lexOrder<KW>(reinterpret_cast<uint16_t*>(slab + SL.lex));
+#ifdef MANTA_LG_PROFILE_PEEL
+    tick(1, 1);
+#endif
     const unsigned need    = ckNeedOf<LgL>(nNodes, nFat, acyclic);
     unsigned       cls     = LG_CLASSES;
     for (unsigned c = LG_CLASSES; c-- > 0;)
