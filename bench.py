@@ -654,8 +654,8 @@ def main():
                 at = tj.get("align_kernel<JUMP>" if spanning else "align_kernel<LARGE_INDEL>")
                 if at and tj.get("loci") and n_loci % tj["loci"] == 0 and align_sum > 0:
                     at = at * (n_loci // tj["loci"])
-                    gbps = at / (align_sum / n_blocks / steps * 1e-3) / 1e9
-                    o["roofline"]["aligner_hbm"] = {"kernel": align_name, "traffic_bytes_per_launch": int(at), "avg_launch_ms": round(align_sum / n_blocks / steps, 3),
+                    gbps = at / (align_sum / n_blocks * 1e-3) / 1e9  # (align_sum: HIP-event ms summed over the timed region's blocks)
+                    o["roofline"]["aligner_hbm"] = {"kernel": align_name, "traffic_bytes_per_launch": int(at), "avg_launch_ms": round(align_sum / n_blocks, 3),
                                                     "achieved_GBps": round(gbps, 1), "peak": HBM_PEAK_GBPS, "frac": round(gbps / HBM_PEAK_GBPS, 4),
                                                     "note": "counter bytes of the builder's rocprofv3 --pmc passes (profiles/) over this run's aligner time: the back-pointer stream, written once, read along the traceback"}
             cpath = os.path.join(ROOT, "profiles", "ceilings.json")
