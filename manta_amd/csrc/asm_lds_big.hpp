@@ -895,20 +895,31 @@ struct LdsGraphL {
     uint16_t *     src = sortA, *dst = sortB;
     uint32_t*      myHist = whist + 256 * tw;
     const int      nb = int((k + 3) >> 2);  // bytes of a word
+    static const unsigned SORT_IT = (LGL_MAX_NODES / LGL_WAVES + 63) / 64;  // 64-element steps of a wave's share
+    static_assert(64 * SORT_IT * LGL_WAVES >= LGL_MAX_NODES, "a wave's share of the words in SORT_IT steps");
     for (int pass = 0; pass <= nb; ++pass) {
       // after the byte passes `src` is the words in lexicographic order: the repeat search of a cyclic graph wants exactly these ranks
       // (lexOrder) -- kept by table slot in the workgroup's device-memory workspace instead of sorting the words a second time
       if (pass == nb && lexBySlot)
         for (unsigned i = tid(); i < n; i += nThreads()) lexBySlot[src[i]] = uint16_t(i);
-      for (unsigned i = tid(); i < 256 * tn; i += nThreads()) whist[i] = 0;
-      teamSync();
       auto digitOf = [&](const unsigned slot) -> unsigned {
         return (pass < nb) ? keyByte(aPb(slots[slot]), unsigned(nb - 1 - pass)) : (255u - unsigned(cntArr[slot]));
       };
-      for (unsigned i0 = c0; i0 < c1; i0 += 64) {
-        const unsigned i = i0 + lane;
-        if (i < c1) wv::atomic_add(&myHist[digitOf(src[i])], 1u);
+      // this lane's (at most SORT_IT) elements and their digits, fetched ONCE per pass -- independent LDS chains in flight -- for the count
+      // below and the scatter further down; the wave's own histogram needs no workgroup barrier to be cleared (nobody reads it before the next one)
+      unsigned sv[SORT_IT], dv[SORT_IT];
+#pragma unroll
+      for (unsigned j = 0; j < SORT_IT; ++j) {
+        const unsigned i = c0 + 64 * j + lane;
+        sv[j]            = (i < c1) ? unsigned(src[i]) : 0xffffffffu;
       }
+#pragma unroll
+      for (unsigned j = 0; j < SORT_IT; ++j) dv[j] = (sv[j] != 0xffffffffu) ? digitOf(sv[j]) : 0u;
+      for (unsigned q = lane; q < 256; q += 64) myHist[q] = 0;
+      wv::sync();
+#pragma unroll
+      for (unsigned j = 0; j < SORT_IT; ++j)
+        if (sv[j] != 0xffffffffu) wv::atomic_add(&myHist[dv[j]], 1u);
       teamSync();
       // per digit: running offsets over the waves, totals; then the digit bases (four quarters of 64 digits, one wave each)
       for (unsigned q = tw; q < 4; q += tn) {
@@ -934,11 +945,12 @@ struct LdsGraphL {
         dbase[64 * q + lane] += before;
       }
       teamSync();
-      for (unsigned i0 = c0; i0 < c1; i0 += 64) {
-        const unsigned i     = i0 + lane;
-        const bool     valid = i < c1;
-        const unsigned slot  = valid ? unsigned(src[i]) : 0u;
-        const unsigned d     = valid ? digitOf(slot) : 0u;
+#pragma unroll
+      for (unsigned j = 0; j < SORT_IT; ++j) {
+        if (c0 + 64 * j >= c1) break;  // (wave-uniform)
+        const bool     valid = sv[j] != 0xffffffffu;
+        const unsigned slot  = valid ? sv[j] : 0u;
+        const unsigned d     = dv[j];
         uint64_t       peers = wv::ballot(valid);
         for (int bit = 0; bit < 8; ++bit) {
           const bool     on = (d >> bit) & 1u;

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <exception>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <sstream>
@@ -840,6 +841,26 @@ private:
     detail::AlignJob      job;
   };
 
+  /// frees the read copies of the given plans on half the host threads, in the background (the plans are the batch call's own objects; the
+  /// device stage that follows only reads the flattened piles).  wait() before the caller goes on; the destructor waits too.
+  struct ReadsTeardown {
+    std::future<void> done;
+    ReadsTeardown(const SVCandidateAssemblyRefiner& r, const std::vector<Plan>& plans, const std::vector<size_t>& which)
+    {
+      const unsigned threads = std::max(1u, r._hostThreads / 2);
+      done = std::async(std::launch::async, [&plans, &which, threads] {
+        detail::parallelFor(which.size(), threads, [&](const size_t w) { AssemblyReadInput().swap(const_cast<Plan&>(plans[which[w]]).reads); });
+      });
+    }
+    void wait()
+    {
+      if (done.valid()) done.get();
+    }
+    ~ReadsTeardown()
+    {
+      if (done.valid()) done.wait();
+    }
+  };
   void runSmall(const std::vector<Plan>& plans, const bool isFindLargeInsertions, std::vector<SVCandidateAssemblyData>& out) const
   {
     const double                    tStart = now();
@@ -862,11 +883,15 @@ private:
                          cuts[w].leading_cut, cuts[w].trailing_cut, cuts[w].max_leading_cut, cuts[w].max_trailing_cut);
     packed.finish(_hostThreads, &_stage);
     _stats.smallLoci += which.size();
+    // the plans' own copies of the reads (80 strings per candidate) are flattened now: their teardown -- a tenth of a second of `free` on a
+    // large batch -- runs on a few host threads WHILE the device works, not behind it
+    ReadsTeardown teardown(*this, plans, which);
     const double          tPacked = now();
     _times.pack += tPacked - tStart;
     detail::SmallSvOutput& dev(_smallDev);  // (kept across calls: no re-allocation and zero-fill of tens of MB per batch)
     detail::smallSvBatch(deviceContext(), _smallPipe, _opt.refineOpt.smallSVAssembleOpt, _opt.refineOpt.largeSVAlignScores, _opt.refineOpt.largeGapOpenScore, packed,
                          refs, cuts, dev, _hostThreads, _refStage);
+    teardown.wait();
     const double tDevice = now();
     _times.device += tDevice - tPacked;
 
@@ -1109,6 +1134,8 @@ private:
     if (loci.empty()) return;
     packed.finish(_hostThreads, &_stage);
     _stats.spanningLoci += loci.size();
+    std::vector<size_t> spanPlans;
+    for (const SpanningLocus& sl : loci) spanPlans.push_back(sl.planIndex);
 
     // orientation step of alignJumpContigs (:1533-1550)
     std::vector<const std::string*> refs1, refs2;
@@ -1145,12 +1172,14 @@ private:
       for (size_t l = 0; l < loci.size(); ++l)
         _pileDump->spanning(_opt.refineOpt.spanningAssembleOpt, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, plans[loci[l].planIndex].reads, *refs1[l],
                             *refs2[l], cuts[l].align1_leading_cut, cuts[l].align1_trailing_cut, cuts[l].align2_leading_cut, cuts[l].align2_trailing_cut);
+    ReadsTeardown teardown(*this, plans, spanPlans);  // (see runSmall; the pile dump above was the reads' last user)
     // assemble -> jump-align (cut references) -> re-align rule -> jump-align (uncut), all on the device
     const double           tPacked = now();
     _times.pack += tPacked - tStart;
     detail::SpanningOutput& dev(_spanDev);
     detail::spanningBatch(deviceContext(), _spanPipe, _opt.refineOpt.spanningAssembleOpt, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, packed, refs1,
                           refs2, cuts, dev, _hostThreads, _refStage, _ref2Stage);
+    teardown.wait();
     const double tDevice = now();
     _times.device += tDevice - tPacked;
 
