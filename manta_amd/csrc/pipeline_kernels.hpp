@@ -359,7 +359,7 @@ WV_KERNEL void smallsv_schedule_kernel(const ScheduleParams P)
 // bucket).  Longest first also keeps the launch's tail short.
 // ------------------------------------------------------------------------------------------------------------------
 static const unsigned BS_CLASSES = 512;
-static const unsigned BS_WAVES   = 4;
+static const unsigned BS_WAVES   = 16;  // (four waves took 0.24 ms over the metric's 10 000 loci: a latency chain per 64 loci, so more waves, shorter shares)
 static const unsigned BS_LDS_BYTES = 4 * (BS_WAVES * BS_CLASSES + BS_CLASSES + 8);
 struct BucketSortParams {
   const AlignTaskDev*    tasks;
@@ -374,13 +374,13 @@ struct BucketSortParams {
 // ones, ... -- and the counting sort is stable, so the sorted order, and with it which two tasks share a wave in align_pair_kernel,
 // depends on the batch alone.  (The schedule kernel's own bucket lists are in the order its waves' atomic appends happened to land: up
 // to round 5 the pairing, and so the aligner's time to the last few percent, differed from run to run.)  Every wave takes a contiguous
-// quarter of the loci and keeps its own class histogram; class bases are the exclusive scan over (class, wave); inside a step the lanes of
+// share of the loci and keeps its own class histogram; class bases are the exclusive scan over (class, wave); inside a step the lanes of
 // a class rank themselves by ballots (asm_lds_big.hpp: radixPassIds).  Only the slots that hold a contig are read: n_loci records and
 // ~1.5 slots per locus, not n_loci x maxAssemblyCount.
 #if !MANTA_TU_DEFINES(MANTA_TU_GLUE)
-WV_KERNEL_WG(4) void bucket_sort_kernel(const BucketSortParams P);
+WV_KERNEL_WG(16) void bucket_sort_kernel(const BucketSortParams P);
 #else
-WV_KERNEL_WG(4) void bucket_sort_kernel(const BucketSortParams P)
+WV_KERNEL_WG(16) void bucket_sort_kernel(const BucketSortParams P)
 {
   const unsigned b = unsigned(wv::block_single());
   if (!((P.mask >> b) & 1u)) return;
