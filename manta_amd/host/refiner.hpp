@@ -637,6 +637,10 @@ struct SVCandidateAssemblyRefiner {
     const size_t n = svs.size();
     out.resize(n);  // (plan() clears every entry)
     std::vector<Plan> plans(n);
+    struct JoinTeardowns {  // (declared behind `plans`: the background frees end before the plans do, whichever way this call is left)
+      std::vector<std::unique_ptr<ReadsTeardown>>& v;
+      ~JoinTeardowns() { v.clear(); }
+    } joinTeardowns{_teardowns};
     _times = RefinerTimes();
     _errors.assign(n, std::exception_ptr());
     const double t0 = now();
@@ -671,7 +675,9 @@ struct SVCandidateAssemblyRefiner {
     _times.plan = now() - t0;
     runSmall(plans, isFindLargeInsertions, out);
     runSpanning(plans, out);
-    // (the plans hold a copy of every read: their teardown is spread over the host threads as well)
+    // (the plans hold a copy of every read: the candidates that went to the device are being freed in the background since their piles
+    // were flattened -- joined here --, what is left -- candidates without a device stage -- is spread over the host threads as well)
+    _teardowns.clear();
     detail::parallelFor(n, _hostThreads, [&](const size_t i) { AssemblyReadInput().swap(plans[i].reads); });
     if (errors) {
       *errors = _errors;
@@ -842,14 +848,17 @@ private:
   };
 
   /// frees the read copies of the given plans on half the host threads, in the background (the plans are the batch call's own objects; the
-  /// device stage that follows only reads the flattened piles).  wait() before the caller goes on; the destructor waits too.
+  /// device stage and the per-candidate glue that follow only read the flattened piles and the results).  The batch call joins them before
+  /// it returns (`_teardowns`, cleared by a guard declared behind the plans); the destructor waits.
   struct ReadsTeardown {
-    std::future<void> done;
-    ReadsTeardown(const SVCandidateAssemblyRefiner& r, const std::vector<Plan>& plans, const std::vector<size_t>& which)
+    std::future<void>   done;
+    std::vector<size_t> mine;  ///< (the caller's index list is a local of runSmall / runSpanning: this object outlives it)
+    ReadsTeardown(const SVCandidateAssemblyRefiner& r, const std::vector<Plan>& plans, const std::vector<size_t>& which) : mine(which)
     {
-      const unsigned threads = std::max(1u, r._hostThreads / 2);
-      done = std::async(std::launch::async, [&plans, &which, threads] {
-        detail::parallelFor(which.size(), threads, [&](const size_t w) { AssemblyReadInput().swap(const_cast<Plan&>(plans[which[w]]).reads); });
+      const unsigned             threads = std::max(1u, r._hostThreads / 2);
+      const std::vector<size_t>* idx     = &mine;
+      done = std::async(std::launch::async, [&plans, idx, threads] {
+        detail::parallelFor(idx->size(), threads, [&](const size_t w) { AssemblyReadInput().swap(const_cast<Plan&>(plans[(*idx)[w]]).reads); });
       });
     }
     void wait()
@@ -885,13 +894,12 @@ private:
     _stats.smallLoci += which.size();
     // the plans' own copies of the reads (80 strings per candidate) are flattened now: their teardown -- a tenth of a second of `free` on a
     // large batch -- runs on a few host threads WHILE the device works, not behind it
-    ReadsTeardown teardown(*this, plans, which);
+    _teardowns.emplace_back(new ReadsTeardown(*this, plans, which));  // (joined at the end of the batch call)
     const double          tPacked = now();
     _times.pack += tPacked - tStart;
     detail::SmallSvOutput& dev(_smallDev);  // (kept across calls: no re-allocation and zero-fill of tens of MB per batch)
     detail::smallSvBatch(deviceContext(), _smallPipe, _opt.refineOpt.smallSVAssembleOpt, _opt.refineOpt.largeSVAlignScores, _opt.refineOpt.largeGapOpenScore, packed,
                          refs, cuts, dev, _hostThreads, _refStage);
-    teardown.wait();
     const double tDevice = now();
     _times.device += tDevice - tPacked;
 
@@ -1172,14 +1180,13 @@ private:
       for (size_t l = 0; l < loci.size(); ++l)
         _pileDump->spanning(_opt.refineOpt.spanningAssembleOpt, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, plans[loci[l].planIndex].reads, *refs1[l],
                             *refs2[l], cuts[l].align1_leading_cut, cuts[l].align1_trailing_cut, cuts[l].align2_leading_cut, cuts[l].align2_trailing_cut);
-    ReadsTeardown teardown(*this, plans, spanPlans);  // (see runSmall; the pile dump above was the reads' last user)
+    _teardowns.emplace_back(new ReadsTeardown(*this, plans, spanPlans));  // (see runSmall; the pile dump above was the reads' last user)
     // assemble -> jump-align (cut references) -> re-align rule -> jump-align (uncut), all on the device
     const double           tPacked = now();
     _times.pack += tPacked - tStart;
     detail::SpanningOutput& dev(_spanDev);
     detail::spanningBatch(deviceContext(), _spanPipe, _opt.refineOpt.spanningAssembleOpt, _opt.refineOpt.spanningAlignScores, _opt.refineOpt.jumpScore, packed, refs1,
                           refs2, cuts, dev, _hostThreads, _refStage, _ref2Stage);
-    teardown.wait();
     const double tDevice = now();
     _times.device += tDevice - tPacked;
 
@@ -1263,6 +1270,7 @@ private:
   unsigned                      _hostThreads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
   unsigned                      _planThreads = 1;
   PileDumpWriter*               _pileDump = nullptr;
+  mutable std::vector<std::unique_ptr<ReadsTeardown>> _teardowns;  ///< background frees of the current batch call
 };
 
 }  // namespace manta_amd
