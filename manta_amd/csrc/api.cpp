@@ -383,6 +383,15 @@ int manta_smallsv_upload(
     rt::ScopedStream onStream(b->main);
     b->uploaded = false;
     const double tP0 = nowMs();
+    const bool streamed = b->streamUploads && !std::getenv("MANTA_AMD_NO_STREAM_UPLOAD");
+    // a streamed upload starts the DMA of the read bases before anything else: plan()'s pass over the read offsets runs beside it
+    const bool noEarlyStream = std::getenv("MANTA_AMD_NO_EARLY_STREAM") != nullptr;  // A/B knob (read per call: the tests flip it)
+    const bool        chunksInFlight = streamed && !noEarlyStream && b->asmStage.startStream(n_loci, bases, read_off, locus_read_begin, b->copy);
+    struct DrainOnFailure {  // (a failed call must not leave DMA reads of the caller's buffers queued)
+      manta_smallsv_t* b;
+      bool             armed;
+      ~DrainOnFailure() { if (armed) drainCopyStream(b); }
+    } drain{b, chunksInFlight};
     int rc      = b->asmStage.plan(b->opt, n_loci, read_off, locus_read_begin);
     if (rc != MANTA_OK) return rc;
     const double tP1 = nowMs();
@@ -399,7 +408,6 @@ int manta_smallsv_upload(
     uint64_t* dRefOff = b->dRefOff.as<uint64_t>(n_loci + 1);
     auto*     dCuts   = b->dCuts.as<SmallSvCuts>(n_loci);
     static_assert(sizeof(SmallSvCuts) == sizeof(manta_ref_cuts_t), "cuts layout");
-    const bool streamed = b->streamUploads && !std::getenv("MANTA_AMD_NO_STREAM_UPLOAD");
     b->refsOnCopy       = streamed;
     if (streamed) {
       // the assembler does not read the reference windows: they travel on the copy stream BEHIND the read bases and the
@@ -419,6 +427,7 @@ int manta_smallsv_upload(
     }
     if (std::getenv("MANTA_AMD_DEBUG_TIMING"))
       std::fprintf(stderr, "manta_amd: smallsv_upload plan %.2f ms, upload (%s) %.2f ms\n", tP1 - tP0, b->asmStage.streaming ? "streamed" : "blocking", nowMs() - tP1);
+    drain.armed = false;
     b->uploaded = true;
     return MANTA_OK;
   } catch (const std::exception& e) {
@@ -522,6 +531,7 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
       std::unique_lock<std::mutex> streamedOnly(streamedAsmMu(ctx), std::defer_lock);
       if (as.streaming) streamedOnly.lock();
       as.stageQueued = false;  // (a run that failed behind its queued staging must not leave the flag to the next one)
+      as.earlyStaged = false;
       b->evStart.record();
       as.launch();
       b->evAsm.record();
@@ -534,6 +544,10 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
       }
     }
     stage("assembled");
+    // whole-batch calls: the assembler's outputs leave for the host now, on the copy stream, beside the schedule kernel and the aligners
+    const bool noEarlyStage = std::getenv("MANTA_AMD_NO_EARLY_STAGE") != nullptr;  // A/B knob (read per call: the tests flip it)
+    const bool        earlyStage   = b->stageBehindRun && b->whileAligning && !noEarlyStage;
+    if (earlyStage) as.stageEarly(b->copy, asmCnt, b->evEarlyStaged);
     // CIGAR scratch, sized from what the assembler produced (as in spanningRunImpl): a task takes 4 * contig length + 16 words
     // (smallsv_schedule_kernel), every contig is aligned once, and the text arena counter bounds the summed contig lengths.  A
     // worst case per slot would be tens of GB at 65536-locus blocks and overflow the 32-bit offsets of the task records.
@@ -777,6 +791,11 @@ int smallsvRunImpl(manta_smallsv_t* b, StageGates* gates)
     uint32_t* hSmallPin = b->pSmall.as<uint32_t>(40);
     rt::d2hAsync(hSmallPin, dSmall, sizeof(uint32_t) * 40);
     if (b->stageBehindRun) pipeStageEnqueue(b);  // the results start for the host behind the last kernel: no wake-up in between
+    if (earlyStage) {  // everything is queued and the aligners have ~2 ms to go: the host's share of the assembler's outputs
+      b->evEarlyStaged.sync();
+      as.finishEarly();
+      b->whileAligning();
+    }
     rt::sync();
     std::memcpy(b->lastSmall, hSmallPin, sizeof(b->lastSmall));
     b->bucketHistory = true;

@@ -836,30 +836,62 @@ struct AsmStage {
   /// synchronises copyStream before it touches them again.
   void uploadStreamed(const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, rt::Stream& copyStream)
   {
-    chunkLoci = std::max<uint32_t>(1, (nLoci + kStreamChunks - 1) / kStreamChunks);
-    const uint32_t nChunks = (nLoci + chunkLoci - 1) / chunkLoci;
-    std::vector<uint32_t> host(1 + kStreamChunks, 0u);
-    std::vector<uint64_t> hostBegin(nChunks + 1), devBegin(nChunks + 1);
-    uint64_t              cursor = 0;
-    for (uint32_t c = 0; c < nChunks; ++c) {
-      const uint32_t l0 = c * chunkLoci, l1 = std::min(nLoci, l0 + chunkLoci);
-      hostBegin[c]      = read_off[locus_read_begin[l0]];
-      const uint64_t len = read_off[locus_read_begin[l1]] - hostBegin[c];
-      devBegin[c]        = cursor;
-      host[1 + c]        = uint32_t(devBegin[c] - hostBegin[c]);  // modulo 2^32: the kernel adds it in 32-bit arithmetic to a 64-bit offset
-      cursor             = (cursor + len + 64 + 255) & ~uint64_t(255);
+    const bool chunksQueued = preStreamed && preLoci == nLoci;  // startStream() ran for this batch: the chunks are in flight already
+    if (preStreamed && !chunksQueued) {  // (cannot happen: startStream() and plan() are given the same batch)
+      rt::ScopedStream onCopy(copyStream);
+      rt::sync();
     }
-    hostBegin[nChunks] = read_off[nReadsTotal];
-    // shifts must be exact in 64 bits: keep them small by construction (device offsets only grow by the padding)
-    for (uint32_t c = 0; c < nChunks; ++c) host[1 + c] = uint32_t(devBegin[c] - hostBegin[c]);
+    preStreamed = false;
+    StreamLayout L;
+    if (chunksQueued)
+      L = preLayout;
+    else
+      L = streamLayout(nLoci, read_off, locus_read_begin);
+    chunkLoci                 = L.chunkLoci;
     const uint64_t savedBases = nBases;
-    nBases                    = cursor + 64;  // device arena incl. the per-chunk padding
-    upload(nullptr, nullptr, locus_read_begin);  // allocations + the small arrays (order, word lengths, growth schedule, locus begins)
+    nBases                    = L.cursor + 64;  // device arena incl. the per-chunk padding
+    upload(nullptr, nullptr, chunksQueued ? nullptr : locus_read_begin);  // allocations + the small arrays (order, word lengths, growth schedule, locus begins)
     nBases  = savedBases;
     dPlCodes = nullptr;
-    rt::h2d(dOff, read_off, sizeof(uint64_t) * (nReadsTotal + 1));
+    if (!chunksQueued) rt::h2d(dOff, read_off, sizeof(uint64_t) * (nReadsTotal + 1));
     dStream = bStream.as<uint32_t>(1 + kStreamChunks);
-    rt::h2d(dStream, host.data(), sizeof(uint32_t) * (1 + kStreamChunks));
+    rt::h2d(dStream, L.shift, sizeof(uint32_t) * (1 + kStreamChunks));
+    if (!chunksQueued) resetChunkCounter(copyStream);
+    if (chunksQueued) rt::curStreamWaits(evPreSmall);  // (read offsets and locus table: ahead of the chunks on the copy stream)
+    rt::sync();  // the counter is zero and the small arrays are in place before the first chunk can land / the kernel starts
+    if (!chunksQueued) queueChunks(L, bases, copyStream);
+    streaming = true;
+  }
+
+  /// where the chunks of a streamed upload lie on the host and on the device (chunks of whole loci, in locus order)
+  struct StreamLayout {
+    uint32_t chunkLoci = 0, nChunks = 0;
+    uint64_t cursor = 0;  ///< bytes of the device arena the chunks take (per-chunk padding included)
+    uint64_t hostBegin[kStreamChunks + 1] = {0}, devBegin[kStreamChunks + 1] = {0};
+    uint32_t shift[1 + kStreamChunks] = {0};  ///< AsmParams::chunk_shift: device - host offset of chunk c at [1 + c]
+    bool     monotone = true;
+  };
+  static StreamLayout streamLayout(const uint32_t n, const uint64_t* read_off, const uint32_t* locus_read_begin)
+  {
+    StreamLayout L;
+    L.chunkLoci = std::max<uint32_t>(1, (n + kStreamChunks - 1) / kStreamChunks);
+    L.nChunks   = (n + L.chunkLoci - 1) / L.chunkLoci;
+    for (uint32_t c = 0; c < L.nChunks; ++c) {
+      const uint32_t l0 = c * L.chunkLoci, l1 = std::min(n, l0 + L.chunkLoci);
+      L.hostBegin[c]    = read_off[locus_read_begin[l0]];
+      const uint64_t end = read_off[locus_read_begin[l1]];
+      if (end < L.hostBegin[c]) L.monotone = false;
+      const uint64_t len = end - L.hostBegin[c];
+      L.devBegin[c]      = L.cursor;
+      // (modulo 2^32: the kernel adds it in 32-bit arithmetic to a 64-bit offset; device offsets only grow by the padding, so the shifts stay small)
+      L.shift[1 + c]     = uint32_t(L.devBegin[c] - L.hostBegin[c]);
+      L.cursor           = (L.cursor + len + 64 + 255) & ~uint64_t(255);
+    }
+    L.hostBegin[L.nChunks] = read_off[locus_read_begin[n]];
+    return L;
+  }
+  void resetChunkCounter(rt::Stream& copyStream)
+  {
     if (!dChunksDone) dChunksDone = static_cast<uint32_t*>(rt::dmallocFine(64));
     uint32_t* ids = pChunkIds.as<uint32_t>(kStreamChunks + 1);
     for (uint32_t c = 0; c <= kStreamChunks; ++c) ids[c] = c;
@@ -868,18 +900,53 @@ struct AsmStage {
       rt::sync();
     }
     rt::h2d(dChunksDone, ids, sizeof(uint32_t));  // = 0
-    rt::sync();  // the counter is zero and the small arrays are in place before the first chunk can land
-    {
-      // one copy per chunk, each followed by a stream-ordered 32-bit write of the counter (command processor; a 4-byte copy
-      // if the runtime refuses): the counter says c+1 only after chunk c is in HBM.  Nothing here needs a workgroup slot --
-      // the persistent assembler, or another process' kernels, may own every one of them.
-      rt::ScopedStream onCopy(copyStream);
-      for (uint32_t c = 0; c < nChunks; ++c) {
-        rt::h2d(dBases + devBegin[c], bases + hostBegin[c], hostBegin[c + 1] - hostBegin[c]);
-        if (!rt::streamWrite32(dChunksDone, c + 1)) rt::h2d(dChunksDone, ids + c + 1, sizeof(uint32_t));
-      }
+  }
+  void queueChunks(const StreamLayout& L, const uint8_t* bases, rt::Stream& copyStream)
+  {
+    // one copy per chunk, each followed by a stream-ordered 32-bit write of the counter (command processor; a 4-byte copy
+    // if the runtime refuses): the counter says c+1 only after chunk c is in HBM.  Nothing here needs a workgroup slot --
+    // the persistent assembler, or another process' kernels, may own every one of them.
+    const uint32_t*   ids = pChunkIds.as<uint32_t>(kStreamChunks + 1);
+    rt::ScopedStream onCopy(copyStream);
+    for (uint32_t c = 0; c < L.nChunks; ++c) {
+      rt::h2d(dBases + L.devBegin[c], bases + L.hostBegin[c], L.hostBegin[c + 1] - L.hostBegin[c]);
+      if (!rt::streamWrite32(dChunksDone, c + 1)) rt::h2d(dChunksDone, ids + c + 1, sizeof(uint32_t));
     }
-    streaming = true;
+  }
+  /// The first thing a streamed upload does, BEFORE plan(): the read bases start for the device while the host still sizes the batch
+  /// (plan()'s pass over every read offset: ~0.5 ms for the metric's 800 k reads, which the kernel used to spend waiting for chunks
+  /// later).  Needs nothing of the plan: chunks are whole loci in locus order.  False (nothing queued): offsets that are not monotone
+  /// at the chunk boundaries -- plan() names the error.  The caller drains copyStream if it fails before uploadStreamed().
+  bool                  preStreamed = false;
+  rt::Event             evPreSmall;
+  uint32_t              preLoci     = 0;
+  StreamLayout          preLayout;
+  bool startStream(const uint32_t n_loci, const uint8_t* bases, const uint64_t* read_off, const uint32_t* locus_read_begin, rt::Stream& copyStream)
+  {
+    preStreamed = false;
+    for (uint32_t l = 0; l < n_loci; ++l)
+      if (locus_read_begin[l + 1] < locus_read_begin[l]) return false;
+    preLayout = streamLayout(n_loci, read_off, locus_read_begin);
+    if (!preLayout.monotone) return false;
+    dBases = bBases.as<uint8_t>(preLayout.cursor + 64 + 64);  // (upload() asks for the same sizes again)
+    const uint32_t nReads = locus_read_begin[n_loci];
+    dOff   = bReadOff.as<uint64_t>(size_t(nReads) + 1);
+    dBegin = bLocusBegin.as<uint32_t>(size_t(n_loci) + 1);
+    resetChunkCounter(copyStream);
+    rt::sync();
+    {
+      // the per-read offsets (6.4 MB for the metric's batch) and the locus table go first, on the chunks' own stream: on another stream,
+      // issued later, they share the link with the chunks -- or queue behind all of them on the same DMA engine (measured: the host then
+      // waits 2.4 ms for its small arrays).  uploadStreamed() makes the pipeline's stream wait for them.
+      rt::ScopedStream onCopy(copyStream);
+      rt::h2d(dOff, read_off, sizeof(uint64_t) * (size_t(nReads) + 1));
+      rt::h2d(dBegin, locus_read_begin, sizeof(uint32_t) * (size_t(n_loci) + 1));
+      evPreSmall.record();
+    }
+    queueChunks(preLayout, bases, copyStream);
+    preStreamed = true;
+    preLoci     = n_loci;
+    return true;
   }
 
   /// uploadStreamed() for packed piles: per chunk the slices of the five pile arrays (codes, N masks, read lengths and the two
@@ -1002,7 +1069,7 @@ struct AsmStage {
       rt::h2d(dBases, bases, nBases);
       rt::h2d(dOff, read_off, sizeof(uint64_t) * (nReadsTotal + 1));
     }
-    rt::h2d(dBegin, locus_read_begin, sizeof(uint32_t) * (nLoci + 1));
+    if (locus_read_begin) rt::h2d(dBegin, locus_read_begin, sizeof(uint32_t) * (nLoci + 1));  // (nullptr: startStream() has sent it)
     rt::h2d(dGrowth, ctx->growthSize.data(), sizeof(uint32_t) * ctx->growthSize.size());
     rt::h2d(dGrowth + ctx->growthSize.size(), ctx->growthBuckets.data(), sizeof(uint32_t) * ctx->growthBuckets.size());
   }
@@ -1385,23 +1452,69 @@ struct AsmStage {
   void stageFinish(F moreCopies)
   {
     stageQueued = false;
-    seqUsedDev  = std::min<uint64_t>(hCnt[1], devSeqCap);
-    bitsUsedDev = std::min<uint64_t>(hCnt[2], devBitsCap);
-    seqLast     = seqUsedDev;
-    bitsLast    = bitsUsedDev;
     bool queued = false;
-    if (seqUsedDev > seqCopied) {  // (the staging buffer keeps what it holds when it grows)
-      hSeq = pSeq.as<uint8_t>(seqUsedDev + 1, true);
-      rt::d2hAsync(hSeq + seqCopied, dSeq + seqCopied, seqUsedDev - seqCopied);
-      queued = true;
-    }
-    if (bitsUsedDev > bitsCopied) {
-      hBits = pBits.as<uint64_t>(bitsUsedDev + 1, true);
-      rt::d2hAsync(hBits + bitsCopied, dBits + bitsCopied, sizeof(uint64_t) * (bitsUsedDev - bitsCopied));
-      queued = true;
+    if (!earlyStaged) {
+      seqUsedDev  = std::min<uint64_t>(hCnt[1], devSeqCap);
+      bitsUsedDev = std::min<uint64_t>(hCnt[2], devBitsCap);
+      seqLast     = seqUsedDev;
+      bitsLast    = bitsUsedDev;
+      if (seqUsedDev > seqCopied) {  // (the staging buffer keeps what it holds when it grows)
+        hSeq = pSeq.as<uint8_t>(seqUsedDev + 1, true);
+        rt::d2hAsync(hSeq + seqCopied, dSeq + seqCopied, seqUsedDev - seqCopied);
+        queued = true;
+      }
+      if (bitsUsedDev > bitsCopied) {
+        hBits = pBits.as<uint64_t>(bitsUsedDev + 1, true);
+        rt::d2hAsync(hBits + bitsCopied, dBits + bitsCopied, sizeof(uint64_t) * (bitsUsedDev - bitsCopied));
+        queued = true;
+      }
     }
     moreCopies(queued);
     if (queued) rt::sync();
+    if (!earlyStaged) stagedTotals();  // (an early staging has done this: finishEarly)
+    earlyStaged = false;
+  }
+  /// The assembler's outputs for the host WHILE THE ALIGNERS RUN (whole-batch small-SV calls, smallsvRunImpl): queued on the copy
+  /// stream as soon as the run has read the assembler's counters `cnt` -- the assembler has left the device, the arenas' used sizes are
+  /// known, nothing is speculative -- so that the caller can compact them into its arrays before the alignments arrive.  Brings the
+  /// per-slot contig records (the packed ones are written after the aligners).
+  bool earlyStaged = false;
+  void stageEarly(rt::Stream& copyStream, const uint64_t* cnt, rt::Event& done)
+  {
+    rt::ScopedStream onCopy(copyStream);
+    hCnt  = pCnt.as<uint64_t>(16);
+    hLoci = pLoci.as<AsmLocusOut>(nLoci);
+    hCont = pCont.as<AsmContigOut>(uint64_t(nLoci) * opt.max_assembly_count);
+    seqCopied  = std::min<uint64_t>(cnt[1], devSeqCap);
+    bitsCopied = std::min<uint64_t>(cnt[2], devBitsCap);
+    hSeq       = pSeq.as<uint8_t>(seqCopied + 1);
+    hBits      = pBits.as<uint64_t>(bitsCopied + 1);
+    rt::d2hAsync(hCnt, dCnt, sizeof(uint64_t) * 16);
+    rt::d2hAsync(hLoci, dLoci, sizeof(AsmLocusOut) * nLoci);
+    rt::d2hAsync(hCont, dCont, sizeof(AsmContigOut) * uint64_t(nLoci) * opt.max_assembly_count);
+    rt::d2hAsync(hSeq, dSeq, seqCopied);
+    rt::d2hAsync(hBits, dBits, sizeof(uint64_t) * bitsCopied);
+    done.record();
+    earlyStaged = true;
+  }
+  /// after the host has waited for stageEarly()'s event
+  void finishEarly()
+  {
+    seqUsedDev  = seqCopied;
+    bitsUsedDev = bitsCopied;
+    seqLast     = seqUsedDev;
+    bitsLast    = bitsUsedDev;
+    stagedTotals();
+  }
+  /// the pipeline's own copies behind an early staging (pipeStageEnqueue)
+  template <typename F0>
+  void stageEnqueueRest(F0 firstCopies)
+  {
+    firstCopies();
+    stageQueued = true;
+  }
+  void stagedTotals()
+  {
     nContigsOut = pseudoBytesOut = pseudoCountOut = 0;
     for (uint32_t l = 0; l < nLoci; ++l) {
       const AsmLocusOut& h(hLoci[l]);
@@ -1622,6 +1735,11 @@ struct manta_smallsv {
   bool                  bucketHistory = false;
   bool                  stageBehindRun = false;  // whole-batch calls: the run queues the staging behind its last kernel
   bool                  staged = false;
+  // whole-batch calls: the host's work on the assembler's outputs (sizes, compaction into the caller's arrays) while the aligners run.
+  // The run stages those outputs on the copy stream as soon as the assembler has left the device (AsmStage::stageEarly) and calls the
+  // hook after its last launch, before it waits for the device.
+  std::function<void()> whileAligning;
+  rt::Event             evEarlyStaged;
   PinnedBuf             hostOff[3], hostBegin;  // whole-batch worker: a block's rebased offset arrays (api_batch.cpp: rebase), kept across calls
   explicit manta_smallsv(manta_ctx_t* c) : ctx(c), asmStage(c) {}
 };
@@ -1752,8 +1870,7 @@ void pipeStageEnqueue(Pipe* b)
   const uint32_t nLoci = b->nLoci;
   b->hPackCnt          = b->pPackCnt.template as<uint32_t>(4);
   b->hFirst            = b->pFirst.template as<uint32_t>(nLoci);
-  b->asmStage.stageEnqueue(
-      [&] {
+  auto packCopies = [&] {
         rt::d2hAsync(b->hPackCnt, b->dPackCnt.p, 16);
         rt::d2hAsync(b->hFirst, b->dFirst.p, sizeof(uint32_t) * nLoci);
         // packed contig records and CIGARs: as many as the previous run had, a quarter on top
@@ -1765,8 +1882,11 @@ void pipeStageEnqueue(Pipe* b)
         b->hCig         = b->pCig.template as<uint32_t>(b->cigCopied + 1);
         rt::d2hAsync(b->hPacked, b->dPacked.p, sizeof(PackedContigOut) * b->packedCopied);
         rt::d2hAsync(b->hCig, b->dCigPacked.p, sizeof(uint32_t) * b->cigCopied);
-      },
-      false);
+      };
+  if (b->asmStage.earlyStaged)  // the assembler's outputs are on the host already (AsmStage::stageEarly)
+    b->asmStage.stageEnqueueRest(packCopies);
+  else
+    b->asmStage.stageEnqueue(packCopies, false);
 }
 template <typename Pipe>
 void pipeStageFinish(Pipe* b)
@@ -1818,6 +1938,9 @@ uint64_t pipeStagedBytes(const Pipe* b)
 /// staging -> caller records/arenas.  `loci` is this block's slice; `contigs` / `alignments` are the caller's whole arrays
 /// and this block writes [contigBase, contigBase + contigs_cap); the three arenas are this block's regions, offsets in the
 /// records are made relative to the caller's arena starts by adding the *Base values.
+inline int smallsvCompactAlign(
+    manta_smallsv* b, const manta_asm_locus_result_t* loci, manta_smallsv_alignment_t* alignments, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
+    uint64_t cigarBase, uint64_t* cigar_arena_used, uint32_t lBegin, uint32_t lEnd, uint64_t* cellsOut, uint64_t* ptrBytesOut, int worst);
 inline int smallsvCompact(
     manta_smallsv* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_smallsv_alignment_t* alignments,
     uint64_t contigBase, uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t seqBase, uint64_t* seq_arena_used,
@@ -1827,13 +1950,21 @@ inline int smallsvCompact(
 {
   // [lBegin, lEnd): the loci of this call (a whole-batch call compacts a block in a few ranges, one host thread each); every
   // output pointer / base is that of the range's first record
-  manta_ctx_t* ctx = b->ctx;
-  lEnd             = std::min(lEnd, b->nLoci);
+  lEnd   = std::min(lEnd, b->nLoci);
   int rc = b->asmStage.compact(PackedContigs<manta_smallsv>{b}, loci, contigs + contigBase, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used,
                                bits_arena, bits_arena_cap, bits_arena_used, contigBase, seqBase, bitsBase, lBegin, lEnd);
   if (rc != MANTA_OK && !perItemCode(rc)) return rc;
-  uint64_t       used = 0, cells = 0, ptrBytes = 0;
-  int            worst = rc;
+  return smallsvCompactAlign(b, loci, alignments, cigar_arena, cigar_arena_cap, cigarBase, cigar_arena_used, lBegin, lEnd, cellsOut, ptrBytesOut, rc);
+}
+/// the second half of smallsvCompact: the alignment records and CIGARs of the loci [lBegin, lEnd), whose locus records (first_contig,
+/// n_contigs) AsmStage::compact has written; `worst`: what that call returned (a per-item code or MANTA_OK)
+inline int smallsvCompactAlign(
+    manta_smallsv* b, const manta_asm_locus_result_t* loci, manta_smallsv_alignment_t* alignments, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
+    uint64_t cigarBase, uint64_t* cigar_arena_used, uint32_t lBegin, uint32_t lEnd, uint64_t* cellsOut, uint64_t* ptrBytesOut, int worst)
+{
+  manta_ctx_t* ctx = b->ctx;
+  lEnd             = std::min(lEnd, b->nLoci);
+  uint64_t used = 0, cells = 0, ptrBytes = 0;
   for (uint32_t l = lBegin; l < lEnd; ++l) {
     if (loci[l].status != MANTA_OK) continue;
     for (uint32_t c = 0; c < loci[l].n_contigs; ++c) {

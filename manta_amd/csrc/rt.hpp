@@ -47,7 +47,7 @@ struct Stream {
 };
 inline void useStream(Stream*) {}
 struct ScopedStream { explicit ScopedStream(Stream&) {} };
-struct Event { void record() {} void recordOn(Stream&) {} };
+struct Event { void record() {} void recordOn(Stream&) {} void sync() {} };
 inline void curStreamWaits(Event&) {}
 inline void streamWaits(Stream&, Event&) {}
 inline float elapsedMs(const Event&, const Event&) { return 0.f; }
@@ -256,6 +256,7 @@ struct Event {
   Event& operator=(const Event&) = delete;
   void record() { check(hipEventRecord(e, launchStream()), "hipEventRecord"); }
   void recordOn(Stream& st) { check(hipEventRecord(e, st.s), "hipEventRecord"); }
+  void sync() { check(hipEventSynchronize(e), "hipEventSynchronize"); }  // the host waits
 };
 inline void curStreamWaits(Event& ev) { check(hipStreamWaitEvent(launchStream(), ev.e, 0), "hipStreamWaitEvent"); }
 inline void streamWaits(Stream& st, Event& ev) { check(hipStreamWaitEvent(st.s, ev.e, 0), "hipStreamWaitEvent"); }

@@ -95,6 +95,31 @@ def test_emulated_batch_host_ranges(emu, oracle, monkeypatch):
     check_spanning(emu, oracle, 5, block=5, workers=1)
 
 
+def overlap_knobs(lib, oracle, monkeypatch, n, block, workers):
+    """the whole-batch small-SV call starts the DMA of the read bases before it sizes the batch (AsmStage::startStream) and compacts
+    the assembler's outputs while the aligners run (manta_smallsv::whileAligning): each switched off gives the same records"""
+    want = check_smallsv(lib, oracle, n, block=block, workers=workers, mixed=True)
+    for knob in ("MANTA_AMD_NO_EARLY_STREAM", "MANTA_AMD_NO_EARLY_STAGE"):
+        monkeypatch.setenv(knob, "1")
+        got = check_smallsv(lib, oracle, n, block=block, workers=workers, mixed=True)
+        monkeypatch.delenv(knob)
+        assert [small_sv_text(r) for r in got] == [small_sv_text(r) for r in want], knob
+
+
+def test_emulated_batch_overlap_knobs(emu, oracle, monkeypatch):
+    monkeypatch.setenv("MANTA_AMD_HOST_PARTS", "3")
+    overlap_knobs(emu, oracle, monkeypatch, 10, block=4, workers=2)
+    overlap_knobs(emu, oracle, monkeypatch, 9, block=9, workers=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_gpu_batch_overlap_knobs(gpu, oracle, monkeypatch):
+    overlap_knobs(gpu, oracle, monkeypatch, 300, block=300, workers=1)
+    monkeypatch.setenv("MANTA_AMD_HOST_PARTS", "4")
+    overlap_knobs(gpu, oracle, monkeypatch, 200, block=64, workers=3)
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
 def test_gpu_batch_calls(gpu, oracle):

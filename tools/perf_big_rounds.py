@@ -11,7 +11,7 @@ from manta_amd._capi import Lib
 from oracle_lib import asm_opts
 from synth import breakend_locus
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-lib = Lib(path=os.path.join(ROOT, "manta_amd", "libmanta_amd_profg.so"))
+lib = Lib(path=os.path.join(ROOT, "manta_amd", "libmanta_amd_profg.so" if len(sys.argv) < 3 else sys.argv[2]))
 for frac in (0.0, 1.0):
     base = [breakend_locus(s, tandem_frac=frac)[0] for s in range(64)]
     loci = [base[i % 64] for i in range(n)]
