@@ -1183,6 +1183,7 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
       std::unique_lock<std::mutex> streamedOnly(streamedAsmMu(ctx), std::defer_lock);  // see smallsvRunImpl
       if (as.streaming) streamedOnly.lock();
       as.stageQueued = false;  // (a run that failed behind its queued staging must not leave the flag to the next one)
+      as.earlyStaged = false;
       b->evStart.record();
       if (early) {
         as.afterFirstRound = [&] {
@@ -1239,6 +1240,9 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
       }
     }
     stage("assembled");
+    // whole-batch calls: the assembler's outputs leave for the host now, beside the (last) alignment pass (as smallsvRunImpl)
+    const bool earlyStage = b->stageBehindRun && b->whileAligning && !std::getenv("MANTA_AMD_NO_EARLY_STAGE");
+    if (earlyStage) as.stageEarly(b->copy, asmCnt, b->evEarlyStaged);
     GateLock alignOnly(gates, &StageGates::alignMu);
     if (b->refsOnCopy) rt::curStreamWaits(b->refsReady);  // reference windows of a streamed upload (manta_spanning_upload)
     uint64_t cigarCap = 0;
@@ -1265,6 +1269,11 @@ int spanningRunImpl(manta_spanning_t* b, StageGates* gates)
     launchPack(b, dTasks, dTasks2, dResults, dResults2, nullptr, dInfo, dCigar, cigarCap);
     b->evAlign.record();
     if (b->stageBehindRun) pipeStageEnqueue(b);
+    if (earlyStage) {
+      b->evEarlyStaged.sync();
+      as.finishEarly();
+      b->whileAligning();
+    }
     rt::sync();
     alignOnly.release();
     if (as.streaming) {  // every chunk was consumed by the kernel, so this returns at once; it closes the copy stream's error state

@@ -498,49 +498,68 @@ int spanningBatchImpl(
           break;
         }
         const double t1 = nowMs();
+        // compaction in a few locus ranges, one host thread each; the assembler's share of it while the last alignment pass runs (as smallsvBatchImpl)
+        struct Range {
+          uint64_t nC = 0, nS = 0, nB = 0, nG = 0, cells = 0, ptrBytes = 0;
+          uint64_t c0 = 0, s0 = 0, b0 = 0, g0 = 0;
+          int      rc = MANTA_OK, rcAsm = MANTA_OK;
+        };
+        const unsigned     parts = hostParts(uint64_t(n) * 4);
+        std::vector<Range> rg(parts);
+        uint64_t           nC = 0, nS = 0, nB = 0, nG = 0, cBase = 0, sBase = 0, bBase = 0;
+        bool               asmDone = false, asmFits = true;
+        auto asmShare = [&](auto contigAt) {
+          hostParallel(n, parts, [&](unsigned t, uint64_t a, uint64_t z) { b->asmStage.rangeSizes(contigAt, uint32_t(a), uint32_t(z), rg[t].nC, rg[t].nS, rg[t].nB); });
+          for (unsigned t = 0; t < parts; ++t) {
+            rg[t].c0 = nC, rg[t].s0 = nS, rg[t].b0 = nB;
+            nC += rg[t].nC, nS += rg[t].nS, nB += rg[t].nB;
+          }
+          cBase   = sh.contigsUsed.fetch_add(nC), sBase = sh.seqUsed.fetch_add(nS), bBase = sh.bitsUsed.fetch_add(nB);
+          asmDone = true;
+          asmFits = cBase + nC <= contigs_cap && sBase + nS <= seq_arena_cap && bBase + nB <= bits_arena_cap;
+          if (!asmFits) return;
+          hostParallel(n, parts, [&](unsigned t, uint64_t a, uint64_t z) {
+            const Range& r(rg[t]);
+            rg[t].rcAsm = b->asmStage.compact(contigAt, loci + l0, contigs + cBase + r.c0, r.nC, seq_arena + sBase + r.s0, r.nS, nullptr, bits_arena + bBase + r.b0, r.nB,
+                                              nullptr, cBase + r.c0, sBase + r.s0, bBase + r.b0, uint32_t(a), uint32_t(z));
+          });
+        };
+        b->whileAligning = [&] { asmShare(AsmStage::SparseContigs{&b->asmStage}); };
         {
           std::unique_lock<std::mutex> only(sh.kernelMu, std::defer_lock);
           if (sh.serialKernels) only.lock();
           b->stageBehindRun = true;
           rc = spanningRunImpl(b, sh.pipelineStages ? &sh.gates[w % nCtx] : nullptr);
         }
+        b->whileAligning = nullptr;
         if (rc != MANTA_OK) {
           sh.error(rc, lastErrorOf(ctx), true);
           break;
         }
         const double t2 = nowMs();
-        uint64_t     nC = 0, nS = 0, nB = 0, nG = 0;
         {
           rt::ScopedStream onStream(b->main);
           pipeStage(b);
         }
-        // compaction in a few locus ranges, one host thread each (as smallsvBatchImpl)
-        struct Range {
-          uint64_t nC = 0, nS = 0, nB = 0, nG = 0, cells = 0, ptrBytes = 0;
-          uint64_t c0 = 0, s0 = 0, b0 = 0, g0 = 0;
-          int      rc = MANTA_OK;
-        };
-        const unsigned     parts = hostParts(uint64_t(n) * 4);
-        std::vector<Range> rg(parts);
-        hostParallel(n, parts, [&](unsigned t, uint64_t a, uint64_t z) {
-          b->asmStage.rangeSizes(PackedContigs<manta_spanning>{b}, uint32_t(a), uint32_t(z), rg[t].nC, rg[t].nS, rg[t].nB);
-          rg[t].nG = spanningCigarWords(b, uint32_t(a), uint32_t(z));
-        });
+        if (!asmDone) asmShare(PackedContigs<manta_spanning>{b});  // (the run did not call the hook: MANTA_AMD_NO_EARLY_STAGE)
+        hostParallel(n, parts, [&](unsigned t, uint64_t a, uint64_t z) { rg[t].nG = spanningCigarWords(b, uint32_t(a), uint32_t(z)); });
         for (unsigned t = 0; t < parts; ++t) {
-          rg[t].c0 = nC, rg[t].s0 = nS, rg[t].b0 = nB, rg[t].g0 = nG;
-          nC += rg[t].nC, nS += rg[t].nS, nB += rg[t].nB, nG += rg[t].nG;
+          rg[t].g0 = nG;
+          nG += rg[t].nG;
         }
-        const uint64_t cBase = sh.contigsUsed.fetch_add(nC), sBase = sh.seqUsed.fetch_add(nS), bBase = sh.bitsUsed.fetch_add(nB),
-                       gBase = sh.cigarUsed.fetch_add(nG);
-        if (cBase + nC > contigs_cap || sBase + nS > seq_arena_cap || bBase + nB > bits_arena_cap || gBase + nG > cigar_arena_cap) {
+        const uint64_t gBase = sh.cigarUsed.fetch_add(nG);
+        if (!asmFits || gBase + nG > cigar_arena_cap) {
           sh.error(MANTA_E_CAPACITY, "manta_spanning_batch: caller arenas too small", true);
           break;
         }
         hostParallel(n, parts, [&](unsigned t, uint64_t a, uint64_t z) {
           const Range& r(rg[t]);
-          rg[t].rc = spanningCompact(b, loci + l0, contigs, alignments, cBase + r.c0, r.nC, seq_arena + sBase + r.s0, r.nS, sBase + r.s0, nullptr,
-                                     bits_arena + bBase + r.b0, r.nB, bBase + r.b0, nullptr, cigar_arena + gBase + r.g0, r.nG, gBase + r.g0,
-                                     nullptr, uint32_t(a), uint32_t(z), &rg[t].cells, &rg[t].ptrBytes);
+          if (r.rcAsm != MANTA_OK && !perItemCode(r.rcAsm)) {
+            rg[t].rc = r.rcAsm;
+            return;
+          }
+          rg[t].rc = spanningCompactAlign(b, loci + l0, alignments, cigar_arena + gBase + r.g0, r.nG, gBase + r.g0, nullptr, uint32_t(a), uint32_t(z), &rg[t].cells,
+                                          &rg[t].ptrBytes, r.rcAsm);
         });
         rc = MANTA_OK;
         b->stats.dp_cells = b->stats.ptr_matrix_bytes = 0;

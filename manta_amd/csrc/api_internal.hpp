@@ -327,15 +327,45 @@ inline size_t workspaceBudget(const size_t capBytes)
 
 /// Host loops over a whole batch (validation scan of the offset arrays, compaction of the results) split over a few
 /// threads: fn(part, begin, end) for `parts` contiguous ranges of [0, n); the caller's thread takes part 0.
+/// plan()'s inner loops over one locus' reads: dwords of 2-bit codes (16 bases each) and the longest read (all ones: a negative step /
+/// a read of 4 G bases).  The second form is the first compiled for AVX2 -- the host translation units are built for baseline x86-64,
+/// where the loop stays scalar (~1.1 ns per read; the metric's batch has 800 k) -- and is taken where the CPU has it.
+#define MANTA_SCAN_OFFSETS_BODY                                                      \
+  uint64_t w = 0, hi = 0;                                                            \
+  uint32_t m = 0;                                                                    \
+  for (uint32_t i = 0; i < n; ++i) {                                                 \
+    const uint64_t len = o[i + 1] - o[i];                                            \
+    w += (len + 15) >> 4;                                                            \
+    hi |= len >> 32;                                                                 \
+    const uint32_t l32 = uint32_t(len);                                              \
+    m                  = m > l32 ? m : l32;                                          \
+  }                                                                                  \
+  wOut       = w;                                                                    \
+  longestOut = hi ? ~uint64_t(0) : uint64_t(m);
+inline void scanOffsetsBase(const uint64_t* o, const uint32_t n, uint64_t& wOut, uint64_t& longestOut) { MANTA_SCAN_OFFSETS_BODY }
+#if defined(__x86_64__) && !defined(MANTA_NO_AVX2_SCAN)
+__attribute__((target("avx2"))) inline void scanOffsetsAvx2(const uint64_t* o, const uint32_t n, uint64_t& wOut, uint64_t& longestOut) { MANTA_SCAN_OFFSETS_BODY }
+inline bool hostHasAvx2()
+{
+  static const bool has = __builtin_cpu_supports("avx2") != 0;
+  return has;
+}
+#else
+inline void scanOffsetsAvx2(const uint64_t* o, const uint32_t n, uint64_t& wOut, uint64_t& longestOut) { MANTA_SCAN_OFFSETS_BODY }
+inline bool hostHasAvx2() { return false; }
+#endif
+#undef MANTA_SCAN_OFFSETS_BODY
+
+static const unsigned kHostPartsMax = 8;
 inline unsigned hostParts(const uint64_t n)
 {
   static const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   if (const char* forced = std::getenv("MANTA_AMD_HOST_PARTS"))  // tests: take the multi-range paths on small batches too
-    return unsigned(std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n, 4), uint64_t(std::max(1, std::atoi(forced))))));
+    return unsigned(std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n, kHostPartsMax), uint64_t(std::max(1, std::atoi(forced))))));
   if (n < 4096) return 1;
-  return std::min(4u, hw);
+  return std::min(n < 262144 ? 4u : kHostPartsMax, hw);  // (eight for the passes over every read of a large batch)
 }
-/// three helper threads per process, parked on a condition variable between jobs (starting std::threads per call costs more
+/// seven helper threads per process, parked on a condition variable between jobs (starting std::threads per call costs more
 /// than the loops they would share on a 256-core host)
 class HostPool {
  public:
@@ -344,7 +374,7 @@ class HostPool {
     static HostPool pool;
     return pool;
   }
-  /// fn(part, begin, end) for `parts` (<= 4) contiguous ranges of [0, n); part 0 runs on the caller's thread.  One job at a
+  /// fn(part, begin, end) for `parts` (<= kHostPartsMax) contiguous ranges of [0, n); part 0 runs on the caller's thread.  One job at a
   /// time: concurrent callers (workers of a batch call) queue up behind runMu.
   template <typename F>
   void run(const uint64_t n, const unsigned parts, F fn)
@@ -379,7 +409,7 @@ class HostPool {
  private:
   HostPool() : owner(getpid())
   {
-    for (unsigned i = 0; i < 3; ++i) threads.emplace_back([this, i] { loop(i + 1); });
+    for (unsigned i = 0; i + 1 < kHostPartsMax; ++i) threads.emplace_back([this, i] { loop(i + 1); });
   }
   ~HostPool()
   {
@@ -573,8 +603,16 @@ struct AsmStage {
       const unsigned    parts = hostParts(nReadsTotal);
       std::vector<Part> part(parts);
       const uint32_t    maxAsm = opt.max_assembly_count;
+      const bool        avx2   = hostHasAvx2();
       hostParallel(n_loci, parts, [&](unsigned t, uint64_t l0, uint64_t l1) {
-        Part& p(part[t]);
+        // (the totals are kept in a local and stored once: the Part records of the threads share cache lines, and a store per locus into
+        //  them made the threads take turns: 0.45 ms for the metric's 800 k reads on four threads, 0.07 ms now on eight)
+        Part p;
+        struct StoreAtExit {
+          Part& to;
+          Part& from;
+          ~StoreAtExit() { to = from; }
+        } storeAtExit{part[t], p};
         for (uint64_t l = l0; l < l1; ++l) {
           const uint32_t rb = locus_read_begin[l], re = locus_read_begin[l + 1];
           if (re < rb || re > nReadsTotal) {
@@ -585,11 +623,7 @@ struct AsmStage {
           uint64_t b = 0, w = 0, longest = 0;
           if (read_off) {
             const uint64_t* o = read_off + rb;
-            for (uint32_t i = 0; i < re - rb; ++i) {
-              const uint64_t len = o[i + 1] - o[i];
-              w += (len + 15) >> 4;
-              longest = std::max(longest, len);
-            }
+            (avx2 ? scanOffsetsAvx2 : scanOffsetsBase)(o, re - rb, w, longest);
             b = o[re - rb] - o[0];
           } else {
             const uint32_t* o = read_len + rb;
@@ -1783,6 +1817,8 @@ struct manta_spanning {
   uint64_t              packLast[2] = {0, 0}, packedCopied = 0, cigCopied = 0;
   bool                  stageBehindRun = false;
   bool                  staged = false;
+  std::function<void()> whileAligning;  // as manta_smallsv::whileAligning (called while the last alignment pass runs)
+  rt::Event             evEarlyStaged;
   PinnedBuf             hostOff[3], hostBegin;  // whole-batch worker: a block's rebased offset arrays, kept across calls
   explicit manta_spanning(manta_ctx_t* c) : ctx(c), asmStage(c) {}
 };
@@ -2026,6 +2062,9 @@ using namespace manta_host;
 
 namespace manta_host {
 
+inline int spanningCompactAlign(
+    manta_spanning* b, const manta_asm_locus_result_t* loci, manta_spanning_alignment_t* alignments, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
+    uint64_t cigarBase, uint64_t* cigar_arena_used, uint32_t lBegin, uint32_t lEnd, uint64_t* cellsOut, uint64_t* ptrBytesOut, int worst);
 inline int spanningCompact(
     manta_spanning* b, manta_asm_locus_result_t* loci, manta_asm_contig_t* contigs, manta_spanning_alignment_t* alignments,
     uint64_t contigBase, uint64_t contigs_cap, uint8_t* seq_arena, uint64_t seq_arena_cap, uint64_t seqBase, uint64_t* seq_arena_used,
@@ -2034,13 +2073,20 @@ inline int spanningCompact(
     uint64_t* cellsOut = nullptr, uint64_t* ptrBytesOut = nullptr)
 {
   // [lBegin, lEnd) and the *Out totals: as smallsvCompact
-  manta_ctx_t* ctx = b->ctx;
-  lEnd             = std::min(lEnd, b->nLoci);
+  lEnd   = std::min(lEnd, b->nLoci);
   int rc = b->asmStage.compact(PackedContigs<manta_spanning>{b}, loci, contigs + contigBase, contigs_cap, seq_arena, seq_arena_cap, seq_arena_used,
                                bits_arena, bits_arena_cap, bits_arena_used, contigBase, seqBase, bitsBase, lBegin, lEnd);
   if (rc != MANTA_OK && !perItemCode(rc)) return rc;
-  uint64_t       used = 0, cells = 0, ptrBytes = 0;
-  int            worst = rc;
+  return spanningCompactAlign(b, loci, alignments, cigar_arena, cigar_arena_cap, cigarBase, cigar_arena_used, lBegin, lEnd, cellsOut, ptrBytesOut, rc);
+}
+/// the second half of spanningCompact (as smallsvCompactAlign)
+inline int spanningCompactAlign(
+    manta_spanning* b, const manta_asm_locus_result_t* loci, manta_spanning_alignment_t* alignments, uint32_t* cigar_arena, uint64_t cigar_arena_cap,
+    uint64_t cigarBase, uint64_t* cigar_arena_used, uint32_t lBegin, uint32_t lEnd, uint64_t* cellsOut, uint64_t* ptrBytesOut, int worst)
+{
+  manta_ctx_t* ctx = b->ctx;
+  lEnd             = std::min(lEnd, b->nLoci);
+  uint64_t used = 0, cells = 0, ptrBytes = 0;
   for (uint32_t l = lBegin; l < lEnd; ++l) {
     if (loci[l].status != MANTA_OK) continue;
     for (uint32_t c = 0; c < loci[l].n_contigs; ++c) {

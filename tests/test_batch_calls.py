@@ -104,6 +104,10 @@ def overlap_knobs(lib, oracle, monkeypatch, n, block, workers):
         got = check_smallsv(lib, oracle, n, block=block, workers=workers, mixed=True)
         monkeypatch.delenv(knob)
         assert [small_sv_text(r) for r in got] == [small_sv_text(r) for r in want], knob
+    check_spanning(lib, oracle, max(4, n // 4), block=max(2, block // 4), workers=workers)  # (every locus against the oracle)
+    monkeypatch.setenv("MANTA_AMD_NO_EARLY_STAGE", "1")
+    check_spanning(lib, oracle, max(4, n // 4), block=max(2, block // 4), workers=workers)
+    monkeypatch.delenv("MANTA_AMD_NO_EARLY_STAGE")
 
 
 def test_emulated_batch_overlap_knobs(emu, oracle, monkeypatch):
