@@ -854,7 +854,25 @@ struct AsmStage {
 
   // ---- streamed upload (whole-batch calls): the read bases arrive chunk by chunk on `copyStream` while assemble_kernel,
   // launched right away on the pipeline's stream, works through the loci whose chunk has landed (AsmParams::upload_*)
-  static const uint32_t kStreamChunks = 8;
+  static const uint32_t kStreamChunks = 32;  ///< at most (array sizes)
+  /// chunks a streamed upload is cut into: the kernel cannot start on a chunk before all of it has landed, so the last chunk's loci are the
+  /// tail behind the DMA (1 / chunks of the kernel's work); every chunk costs a copy command and a counter write
+  /// Workgroup slots a streamed launch of the LDS pipeline leaves free for the runtime's copy kernels and stream writes (launch()): two
+  /// per XCD.  Workgroups are dealt to the eight XCDs round-robin and stay there, so what matters is a free slot in EVERY XCD: with 4 free
+  /// slots (one in each of four XCDs) a 16 384-locus config-5 block starved until the kernel's time-out, with 16 it runs -- and the quarter
+  /// of the CUs that rounds 4-5 left free cost graph_kernel 12 % and graph_big_kernel 25 % of their workgroups for the whole launch
+  /// (metric step 8.83 -> 8.60 ms, 16 384 config-5 loci 268 -> 257 ms).  MANTA_AMD_STREAM_FREE_WGS overrides (rounded up to whole eights).
+  static int streamFreeSlots(const int cuCount)
+  {
+    static const int forced = std::getenv("MANTA_AMD_STREAM_FREE_WGS") ? std::max(1, std::atoi(std::getenv("MANTA_AMD_STREAM_FREE_WGS"))) : 0;
+    const int        want   = forced ? forced : 16;
+    return std::min(((want + 7) / 8) * 8, std::max(8, cuCount / 2));
+  }
+  static uint32_t streamChunks()
+  {
+    static const uint32_t n = std::getenv("MANTA_AMD_STREAM_CHUNKS") ? uint32_t(std::max(1, std::min(int(kStreamChunks), std::atoi(std::getenv("MANTA_AMD_STREAM_CHUNKS"))))) : 16u;
+    return n;
+  }
   DevBuf                bPlShift;  // streamed packed piles: three shifts per chunk
   uint64_t*             dPlShift = nullptr;
   bool                  streamingPiles = false;
@@ -908,7 +926,7 @@ struct AsmStage {
   static StreamLayout streamLayout(const uint32_t n, const uint64_t* read_off, const uint32_t* locus_read_begin)
   {
     StreamLayout L;
-    L.chunkLoci = std::max<uint32_t>(1, (n + kStreamChunks - 1) / kStreamChunks);
+    L.chunkLoci = std::max<uint32_t>(1, (n + streamChunks() - 1) / streamChunks());
     L.nChunks   = (n + L.chunkLoci - 1) / L.chunkLoci;
     for (uint32_t c = 0; c < L.nChunks; ++c) {
       const uint32_t l0 = c * L.chunkLoci, l1 = std::min(n, l0 + L.chunkLoci);
@@ -988,7 +1006,7 @@ struct AsmStage {
   /// locus' slices through three per-chunk shifts (AsmParams::pl_chunk_shift).  Only the locus table goes first.
   void uploadPilesStreamed(const manta_packed_piles_t& pl, rt::Stream& copyStream)
   {
-    chunkLoci = std::max<uint32_t>(1, (nLoci + kStreamChunks - 1) / kStreamChunks);
+    chunkLoci = std::max<uint32_t>(1, (nLoci + streamChunks() - 1) / streamChunks());
     const uint32_t nChunks = (nLoci + chunkLoci - 1) / chunkLoci;
     struct Piece {
       uint32_t r0, r1;
@@ -1212,11 +1230,12 @@ struct AsmStage {
       A.G.rws_stride = 0;
       A.G.gws        = nullptr;
       A.G.rprof      = nullptr;
-      // streamed upload: a chunk the runtime moves with a shader copy needs a free workgroup slot (and, as far as this launch can
-      // know, LDS): graph_kernel's two workgroups per CU own all 160 KB, so a quarter of the CUs keep one slot free -- without it
-      // the copies never run and the persistent workgroups wait for their chunks forever (seen on hardware, round 4)
+      // streamed upload: a chunk the runtime moves with a shader copy -- and every hipStreamWriteValue32, a one-workgroup kernel --
+      // needs a free workgroup slot: graph_kernel's two workgroups per CU own all 160 KB of LDS and every VGPR, so a few slots stay
+      // free (streamFreeSlots) -- without them the copies never run and the persistent workgroups wait for their chunks forever
+      // (seen on hardware, round 4)
       int gf = gridFast;
-      if (streaming && gf >= ctx->cuCount * 2) gf -= std::max(1, ctx->cuCount / 4);
+      if (streaming && gf >= ctx->cuCount * 2) gf -= streamFreeSlots(ctx->cuCount);
       // (the instantiation by the longest first word length among the loci of this launch: keys of 2 / 4 / 8 dwords)
       if (!fastIds.empty()) {
         uint32_t firstWl = opt.min_word_length;
@@ -1263,7 +1282,7 @@ struct AsmStage {
         B.G.cws        = bCwsBig.as<uint8_t>(cwsStrideBig * uint64_t(maxGridBig));
         B.G.cws_stride = cwsStrideBig;
         int gb = gridBig;
-        if (streaming && gb >= ctx->cuCount) gb -= std::max(1, ctx->cuCount / 4);  // (as above: one workgroup owns a CU's whole LDS)
+        if (streaming && gb >= ctx->cuCount) gb -= streamFreeSlots(ctx->cuCount);  // (as above: one workgroup owns a CU's whole LDS)
         // (the instantiation by the longest word length the kernel may meet: the first one without the rounds, any of them with)
         uint32_t firstWl = bigRounds ? opt.max_word_length : opt.min_word_length;
         if (!locusMinWl.empty()) {
