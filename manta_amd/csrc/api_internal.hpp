@@ -866,7 +866,7 @@ struct AsmStage {
   {
     static const int forced = std::getenv("MANTA_AMD_STREAM_FREE_WGS") ? std::max(1, std::atoi(std::getenv("MANTA_AMD_STREAM_FREE_WGS"))) : 0;
     const int        want   = forced ? forced : 16;
-    return std::min(((want + 7) / 8) * 8, std::max(8, cuCount / 2));
+    return std::max(1, std::min(((want + 7) / 8) * 8, cuCount / 4));  // (never more than the quarter of the CUs of rounds 4-5: small devices, the emulator)
   }
   static uint32_t streamChunks()
   {
