@@ -17,6 +17,10 @@
 // (Round 4's first cut kept a 64-bit lane mask per word, updated by one L2 atomic per lane and step: 230 M atomics per 10 000
 // loci -- the L2's atomic rate, not the waves in flight, set the kernel's speed.)
 #pragma once
+#ifdef MANTA_WAVE_EMU
+#include <map>
+#include <set>
+#endif
 #include "asm_lds.hpp"
 
 namespace manta_dev {
@@ -385,9 +389,22 @@ struct LdsContig {
   /// words are looked at, each is followed to the end of its stretch (the label), later words under a label are dropped, the first 64
   /// kept ones are the list.  The replay stays exact because it only ever accepts THE lowest unused word (contigRounds): a dropped
   /// word that its stretch's walk did not consume simply ends the replay and heads the next list.
-  WV_DEV unsigned stretchSeedList()
+#ifdef MANTA_WAVE_EMU
+  struct Dbg { std::set<unsigned> looked, listed, dropped, walked, evicted; };
+  static Dbg& dbg() { static Dbg d; return d; }
+#endif
+#ifndef MANTA_STRETCH_PLAIN
+#define MANTA_STRETCH_PLAIN 24
+#endif
+#ifndef MANTA_STRETCH_LATE
+#define MANTA_STRETCH_LATE 7
+#endif
+#ifndef MANTA_STRETCH_EVICT
+#define MANTA_STRETCH_EVICT 1
+#endif
+  WV_DEV unsigned stretchSeedList(const unsigned PLAIN = 0)
   {
-    static const unsigned WIN = 4;  // entries per lane: 256 unused words are looked at
+    static const unsigned WIN = LGL_STRETCH_WIN;  // entries per lane: 64 x WIN unused words are looked at
     const unsigned nW = firstUnused(64 * WIN);
     if (nW <= 1) return nW;
     unsigned ent[WIN], lab[WIN];
@@ -412,12 +429,21 @@ struct LdsContig {
       for (unsigned j = 0; j < gEnd; ++j) {
         const unsigned v = wv::readlane(lab[g], int(j));
         for (unsigned h = g; h < WIN; ++h)
-          if (64 * g + j < lane + 64 * h && v == lab[h]) dup[h] = true;
+          if (64 * g + j < lane + 64 * h && v == lab[h] && lane + 64 * h >= PLAIN) dup[h] = true;
       }
     }
     unsigned base = 0;
     uint64_t keepM[WIN];
     for (unsigned h = 0; h < WIN; ++h) keepM[h] = wv::ballot(ent[h] != ASM_NONE && !dup[h]);
+#ifdef MANTA_WAVE_EMU
+    if (std::getenv("MANTA_EMU_WHY")) {
+      for (unsigned h = 0; h < WIN; ++h)
+        if (ent[h] != ASM_NONE) {
+          dbg().looked.insert(ent[h]);
+          if (dup[h]) dbg().dropped.insert(ent[h]);
+        }
+    }
+#endif
     const uint64_t below = (uint64_t(1) << lane) - 1;
     wv::sync();
     for (unsigned h = 0; h < WIN; ++h) {
@@ -905,6 +931,9 @@ struct LdsContig {
     if (nNodes == 0 || nEligible == 0) return 0;
     slotNode[lane] = uint16_t(LG_NO_SLOT);
     uint64_t cached = 0, accAll = 0;
+#ifdef MANTA_WAVE_EMU
+    if (lane == 0) dbg() = Dbg();
+#endif
     {  // round 0: the first seed (id 0) and beside it graph_big_kernel's speculation list
       const uint16_t* spec = gSpecList();
       const unsigned  n0   = (nSpec < 1) ? 1u : ((nSpec > 64) ? 64u : nSpec);
@@ -937,8 +966,17 @@ struct LdsContig {
         continue;
       }
       tick(7);
+#ifdef MANTA_WAVE_EMU
+      if (std::getenv("MANTA_EMU_WHY") && lane == 0) {
+        const char* why = dbg().evicted.count(nd) ? "walked-then-evicted" : dbg().walked.count(nd) ? "walked(?)" : dbg().listed.count(nd) ? "listed-not-walked" : dbg().dropped.count(nd) ? "dropped-as-stretch-duplicate" : dbg().looked.count(nd) ? "looked" : "outside-every-window";
+        std::fprintf(stderr, "WHY round at %u cands: seed %u count %u: %s\n", nCand, nd, R::cnt(nodes[nd]), why);
+      }
+#endif
       // ---- a walk round: the next seed and, beside it, the words most likely to follow it ----
-      unsigned       nL   = stretchSeedList();
+      unsigned       nL   = stretchSeedList((capCand - nCand <= MANTA_STRETCH_LATE) ? unsigned(MANTA_STRETCH_PLAIN) : 0u);
+#ifdef MANTA_WAVE_EMU
+      if (std::getenv("MANTA_EMU_WHY") && lane < nL) dbg().listed.insert(unsigned(tent[lane]));
+#endif
       const unsigned node = (lane < nL) ? unsigned(tent[lane]) : ASM_NONE;
       unsigned       slot = LG_NO_SLOT;
       auto findSlots = [&]() {
@@ -969,10 +1007,46 @@ struct LdsContig {
           wv::sync();
         }
       }
+#if MANTA_STRETCH_EVICT
+      if (!acyclic && unsigned(wv::popc(~cached)) < unsigned(wv::popc(miss))) {
+        // still short, on a graph without a proof of acyclicity (a pile with a tandem repeat: its first contigs end at the repeat and the next
+        // seeds are well-covered words far up the order): the cached walks nobody asks for now, latest in seed order first, make room for
+        // the list's entries -- an entry that waits for a slot costs a walk round of its own as soon as its turn comes.  (On the piles
+        // without a repeat the round-0 speculation is what the late seeds need: evicting it cost them 7 % more rounds.)
+        const unsigned sn     = unsigned(slotNode[lane]);
+        bool           listed = false;
+        for (unsigned j = 0; j < nL; ++j) {
+          const unsigned v = wv::readlane(node, int(j));
+          listed           = listed || (v == sn);
+        }
+        bool     evictable = (((cached & ~accAll) >> lane) & 1u) && sn != LG_NO_SLOT && !listed;
+        unsigned need      = unsigned(wv::popc(miss)) - unsigned(wv::popc(~cached));
+        while (need) {
+          const unsigned key = evictable ? sn + 1u : 0u;
+          unsigned       mx  = key;
+          for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = wv::shfl(mx, int(lane) ^ off);
+            mx               = (o > mx) ? o : mx;
+          }
+          if (mx == 0) break;
+          const uint64_t out = wv::ballot(evictable && key == mx);
+          if ((out >> lane) & 1u) {
+            slotNode[lane] = uint16_t(LG_NO_SLOT);
+            evictable      = false;
+          }
+          cached &= ~out;
+          need -= (unsigned(wv::popc(out)) < need) ? unsigned(wv::popc(out)) : need;
+        }
+        wv::sync();
+      }
+#endif
       if (cached == ~uint64_t(0)) {
         // still full (and the next seed has no walk): drop every cached walk that is not an accepted candidate
         // (making room for the first few missing entries only, at the cost of the cached walks latest in seed order, was tried: fewer
         // walks, the same number of rounds -- the single-read words' walks it gives up are the ones needed last)
+#ifdef MANTA_WAVE_EMU
+        if (std::getenv("MANTA_EMU_WHY") && !((accAll >> lane) & 1u) && slotNode[lane] != LG_NO_SLOT) dbg().evicted.insert(unsigned(slotNode[lane]));
+#endif
         if (!((accAll >> lane) & 1u)) slotNode[lane] = uint16_t(LG_NO_SLOT);
         cached = accAll;
         LG_STAT(4, 1);
@@ -991,6 +1065,9 @@ struct LdsContig {
       if (take) {
         slot           = tbl[rnk];
         slotNode[slot] = uint16_t(node);
+#ifdef MANTA_WAVE_EMU
+        if (std::getenv("MANTA_EMU_WHY")) dbg().walked.insert(node);
+#endif
       }
       uint64_t walkMask = 0;
       {

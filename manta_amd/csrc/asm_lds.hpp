@@ -289,11 +289,15 @@ WV_HD LgSlab lgSlabOf(const unsigned nNodes, const unsigned nFat, const unsigned
 }
 
 /// contig_kernel's LDS map by class (the small class' offsets are the CK_OFF_* above)
+#ifndef MANTA_STRETCH_WIN
+#define MANTA_STRETCH_WIN 4
+#endif
+static const unsigned LGL_STRETCH_WIN = MANTA_STRETCH_WIN;  ///< contig_big_kernel's walk-round lists: unused words looked at, per lane
 template <class C>
 struct CkMap {
   static const unsigned UNUSED = 64;
   static const unsigned TENT   = UNUSED + 4 * C::UNUSED_DW;
-  static const unsigned SLOTND = TENT + (C::BIG ? 512 : 256);  // (big class: 256 words looked at per list, stretchSeedList)
+  static const unsigned SLOTND = TENT + (C::BIG ? 2 * 64 * LGL_STRETCH_WIN : 256);  // (big class: 64 x LGL_STRETCH_WIN words looked at per list, stretchSeedList)
   static const unsigned TBL    = SLOTND + 128;
   static const unsigned SIB    = TBL + 64;
   static const unsigned SOVF   = SIB + 8 * LG_SIB_CAP;
