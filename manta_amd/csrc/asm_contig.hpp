@@ -393,6 +393,11 @@ struct LdsContig {
   struct Dbg { std::set<unsigned> looked, listed, dropped, walked, evicted; };
   static Dbg& dbg() { static Dbg d; return d; }
 #endif
+  // Round 6 ("the walk rounds of a tandem pile's passes"; counted with MANTA_EMU_WHY on the emulator):
+  //   PLAIN  the first PLAIN looked-at words are all kept, duplicates of a stretch or not.  Used when MANTA_STRETCH_LATE or fewer candidates
+  //          are still wanted: the last seeds are the next few unused words, and a word dropped as the duplicate of a stretch whose first
+  //          word went another way cost a walk round of its own (0.7 rounds per tandem pass).
+  //   MANTA_STRETCH_EVICT  contigRoundsStretch: eviction by seed order when a round is short of slots (graphs without a proof only).
 #ifndef MANTA_STRETCH_PLAIN
 #define MANTA_STRETCH_PLAIN 24
 #endif
